@@ -1,0 +1,42 @@
+# Build of the MI355X-native drprg predict hot path.
+#   make            -> drprg_amd/lib/libdrprg_hip.so, drprg_amd/bin/pandora, oracle/liboracle.so
+# hipcc cross-compiles gfx950 without a GPU present.
+HIPCC    ?= /opt/rocm/bin/hipcc
+CC       ?= gcc
+ARCH     ?= gfx950
+CXXFLAGS := -O3 -std=c++17 -fPIC -Wall -Wno-unused-result -Iinclude
+HIPFLAGS := $(CXXFLAGS) --offload-arch=$(ARCH)
+
+SRC  := drprg_amd/csrc
+OBJD := build/obj
+HOST_SRCS := prg.cpp kmergraph.cpp index.cpp fastx.cpp genotype.cpp mapper.cpp capi.cpp
+OBJS := $(addprefix $(OBJD)/,$(HOST_SRCS:.cpp=.o)) $(OBJD)/kernels.o
+LIB  := drprg_amd/lib/libdrprg_hip.so
+BIN  := drprg_amd/bin/pandora
+ORACLE := oracle/liboracle.so
+
+all: $(LIB) $(BIN) $(ORACLE)
+
+$(OBJD)/%.o: $(SRC)/%.cpp $(wildcard $(SRC)/*.h) include/drprg_hip.h
+	@mkdir -p $(OBJD)
+	$(HIPCC) $(CXXFLAGS) -x hip --offload-arch=$(ARCH) -c $< -o $@
+
+$(OBJD)/kernels.o: $(SRC)/kernels.hip $(SRC)/kernels.h
+	@mkdir -p $(OBJD)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIB): $(OBJS)
+	@mkdir -p $(dir $@)
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $(OBJS) -lz
+
+$(BIN): $(SRC)/pandora_main.cpp $(LIB)
+	@mkdir -p $(dir $@)
+	$(HIPCC) $(CXXFLAGS) -o $@ $< -Ldrprg_amd/lib -ldrprg_hip -Wl,-rpath,'$$ORIGIN/../lib'
+
+$(ORACLE): oracle/oracle.c
+	$(CC) -O2 -fPIC -shared -Wall -o $@ $< -lm
+
+clean:
+	rm -rf build $(LIB) $(BIN) $(ORACLE)
+
+.PHONY: all clean

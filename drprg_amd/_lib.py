@@ -1,0 +1,66 @@
+"""ctypes binding of libdrprg_hip.so (the C ABI of include/drprg_hip.h).
+
+There is no Python or CPU fallback for the hot path: if the shared library has not been built this
+module raises ImportError with the build command, and every map call on a GPU-less host returns
+-ENODEV from the library itself.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdrprg_hip.so")
+PANDORA_EXE = os.path.join(_HERE, "bin", "pandora")
+
+
+class MapOpts(C.Structure):
+    """struct drprg_hip_map_opts"""
+    _fields_ = [
+        ("max_diff", C.c_int32),
+        ("error_rate", C.c_double),
+        ("min_cluster_size", C.c_uint32),
+        ("illumina", C.c_int32),
+        ("genome_size", C.c_uint64),
+        ("genotyping_error_rate", C.c_double),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/drprg_hip.h declares
+SIGNATURES = {
+    "drprg_hip_index": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int]),
+    "drprg_hip_open": (C.c_void_p, [C.c_char_p, C.c_int, C.c_int, C.c_int]),
+    "drprg_hip_open_prg": (C.c_void_p, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "drprg_hip_close": (None, [C.c_void_p]),
+    "drprg_hip_last_error": (C.c_char_p, [C.c_void_p]),
+    "drprg_hip_set_opts": (C.c_int, [C.c_void_p, C.POINTER(MapOpts)]),
+    "drprg_hip_map_fastx": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "drprg_hip_map_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "drprg_hip_map_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p,
+                                       C.c_void_p, C.c_void_p]),
+    "drprg_hip_coverage_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "drprg_hip_coverage": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]),
+    "drprg_hip_set_coverage": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64]),
+    "drprg_hip_device_coverage": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "drprg_hip_reset": (C.c_int, [C.c_void_p]),
+    "drprg_hip_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "drprg_hip_genotype": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p]),
+    "drprg_hip_genotype_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
+    "drprg_hip_index_sizes": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "drprg_hip_index_export": (C.c_int, [C.c_void_p] + [C.c_void_p] * 7),
+    "drprg_hip_kernel_timing": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+}
+
+
+def load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build the HIP extension first (`make` at the repo root or "
+            "`python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = load()

@@ -1,0 +1,300 @@
+// capi.cpp -- the C ABI declared in include/drprg_hip.h.
+#include "../../include/drprg_hip.h"
+#include "fastx.h"
+#include "genotype.h"
+#include "mapper.h"
+#include <cstring>
+#include <memory>
+
+using namespace drprg;
+
+struct drprg_hip_ctx {
+    PrgIndex index;
+    std::unique_ptr<Mapper> mapper; // null for a host-only context
+    MapParams params;
+    std::string prg_file;
+    std::string last_error;
+    // host copy of the coverage (set by set_coverage, or downloaded lazily)
+    std::vector<uint32_t> covg, prg_reads;
+    bool host_coverage_valid = false;
+    uint64_t total_bases = 0;
+    uint32_t ginfo[4] = { 0, 0, 0, 0 };
+};
+
+static thread_local std::string g_last_error;
+
+#define API_BEGIN(ctx)                                  \
+    if (!(ctx)) return DRPRG_EINVAL;                    \
+    try {
+#define API_END(ctx)                                    \
+    }                                                   \
+    catch (const Error& e) {                            \
+        (ctx)->last_error = e.what();                   \
+        return e.code;                                  \
+    }                                                   \
+    catch (const std::bad_alloc&) {                     \
+        (ctx)->last_error = "out of host memory";       \
+        return DRPRG_ENOMEM;                            \
+    }                                                   \
+    catch (const std::exception& e) {                   \
+        (ctx)->last_error = e.what();                   \
+        return DRPRG_EIO;                               \
+    }                                                   \
+    return DRPRG_OK;
+
+static void apply_defaults(MapParams& p, const drprg_hip_map_opts* o)
+{
+    p.illumina = o && o->illumina;
+    p.error_rate = (o && o->error_rate > 0) ? o->error_rate : (p.illumina ? 0.001 : 0.11);
+    p.max_diff = (o && o->max_diff > 0) ? o->max_diff : (p.illumina ? 2 * p.k + 1 : 250);
+    p.min_cluster_size = o ? o->min_cluster_size : 10;
+    p.genome_size = (o && o->genome_size) ? o->genome_size : 5000000;
+    p.genotyping_error_rate = (o && o->genotyping_error_rate > 0) ? o->genotyping_error_rate : 0.01;
+}
+
+extern "C" {
+
+int drprg_hip_index(const char* prg_file, int w, int k, int threads)
+{
+    if (!prg_file) return DRPRG_EINVAL;
+    try {
+        PrgIndex::build_and_save(prg_file, w, k, threads > 0 ? threads : 1);
+    } catch (const Error& e) {
+        g_last_error = e.what();
+        return e.code;
+    } catch (const std::exception& e) {
+        g_last_error = e.what();
+        return DRPRG_EIO;
+    }
+    return DRPRG_OK;
+}
+
+static drprg_hip_ctx* open_impl(const char* prg_file, int w, int k, int device, bool from_files, int threads)
+{
+    if (!prg_file) {
+        g_last_error = "null PRG path";
+        return nullptr;
+    }
+    std::unique_ptr<drprg_hip_ctx> ctx(new (std::nothrow) drprg_hip_ctx);
+    if (!ctx) return nullptr;
+    try {
+        ctx->prg_file = prg_file;
+        if (from_files) ctx->index.load(prg_file, w, k);
+        else ctx->index.build(prg_file, w, k, threads > 0 ? threads : 1);
+        ctx->params.w = w;
+        ctx->params.k = k;
+        apply_defaults(ctx->params, nullptr);
+        if (device >= 0) ctx->mapper.reset(new Mapper(ctx->index.flat, ctx->params, device));
+    } catch (const std::exception& e) {
+        g_last_error = e.what();
+        return nullptr;
+    }
+    return ctx.release();
+}
+
+drprg_hip_ctx* drprg_hip_open(const char* prg_file, int w, int k, int device)
+{
+    return open_impl(prg_file, w, k, device, true, 1);
+}
+
+drprg_hip_ctx* drprg_hip_open_prg(const char* prg_file, int w, int k, int device, int threads)
+{
+    return open_impl(prg_file, w, k, device, false, threads);
+}
+
+void drprg_hip_close(drprg_hip_ctx* ctx) { delete ctx; }
+
+const char* drprg_hip_last_error(const drprg_hip_ctx* ctx) { return ctx ? ctx->last_error.c_str() : g_last_error.c_str(); }
+
+int drprg_hip_set_opts(drprg_hip_ctx* ctx, const drprg_hip_map_opts* opts)
+{
+    API_BEGIN(ctx)
+    apply_defaults(ctx->params, opts);
+    if (ctx->mapper) ctx->mapper->set_params(ctx->params);
+    API_END(ctx)
+}
+
+static Mapper& need_mapper(drprg_hip_ctx* ctx)
+{
+    if (!ctx->mapper) throw Error(DRPRG_ENODEV, "host-only context: the hot path runs on a HIP device only (no CPU fallback)");
+    return *ctx->mapper;
+}
+
+int drprg_hip_map_fastx(drprg_hip_ctx* ctx, const char* reads_path)
+{
+    API_BEGIN(ctx)
+    if (!reads_path) throw Error(DRPRG_EINVAL, "null reads path");
+    Mapper& m = need_mapper(ctx);
+    FastxReader rd(reads_path);
+    ReadBatch batch;
+    while (rd.next_batch(batch, 8u << 20, 1ull << 30)) {
+        m.map_host(batch.bases.data(), batch.offsets.data(), batch.n_reads());
+        ctx->total_bases += batch.bases.size();
+    }
+    ctx->host_coverage_valid = false;
+    API_END(ctx)
+}
+
+int drprg_hip_map_host(drprg_hip_ctx* ctx, const uint8_t* bases, const uint64_t* offsets, uint64_t n_reads)
+{
+    API_BEGIN(ctx)
+    if (n_reads && (!bases || !offsets)) throw Error(DRPRG_EINVAL, "null buffer");
+    Mapper& m = need_mapper(ctx);
+    if (n_reads) {
+        m.map_host(bases, offsets, n_reads);
+        ctx->total_bases += offsets[n_reads];
+    }
+    ctx->host_coverage_valid = false;
+    API_END(ctx)
+}
+
+int drprg_hip_map_device(drprg_hip_ctx* ctx, const void* d_bases, const void* d_offsets, uint64_t n_reads, uint64_t n_bases,
+    void* d_covg, void* d_prg_reads, void* hip_stream)
+{
+    API_BEGIN(ctx)
+    Mapper& m = need_mapper(ctx);
+    m.map_device((const uint8_t*)d_bases, (const uint64_t*)d_offsets, n_reads, n_bases, (uint32_t*)d_covg,
+        (uint32_t*)d_prg_reads, (hipStream_t)hip_stream);
+    ctx->total_bases += n_bases;
+    ctx->host_coverage_valid = false;
+    API_END(ctx)
+}
+
+int drprg_hip_coverage_size(const drprg_hip_ctx* ctx, uint64_t* n_covg, uint64_t* n_prgs)
+{
+    if (!ctx) return DRPRG_EINVAL;
+    if (n_covg) *n_covg = 2 * (uint64_t)ctx->index.flat.total_knodes();
+    if (n_prgs) *n_prgs = ctx->index.prgs.size();
+    return DRPRG_OK;
+}
+
+static void sync_host_coverage(drprg_hip_ctx* ctx)
+{
+    if (ctx->host_coverage_valid) return;
+    if (ctx->mapper) {
+        ctx->mapper->download(ctx->covg, ctx->prg_reads);
+    } else {
+        ctx->covg.assign(2 * (size_t)ctx->index.flat.total_knodes(), 0);
+        ctx->prg_reads.assign(ctx->index.prgs.size(), 0);
+    }
+    ctx->host_coverage_valid = true;
+}
+
+int drprg_hip_coverage(drprg_hip_ctx* ctx, uint32_t* covg, uint64_t n_covg, uint32_t* prg_reads, uint64_t n_prgs)
+{
+    API_BEGIN(ctx)
+    sync_host_coverage(ctx);
+    if ((covg && n_covg != ctx->covg.size()) || (prg_reads && n_prgs != ctx->prg_reads.size()))
+        throw Error(DRPRG_EINVAL, "coverage buffer size mismatch");
+    if (covg) std::memcpy(covg, ctx->covg.data(), ctx->covg.size() * sizeof(uint32_t));
+    if (prg_reads) std::memcpy(prg_reads, ctx->prg_reads.data(), ctx->prg_reads.size() * sizeof(uint32_t));
+    API_END(ctx)
+}
+
+int drprg_hip_set_coverage(drprg_hip_ctx* ctx, const uint32_t* covg, uint64_t n_covg, const uint32_t* prg_reads, uint64_t n_prgs,
+    uint64_t total_bases)
+{
+    API_BEGIN(ctx)
+    if (!covg || !prg_reads || n_covg != 2 * (uint64_t)ctx->index.flat.total_knodes() || n_prgs != ctx->index.prgs.size())
+        throw Error(DRPRG_EINVAL, "coverage buffer size mismatch");
+    ctx->covg.assign(covg, covg + n_covg);
+    ctx->prg_reads.assign(prg_reads, prg_reads + n_prgs);
+    ctx->host_coverage_valid = true;
+    ctx->total_bases = total_bases;
+    if (ctx->mapper) ctx->mapper->upload(ctx->covg, ctx->prg_reads);
+    API_END(ctx)
+}
+
+int drprg_hip_device_coverage(drprg_hip_ctx* ctx, void** d_covg, void** d_prg_reads)
+{
+    API_BEGIN(ctx)
+    Mapper& m = need_mapper(ctx);
+    if (d_covg) *d_covg = m.d_covg();
+    if (d_prg_reads) *d_prg_reads = m.d_prg_reads();
+    API_END(ctx)
+}
+
+int drprg_hip_reset(drprg_hip_ctx* ctx)
+{
+    API_BEGIN(ctx)
+    if (ctx->mapper) ctx->mapper->reset_coverage();
+    ctx->covg.clear();
+    ctx->prg_reads.clear();
+    ctx->host_coverage_valid = false;
+    ctx->total_bases = 0;
+    API_END(ctx)
+}
+
+int drprg_hip_counters(drprg_hip_ctx* ctx, uint64_t out[8])
+{
+    API_BEGIN(ctx)
+    if (!out) throw Error(DRPRG_EINVAL, "null output");
+    std::memset(out, 0, 8 * sizeof(uint64_t));
+    if (ctx->mapper) {
+        MapCounters c = ctx->mapper->counters();
+        out[0] = c.reads; out[1] = c.bases; out[2] = c.minimizers; out[3] = c.hits;
+        out[4] = c.clusters_kept; out[5] = c.hits_kept;
+    }
+    API_END(ctx)
+}
+
+int drprg_hip_genotype(drprg_hip_ctx* ctx, const char* vcf_refs, const char* out_vcf, const char* sample)
+{
+    API_BEGIN(ctx)
+    if (!out_vcf) throw Error(DRPRG_EINVAL, "null output path");
+    sync_host_coverage(ctx);
+    GenotypeResult r = genotype(ctx->index, ctx->covg, ctx->prg_reads, ctx->total_bases, ctx->params, vcf_refs ? vcf_refs : "");
+    write_vcf(out_vcf, r, sample && *sample ? sample : "sample");
+    ctx->ginfo[0] = r.exp_depth_covg;
+    ctx->ginfo[1] = r.min_kmer_covg;
+    ctx->ginfo[2] = (uint32_t)r.present.size();
+    ctx->ginfo[3] = (uint32_t)r.records.size();
+    API_END(ctx)
+}
+
+int drprg_hip_genotype_info(const drprg_hip_ctx* ctx, uint32_t out[4])
+{
+    if (!ctx || !out) return DRPRG_EINVAL;
+    std::memcpy(out, ctx->ginfo, sizeof ctx->ginfo);
+    return DRPRG_OK;
+}
+
+int drprg_hip_index_sizes(const drprg_hip_ctx* ctx, uint64_t sizes[5])
+{
+    if (!ctx || !sizes) return DRPRG_EINVAL;
+    const FlatIndex& f = ctx->index.flat;
+    sizes[0] = f.keys.size();
+    sizes[1] = f.rec_prg.size();
+    sizes[2] = ctx->index.prgs.size();
+    sizes[3] = f.total_knodes();
+    sizes[4] = f.slot_key.size();
+    return DRPRG_OK;
+}
+
+int drprg_hip_index_export(const drprg_hip_ctx* ctx, uint64_t* keys, uint32_t* rec_off, uint32_t* rec_prg, uint32_t* rec_knode,
+    uint8_t* rec_strand, uint32_t* prg_min_path_len, uint32_t* prg_knode_base)
+{
+    if (!ctx) return DRPRG_EINVAL;
+    const FlatIndex& f = ctx->index.flat;
+    if (keys) std::memcpy(keys, f.keys.data(), f.keys.size() * sizeof(uint64_t));
+    if (rec_off) std::memcpy(rec_off, f.rec_off.data(), f.rec_off.size() * sizeof(uint32_t));
+    if (rec_prg) std::memcpy(rec_prg, f.rec_prg.data(), f.rec_prg.size() * sizeof(uint32_t));
+    if (rec_knode) std::memcpy(rec_knode, f.rec_knode_global.data(), f.rec_knode_global.size() * sizeof(uint32_t));
+    if (rec_strand) std::memcpy(rec_strand, f.rec_strand.data(), f.rec_strand.size());
+    if (prg_min_path_len) std::memcpy(prg_min_path_len, f.min_path_len.data(), f.min_path_len.size() * sizeof(uint32_t));
+    if (prg_knode_base) std::memcpy(prg_knode_base, f.knode_base.data(), f.knode_base.size() * sizeof(uint32_t));
+    return DRPRG_OK;
+}
+
+int drprg_hip_kernel_timing(drprg_hip_ctx* ctx, int enable, int reset, double* ms_total, uint64_t* launches)
+{
+    API_BEGIN(ctx)
+    Mapper& m = need_mapper(ctx);
+    m.enable_kernel_timing(enable != 0);
+    if (ms_total) *ms_total = m.sketch_ms_total();
+    if (launches) *launches = m.sketch_launches();
+    if (reset) m.reset_kernel_timing();
+    API_END(ctx)
+}
+
+} // extern "C"

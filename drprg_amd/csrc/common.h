@@ -1,0 +1,88 @@
+// common.h -- shared host-side types and the k-mer hash for the MI355X predict hot path.
+//
+// The hash and base encoding follow pandora's KmerHash / inthash (external program invoked at
+// /root/reference/src/lib.rs:580-642); see DESIGN.md "Semantics".
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace drprg {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+// errno-style negative return codes of the C ABI (include/drprg_hip.h)
+enum : int {
+    DRPRG_OK = 0,
+    DRPRG_EINVAL = -22,
+    DRPRG_ENOENT = -2,
+    DRPRG_EIO = -5,
+    DRPRG_ENOMEM = -12,
+    DRPRG_ENODEV = -19,
+    DRPRG_EOVERFLOW = -75,
+    DRPRG_EFORMAT = -84,
+};
+
+inline uint64_t kmer_mask(int k) { return k >= 32 ? ~0ULL : ((1ULL << (2 * k)) - 1); }
+
+inline uint64_t hash64(uint64_t key, uint64_t mask)
+{
+    key = (~key + (key << 21)) & mask;
+    key = key ^ key >> 24;
+    key = ((key + (key << 3)) + (key << 8)) & mask;
+    key = key ^ key >> 14;
+    key = ((key + (key << 2)) + (key << 4)) & mask;
+    key = key ^ key >> 28;
+    key = (key + (key << 31)) & mask;
+    return key;
+}
+
+inline int nt4(unsigned char c)
+{
+    switch (c) {
+    case 'A': case 'a': return 0;
+    case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;
+    case 'T': case 't': return 3;
+    default: return 4;
+    }
+}
+
+// canonical hash of a k-mer given as a string of exactly k ACGT characters.
+// strand = true when the forward k-mer hashes <= its reverse complement.
+inline bool canonical_kmer_hash(const char* s, int k, uint64_t& h, bool& strand)
+{
+    const uint64_t mask = kmer_mask(k);
+    uint64_t f = 0, r = 0;
+    for (int i = 0; i < k; ++i) {
+        int c = nt4((unsigned char)s[i]);
+        if (c > 3) return false;
+        f = (f << 2) | (uint64_t)c;
+        r = (r >> 2) | ((uint64_t)(3 - c) << (2 * (k - 1)));
+    }
+    uint64_t hf = hash64(f & mask, mask), hr = hash64(r & mask, mask);
+    h = hf < hr ? hf : hr;
+    strand = hf <= hr;
+    return true;
+}
+
+// Mapping parameters of one `pandora map` / `discover` invocation
+// (argv built at /root/reference/src/predict.rs:236-245 and src/lib.rs:594-618).
+struct MapParams {
+    int w = 11;
+    int k = 15;
+    int max_diff = 250;             // --max-diff; 2k+1 with -I
+    double error_rate = 0.11;       // -e; 0.001 with -I
+    uint32_t min_cluster_size = 10; // -c
+    bool illumina = false;          // -I
+    uint64_t genome_size = 5000000; // -g
+    double genotyping_error_rate = 0.01;
+    double cluster_fraction() const; // 0.5 / exp(error_rate * k)
+};
+
+} // namespace drprg

@@ -1,0 +1,51 @@
+// genotype.h -- coverage vector -> pandora_genotyped.vcf (host side, O(#sites)).
+//
+// Restates the tail of `pandora map --genotype --local` (estimate_parameters, build_vcf,
+// add_sample_covgs_to_vcf, SampleInfo likelihood/GT/GT_CONF).  The output surface is pinned by
+// /root/reference/tests/cases/predict/ERR4796933.pandora.vcf and consumed by
+// /root/reference/src/lib.rs:935-1181, src/filter.rs:50-55, src/minor.rs:85-97.
+#pragma once
+#include "index.h"
+
+namespace drprg {
+
+struct AlleleStats {
+    uint32_t mean_fwd = 0, mean_rev = 0, med_fwd = 0, med_rev = 0, sum_fwd = 0, sum_rev = 0;
+    double gaps = 1.0;
+    double likelihood = 0.0;
+};
+
+struct VcfRecord {
+    std::string chrom;
+    uint32_t pos = 0; // 1-based
+    std::string ref;
+    std::vector<std::string> alts;
+    std::string vc, graphtype;
+    std::vector<AlleleStats> alleles; // ref first
+    int gt = 0;
+    double gt_conf = 0.0;
+};
+
+struct GenotypeResult {
+    uint32_t exp_depth_covg = 1;
+    uint32_t min_kmer_covg = 0;
+    std::vector<std::string> present; // loci with a ##contig line, sorted
+    std::vector<std::string> absent;
+    std::vector<VcfRecord> records;   // sorted by (chrom, pos, ref, alts)
+};
+
+// per-allele statistics from the k-mer coverages of one allele (SampleInfo)
+AlleleStats allele_stats(const std::vector<uint32_t>& fwd, const std::vector<uint32_t>& rev, uint32_t min_kmer_covg);
+double allele_likelihood(double e, double c_a, double c_other, double eps, double gaps);
+void genotype_site(std::vector<AlleleStats>& alleles, double e, double eps, int& gt, double& gt_conf);
+uint32_t estimate_exp_depth_covg(const std::vector<uint32_t>& kmer_total_covg, uint32_t zero_thresh);
+
+// covg: u32[2*total_knodes] ([2g] fwd, [2g+1] rev); prg_reads: clusters placed per PRG;
+// total_bases: bases mapped (for the genome-size coverage estimate); vcf_refs: genes.fa or "".
+GenotypeResult genotype(const PrgIndex& idx, const std::vector<uint32_t>& covg, const std::vector<uint32_t>& prg_reads,
+    uint64_t total_bases, const MapParams& p, const std::string& vcf_refs);
+
+void write_vcf(const std::string& path, const GenotypeResult& r, const std::string& sample);
+std::string format_g(double v); // ostream default formatting (%g, 6 significant digits)
+
+} // namespace drprg

@@ -1,0 +1,166 @@
+// index.cpp -- build / save / load the minimizer index.  See index.h.
+#include "index.h"
+#include <algorithm>
+#include <atomic>
+#include <cerrno>
+#include <cmath>
+#include <fstream>
+#include <sstream>
+#include <sys/stat.h>
+#include <thread>
+
+namespace drprg {
+
+static std::string dir_of(const std::string& p)
+{
+    size_t s = p.find_last_of('/');
+    return s == std::string::npos ? std::string(".") : p.substr(0, s);
+}
+
+std::string PrgIndex::idx_path(const std::string& prg_file, int w, int k)
+{
+    return prg_file + ".k" + std::to_string(k) + ".w" + std::to_string(w) + ".idx";
+}
+
+std::string PrgIndex::gfa_path(const std::string& prg_file, const std::string& name, int w, int k)
+{
+    return dir_of(prg_file) + "/kmer_prgs/" + name + ".k" + std::to_string(k) + ".w" + std::to_string(w) + ".gfa";
+}
+
+void PrgIndex::build(const std::string& prg_file, int w_, int k_, int threads)
+{
+    if (k_ < 1 || k_ > 32 || w_ < 1) throw Error(DRPRG_EINVAL, "need 1 <= k <= 32 and w >= 1");
+    w = w_;
+    k = k_;
+    prgs = load_prg_file(prg_file);
+    kgs.assign(prgs.size(), KmerGraph());
+    std::atomic<size_t> next { 0 };
+    std::string err;
+    std::atomic<bool> failed { false };
+    auto work = [&]() {
+        for (size_t i; (i = next.fetch_add(1)) < prgs.size();) {
+            try {
+                kgs[i].build(prgs[i], w, k);
+            } catch (const std::exception& e) {
+                if (!failed.exchange(true)) err = e.what();
+            }
+        }
+    };
+    int nt = std::max(1, std::min<int>(threads, (int)prgs.size()));
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+    work();
+    for (auto& t : pool) t.join();
+    if (failed) throw Error(DRPRG_EFORMAT, err);
+    flatten();
+}
+
+void PrgIndex::flatten()
+{
+    FlatIndex& f = flat;
+    f = FlatIndex();
+    f.knode_base.assign(prgs.size() + 1, 0);
+    f.min_path_len.assign(prgs.size(), 0);
+    struct Rec {
+        uint64_t key;
+        uint32_t prg, knode;
+        uint8_t strand;
+    };
+    std::vector<Rec> recs;
+    for (size_t p = 0; p < prgs.size(); ++p) {
+        f.knode_base[p + 1] = f.knode_base[p] + (uint32_t)kgs[p].nodes.size();
+        f.min_path_len[p] = kgs[p].shortest_path_length;
+        const auto& nodes = kgs[p].nodes;
+        for (size_t i = 1; i + 1 < nodes.size(); ++i)
+            recs.push_back(Rec { nodes[i].hash, (uint32_t)p, nodes[i].id, (uint8_t)(nodes[i].strand ? 1 : 0) });
+    }
+    std::sort(recs.begin(), recs.end(), [](const Rec& a, const Rec& b) {
+        if (a.key != b.key) return a.key < b.key;
+        if (a.prg != b.prg) return a.prg < b.prg;
+        return a.knode < b.knode;
+    });
+    for (size_t i = 0; i < recs.size(); ++i) {
+        if (i == 0 || recs[i].key != recs[i - 1].key) {
+            f.keys.push_back(recs[i].key);
+            f.rec_off.push_back((uint32_t)i);
+        }
+        f.rec_prg.push_back(recs[i].prg);
+        f.rec_knode_global.push_back(f.knode_base[recs[i].prg] + recs[i].knode);
+        f.rec_strand.push_back(recs[i].strand);
+    }
+    f.rec_off.push_back((uint32_t)recs.size());
+    // open-addressed table at <= 50 % load
+    uint32_t bits = 4;
+    while ((1ULL << bits) < 2 * f.keys.size() + 1) ++bits;
+    f.table_bits = bits;
+    const size_t nslot = (size_t)1 << bits;
+    f.slot_key.assign(nslot, 0);
+    f.slot_off.assign(nslot, 0);
+    f.slot_cnt.assign(nslot, 0);
+    for (size_t i = 0; i < f.keys.size(); ++i) {
+        uint32_t s = table_slot(f.keys[i], bits);
+        while (f.slot_cnt[s] != 0) s = (s + 1) & (uint32_t)(nslot - 1);
+        f.slot_key[s] = f.keys[i];
+        f.slot_off[s] = f.rec_off[i];
+        f.slot_cnt[s] = f.rec_off[i + 1] - f.rec_off[i];
+    }
+}
+
+void PrgIndex::save(const std::string& prg_file) const
+{
+    std::string kdir = dir_of(prg_file) + "/kmer_prgs";
+    if (mkdir(kdir.c_str(), 0777) != 0 && errno != EEXIST) throw Error(DRPRG_EIO, "cannot create " + kdir);
+    for (size_t p = 0; p < prgs.size(); ++p) kgs[p].save_gfa(gfa_path(prg_file, prgs[p].name, w, k), prgs[p]);
+    std::ofstream out(idx_path(prg_file, w, k));
+    if (!out) throw Error(DRPRG_EIO, "cannot write " + idx_path(prg_file, w, k));
+    const FlatIndex& f = flat;
+    out << f.keys.size() << "\n";
+    for (size_t i = 0; i < f.keys.size(); ++i) {
+        out << f.keys[i] << "\t" << (f.rec_off[i + 1] - f.rec_off[i]);
+        for (uint32_t j = f.rec_off[i]; j < f.rec_off[i + 1]; ++j)
+            out << "\t" << f.rec_prg[j] << " " << (f.rec_knode_global[j] - f.knode_base[f.rec_prg[j]]) << " " << (int)f.rec_strand[j];
+        out << "\n";
+    }
+    if (!out) throw Error(DRPRG_EIO, "short write to " + idx_path(prg_file, w, k));
+}
+
+void PrgIndex::build_and_save(const std::string& prg_file, int w, int k, int threads)
+{
+    PrgIndex idx;
+    idx.build(prg_file, w, k, threads);
+    idx.save(prg_file);
+}
+
+void PrgIndex::load(const std::string& prg_file, int w_, int k_)
+{
+    w = w_;
+    k = k_;
+    prgs = load_prg_file(prg_file);
+    kgs.assign(prgs.size(), KmerGraph());
+    for (size_t p = 0; p < prgs.size(); ++p) kgs[p].load_gfa(gfa_path(prg_file, prgs[p].name, w, k), prgs[p], w, k);
+    flatten();
+    // the .idx file must agree with what the k-mer graphs imply
+    std::ifstream in(idx_path(prg_file, w, k));
+    if (!in) throw Error(DRPRG_ENOENT, "cannot open " + idx_path(prg_file, w, k));
+    size_t nkeys = 0, nrec = 0;
+    in >> nkeys;
+    std::string line;
+    std::getline(in, line);
+    if (nkeys != flat.keys.size())
+        throw Error(DRPRG_EFORMAT, idx_path(prg_file, w, k) + " does not match kmer_prgs/ (key count)");
+    for (size_t i = 0; i < nkeys; ++i) {
+        if (!std::getline(in, line)) throw Error(DRPRG_EFORMAT, idx_path(prg_file, w, k) + " is truncated");
+        std::istringstream is(line);
+        uint64_t key;
+        uint32_t n;
+        is >> key >> n;
+        if (key != flat.keys[i] || n != flat.rec_off[i + 1] - flat.rec_off[i])
+            throw Error(DRPRG_EFORMAT, idx_path(prg_file, w, k) + " does not match kmer_prgs/ (key " + std::to_string(i) + ")");
+        nrec += n;
+    }
+    (void)nrec;
+}
+
+double MapParams::cluster_fraction() const { return 0.5 / std::exp(error_rate * (double)k); }
+
+} // namespace drprg

@@ -1,0 +1,63 @@
+// index.h -- minimizer index of a set of PRGs: hash -> (prg, k-mer node, strand) records, plus the
+// flattened tables the HIP kernels probe.
+//
+// Stands in for pandora's Index (`pandora index`, reference call site
+// /root/reference/src/lib.rs:479-510; on-disk names /root/reference/src/builder.rs:263-269:
+// `<prg>.k<K>.w<W>.idx` and `kmer_prgs/`).
+#pragma once
+#include "kmergraph.h"
+
+namespace drprg {
+
+struct MiniRecord {
+    uint32_t prg;
+    uint32_t knode; // k-mer node id local to the PRG's k-mer graph
+    uint8_t strand; // 1 = the node's forward k-mer is the canonical one
+};
+
+// Flat, device-friendly view of the index (all arrays owned by PrgIndex).
+struct FlatIndex {
+    // sorted distinct keys + CSR records (what the oracle consumes)
+    std::vector<uint64_t> keys;
+    std::vector<uint32_t> rec_off; // keys.size()+1
+    std::vector<uint32_t> rec_prg, rec_knode_global;
+    std::vector<uint8_t> rec_strand;
+    // per-PRG
+    std::vector<uint32_t> knode_base;    // prefix sum of k-mer-graph sizes (nprg+1)
+    std::vector<uint32_t> min_path_len;  // KmerGraph::shortest_path_length
+    // open-addressed probe table: slot = {key, rec_off, rec_cnt}; empty slot has cnt == 0
+    uint32_t table_bits = 0;
+    std::vector<uint64_t> slot_key;
+    std::vector<uint32_t> slot_off, slot_cnt;
+    uint32_t total_knodes() const { return knode_base.empty() ? 0 : knode_base.back(); }
+};
+
+struct PrgIndex {
+    int w = 0, k = 0;
+    std::vector<LocalGraph> prgs;
+    std::vector<KmerGraph> kgs;
+    FlatIndex flat;
+
+    // `pandora index`: sketch every PRG of prg_file, write <prg_file>.k<k>.w<w>.idx and
+    // <dir>/kmer_prgs/<name>.k<k>.w<w>.gfa
+    static void build_and_save(const std::string& prg_file, int w, int k, int threads);
+    // in-memory build (no files touched)
+    void build(const std::string& prg_file, int w, int k, int threads);
+    // load what build_and_save wrote
+    void load(const std::string& prg_file, int w, int k);
+    void save(const std::string& prg_file) const;
+
+    static std::string idx_path(const std::string& prg_file, int w, int k);
+    static std::string gfa_path(const std::string& prg_file, const std::string& name, int w, int k);
+
+private:
+    void flatten();
+};
+
+// slot index of `key` in a table of 2^bits slots (multiplicative hash; same function on the device)
+inline uint32_t table_slot(uint64_t key, uint32_t bits)
+{
+    return (uint32_t)((key * 0x9E3779B97F4A7C15ULL) >> (64 - bits));
+}
+
+} // namespace drprg

@@ -1,0 +1,89 @@
+// kernels.h -- argument blocks and launch wrappers of kernels.hip (host side sees only hip_runtime_api).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <hip/hip_runtime_api.h>
+
+#if defined(__HIPCC__)
+#define DRPRG_HD __host__ __device__
+#else
+#define DRPRG_HD
+#endif
+
+namespace drprg {
+namespace dev {
+
+// hit sort key: [read:28][prg:12][rev:1][pos:23]; forward hits (rev=0) sort first
+constexpr int HIT_POS_BITS = 23;
+constexpr int HIT_PRG_BITS = 12;
+constexpr int HIT_READ_BITS = 28;
+constexpr uint64_t HIT_POS_MASK = (1ull << HIT_POS_BITS) - 1;
+constexpr uint32_t MAX_BATCH_READS = 1u << HIT_READ_BITS;
+constexpr uint32_t MAX_PRGS = 1u << HIT_PRG_BITS;
+
+DRPRG_HD inline uint64_t pack_hit_key(uint32_t read, uint32_t prg, uint32_t rev, uint32_t pos)
+{
+    return ((uint64_t)read << (HIT_PRG_BITS + 1 + HIT_POS_BITS)) | ((uint64_t)prg << (1 + HIT_POS_BITS))
+        | ((uint64_t)rev << HIT_POS_BITS) | (uint64_t)pos;
+}
+DRPRG_HD inline uint32_t hit_read(uint64_t k) { return (uint32_t)(k >> (HIT_PRG_BITS + 1 + HIT_POS_BITS)); }
+DRPRG_HD inline uint32_t hit_prg(uint64_t k) { return (uint32_t)(k >> (1 + HIT_POS_BITS)) & (MAX_PRGS - 1); }
+DRPRG_HD inline uint32_t hit_rev(uint64_t k) { return (uint32_t)(k >> HIT_POS_BITS) & 1u; }
+
+struct SketchArgs {
+    const uint8_t* bases;    // 16-byte aligned
+    const uint64_t* offsets; // n_reads + 1
+    uint64_t n_bases;
+    uint32_t n_reads;
+    int w, k, halo;
+    // index
+    const void* slot_key; // u32[2^bits] (k <= 15) or u64[2^bits]
+    const uint2* slot_rec; // {record offset, record count}; count 0 = empty slot
+    uint32_t table_bits;
+    const uint32_t* rec_knode; // (global k-mer node << 1) | strand
+    const uint16_t* rec_prg;
+    // outputs
+    uint64_t* hit_key;
+    uint32_t* hit_val;
+    uint64_t hit_capacity;
+    unsigned long long* n_hits;
+    unsigned long long* n_minimizers;
+    uint32_t* overflow; // bit 0: hit buffer too small, bit 1: read longer than 2^HIT_POS_BITS
+};
+
+struct ClusterRec {
+    uint32_t read, prg_rev, first_pos, last_pos, n, state;
+};
+
+struct ClusterArgs {
+    const uint64_t* key; // sorted hits
+    const uint32_t* val;
+    const uint32_t* scan;   // inclusive scan of cluster-head flags
+    const uint32_t* cstart; // n_clusters + 1
+    const uint32_t* d_n_clusters; // device scalar
+    const uint64_t* offsets;
+    const uint32_t* prg_min_path_len;
+    ClusterRec* clusters;
+    uint32_t* order;
+    int w;
+    double fraction;
+    uint32_t min_cluster_size;
+    uint32_t* covg;
+    uint32_t* prg_reads;
+    unsigned long long* n_clusters_kept;
+    unsigned long long* n_hits_kept;
+};
+
+uint32_t sketch_tile_eval(int halo);
+hipError_t launch_sketch_probe(const SketchArgs& a, bool wide_hash, hipStream_t stream);
+size_t sort_temp_bytes(uint32_t n);
+size_t scan_temp_bytes(uint32_t n);
+hipError_t sort_hits(void* temp, size_t temp_bytes, const uint64_t* key_in, uint64_t* key_out, const uint32_t* val_in,
+    uint32_t* val_out, uint32_t n, hipStream_t stream);
+hipError_t launch_cluster_flags(const uint64_t* key, uint32_t n, int max_diff, uint32_t* head, uint32_t* scan, void* temp,
+    size_t temp_bytes, hipStream_t stream);
+hipError_t launch_cluster_starts(const uint32_t* head, const uint32_t* scan, uint32_t n, uint32_t* cstart, hipStream_t stream);
+hipError_t launch_cluster_pipeline(const ClusterArgs& a, uint32_t n_hits, hipStream_t stream);
+
+} // namespace dev
+} // namespace drprg

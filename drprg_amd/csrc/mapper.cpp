@@ -1,0 +1,290 @@
+// mapper.cpp -- device context and per-batch launch sequence.  See mapper.h.
+#include "mapper.h"
+#include <algorithm>
+#include <cstring>
+#include <hip/hip_runtime.h>
+
+namespace drprg {
+
+#define HIPCHK(x)                                                                                              \
+    do {                                                                                                       \
+        hipError_t e_ = (x);                                                                                   \
+        if (e_ != hipSuccess)                                                                                  \
+            throw Error(e_ == hipErrorOutOfMemory ? DRPRG_ENOMEM : DRPRG_EIO,                                  \
+                std::string("HIP error: ") + hipGetErrorString(e_) + " at " + __FILE__ + ":" + std::to_string(__LINE__)); \
+    } while (0)
+
+template <typename T> static void dmalloc(T*& p, size_t n)
+{
+    p = nullptr;
+    if (n == 0) n = 1;
+    HIPCHK(hipMalloc((void**)&p, n * sizeof(T)));
+}
+template <typename T> static void dfree(T*& p)
+{
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+// counter slots
+enum { C_HITS = 0, C_MINIMIZERS = 1, C_CLUSTERS_KEPT = 2, C_HITS_KEPT = 3, C_OVERFLOW = 4, C_N = 8 };
+
+Mapper::Mapper(const FlatIndex& idx, const MapParams& p, int device) : device_(device)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        throw Error(DRPRG_ENODEV, "no HIP device is visible: the drprg hot path has no CPU fallback");
+    if (device < 0 || device >= ndev) throw Error(DRPRG_ENODEV, "HIP device " + std::to_string(device) + " does not exist");
+    HIPCHK(hipSetDevice(device_));
+    HIPCHK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    n_prgs_ = (uint32_t)idx.min_path_len.size();
+    n_knodes_ = idx.total_knodes();
+    table_bits_ = idx.table_bits;
+    if (n_prgs_ > dev::MAX_PRGS) throw Error(DRPRG_EOVERFLOW, "more than " + std::to_string(dev::MAX_PRGS) + " PRGs");
+    set_params(p);
+
+    const size_t nslot = idx.slot_key.size();
+    if (wide_hash_) {
+        uint64_t* k = nullptr;
+        dmalloc(k, nslot);
+        HIPCHK(hipMemcpy(k, idx.slot_key.data(), nslot * sizeof(uint64_t), hipMemcpyHostToDevice));
+        d_slot_key_ = k;
+    } else {
+        std::vector<uint32_t> k32(nslot);
+        for (size_t i = 0; i < nslot; ++i) k32[i] = (uint32_t)idx.slot_key[i];
+        uint32_t* k = nullptr;
+        dmalloc(k, nslot);
+        HIPCHK(hipMemcpy(k, k32.data(), nslot * sizeof(uint32_t), hipMemcpyHostToDevice));
+        d_slot_key_ = k;
+    }
+    std::vector<uint2> rec(nslot);
+    for (size_t i = 0; i < nslot; ++i) rec[i] = make_uint2(idx.slot_off[i], idx.slot_cnt[i]);
+    dmalloc(d_slot_rec_, nslot);
+    HIPCHK(hipMemcpy(d_slot_rec_, rec.data(), nslot * sizeof(uint2), hipMemcpyHostToDevice));
+    const size_t nrec = idx.rec_prg.size();
+    std::vector<uint32_t> rk(nrec);
+    std::vector<uint16_t> rp(nrec);
+    for (size_t i = 0; i < nrec; ++i) {
+        rk[i] = (idx.rec_knode_global[i] << 1) | idx.rec_strand[i];
+        rp[i] = (uint16_t)idx.rec_prg[i];
+    }
+    if (n_knodes_ >= (1u << 31)) throw Error(DRPRG_EOVERFLOW, "too many k-mer nodes");
+    dmalloc(d_rec_knode_, nrec);
+    dmalloc(d_rec_prg_, nrec);
+    HIPCHK(hipMemcpy(d_rec_knode_, rk.data(), nrec * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_rec_prg_, rp.data(), nrec * sizeof(uint16_t), hipMemcpyHostToDevice));
+    dmalloc(d_min_path_len_, (size_t)n_prgs_);
+    HIPCHK(hipMemcpy(d_min_path_len_, idx.min_path_len.data(), n_prgs_ * sizeof(uint32_t), hipMemcpyHostToDevice));
+    dmalloc(d_covg_, 2 * (size_t)n_knodes_);
+    dmalloc(d_prg_reads_, (size_t)n_prgs_);
+    dmalloc(d_counters_, (size_t)C_N);
+    HIPCHK(hipHostMalloc((void**)&h_counters_, C_N * sizeof(unsigned long long), hipHostMallocDefault));
+    HIPCHK(hipEventCreate(&ev0_));
+    HIPCHK(hipEventCreate(&ev1_));
+    reset_coverage();
+}
+
+Mapper::~Mapper()
+{
+    (void)hipSetDevice(device_);
+    if (stream_) (void)hipStreamSynchronize(stream_);
+    dfree(d_slot_rec_); dfree(d_rec_knode_); dfree(d_rec_prg_); dfree(d_min_path_len_);
+    if (d_slot_key_) (void)hipFree(d_slot_key_);
+    dfree(d_covg_); dfree(d_prg_reads_); dfree(d_counters_);
+    dfree(d_key_a_); dfree(d_key_b_); dfree(d_val_a_); dfree(d_val_b_);
+    dfree(d_head_); dfree(d_scan_); dfree(d_cstart_); dfree(d_order_); dfree(d_clusters_);
+    if (d_temp_) (void)hipFree(d_temp_);
+    dfree(d_bases_); dfree(d_offsets_);
+    if (h_counters_) (void)hipHostFree(h_counters_);
+    if (h_bases_) (void)hipHostFree(h_bases_);
+    if (h_offsets_) (void)hipHostFree(h_offsets_);
+    if (ev0_) (void)hipEventDestroy(ev0_);
+    if (ev1_) (void)hipEventDestroy(ev1_);
+    if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+void Mapper::set_params(const MapParams& p)
+{
+    if (p.k < 1 || p.k > 31) throw Error(DRPRG_EINVAL, "k must be in [1,31]");
+    if (p.w < 1 || p.w > 1024) throw Error(DRPRG_EINVAL, "w must be in [1,1024]");
+    params_ = p;
+    wide_hash_ = p.k > 15;
+    halo_ = std::max(16, ((p.w - 1 + 15) / 16) * 16);
+}
+
+void Mapper::reset_coverage()
+{
+    HIPCHK(hipSetDevice(device_));
+    HIPCHK(hipMemsetAsync(d_covg_, 0, 2 * (size_t)n_knodes_ * sizeof(uint32_t), stream_));
+    HIPCHK(hipMemsetAsync(d_prg_reads_, 0, (size_t)n_prgs_ * sizeof(uint32_t), stream_));
+    HIPCHK(hipMemsetAsync(d_counters_, 0, C_N * sizeof(unsigned long long), stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    tot_reads_ = tot_bases_ = tot_hits_ = 0;
+    last_minimizers_ = 0;
+}
+
+void Mapper::ensure_workspace(uint64_t cap)
+{
+    if (cap <= hit_capacity_) return;
+    if (cap >= (1ull << 31)) throw Error(DRPRG_EOVERFLOW, "more than 2^31 minimizer hits in one batch; map smaller batches");
+    dfree(d_key_a_); dfree(d_key_b_); dfree(d_val_a_); dfree(d_val_b_);
+    dfree(d_head_); dfree(d_scan_); dfree(d_cstart_); dfree(d_order_); dfree(d_clusters_);
+    if (d_temp_) (void)hipFree(d_temp_);
+    d_temp_ = nullptr;
+    hit_capacity_ = cap;
+    dmalloc(d_key_a_, cap); dmalloc(d_key_b_, cap); dmalloc(d_val_a_, cap); dmalloc(d_val_b_, cap);
+    dmalloc(d_head_, cap); dmalloc(d_scan_, cap); dmalloc(d_cstart_, cap + 1); dmalloc(d_order_, cap);
+    dmalloc(d_clusters_, cap);
+    temp_bytes_ = std::max(dev::sort_temp_bytes((uint32_t)cap), dev::scan_temp_bytes((uint32_t)cap));
+    HIPCHK(hipMalloc(&d_temp_, temp_bytes_ ? temp_bytes_ : 1));
+}
+
+void Mapper::run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads, uint64_t n_bases,
+    uint32_t* covg, uint32_t* prg_reads, hipStream_t stream)
+{
+    ensure_workspace(std::max<uint64_t>(1u << 20, n_bases / 64));
+    for (int attempt = 0;; ++attempt) {
+        HIPCHK(hipMemsetAsync(&d_counters_[C_HITS], 0, sizeof(unsigned long long), stream));
+        HIPCHK(hipMemsetAsync(&d_counters_[C_OVERFLOW], 0, sizeof(unsigned long long), stream));
+        dev::SketchArgs a {};
+        a.bases = d_bases;
+        a.offsets = d_offsets;
+        a.n_bases = n_bases;
+        a.n_reads = n_reads;
+        a.w = params_.w;
+        a.k = params_.k;
+        a.halo = halo_;
+        a.slot_key = d_slot_key_;
+        a.slot_rec = d_slot_rec_;
+        a.table_bits = table_bits_;
+        a.rec_knode = d_rec_knode_;
+        a.rec_prg = d_rec_prg_;
+        a.hit_key = d_key_a_;
+        a.hit_val = d_val_a_;
+        a.hit_capacity = hit_capacity_;
+        a.n_hits = &d_counters_[C_HITS];
+        a.n_minimizers = &d_counters_[C_MINIMIZERS];
+        a.overflow = reinterpret_cast<uint32_t*>(&d_counters_[C_OVERFLOW]);
+        if (timing_) HIPCHK(hipEventRecord(ev0_, stream));
+        HIPCHK(dev::launch_sketch_probe(a, wide_hash_, stream));
+        if (timing_) HIPCHK(hipEventRecord(ev1_, stream));
+        HIPCHK(hipMemcpyAsync(h_counters_, d_counters_, C_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        if (timing_) {
+            float ms = 0;
+            HIPCHK(hipEventElapsedTime(&ms, ev0_, ev1_));
+            sketch_ms_ += ms;
+            sketch_launches_ += 1;
+        }
+        uint32_t ovf = (uint32_t)h_counters_[C_OVERFLOW];
+        if (ovf & 2u) throw Error(DRPRG_EOVERFLOW, "a read is longer than 2^" + std::to_string(dev::HIT_POS_BITS) + " bases");
+        if (h_counters_[C_HITS] > hit_capacity_) {
+            if (attempt > 0) throw Error(DRPRG_EOVERFLOW, "hit buffer overflow after regrow");
+            // undo the minimizer count of the aborted pass, grow, and re-run the sketch
+            unsigned long long restored = last_minimizers_;
+            HIPCHK(hipMemcpyAsync(&d_counters_[C_MINIMIZERS], &restored, sizeof(restored), hipMemcpyHostToDevice, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            ensure_workspace(h_counters_[C_HITS] + h_counters_[C_HITS] / 8 + 1024);
+            continue;
+        }
+        last_minimizers_ = h_counters_[C_MINIMIZERS];
+        break;
+    }
+    const uint32_t n_hits = (uint32_t)h_counters_[C_HITS];
+    tot_hits_ += n_hits;
+    if (n_hits == 0) return;
+    HIPCHK(dev::sort_hits(d_temp_, temp_bytes_, d_key_a_, d_key_b_, d_val_a_, d_val_b_, n_hits, stream));
+    HIPCHK(dev::launch_cluster_flags(d_key_b_, n_hits, params_.max_diff, d_head_, d_scan_, d_temp_, temp_bytes_, stream));
+    HIPCHK(dev::launch_cluster_starts(d_head_, d_scan_, n_hits, d_cstart_, stream));
+    dev::ClusterArgs c {};
+    c.key = d_key_b_;
+    c.val = d_val_b_;
+    c.scan = d_scan_;
+    c.cstart = d_cstart_;
+    c.d_n_clusters = d_scan_ + (n_hits - 1);
+    c.offsets = d_offsets;
+    c.prg_min_path_len = d_min_path_len_;
+    c.clusters = d_clusters_;
+    c.order = d_order_;
+    c.w = params_.w;
+    c.fraction = params_.cluster_fraction();
+    c.min_cluster_size = params_.min_cluster_size;
+    c.covg = covg;
+    c.prg_reads = prg_reads;
+    c.n_clusters_kept = &d_counters_[C_CLUSTERS_KEPT];
+    c.n_hits_kept = &d_counters_[C_HITS_KEPT];
+    HIPCHK(dev::launch_cluster_pipeline(c, n_hits, stream));
+}
+
+void Mapper::map_device(const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n_reads, uint64_t n_bases,
+    uint32_t* covg, uint32_t* prg_reads, hipStream_t stream)
+{
+    if (n_reads == 0) return;
+    if (!d_bases || !d_offsets) throw Error(DRPRG_EINVAL, "null device pointer");
+    if ((reinterpret_cast<uintptr_t>(d_bases) & 15u) != 0) throw Error(DRPRG_EINVAL, "d_bases must be 16-byte aligned");
+    if (n_reads > dev::MAX_BATCH_READS)
+        throw Error(DRPRG_EOVERFLOW, "at most " + std::to_string(dev::MAX_BATCH_READS) + " reads per batch");
+    HIPCHK(hipSetDevice(device_));
+    run_batch(d_bases, d_offsets, (uint32_t)n_reads, n_bases, covg ? covg : d_covg_, prg_reads ? prg_reads : d_prg_reads_,
+        stream ? stream : stream_);
+    tot_reads_ += n_reads;
+    tot_bases_ += n_bases;
+}
+
+void Mapper::map_host(const uint8_t* bases, const uint64_t* offsets, uint64_t n_reads)
+{
+    if (n_reads == 0) return;
+    HIPCHK(hipSetDevice(device_));
+    if (offsets[0] != 0) throw Error(DRPRG_EINVAL, "offsets[0] must be 0");
+    const uint64_t n_bases = offsets[n_reads];
+    if (n_bases + 64 > stage_bases_cap_) {
+        dfree(d_bases_);
+        stage_bases_cap_ = n_bases + n_bases / 4 + 64;
+        dmalloc(d_bases_, stage_bases_cap_);
+    }
+    if (n_reads + 1 > stage_reads_cap_) {
+        dfree(d_offsets_);
+        stage_reads_cap_ = n_reads + n_reads / 4 + 1;
+        dmalloc(d_offsets_, stage_reads_cap_);
+    }
+    HIPCHK(hipMemcpyAsync(d_bases_, bases, n_bases, hipMemcpyHostToDevice, stream_));
+    HIPCHK(hipMemcpyAsync(d_offsets_, offsets, (n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream_));
+    map_device(d_bases_, d_offsets_, n_reads, n_bases, nullptr, nullptr, stream_);
+    HIPCHK(hipStreamSynchronize(stream_)); // the staging buffers are reused by the next call
+}
+
+void Mapper::download(std::vector<uint32_t>& covg, std::vector<uint32_t>& prg_reads)
+{
+    HIPCHK(hipSetDevice(device_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    covg.resize(2 * (size_t)n_knodes_);
+    prg_reads.resize(n_prgs_);
+    HIPCHK(hipMemcpy(covg.data(), d_covg_, covg.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(prg_reads.data(), d_prg_reads_, prg_reads.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+}
+
+void Mapper::upload(const std::vector<uint32_t>& covg, const std::vector<uint32_t>& prg_reads)
+{
+    if (covg.size() != 2 * (size_t)n_knodes_ || prg_reads.size() != n_prgs_) throw Error(DRPRG_EINVAL, "coverage size mismatch");
+    HIPCHK(hipSetDevice(device_));
+    HIPCHK(hipMemcpy(d_covg_, covg.data(), covg.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_prg_reads_, prg_reads.data(), prg_reads.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+}
+
+MapCounters Mapper::counters()
+{
+    HIPCHK(hipSetDevice(device_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    unsigned long long c[C_N];
+    HIPCHK(hipMemcpy(c, d_counters_, sizeof(c), hipMemcpyDeviceToHost));
+    MapCounters m;
+    m.reads = tot_reads_;
+    m.bases = tot_bases_;
+    m.minimizers = c[C_MINIMIZERS];
+    m.hits = tot_hits_;
+    m.clusters_kept = c[C_CLUSTERS_KEPT];
+    m.hits_kept = c[C_HITS_KEPT];
+    return m;
+}
+
+} // namespace drprg

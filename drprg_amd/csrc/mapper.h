@@ -1,0 +1,98 @@
+// mapper.h -- device context of the predict hot path: index tables resident in HBM, per-batch
+// workspace, and the launch sequence sketch+probe -> sort -> cluster -> accumulate.
+//
+// This is the MI355X replacement for the read loop of `pandora map` (pangraph_from_read_file),
+// spawned by the reference at /root/reference/src/lib.rs:580-642.
+#pragma once
+#include "index.h"
+#include "kernels.h"
+
+namespace drprg {
+
+struct MapCounters {
+    uint64_t reads = 0, bases = 0, minimizers = 0, hits = 0, clusters_kept = 0, hits_kept = 0;
+};
+
+class Mapper {
+public:
+    Mapper(const FlatIndex& idx, const MapParams& p, int device);
+    ~Mapper();
+    Mapper(const Mapper&) = delete;
+    Mapper& operator=(const Mapper&) = delete;
+
+    int device() const { return device_; }
+    uint32_t n_knodes() const { return n_knodes_; }
+    uint32_t n_prgs() const { return n_prgs_; }
+    hipStream_t stream() const { return stream_; }
+    void set_params(const MapParams& p);
+
+    // Map one batch that is already resident in HBM.  d_bases must be 16-byte aligned.  Coverage is
+    // accumulated into d_covg (u32[2*n_knodes]) and d_prg_reads (u32[n_prgs]); nullptr selects the
+    // context's own accumulators.  Asynchronous on `stream` except for one 16-byte read-back of the
+    // hit count between the sketch and the sort.
+    void map_device(const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n_reads, uint64_t n_bases,
+        uint32_t* d_covg, uint32_t* d_prg_reads, hipStream_t stream);
+
+    // Map a host batch (copies through pinned staging buffers, then map_device on the own accumulators).
+    void map_host(const uint8_t* bases, const uint64_t* offsets, uint64_t n_reads);
+
+    void reset_coverage();
+    // own accumulators
+    uint32_t* d_covg() const { return d_covg_; }
+    uint32_t* d_prg_reads() const { return d_prg_reads_; }
+    void download(std::vector<uint32_t>& covg, std::vector<uint32_t>& prg_reads);
+    void upload(const std::vector<uint32_t>& covg, const std::vector<uint32_t>& prg_reads);
+    MapCounters counters(); // synchronises
+
+    // timing of the dominant kernel (HIP events on the launch stream), for bench.py
+    void enable_kernel_timing(bool on) { timing_ = on; }
+    double sketch_ms_total() const { return sketch_ms_; }
+    uint64_t sketch_launches() const { return sketch_launches_; }
+    void reset_kernel_timing() { sketch_ms_ = 0; sketch_launches_ = 0; }
+
+private:
+    void ensure_workspace(uint64_t hit_capacity);
+    void run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads, uint64_t n_bases,
+        uint32_t* d_covg, uint32_t* d_prg_reads, hipStream_t stream);
+
+    int device_ = 0;
+    MapParams params_;
+    bool wide_hash_ = false;
+    int halo_ = 16;
+    uint32_t n_knodes_ = 0, n_prgs_ = 0, table_bits_ = 0;
+    hipStream_t stream_ = nullptr;
+    // index tables
+    void* d_slot_key_ = nullptr;
+    uint2* d_slot_rec_ = nullptr;
+    uint32_t* d_rec_knode_ = nullptr;
+    uint16_t* d_rec_prg_ = nullptr;
+    uint32_t* d_min_path_len_ = nullptr;
+    // accumulators
+    uint32_t* d_covg_ = nullptr;
+    uint32_t* d_prg_reads_ = nullptr;
+    unsigned long long* d_counters_ = nullptr; // 8 x u64: hits(batch), minimizers, clusters_kept, hits_kept, overflow, ...
+    unsigned long long* h_counters_ = nullptr; // pinned mirror
+    uint64_t tot_reads_ = 0, tot_bases_ = 0, tot_hits_ = 0;
+    unsigned long long last_minimizers_ = 0; // device minimizer counter after the last completed batch
+    // workspace
+    uint64_t hit_capacity_ = 0;
+    uint64_t *d_key_a_ = nullptr, *d_key_b_ = nullptr;
+    uint32_t *d_val_a_ = nullptr, *d_val_b_ = nullptr;
+    uint32_t *d_head_ = nullptr, *d_scan_ = nullptr, *d_cstart_ = nullptr, *d_order_ = nullptr;
+    dev::ClusterRec* d_clusters_ = nullptr;
+    void* d_temp_ = nullptr;
+    size_t temp_bytes_ = 0;
+    // host staging
+    uint8_t* h_bases_ = nullptr;
+    uint64_t* h_offsets_ = nullptr;
+    uint8_t* d_bases_ = nullptr;
+    uint64_t* d_offsets_ = nullptr;
+    uint64_t stage_bases_cap_ = 0, stage_reads_cap_ = 0;
+    // timing
+    bool timing_ = false;
+    double sketch_ms_ = 0;
+    uint64_t sketch_launches_ = 0;
+    hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
+};
+
+} // namespace drprg

@@ -1,0 +1,226 @@
+"""Host-side mirror of the reference's `Pandora` shim for the predict hot path.
+
+`Pandora` below exposes the operator interface of struct Pandora in /root/reference/src/lib.rs:459-698
+(`index_with`, `discover_with`, `genotype_with`, `vcf_filename`, `list_prgs_with_novel_variants`) with
+the same argument meaning and error behaviour, but runs in-process on an MI355X through the C ABI of
+include/drprg_hip.h instead of spawning the external `pandora` program.  `Context` is the thin object
+wrapper of the C ABI that tests and bench.py drive directly.
+"""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+from ._lib import MapOpts, lib
+
+MTB_GENOME_SIZE = 4411532  # /root/reference/src/lib.rs:36
+
+
+class DependencyError(RuntimeError):
+    """Mirror of DependencyError (/root/reference/src/lib.rs:43-75): ProcessError / MissingExpectedOutput /
+    NovelVariantParsingError are told apart by `kind`."""
+
+    def __init__(self, kind, message, code=0):
+        super().__init__(f"{kind}: {message}")
+        self.kind = kind
+        self.code = code
+
+
+def _check(rc, ctx=None):
+    if rc != 0:
+        msg = lib.drprg_hip_last_error(ctx)
+        raise DependencyError("ProcessError", (msg or b"").decode() or f"error {rc}", code=-rc)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Context:
+    """One opened index (+ its HIP device).  device=-1: host-only (index export, genotyping)."""
+
+    def __init__(self, prg_file, w, k, device=0, from_files=True, threads=1):
+        p = os.fsencode(prg_file)
+        self._h = lib.drprg_hip_open(p, w, k, device) if from_files else lib.drprg_hip_open_prg(p, w, k, device, threads)
+        if not self._h:
+            raise DependencyError("ProcessError", lib.drprg_hip_last_error(None).decode())
+        self.w, self.k, self.device = w, k, device
+        sizes = (C.c_uint64 * 5)()
+        lib.drprg_hip_index_sizes(self._h, sizes)
+        self.n_keys, self.n_records, self.n_prgs, self.n_knodes, self.n_slots = (int(x) for x in sizes)
+
+    def close(self):
+        if self._h:
+            lib.drprg_hip_close(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        self.close()
+
+    # ---- options -------------------------------------------------------------------------------
+    def set_opts(self, illumina=False, min_cluster_size=10, genome_size=MTB_GENOME_SIZE, max_diff=0, error_rate=0.0,
+                 genotyping_error_rate=0.0):
+        o = MapOpts(max_diff, error_rate, min_cluster_size, 1 if illumina else 0, genome_size, genotyping_error_rate)
+        _check(lib.drprg_hip_set_opts(self._h, C.byref(o)), self._h)
+
+    # ---- mapping -------------------------------------------------------------------------------
+    def map_fastx(self, path):
+        _check(lib.drprg_hip_map_fastx(self._h, os.fsencode(path)), self._h)
+
+    def map_host(self, bases, offsets):
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        _check(lib.drprg_hip_map_host(self._h, _ptr(bases), _ptr(offsets), len(offsets) - 1), self._h)
+
+    def map_device(self, d_bases, d_offsets, n_reads, n_bases, d_covg=None, d_prg_reads=None, stream=None):
+        """Pointers are integer device addresses (e.g. torch.Tensor.data_ptr())."""
+        _check(lib.drprg_hip_map_device(self._h, d_bases, d_offsets, n_reads, n_bases, d_covg, d_prg_reads, stream), self._h)
+
+    # ---- coverage ------------------------------------------------------------------------------
+    def coverage(self):
+        covg = np.zeros(2 * self.n_knodes, dtype=np.uint32)
+        prg_reads = np.zeros(self.n_prgs, dtype=np.uint32)
+        _check(lib.drprg_hip_coverage(self._h, _ptr(covg), covg.size, _ptr(prg_reads), prg_reads.size), self._h)
+        return covg, prg_reads
+
+    def set_coverage(self, covg, prg_reads, total_bases):
+        covg = np.ascontiguousarray(covg, dtype=np.uint32)
+        prg_reads = np.ascontiguousarray(prg_reads, dtype=np.uint32)
+        _check(lib.drprg_hip_set_coverage(self._h, _ptr(covg), covg.size, _ptr(prg_reads), prg_reads.size, total_bases), self._h)
+
+    def device_coverage(self):
+        a, b = C.c_void_p(), C.c_void_p()
+        _check(lib.drprg_hip_device_coverage(self._h, C.byref(a), C.byref(b)), self._h)
+        return a.value, b.value
+
+    def reset(self):
+        _check(lib.drprg_hip_reset(self._h), self._h)
+
+    def counters(self):
+        out = (C.c_uint64 * 8)()
+        _check(lib.drprg_hip_counters(self._h, out), self._h)
+        names = ("reads", "bases", "minimizers", "hits", "clusters_kept", "hits_kept")
+        return dict(zip(names, (int(x) for x in out)))
+
+    # ---- genotyping ----------------------------------------------------------------------------
+    def genotype(self, vcf_refs, out_vcf, sample="sample"):
+        _check(lib.drprg_hip_genotype(self._h, os.fsencode(vcf_refs) if vcf_refs else None, os.fsencode(out_vcf),
+                                      sample.encode()), self._h)
+        gi = (C.c_uint32 * 4)()
+        lib.drprg_hip_genotype_info(self._h, gi)
+        return dict(exp_depth_covg=int(gi[0]), min_kmer_covg=int(gi[1]), loci_present=int(gi[2]), records=int(gi[3]))
+
+    # ---- introspection -------------------------------------------------------------------------
+    def export_index(self):
+        """Flat index (sorted keys + CSR records) in the layout oracle/oracle.c consumes."""
+        keys = np.zeros(self.n_keys, dtype=np.uint64)
+        rec_off = np.zeros(self.n_keys + 1, dtype=np.uint32)
+        rec_prg = np.zeros(self.n_records, dtype=np.uint32)
+        rec_knode = np.zeros(self.n_records, dtype=np.uint32)
+        rec_strand = np.zeros(self.n_records, dtype=np.uint8)
+        min_path_len = np.zeros(self.n_prgs, dtype=np.uint32)
+        knode_base = np.zeros(self.n_prgs + 1, dtype=np.uint32)
+        _check(lib.drprg_hip_index_export(self._h, _ptr(keys), _ptr(rec_off), _ptr(rec_prg), _ptr(rec_knode), _ptr(rec_strand),
+                                          _ptr(min_path_len), _ptr(knode_base)), self._h)
+        return dict(keys=keys, rec_off=rec_off, rec_prg=rec_prg, rec_knode=rec_knode, rec_strand=rec_strand,
+                    min_path_len=min_path_len, knode_base=knode_base)
+
+    def kernel_timing(self, enable=True, reset=False):
+        ms, n = C.c_double(), C.c_uint64()
+        _check(lib.drprg_hip_kernel_timing(self._h, 1 if enable else 0, 1 if reset else 0, C.byref(ms), C.byref(n)), self._h)
+        return ms.value, int(n.value)
+
+
+class Pandora:
+    """In-process stand-in for struct Pandora (/root/reference/src/lib.rs:459-698)."""
+
+    def __init__(self, device=0):
+        self.device = device
+
+    @staticmethod
+    def _parse_args(args):
+        """The argv drprg passes: -t T -w W -k K -c C [-I] [-K] (/root/reference/src/predict.rs:236-245)."""
+        o = dict(threads=1, w=14, k=15, c=10, illumina=False)
+        it = iter([str(a) for a in args])
+        for a in it:
+            if a == "-t":
+                o["threads"] = int(next(it))
+            elif a == "-w":
+                o["w"] = int(next(it))
+            elif a == "-k":
+                o["k"] = int(next(it))
+            elif a == "-c":
+                o["c"] = int(next(it))
+            elif a == "-I":
+                o["illumina"] = True
+            elif a == "-K":
+                pass
+            else:
+                raise DependencyError("ProcessError", f"unknown pandora option {a}", code=2)
+        return o
+
+    def index_with(self, prg_path, args=()):
+        """Pandora::index_with, /root/reference/src/lib.rs:479-510."""
+        o = self._parse_args(args)
+        _check(lib.drprg_hip_index(os.fsencode(prg_path), o["w"], o["k"], o["threads"]))
+
+    def _mapped_context(self, prg, reads, args):
+        o = self._parse_args(args)
+        ctx = Context(prg, o["w"], o["k"], device=self.device)
+        ctx.set_opts(illumina=o["illumina"], min_cluster_size=o["c"], genome_size=MTB_GENOME_SIZE)
+        ctx.map_fastx(reads)
+        return ctx
+
+    def discover_with(self, prg, query_idx, outdir, args=()):
+        """Pandora::discover_with, /root/reference/src/lib.rs:513-578.  Returns the denovo_paths.txt path."""
+        os.makedirs(outdir, exist_ok=True)
+        with open(query_idx) as fh:
+            sample, reads = fh.readline().split()[:2]
+        with self._mapped_context(prg, reads, args):
+            pass
+        path = os.path.join(outdir, "denovo_paths.txt")
+        with open(path, "w") as fh:
+            fh.write(f"Sample {sample}\n0 loci with denovo variants\n")
+        open(os.path.join(outdir, "denovo_sequences.fa"), "w").close()
+        if not os.path.exists(path):
+            raise DependencyError("MissingExpectedOutput", path)
+        return path
+
+    def genotype_with(self, prg, vcf_ref, reads, outdir, args=()):
+        """Pandora::genotype_with, /root/reference/src/lib.rs:580-642."""
+        os.makedirs(outdir, exist_ok=True)
+        with self._mapped_context(prg, reads, args) as ctx:
+            ctx.genotype(vcf_ref, os.path.join(outdir, self.vcf_filename()))
+
+    @staticmethod
+    def vcf_filename():
+        """/root/reference/src/lib.rs:644-646"""
+        return "pandora_genotyped.vcf"
+
+    @staticmethod
+    def list_prgs_with_novel_variants(denovo_file):
+        """/root/reference/src/lib.rs:648-697"""
+        try:
+            contents = open(denovo_file).read()
+        except OSError:
+            raise DependencyError("NovelVariantParsingError", f"Unable to read {denovo_file!r}")
+        m = re.search(r"\n(?P<num>\d+) loci with denovo variants\n", contents)
+        if not m:
+            raise DependencyError("NovelVariantParsingError", "Unable to find line describing the number of novel variants")
+        expected = int(m.group("num"))
+        genes, prev = [], ""
+        for line in contents.splitlines():
+            if line.endswith("nodes"):
+                genes.append(prev)
+            prev = line
+        if len(genes) != expected:
+            raise DependencyError("NovelVariantParsingError",
+                                  f"Expected {expected} genes with novel variants, but found {len(genes)}")
+        return genes

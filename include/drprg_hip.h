@@ -1,0 +1,99 @@
+/*
+ * drprg_hip.h -- C ABI of the MI355X-native drprg predict hot path (libdrprg_hip.so).
+ *
+ * The reference has no FFI for this path: drprg drives the external `pandora` executable through
+ * struct Pandora (/root/reference/src/lib.rs:459-698).  Each entry point below names the reference
+ * interface it replaces; a Rust host binds them with `extern "C"` (stub in INTEGRATION.md), or keeps
+ * using the process boundary through the drop-in executable drprg_amd/bin/pandora (`drprg predict -p`,
+ * /root/reference/src/predict.rs:136-144).
+ *
+ * Conventions: every function returns 0 on success or a negative errno-style code; no exception
+ * crosses the ABI; `drprg_hip_last_error` gives the message of the last failure on that context
+ * (or, with ctx == NULL, of the last failed open/index call on the calling thread).  A context is
+ * not thread-safe.  Buffers passed in stay owned by the caller; nothing returned needs freeing
+ * except the context itself (`drprg_hip_close`).  Plain pointers and sizes only.
+ */
+#ifndef DRPRG_HIP_H
+#define DRPRG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct drprg_hip_ctx drprg_hip_ctx;
+
+/* Mapping options = the argv drprg builds for `pandora map/discover`
+ * (/root/reference/src/predict.rs:236-245, src/lib.rs:594-618). */
+typedef struct drprg_hip_map_opts {
+    int32_t max_diff;          /* --max-diff; <=0: default (250, or 2k+1 with illumina) */
+    double error_rate;         /* -e; <=0: default (0.11, or 0.001 with illumina) */
+    uint32_t min_cluster_size; /* -c (drprg passes 10) */
+    int32_t illumina;          /* -I */
+    uint64_t genome_size;      /* -g (drprg passes 4411532) */
+    double genotyping_error_rate; /* <=0: 0.01 */
+} drprg_hip_map_opts;
+
+/* Replaces Pandora::index_with (`pandora index -t T -w W -k K <prg>`, /root/reference/src/lib.rs:479-510):
+ * writes <prg>.k<K>.w<W>.idx and <dir>/kmer_prgs/ beside the PRG (/root/reference/src/builder.rs:263-269).
+ * Host-only work; needs no GPU. */
+int drprg_hip_index(const char* prg_file, int w, int k, int threads);
+
+/* Opens the index that drprg_hip_index wrote (the files `validate_index` requires,
+ * /root/reference/src/predict.rs:400-418) and uploads its probe tables to HIP device `device`.
+ * device < 0 opens a host-only context: index export and genotyping work, every map call fails with
+ * -ENODEV (there is no CPU fallback for the hot path).  Returns NULL on failure. */
+drprg_hip_ctx* drprg_hip_open(const char* prg_file, int w, int k, int device);
+
+/* Same, but sketches the PRG in memory instead of reading .idx / kmer_prgs (no files needed or written). */
+drprg_hip_ctx* drprg_hip_open_prg(const char* prg_file, int w, int k, int device, int threads);
+
+void drprg_hip_close(drprg_hip_ctx* ctx);
+const char* drprg_hip_last_error(const drprg_hip_ctx* ctx);
+
+int drprg_hip_set_opts(drprg_hip_ctx* ctx, const drprg_hip_map_opts* opts);
+
+/* Read mapping: the loop inside `pandora map` / `pandora discover` that
+ * Pandora::genotype_with / discover_with wait on (/root/reference/src/lib.rs:580-642, :513-578).
+ * Coverage accumulates in the context until drprg_hip_reset. */
+int drprg_hip_map_fastx(drprg_hip_ctx* ctx, const char* reads_path); /* fasta/fastq, plain or .gz */
+int drprg_hip_map_host(drprg_hip_ctx* ctx, const uint8_t* bases, const uint64_t* offsets, uint64_t n_reads);
+/* Batch already resident in HBM.  d_bases: ASCII bases of all reads back to back, 16-byte aligned;
+ * d_offsets: u64[n_reads+1], d_offsets[0] == 0, d_offsets[n_reads] == n_bases.  d_covg (u32[2*n_knodes]) and
+ * d_prg_reads (u32[n_prgs]) may be NULL to use the context's accumulators; hip_stream may be NULL. */
+int drprg_hip_map_device(drprg_hip_ctx* ctx, const void* d_bases, const void* d_offsets, uint64_t n_reads,
+    uint64_t n_bases, void* d_covg, void* d_prg_reads, void* hip_stream);
+
+/* The per-k-mer-node coverage vector (what gets sum-reduced across GPUs):
+ * covg[2g] forward, covg[2g+1] reverse coverage of global k-mer node g; prg_reads[p] clusters on PRG p. */
+int drprg_hip_coverage_size(const drprg_hip_ctx* ctx, uint64_t* n_covg, uint64_t* n_prgs);
+int drprg_hip_coverage(drprg_hip_ctx* ctx, uint32_t* covg, uint64_t n_covg, uint32_t* prg_reads, uint64_t n_prgs);
+int drprg_hip_set_coverage(drprg_hip_ctx* ctx, const uint32_t* covg, uint64_t n_covg, const uint32_t* prg_reads,
+    uint64_t n_prgs, uint64_t total_bases);
+int drprg_hip_device_coverage(drprg_hip_ctx* ctx, void** d_covg, void** d_prg_reads);
+int drprg_hip_reset(drprg_hip_ctx* ctx);
+/* out[0..7] = reads, bases, minimizers, hits, clusters kept, hits kept, 0, 0 */
+int drprg_hip_counters(drprg_hip_ctx* ctx, uint64_t out[8]);
+
+/* Coverage -> VCF: the tail of `pandora map --genotype --local --vcf-refs <genes.fa>`; writes the file
+ * Pandora::vcf_filename names (/root/reference/src/lib.rs:644-646), format of
+ * /root/reference/tests/cases/predict/ERR4796933.pandora.vcf. */
+int drprg_hip_genotype(drprg_hip_ctx* ctx, const char* vcf_refs, const char* out_vcf, const char* sample);
+/* exp_depth_covg / min_kmer_covg / #present / #records of the last drprg_hip_genotype */
+int drprg_hip_genotype_info(const drprg_hip_ctx* ctx, uint32_t out[4]);
+
+/* Index introspection for harnesses: sizes[0..4] = keys, records, prgs, k-mer nodes, table slots. */
+int drprg_hip_index_sizes(const drprg_hip_ctx* ctx, uint64_t sizes[5]);
+int drprg_hip_index_export(const drprg_hip_ctx* ctx, uint64_t* keys, uint32_t* rec_off, uint32_t* rec_prg,
+    uint32_t* rec_knode, uint8_t* rec_strand, uint32_t* prg_min_path_len, uint32_t* prg_knode_base);
+
+/* HIP-event timing of the sketch+probe kernel on the launch stream (bench.py roofline).
+ * enable != 0 starts/keeps timing; ms_total / launches may be NULL; reset != 0 clears the sums. */
+int drprg_hip_kernel_timing(drprg_hip_ctx* ctx, int enable, int reset, double* ms_total, uint64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

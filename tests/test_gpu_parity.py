@@ -1,0 +1,102 @@
+"""HIP path vs CPU oracle, bit-exact, through the C ABI (pytest -m gpu)."""
+import numpy as np
+import pytest
+
+from util import cluster_fraction, map_params
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctx(tmp_path, panel, w, k, illumina, genome_size=20000):
+    from drprg_amd import Context
+    prg = str(tmp_path / "dr.prg")
+    panel.write(prg, str(tmp_path / "genes.fa"))
+    ctx = Context(prg, w, k, device=0, from_files=False)
+    ctx.set_opts(illumina=illumina, genome_size=genome_size)
+    return ctx
+
+
+def _compare(ctx, oracle, bases, offsets, w, k, illumina):
+    idx = ctx.export_index()
+    md, er = map_params(k, illumina)
+    ocov, oprg, ocnt = oracle.map_reads(bases, offsets, idx, w, k, md, cluster_fraction(er, k), 10)
+    ctx.reset()
+    ctx.map_host(bases, offsets)
+    gcov, gprg = ctx.coverage()
+    gcnt = ctx.counters()
+    assert gcnt["minimizers"] == ocnt["minimizers"]
+    assert gcnt["hits"] == ocnt["hits"]
+    assert gcnt["clusters_kept"] == ocnt["clusters_kept"]
+    assert gcnt["hits_kept"] == ocnt["hits_kept"]
+    assert np.array_equal(gprg, oprg)
+    assert np.array_equal(gcov, ocov)
+    return ocnt
+
+
+@pytest.mark.parametrize("w,k", [(11, 15), (14, 15), (5, 9), (19, 21), (1, 15), (11, 31)])
+def test_short_reads_bit_exact(tmp_path, oracle, w, k):
+    from drprg_amd import synth
+    panel = synth.small_panel(seed=w * 100 + k)
+    ctx = _ctx(tmp_path, panel, w, k, True)
+    gen = synth.HaplotypeGenomes(panel, genome_size=20000, n_hap=4, seed=3)
+    bases, offs = synth.sample_short_reads(gen, 20000, seed=5)
+    cnt = _compare(ctx, oracle, bases, offs, w, k, True)
+    assert cnt["clusters_kept"] > 0
+
+
+def test_long_reads_bit_exact(tmp_path, oracle):
+    from drprg_amd import synth
+    panel = synth.small_panel(seed=11, n_loci=6, length=1500)
+    ctx = _ctx(tmp_path, panel, 11, 15, False)
+    gen = synth.HaplotypeGenomes(panel, genome_size=60000, n_hap=4, seed=3)
+    bases, offs = synth.sample_long_reads(gen, 1500, seed=3)
+    cnt = _compare(ctx, oracle, bases, offs, 11, 15, False)
+    assert cnt["clusters_kept"] > 0
+
+
+def test_ragged_and_degenerate_inputs(tmp_path, oracle):
+    """empty reads, reads shorter than k, N runs, lower case, read boundaries at tile edges"""
+    from drprg_amd import synth
+    panel = synth.small_panel(seed=2)
+    ctx = _ctx(tmp_path, panel, 11, 15, True)
+    rng = np.random.default_rng(0)
+    gen = synth.HaplotypeGenomes(panel, genome_size=20000, n_hap=2, seed=3)
+    g = gen.haps[0]
+    reads = []
+    for i in range(6000):
+        L = int(rng.choice([0, 1, 14, 15, 24, 25, 26, 40, 150, 151, 300, 4064, 4096, 5000]))
+        s = int(rng.integers(0, len(g) - L))
+        r = g[s:s + L].copy()
+        if L and rng.random() < 0.3:
+            r[rng.integers(0, L, size=max(1, L // 50))] = ord("N")
+        if L and rng.random() < 0.2:
+            r = np.frombuffer(r.tobytes().lower(), dtype=np.uint8)
+        reads.append(r)
+    offs = np.zeros(len(reads) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(r) for r in reads])
+    bases = np.concatenate(reads)
+    _compare(ctx, oracle, bases, offs, 11, 15, True)
+    # empty batch and a batch of only empty reads
+    ctx.reset()
+    ctx.map_host(np.zeros(0, np.uint8), np.zeros(1, np.uint64))
+    ctx.map_host(np.zeros(0, np.uint8), np.zeros(5, np.uint64))
+    cov, _ = ctx.coverage()
+    assert cov.sum() == 0
+
+
+def test_batches_accumulate(tmp_path, oracle):
+    """mapping in several batches == mapping in one (coverage is additive)"""
+    from drprg_amd import synth
+    panel = synth.small_panel(seed=4)
+    ctx = _ctx(tmp_path, panel, 11, 15, True)
+    gen = synth.HaplotypeGenomes(panel, genome_size=20000, n_hap=4, seed=3)
+    bases, offs = synth.sample_short_reads(gen, 9000, seed=8)
+    ctx.map_host(bases, offs)
+    one, _ = ctx.coverage()
+    ctx.reset()
+    for lo in range(0, 9000, 3000):
+        b = bases[int(offs[lo]):int(offs[lo + 3000])]
+        o = offs[lo:lo + 3001] - offs[lo]
+        ctx.map_host(b, o)
+    three, _ = ctx.coverage()
+    assert np.array_equal(one, three)
