@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py -- reads/s of the drprg predict hot path on MI355X (metric of BASELINE.json).
+
+A "step" is one pass of the hot path (sketch + probe + cluster + coverage accumulation, then the
+sum-reduce of the coverage vector across ranks) over one batch of synthetic reads that is already
+resident in HBM.  At N=1 the workload is BASELINE.json configs[1]: 10M synthetic 150 bp Illumina reads
+against the mtb-like PRG index (18 loci, k=15, w=11).  With N>1 every rank maps its own 10M-read shard
+(weak scaling, reads shard embarrassingly) and the only data-path collective is one RCCL all-reduce of
+the u32 coverage vector per step.
+
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (sketch_probe_kernel) against
+HBM bandwidth using the algorithmic bytes of SURVEY.md section 8d, with its duration measured live
+with HIP events on the launch stream; `cpu_baseline` times the CPU oracle (oracle/oracle.c, a
+single-threaded port) on a bounded sample of the same workload on the host's cores.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def gpu_sample_reads(torch, hap_pad, hap_lens, n_reads, read_len, seed, device, sub_rate=0.001, chunk=1 << 20):
+    """Same distribution as drprg_amd.synth.sample_short_reads, generated on the device (plumbing only)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    n_hap, max_len = hap_pad.shape
+    flat = hap_pad.reshape(-1)
+    out = torch.empty(n_reads * read_len, dtype=torch.uint8, device=device)
+    ar = torch.arange(read_len, device=device, dtype=torch.int64)
+    comp = torch.zeros(256, dtype=torch.uint8, device=device)
+    for a, b in zip(b"ACGTN", b"TGCAN"):
+        comp[a] = b
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+    for lo in range(0, n_reads, chunk):
+        m = min(chunk, n_reads - lo)
+        hap = torch.randint(0, n_hap, (m,), generator=g, device=device)
+        span = (hap_lens[hap] - read_len).to(torch.float64)
+        start = (torch.rand(m, generator=g, device=device, dtype=torch.float64) * span).to(torch.int64)
+        idx = (hap * max_len + start)[:, None] + ar
+        block = flat[idx]
+        rev = torch.rand(m, generator=g, device=device) < 0.5
+        rc = comp[block.flip(1).long()]
+        block = torch.where(rev[:, None], rc, block)
+        err = torch.rand(block.shape, generator=g, device=device) < sub_rate
+        rnd = acgt[torch.randint(0, 4, block.shape, generator=g, device=device)]
+        block = torch.where(err, rnd, block)
+        out[lo * read_len:(lo + m) * read_len] = block.reshape(-1)
+    offsets = torch.arange(n_reads + 1, dtype=torch.int64, device=device) * read_len
+    return out, offsets
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--reads-per-gpu", type=int, default=10_000_000)
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="reads timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--workload", default="mtb", choices=["mtb", "big"], help="mtb = configs[1]; big = configs[4] index")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)  # nccl == RCCL on ROCm
+
+    from drprg_amd import Context, synth
+
+    W, K = 11, 15
+    panel = synth.mtb_like_panel() if args.workload == "mtb" else synth.big_panel()
+    tmp = tempfile.mkdtemp(prefix=f"drprg_bench_r{rank}_")
+    prg = os.path.join(tmp, "dr.prg")
+    panel.write(prg, os.path.join(tmp, "genes.fa"))
+    ctx = Context(prg, W, K, device=local_rank, from_files=False, threads=8)
+    ctx.set_opts(illumina=True, min_cluster_size=10, genome_size=synth.MTB_GENOME_SIZE)
+
+    # synthetic reads, generated on the device; every rank samples a different shard (seed + rank)
+    genomes = synth.HaplotypeGenomes(panel, n_hap=8)
+    hap_pad = torch.from_numpy(genomes.padded()).to(device)
+    hap_lens = torch.from_numpy(genomes.lens).to(device)
+    n_reads = args.reads_per_gpu
+    bases, offsets = gpu_sample_reads(torch, hap_pad, hap_lens, n_reads, args.read_len, 2 + rank, device)
+    n_bases = int(bases.numel())
+    del hap_pad
+    covg = torch.zeros(2 * ctx.n_knodes, dtype=torch.int32, device=device)
+    prg_reads = torch.zeros(ctx.n_prgs, dtype=torch.int32, device=device)
+    stream = torch.cuda.Stream(device)  # the hot path and the collective run on this stream
+    torch.cuda.synchronize()
+
+    def step():
+        with torch.cuda.stream(stream):
+            covg.zero_()
+            prg_reads.zero_()
+            ctx.map_device(bases.data_ptr(), offsets.data_ptr(), n_reads, n_bases, covg.data_ptr(), prg_reads.data_ptr(),
+                           stream.cuda_stream)
+            if world > 1:
+                dist.all_reduce(covg)
+                dist.all_reduce(prg_reads)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.kernel_timing(enable=True, reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    k_ms, k_launches = ctx.kernel_timing(enable=False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # size-independent parity properties at full size: additivity checksum across two halves
+    checksum = int(covg.to(torch.int64).sum().item())
+
+    if rank == 0:
+        total_reads = n_reads * world * args.steps
+        value = total_reads / elapsed
+        # algorithmic bytes per launch: sum(L + 8) over the reads + index table + 8 B per k-mer node
+        table_bytes = ctx.n_slots * (4 + 8) + ctx.n_records * (4 + 2)
+        alg_bytes = n_bases + 8 * n_reads + table_bytes + 8 * ctx.n_knodes
+        avg_ms = k_ms / max(k_launches, 1)
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        out = {
+            "metric": "reads/sec (+ achieved HBM GB/s) predicting on mtb index, 1/2/4/8 GPUs",
+            "value": value,
+            "unit": "reads/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {
+                "workload": ("configs[1]: 10M synthetic 150 bp Illumina reads vs mtb-like PRG index" if args.workload == "mtb"
+                             else "configs[4]: 500-locus / 50k-variant synthetic PRG index"),
+                "reads_per_gpu": n_reads, "read_len": args.read_len, "w": W, "k": K, "loci": ctx.n_prgs,
+                "index_keys": ctx.n_keys, "kmer_nodes": ctx.n_knodes, "sharding": f"reads x{world}",
+                "collective": "all_reduce(u32 coverage) per step" if world > 1 else "none",
+                "coverage_checksum": checksum,
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "sketch_probe_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
+                "avg_launch_ms": avg_ms, "launches_timed": k_launches,
+            },
+        }
+        # CPU baseline: the oracle (single-threaded port of the same path) on a bounded sample, rank 0, N=1 semantics
+        if args.cpu_sample > 0:
+            from util import Oracle, cluster_fraction, map_params
+            orc = Oracle()
+            ns = min(args.cpu_sample, n_reads)
+            hb = bases[:ns * args.read_len].cpu().numpy()
+            ho = offsets[:ns + 1].cpu().numpy().astype(np.uint64)
+            idx = ctx.export_index()
+            md, er = map_params(K, True)
+            t1 = time.perf_counter()
+            ocov, _, _ = orc.map_reads(hb, ho, idx, W, K, md, cluster_fraction(er, K), 10)
+            cpu_s = time.perf_counter() - t1
+            # the same sample through the HIP path must give the identical vector
+            c2 = torch.zeros_like(covg)
+            p2 = torch.zeros_like(prg_reads)
+            torch.cuda.synchronize()
+            ctx.map_device(bases.data_ptr(), offsets.data_ptr(), ns, ns * args.read_len, c2.data_ptr(), p2.data_ptr(),
+                           stream.cuda_stream)
+            torch.cuda.synchronize()
+            parity = bool(np.array_equal(c2.cpu().numpy().view(np.uint32), ocov))
+            out["cpu_baseline"] = {"value": ns / cpu_s, "unit": "reads/s", "cores": 1, "kind": "port",
+                                   "sample": f"first {ns} reads of rank 0's shard, oracle/oracle.c single thread, {cpu_s:.1f}s",
+                                   "host_cores_available": os.cpu_count(), "parity_vs_hip_on_sample": parity}
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
