@@ -42,6 +42,7 @@ struct SketchArgs {
     uint32_t table_bits;
     const uint32_t* rec_knode; // (global k-mer node << 1) | strand
     const uint16_t* rec_prg;
+    uint32_t* tile_first_read; // scratch, one entry per tile (filled by launch_sketch_probe)
     // outputs
     uint64_t* hit_key;
     uint32_t* hit_val;
@@ -75,6 +76,7 @@ struct ClusterArgs {
 };
 
 uint32_t sketch_tile_eval(int halo);
+uint32_t sketch_n_tiles(uint64_t n_bases, int halo);
 hipError_t launch_sketch_probe(const SketchArgs& a, bool wide_hash, hipStream_t stream);
 size_t sort_temp_bytes(uint32_t n);
 size_t scan_temp_bytes(uint32_t n);

@@ -34,7 +34,7 @@ namespace dev {
 // ---------------------------------------------------------------------------------------------
 template <typename HT> struct HashTraits;
 template <> struct HashTraits<uint32_t> {
-    static constexpr uint32_t INVALID = 0xFFFFFFFFu;
+    static constexpr uint32_t EMPTY = 0xFFFFFFFFu; // never a hash: this path serves k <= 15 (30 bits)
     // minimap hash64 restricted to <= 30 bits: every intermediate is taken mod 2^(2k), so 32-bit
     // arithmetic is exact; the final (key + key<<31) term vanishes below 31 bits.
     __device__ static inline uint32_t mix(uint32_t key, uint32_t mask)
@@ -49,7 +49,7 @@ template <> struct HashTraits<uint32_t> {
     }
 };
 template <> struct HashTraits<uint64_t> {
-    static constexpr uint64_t INVALID = ~0ULL;
+    static constexpr uint64_t EMPTY = ~0ULL; // k <= 31: hashes stay below 2^62
     __device__ static inline uint64_t mix(uint64_t key, uint64_t mask)
     {
         key = (~key + (key << 21)) & mask;
@@ -77,16 +77,28 @@ __device__ inline uint32_t encode_base(uint32_t c)
     bool ok = (u == 'A') | (u == 'C') | (u == 'G') | (u == 'T');
     return ok ? x : 4u;
 }
+// four bases at once (SWAR): same mapping on every byte of a dword
 __device__ inline uint32_t encode4(uint32_t word)
 {
-    return encode_base(word & 0xFF) | (encode_base((word >> 8) & 0xFF) << 8) | (encode_base((word >> 16) & 0xFF) << 16)
-        | (encode_base(word >> 24) << 24);
+    const uint32_t u = word & 0xDFDFDFDFu; // upper case
+    uint32_t x = (u >> 1) & 0x03030303u;
+    x ^= (x >> 1) & 0x01010101u;
+    // bit 7 of nz(v) is set in every non-zero byte of v (exact, no carry between bytes)
+    auto nz = [](uint32_t v) { return ((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v; };
+    const uint32_t bad = nz(u ^ 0x41414141u) & nz(u ^ 0x43434343u) & nz(u ^ 0x47474747u) & nz(u ^ 0x54545454u) & 0x80808080u;
+    return x | (bad >> 5); // 0x80 >> 5 = 4: the "not ACGT" flag
 }
 
-// first read r with offsets[r+1] > gp, i.e. the read holding global base position gp
-__device__ inline uint32_t find_read(const uint64_t* __restrict__ offsets, uint32_t n_reads, uint64_t gp)
+// read holding global base position gp, searched upwards from read `lo` (offsets[lo] <= gp)
+__device__ inline uint32_t find_read_from(const uint64_t* __restrict__ offsets, uint32_t n_reads, uint32_t lo, uint64_t gp)
 {
-    uint32_t lo = 0, hi = n_reads; // invariant: offsets[lo] <= gp < offsets[hi]
+    uint32_t step = 1, hi = lo + 1;
+    while (hi < n_reads && offsets[hi] <= gp) { // gallop
+        lo = hi;
+        step <<= 1;
+        hi = (n_reads - lo > step) ? lo + step : n_reads;
+    }
+    // invariant: offsets[lo] <= gp < offsets[hi]  (offsets[n_reads] = n_bases > gp)
     while (hi - lo > 1) {
         uint32_t mid = lo + ((hi - lo) >> 1);
         if (offsets[mid] <= gp) lo = mid; else hi = mid;
@@ -100,31 +112,52 @@ __device__ inline uint32_t find_read(const uint64_t* __restrict__ offsets, uint3
 constexpr int SK_THREADS = 256;
 constexpr int SK_G = 16;                       // k-mer positions per thread
 constexpr int SK_NPOS = SK_THREADS * SK_G;     // 4096 hashed positions per tile
-constexpr int SK_MAXTAIL = 32;                 // k-1 <= 31 extra bases
-constexpr int SK_CODES = SK_NPOS + 48;         // staged bases (multiple of 16 >= NPOS + k - 1)
+constexpr int SK_CODES = SK_NPOS + 48;         // staged bases (multiple of 16 >= NPOS + k - 1, k <= 31)
+constexpr int SK_MAXSTEPS = SK_G + 30;         // bases one thread rolls over (k <= 31)
 
-template <typename HT>
+// first read that starts at or after the first staged base of every tile
+__global__ void tile_first_read_kernel(const uint64_t* __restrict__ offsets, uint32_t n_reads, int t_eval, int halo,
+    uint32_t n_tiles, uint32_t* __restrict__ out)
+{
+    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_tiles) return;
+    int64_t lo_pos = (int64_t)b * t_eval - halo;
+    if (lo_pos < 0) lo_pos = 0;
+    uint32_t lo = 0, hi = n_reads;
+    while (lo < hi) {
+        uint32_t mid = lo + ((hi - lo) >> 1);
+        if ((int64_t)offsets[mid] < lo_pos) lo = mid + 1; else hi = mid;
+    }
+    out[b] = lo;
+}
+
+__device__ __forceinline__ int hpad(int p) { return p + (p >> 4); } // LDS index of tile position p (row of 16 + 1 pad)
+
+// KC / WC: compile-time k / w (0 = take them from the arguments)
+template <typename HT, int KC, int WC>
 __global__ __launch_bounds__(SK_THREADS) void sketch_probe_kernel(SketchArgs a)
 {
     using Tr = HashTraits<HT>;
-    __shared__ __attribute__((aligned(16))) uint8_t s_code[SK_CODES];
-    __shared__ HT s_hash[SK_NPOS];
+    // s_hash holds hash+1 of every valid k-mer of the tile and 0 for an invalid one
+    __shared__ uint4 s_code4[SK_CODES / 16];
+    __shared__ HT s_hash[SK_NPOS + SK_NPOS / 16];
     __shared__ uint16_t s_strand[SK_THREADS];
     __shared__ uint16_t s_mins[SK_NPOS];
     __shared__ uint32_t s_nmin;
-    __shared__ uint32_t s_first_read;
+    uint8_t* s_code = reinterpret_cast<uint8_t*>(s_code4);
 
     const int tid = threadIdx.x;
-    const int w = a.w, k = a.k;
+    const int k = KC ? KC : a.k;
+    const int w = WC ? WC : a.w;
     const int halo = a.halo;                 // multiple of 16, >= w-1
     const int t_eval = SK_NPOS - 2 * halo;   // k-mer positions evaluated by this tile
-    // tile origin in global base coordinates (may be negative for tile 0)
+    // tile origin in global base coordinates (a multiple of 16; negative for tile 0)
     const int64_t origin = (int64_t)blockIdx.x * t_eval - halo;
     const int64_t n_bases = (int64_t)a.n_bases;
 
     if (tid == 0) s_nmin = 0;
 
-    // ---- stage bases -> codes (coalesced 16-byte loads; origin is a multiple of 16) ----
+    // ---- stage bases -> codes (coalesced 16-byte loads) ----
     for (int v = tid; v < SK_CODES / 16; v += SK_THREADS) {
         int64_t g = origin + (int64_t)v * 16;
         uint4 out;
@@ -144,92 +177,132 @@ __global__ __launch_bounds__(SK_THREADS) void sketch_probe_kernel(SketchArgs a)
             }
             out.x = tmp[0]; out.y = tmp[1]; out.z = tmp[2]; out.w = tmp[3];
         }
-        *reinterpret_cast<uint4*>(&s_code[v * 16]) = out;
+        s_code4[v] = out;
     }
-    // ---- locate the first read starting inside the staged range ----
-    if (tid == 0) {
-        int64_t lo_pos = origin < 0 ? 0 : origin;
-        // first r with offsets[r] >= lo_pos
-        uint32_t lo = 0, hi = a.n_reads; // offsets[n_reads] = n_bases >= anything staged
-        while (lo < hi) {
-            uint32_t mid = lo + ((hi - lo) >> 1);
-            if ((int64_t)a.offsets[mid] < lo_pos) lo = mid + 1; else hi = mid;
-        }
-        s_first_read = lo;
-    }
-    __syncthreads();
-    // ---- flag read starts (bit 3) ----
-    {
-        const int64_t end_pos = origin + SK_CODES;
-        for (uint32_t r = s_first_read + tid; r < a.n_reads; r += SK_THREADS) {
-            int64_t o = (int64_t)a.offsets[r];
-            if (o >= end_pos) break;
-            s_code[o - origin] |= 8;
-        }
-    }
+    const uint32_t first_read = a.tile_first_read[blockIdx.x];
     __syncthreads();
 
     // ---- phase 1: rolling canonical hash of SK_G consecutive k-mers per thread ----
+    const int base0 = tid * SK_G;
     {
-        const HT mask = (HT)((k >= 32) ? ~0ULL : ((1ULL << (2 * k)) - 1));
+        const HT mask = (HT)((1ULL << (2 * k)) - 1);
         const int shift1 = 2 * (k - 1);
-        HT fwd = 0, rev = 0;
-        int run = 0;
-        uint32_t strand_bits = 0;
-        const int base0 = tid * SK_G;
         const int nsteps = SK_G + k - 1;
-        for (int s0 = 0; s0 < nsteps; s0 += 4) {
-            uint32_t word = *reinterpret_cast<const uint32_t*>(&s_code[base0 + s0]);
+        uint4 c0 = s_code4[tid], c1 = s_code4[tid + 1], c2 = s_code4[tid + 2];
+        const uint32_t words[12] = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w };
+        HT fwd = 0, rev = 0;
+        uint32_t strand_bits = 0, any_n = 0;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int s = s0 + q;
-                uint32_t c = (word >> (8 * q)) & 0xFF;
-                uint32_t b = c & 3;
-                fwd = ((fwd << 2) | (HT)b) & mask;
-                rev = (rev >> 2) | ((HT)(3 - b) << shift1);
-                run = (c & 4) ? 0 : ((c & 8) ? 1 : run + 1);
-                if (s >= k - 1 && s < nsteps) {
-                    int j = s - (k - 1); // k-mer index within this thread
-                    HT h = Tr::INVALID;
-                    if (run >= k) {
-                        HT hf = Tr::mix(fwd, mask), hr = Tr::mix(rev, mask);
-                        h = hf < hr ? hf : hr;
-                        strand_bits |= (uint32_t)(hf <= hr) << j;
-                    }
-                    s_hash[base0 + j] = h;
+        for (int s = 0; s < SK_MAXSTEPS; ++s) {
+            if (s < nsteps) {
+                const uint32_t c = words[s >> 2] >> (8 * (s & 3));
+                any_n |= c;
+                const HT b = (HT)(c & 3u);
+                fwd = ((fwd << 2) | b) & mask;
+                rev = (rev >> 2) | ((b ^ (HT)3) << shift1);
+                if (s >= k - 1) {
+                    const int j = s - (k - 1);
+                    const HT hf = Tr::mix(fwd, mask), hr = Tr::mix(rev, mask);
+                    strand_bits |= (uint32_t)(hf <= hr) << j;
+                    s_hash[hpad(base0 + j)] = (hf < hr ? hf : hr) + 1;
                 }
+            }
+        }
+        if (any_n & 4u) { // rare: some base of this thread's span is not ACGT (or lies outside the buffer)
+            for (int j = 0; j < SK_G; ++j) {
+                bool bad = false;
+                for (int i = j; i < j + k; ++i) bad |= (s_code[base0 + i] & 4) != 0;
+                if (bad) s_hash[hpad(base0 + j)] = 0;
             }
         }
         s_strand[tid] = (uint16_t)strand_bits;
     }
     __syncthreads();
+    // ---- a k-mer must not straddle two reads: invalidate the k-1 k-mers that end inside the next read ----
+    {
+        const int64_t end_pos = origin + SK_CODES;
+        for (uint32_t r = first_read + tid; r < a.n_reads; r += SK_THREADS) {
+            const int64_t o = (int64_t)a.offsets[r];
+            if (o >= end_pos) break;
+            const int oc = (int)(o - origin);
+            int p0 = oc - k + 1, p1 = oc < SK_NPOS ? oc : SK_NPOS;
+            if (p0 < 0) p0 = 0;
+            for (int p = p0; p < p1; ++p) s_hash[hpad(p)] = 0;
+        }
+    }
+    __syncthreads();
 
     // ---- phase 2a: which of my positions are window minimizers? ----
-    // position j is a minimizer iff a window of w valid k-mers containing j has no hash below h[j]:
-    // count neighbours >= h[j] leftwards (a) and rightwards (b) until w-1 are found.
-    {
-        const int lo = halo, hi = SK_NPOS - halo;
-        const int64_t last_kmer = n_bases - k; // last valid global k-mer start
-        for (int g = 0; g < SK_G; ++g) {
-            int j = tid * SK_G + g;
-            if (j < lo || j >= hi) continue;
-            if (origin + j > last_kmer) continue;
-            HT h = s_hash[j];
-            if (h == Tr::INVALID) continue;
-            int need = w - 1, got = 0;
-            for (int d = 1; d <= need; ++d) { // leftwards (j-d >= 0 because halo >= w-1)
-                HT x = s_hash[j - d];
-                if (x == Tr::INVALID || x < h) break;
-                ++got;
+    // position j is a minimizer iff some window of w consecutive valid k-mers containing j has no value below g[j].
+    if (base0 >= halo && base0 < SK_NPOS - halo) {
+        uint32_t minbits = 0;
+        const int pbase = base0 - (w - 1); // tile position of element 0 of my neighbourhood
+        if constexpr (WC > 0) {
+            // branch-free: sliding minimum over windows (an invalid k-mer is 0, so an invalid window has minimum 0 and
+            // never equals a valid g >= 1), then sliding maximum of the window minima over the windows holding j
+            constexpr int N = SK_G + 2 * (WC - 1);
+            HT m[N], own[SK_G];
+#pragma unroll
+            for (int i = 0; i < N; ++i) m[i] = s_hash[hpad(pbase + i)];
+#pragma unroll
+            for (int j = 0; j < SK_G; ++j) own[j] = m[WC - 1 + j];
+            constexpr int P = (WC >= 16) ? 16 : (WC >= 8) ? 8 : (WC >= 4) ? 4 : (WC >= 2) ? 2 : 1; // largest power of two <= WC
+#pragma unroll
+            for (int sp = 1; sp < P; sp *= 2) {
+#pragma unroll
+                for (int i = 0; i + sp < N; ++i) m[i] = m[i] < m[i + sp] ? m[i] : m[i + sp];
             }
-            for (int d = 1; got < need && d <= need; ++d) {
-                HT x = s_hash[j + d];
-                if (x == Tr::INVALID || x < h) break;
-                ++got;
+#pragma unroll
+            for (int i = 0; i + WC - 1 < N; ++i) m[i] = m[i] < m[i + WC - P] ? m[i] : m[i + WC - P]; // m[i] = min g[i..i+WC-1]
+            constexpr int NW = SK_G + WC - 1; // window starts that matter: 0 .. NW-1
+#pragma unroll
+            for (int sp = 1; sp < P; sp *= 2) {
+#pragma unroll
+                for (int i = 0; i + sp < NW; ++i) m[i] = m[i] > m[i + sp] ? m[i] : m[i + sp];
             }
-            if (got >= need) {
-                uint32_t idx = atomicAdd(&s_nmin, 1u);
-                s_mins[idx] = (uint16_t)j;
+#pragma unroll
+            for (int j = 0; j < SK_G; ++j) {
+                HT best = m[j] > m[j + WC - P] ? m[j] : m[j + WC - P]; // max of the minima of windows j .. j+WC-1
+                minbits |= (uint32_t)(own[j] != 0 && best == own[j]) << j;
+            }
+        } else {
+            // generic w: sequential scan that reports every window arg-min exactly once
+            const int N = SK_G + 2 * (w - 1);
+            HT mn = 0;
+            int mpos = -1, nvalid = 0;
+            for (int i = 0; i < N; ++i) {
+                const HT g = s_hash[hpad(pbase + i)];
+                if (g == 0) { nvalid = 0; continue; }
+                ++nvalid;
+                if (nvalid < w) continue;
+                if (nvalid == w || mpos < i - w + 1) { // first full window after a break, or the minimum slid out
+                    HT best = g;
+                    for (int d = 1; d < w; ++d) {
+                        HT x = s_hash[hpad(pbase + i - d)];
+                        best = x < best ? x : best;
+                    }
+                    mn = best;
+                    for (int d = w - 1; d >= 0; --d) {
+                        if (s_hash[hpad(pbase + i - d)] == mn) {
+                            mpos = i - d;
+                            int j = i - d - (w - 1);
+                            if (j >= 0 && j < SK_G) minbits |= 1u << j;
+                        }
+                    }
+                } else if (g <= mn) {
+                    mn = g;
+                    mpos = i;
+                    int j = i - (w - 1);
+                    if (j >= 0 && j < SK_G) minbits |= 1u << j;
+                }
+            }
+        }
+        if (minbits) {
+            uint32_t at = atomicAdd(&s_nmin, (uint32_t)__popc(minbits));
+            while (minbits) {
+                int j = __ffs(minbits) - 1;
+                minbits &= minbits - 1;
+                s_mins[at++] = (uint16_t)(base0 + j);
             }
         }
     }
@@ -240,31 +313,32 @@ __global__ __launch_bounds__(SK_THREADS) void sketch_probe_kernel(SketchArgs a)
     const uint32_t tmask = (1u << a.table_bits) - 1;
     const HT* __restrict__ slot_key = reinterpret_cast<const HT*>(a.slot_key);
     for (uint32_t i = tid; i < nmin; i += SK_THREADS) {
-        int j = s_mins[i];
-        HT h = s_hash[j];
+        const int j = s_mins[i];
+        const HT h = s_hash[hpad(j)] - 1;
         uint32_t s = table_slot_dev((uint64_t)h, a.table_bits);
-        uint2 rec = make_uint2(0, 0);
+        bool found = false;
         while (true) {
-            uint2 r = a.slot_rec[s];
-            if (r.y == 0) break;
-            if (slot_key[s] == h) { rec = r; break; }
+            const HT key = slot_key[s];
+            if (key == h) { found = true; break; }
+            if (key == Tr::EMPTY) break;
             s = (s + 1) & tmask;
         }
-        if (rec.y == 0) continue;
+        if (!found) continue;
+        const uint2 rec = a.slot_rec[s];
         // a hit: locate the read and emit one hit per index record
-        uint64_t gp = (uint64_t)(origin + j);
-        uint32_t read = find_read(a.offsets, a.n_reads, gp);
-        uint64_t pos = gp - a.offsets[read];
-        uint32_t strand = (s_strand[j / SK_G] >> (j % SK_G)) & 1u;
-        unsigned long long at = atomicAdd(a.n_hits, (unsigned long long)rec.y);
+        const uint64_t gp = (uint64_t)(origin + j);
+        const uint32_t read = find_read_from(a.offsets, a.n_reads, first_read ? first_read - 1 : 0, gp);
+        const uint64_t pos = gp - a.offsets[read];
+        const uint32_t strand = (s_strand[j / SK_G] >> (j % SK_G)) & 1u;
+        const unsigned long long at = atomicAdd(a.n_hits, (unsigned long long)rec.y);
         if (at + rec.y > a.hit_capacity || pos >= (1ull << HIT_POS_BITS)) {
             atomicOr(a.overflow, pos >= (1ull << HIT_POS_BITS) ? 2u : 1u);
             continue;
         }
         for (uint32_t q = 0; q < rec.y; ++q) {
-            uint32_t kn = a.rec_knode[rec.x + q]; // (global knode << 1) | strand
-            uint32_t prg = a.rec_prg[rec.x + q];
-            uint32_t rev = ((kn & 1u) == strand) ? 0u : 1u; // forward hits sort first
+            const uint32_t kn = a.rec_knode[rec.x + q]; // (global knode << 1) | strand
+            const uint32_t prg = a.rec_prg[rec.x + q];
+            const uint32_t rev = ((kn & 1u) == strand) ? 0u : 1u; // forward hits sort first
             a.hit_key[at + q] = pack_hit_key(read, prg, rev, (uint32_t)pos);
             a.hit_val[at + q] = kn >> 1;
         }
@@ -405,16 +479,28 @@ __global__ void accumulate_kernel(ClusterArgs a, uint32_t n_hits)
 
 uint32_t sketch_tile_eval(int halo) { return (uint32_t)(SK_NPOS - 2 * halo); }
 
+uint32_t sketch_n_tiles(uint64_t n_bases, int halo)
+{
+    uint64_t t_eval = sketch_tile_eval(halo);
+    return (uint32_t)((n_bases + t_eval - 1) / t_eval);
+}
+
 hipError_t launch_sketch_probe(const SketchArgs& a, bool wide_hash, hipStream_t stream)
 {
     if (a.n_bases == 0) return hipSuccess;
-    uint64_t t_eval = sketch_tile_eval(a.halo);
-    uint64_t n_kmer_pos = a.n_bases; // positions past n_bases-k are skipped inside the kernel
-    uint32_t grid = (uint32_t)((n_kmer_pos + t_eval - 1) / t_eval);
+    const uint32_t grid = sketch_n_tiles(a.n_bases, a.halo); // positions past n_bases-k are invalid inside the kernel
+    hipLaunchKernelGGL(tile_first_read_kernel, dim3((grid + 255) / 256), dim3(256), 0, stream, a.offsets, a.n_reads,
+        (int)sketch_tile_eval(a.halo), a.halo, grid, a.tile_first_read);
+    HIP_TRY(hipGetLastError());
+    const dim3 g(grid), b(SK_THREADS);
     if (wide_hash)
-        hipLaunchKernelGGL(sketch_probe_kernel<uint64_t>, dim3(grid), dim3(SK_THREADS), 0, stream, a);
+        hipLaunchKernelGGL((sketch_probe_kernel<uint64_t, 0, 0>), g, b, 0, stream, a);
+    else if (a.k == 15 && a.w == 11)
+        hipLaunchKernelGGL((sketch_probe_kernel<uint32_t, 15, 11>), g, b, 0, stream, a);
+    else if (a.k == 15 && a.w == 14)
+        hipLaunchKernelGGL((sketch_probe_kernel<uint32_t, 15, 14>), g, b, 0, stream, a);
     else
-        hipLaunchKernelGGL(sketch_probe_kernel<uint32_t>, dim3(grid), dim3(SK_THREADS), 0, stream, a);
+        hipLaunchKernelGGL((sketch_probe_kernel<uint32_t, 0, 0>), g, b, 0, stream, a);
     return hipGetLastError();
 }
 

@@ -45,13 +45,15 @@ Mapper::Mapper(const FlatIndex& idx, const MapParams& p, int device) : device_(d
 
     const size_t nslot = idx.slot_key.size();
     if (wide_hash_) {
+        std::vector<uint64_t> k64(nslot);
+        for (size_t i = 0; i < nslot; ++i) k64[i] = idx.slot_cnt[i] ? idx.slot_key[i] : ~0ULL; // empty-slot sentinel
         uint64_t* k = nullptr;
         dmalloc(k, nslot);
-        HIPCHK(hipMemcpy(k, idx.slot_key.data(), nslot * sizeof(uint64_t), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(k, k64.data(), nslot * sizeof(uint64_t), hipMemcpyHostToDevice));
         d_slot_key_ = k;
     } else {
         std::vector<uint32_t> k32(nslot);
-        for (size_t i = 0; i < nslot; ++i) k32[i] = (uint32_t)idx.slot_key[i];
+        for (size_t i = 0; i < nslot; ++i) k32[i] = idx.slot_cnt[i] ? (uint32_t)idx.slot_key[i] : 0xFFFFFFFFu; // empty-slot sentinel
         uint32_t* k = nullptr;
         dmalloc(k, nslot);
         HIPCHK(hipMemcpy(k, k32.data(), nslot * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -94,7 +96,7 @@ Mapper::~Mapper()
     dfree(d_key_a_); dfree(d_key_b_); dfree(d_val_a_); dfree(d_val_b_);
     dfree(d_head_); dfree(d_scan_); dfree(d_cstart_); dfree(d_order_); dfree(d_clusters_);
     if (d_temp_) (void)hipFree(d_temp_);
-    dfree(d_bases_); dfree(d_offsets_);
+    dfree(d_bases_); dfree(d_offsets_); dfree(d_tile_first_);
     if (h_counters_) (void)hipHostFree(h_counters_);
     if (h_bases_) (void)hipHostFree(h_bases_);
     if (h_offsets_) (void)hipHostFree(h_offsets_);
@@ -143,6 +145,12 @@ void Mapper::run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32
     uint32_t* covg, uint32_t* prg_reads, hipStream_t stream)
 {
     ensure_workspace(std::max<uint64_t>(1u << 20, n_bases / 64));
+    const uint32_t n_tiles = dev::sketch_n_tiles(n_bases, halo_);
+    if (n_tiles > tile_cap_) {
+        dfree(d_tile_first_);
+        tile_cap_ = n_tiles + n_tiles / 4 + 16;
+        dmalloc(d_tile_first_, (size_t)tile_cap_);
+    }
     for (int attempt = 0;; ++attempt) {
         HIPCHK(hipMemsetAsync(&d_counters_[C_HITS], 0, sizeof(unsigned long long), stream));
         HIPCHK(hipMemsetAsync(&d_counters_[C_OVERFLOW], 0, sizeof(unsigned long long), stream));
@@ -159,6 +167,7 @@ void Mapper::run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32
         a.table_bits = table_bits_;
         a.rec_knode = d_rec_knode_;
         a.rec_prg = d_rec_prg_;
+        a.tile_first_read = d_tile_first_;
         a.hit_key = d_key_a_;
         a.hit_val = d_val_a_;
         a.hit_capacity = hit_capacity_;

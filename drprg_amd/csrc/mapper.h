@@ -81,6 +81,8 @@ private:
     uint32_t *d_head_ = nullptr, *d_scan_ = nullptr, *d_cstart_ = nullptr, *d_order_ = nullptr;
     dev::ClusterRec* d_clusters_ = nullptr;
     void* d_temp_ = nullptr;
+    uint32_t* d_tile_first_ = nullptr;
+    uint32_t tile_cap_ = 0;
     size_t temp_bytes_ = 0;
     // host staging
     uint8_t* h_bases_ = nullptr;
