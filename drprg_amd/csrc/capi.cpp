@@ -286,6 +286,20 @@ int drprg_hip_index_export(const drprg_hip_ctx* ctx, uint64_t* keys, uint32_t* r
     return DRPRG_OK;
 }
 
+int drprg_hip_prg_nodes(const drprg_hip_ctx* ctx, uint32_t prg, uint32_t* starts, uint32_t* ends, uint32_t cap, uint32_t* n_nodes,
+    uint32_t* n_sites)
+{
+    if (!ctx || prg >= ctx->index.prgs.size()) return DRPRG_EINVAL;
+    const LocalGraph& g = ctx->index.prgs[prg];
+    for (uint32_t i = 0; i < g.nodes.size() && i < cap; ++i) {
+        if (starts) starts[i] = g.nodes[i].start;
+        if (ends) ends[i] = g.nodes[i].end;
+    }
+    if (n_nodes) *n_nodes = (uint32_t)g.nodes.size();
+    if (n_sites) *n_sites = (uint32_t)g.sites.size();
+    return DRPRG_OK;
+}
+
 int drprg_hip_kernel_timing(drprg_hip_ctx* ctx, int enable, int reset, double* ms_total, uint64_t* launches)
 {
     API_BEGIN(ctx)

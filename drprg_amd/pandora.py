@@ -132,6 +132,15 @@ class Context:
         return dict(keys=keys, rec_off=rec_off, rec_prg=rec_prg, rec_knode=rec_knode, rec_strand=rec_strand,
                     min_path_len=min_path_len, knode_base=knode_base)
 
+    def prg_nodes(self, prg):
+        """(starts, ends, n_sites) of the local graph of PRG `prg`"""
+        n, ns = C.c_uint32(), C.c_uint32()
+        _check(lib.drprg_hip_prg_nodes(self._h, prg, None, None, 0, C.byref(n), C.byref(ns)), self._h)
+        starts = np.zeros(n.value, dtype=np.uint32)
+        ends = np.zeros(n.value, dtype=np.uint32)
+        _check(lib.drprg_hip_prg_nodes(self._h, prg, _ptr(starts), _ptr(ends), n.value, C.byref(n), C.byref(ns)), self._h)
+        return starts, ends, int(ns.value)
+
     def kernel_timing(self, enable=True, reset=False):
         ms, n = C.c_double(), C.c_uint64()
         _check(lib.drprg_hip_kernel_timing(self._h, 1 if enable else 0, 1 if reset else 0, C.byref(ms), C.byref(n)), self._h)

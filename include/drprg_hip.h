@@ -89,6 +89,12 @@ int drprg_hip_index_sizes(const drprg_hip_ctx* ctx, uint64_t sizes[5]);
 int drprg_hip_index_export(const drprg_hip_ctx* ctx, uint64_t* keys, uint32_t* rec_off, uint32_t* rec_prg,
     uint32_t* rec_knode, uint8_t* rec_strand, uint32_t* prg_min_path_len, uint32_t* prg_knode_base);
 
+/* Local-graph introspection of PRG `prg` (node intervals are offsets into the PRG string, markers and their
+ * spaces included: the convention of pandora's denovo_paths.txt, /root/reference/src/lib.rs:3015-3023).
+ * Writes up to cap node [start,end) pairs; *n_nodes receives the node count, *n_sites the site count. */
+int drprg_hip_prg_nodes(const drprg_hip_ctx* ctx, uint32_t prg, uint32_t* starts, uint32_t* ends, uint32_t cap,
+    uint32_t* n_nodes, uint32_t* n_sites);
+
 /* HIP-event timing of the sketch+probe kernel on the launch stream (bench.py roofline).
  * enable != 0 starts/keeps timing; ms_total / launches may be NULL; reset != 0 clears the sums. */
 int drprg_hip_kernel_timing(drprg_hip_ctx* ctx, int enable, int reset, double* ms_total, uint64_t* launches);

@@ -1,0 +1,86 @@
+"""N>1 path on CPU: two gloo ranks shard the reads, reduce the coverage vector, genotype on rank 0.
+
+The device mapping itself cannot run here (no GPU, no CPU fallback), so each rank fills its shard's
+coverage with the test oracle; what is under test is the product's sharding + reduce + set_coverage +
+genotype plumbing (drprg_amd/distributed.py), i.e. that the N-rank result equals the 1-rank result."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+
+from util import ROOT, cluster_fraction, map_params
+
+WORKER = textwrap.dedent("""
+    import os, sys
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+    from util import Oracle, cluster_fraction, map_params
+    from drprg_amd import Context, synth
+    from drprg_amd.distributed import shard_batch, reduce_coverage
+
+    out = sys.argv[1]
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    w, k = 11, 15
+    panel = synth.small_panel(seed=21)
+    prg, genes = os.path.join(out, f"dr{{rank}}.prg"), os.path.join(out, f"genes{{rank}}.fa")
+    panel.write(prg, genes)
+    ctx = Context(prg, w, k, device=-1, from_files=False)
+    ctx.set_opts(illumina=True, genome_size=20000)
+    gen = synth.HaplotypeGenomes(panel, genome_size=20000, n_hap=4, seed=3)
+    bases, offs = synth.sample_short_reads(gen, 5001, seed=9)       # odd count: uneven shards
+    b, o = shard_batch(bases, offs, rank, world)
+    md, er = map_params(k, True)
+    covg, prg_reads, _ = Oracle().map_reads(b, o, ctx.export_index(), w, k, md, cluster_fraction(er, k), 10)
+    tc = torch.from_numpy(covg.view(np.int32).copy())
+    tp = torch.from_numpy(prg_reads.view(np.int32).copy())
+    total = reduce_coverage(tc, tp, int(o[-1]))
+    if rank == 0:
+        ctx.set_coverage(tc.numpy().view(np.uint32), tp.numpy().view(np.uint32), total)
+        ctx.genotype(genes, os.path.join(out, "multi.vcf"))
+        np.save(os.path.join(out, "multi_covg.npy"), tc.numpy().view(np.uint32))
+    dist.barrier()
+    dist.destroy_process_group()
+""")
+
+
+def test_shard_range_partitions():
+    from drprg_amd.distributed import shard_range
+    for n in (0, 1, 7, 100, 10_000_001):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_two_rank_reduce_equals_single_rank(tmp_path, oracle):
+    from drprg_amd import Context, synth
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29533", str(script), str(tmp_path)],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    # single-process reference on the whole batch
+    w, k = 11, 15
+    panel = synth.small_panel(seed=21)
+    prg, genes = str(tmp_path / "dr.prg"), str(tmp_path / "genes.fa")
+    panel.write(prg, genes)
+    ctx = Context(prg, w, k, device=-1, from_files=False)
+    ctx.set_opts(illumina=True, genome_size=20000)
+    gen = synth.HaplotypeGenomes(panel, genome_size=20000, n_hap=4, seed=3)
+    bases, offs = synth.sample_short_reads(gen, 5001, seed=9)
+    md, er = map_params(k, True)
+    covg, prg_reads, _ = oracle.map_reads(bases, offs, ctx.export_index(), w, k, md, cluster_fraction(er, k), 10)
+    assert np.array_equal(np.load(tmp_path / "multi_covg.npy"), covg)
+    ctx.set_coverage(covg, prg_reads, int(offs[-1]))
+    ctx.genotype(genes, str(tmp_path / "single.vcf"))
+    strip = lambda p: [l for l in open(p) if not l.startswith("##fileDate")]
+    assert strip(tmp_path / "multi.vcf") == strip(tmp_path / "single.vcf")

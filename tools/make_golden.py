@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/ from the reference's own fixtures (run in the build container only; the GPU box
+has no /root/reference).  Everything written is data: known-answer vectors extracted from the
+reference's test VCFs and verbatim copies of small data files its tests hold.
+
+  likelihood_kat.tsv       one row per allele of every record of the seven pandora VCFs under
+                           /root/reference/tests/cases/predict/ (SURVEY.md section 8c): inputs
+                           (exp_depth_covg e, MEAN_FWD, MEAN_REV, GAPS per allele) -> expected LIKELIHOOD,
+                           GT, GT_CONF.  Three hand-assembled records are flagged `excluded`.
+  stats_kat.tsv            MEAN/MED/SUM consistency vectors (integer-mean rule) from the same records
+  pandora_vcf_surface/     header of ERR4796933.pandora.vcf (the raw pandora output format)
+  prg_syntax/dr.prg        /root/reference/tests/cases/expected/dr.prg (PRG-string syntax, 2 loci)
+  denovo_paths_example.txt the denovo_paths.txt embedded in /root/reference/src/lib.rs:3010-3038
+  downstream/              in*.vcf -> out*.vcf -> expected*.json pairs + the test index files, for the
+                           annotate/report stage (SURVEY.md section 8f NEXT-1)
+"""
+import os
+import re
+import shutil
+
+REF = "/root/reference"
+PRED = os.path.join(REF, "tests/cases/predict")
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+# exp_depth_covg per file: read off all-zero records (L = -2e) where present, else least squares
+E = {"in.vcf": 96, "in2.vcf": 238, "in3.vcf": 241, "in4.vcf": 73, "ERR4796933.pandora.vcf": 72, "SRR6824468.vcf": 248,
+     "ERR2510634.drprg.vcf": 17}
+# hand-assembled records of the reference fixtures that do not satisfy pandora's own arithmetic
+EXCLUDED = {("in.vcf", "katG", "1044"), ("in.vcf", "ddn", "627"), ("in4.vcf", "fabG1", "92")}
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    rows, stats = [], []
+    for fname, e in E.items():
+        for line in open(os.path.join(PRED, fname)):
+            if line.startswith("#"):
+                continue
+            t = line.rstrip("\n").split("\t")
+            fmt = dict(zip(t[8].split(":"), t[9].split(":")))
+            excl = int((fname, t[0], t[1]) in EXCLUDED)
+            gt = fmt["GT"]
+            na = len(fmt["MEAN_FWD_COVG"].split(","))
+            for a in range(na):
+                g = lambda key: fmt[key].split(",")[a]
+                rows.append([fname, t[0], t[1], str(e), str(na), str(a), g("MEAN_FWD_COVG"), g("MEAN_REV_COVG"), g("GAPS"),
+                             g("LIKELIHOOD"), gt, fmt["GT_CONF"], str(excl)])
+                stats.append([fname, t[0], t[1], str(a), g("MEAN_FWD_COVG"), g("MEAN_REV_COVG"), g("MED_FWD_COVG"),
+                              g("MED_REV_COVG"), g("SUM_FWD_COVG"), g("SUM_REV_COVG"), g("GAPS"), str(excl)])
+    with open(os.path.join(OUT, "likelihood_kat.tsv"), "w") as fh:
+        fh.write("#file\tchrom\tpos\te\tn_alleles\tallele\tmean_fwd\tmean_rev\tgaps\tlikelihood\tgt\tgt_conf\texcluded\n")
+        for r in rows:
+            fh.write("\t".join(r) + "\n")
+    with open(os.path.join(OUT, "stats_kat.tsv"), "w") as fh:
+        fh.write("#file\tchrom\tpos\tallele\tmean_fwd\tmean_rev\tmed_fwd\tmed_rev\tsum_fwd\tsum_rev\tgaps\texcluded\n")
+        for r in stats:
+            fh.write("\t".join(r) + "\n")
+
+    os.makedirs(os.path.join(OUT, "pandora_vcf_surface"), exist_ok=True)
+    with open(os.path.join(OUT, "pandora_vcf_surface", "header.vcf"), "w") as fh:
+        for line in open(os.path.join(PRED, "ERR4796933.pandora.vcf")):
+            if line.startswith("#"):
+                fh.write(line)
+    shutil.copy(os.path.join(PRED, "ERR4796933.pandora.vcf"), os.path.join(OUT, "pandora_vcf_surface", "ERR4796933.pandora.vcf"))
+
+    os.makedirs(os.path.join(OUT, "prg_syntax"), exist_ok=True)
+    shutil.copy(os.path.join(REF, "tests/cases/expected/dr.prg"), os.path.join(OUT, "prg_syntax", "dr.prg"))
+
+    src = open(os.path.join(REF, "src/lib.rs")).read()
+    m = re.search(r'fn test_list_prgs_with_novel_variants\(\) \{\s*let contents = r"(.*?)"\.to_string', src, re.S)
+    if m:
+        with open(os.path.join(OUT, "denovo_paths_example.txt"), "w") as fh:
+            fh.write(m.group(1))
+
+    ds = os.path.join(OUT, "downstream")
+    os.makedirs(ds, exist_ok=True)
+    for f in sorted(os.listdir(PRED)):
+        shutil.copy(os.path.join(PRED, f), os.path.join(ds, f))
+    for f in os.listdir(ds):
+        os.chmod(os.path.join(ds, f), 0o644)
+    for d, _, fs in os.walk(OUT):
+        for f in fs:
+            os.chmod(os.path.join(d, f), 0o644)
+    print(f"wrote {len(rows)} likelihood rows to {OUT}")
+
+
+if __name__ == "__main__":
+    main()
