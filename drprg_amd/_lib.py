@@ -21,6 +21,7 @@ class MapOpts(C.Structure):
         ("illumina", C.c_int32),
         ("genome_size", C.c_uint64),
         ("genotyping_error_rate", C.c_double),
+        ("kernel", C.c_int32),
     ]
 
 

@@ -50,6 +50,7 @@ static void apply_defaults(MapParams& p, const drprg_hip_map_opts* o)
     p.min_cluster_size = o ? o->min_cluster_size : 10;
     p.genome_size = (o && o->genome_size) ? o->genome_size : 5000000;
     p.genotyping_error_rate = (o && o->genotyping_error_rate > 0) ? o->genotyping_error_rate : 0.01;
+    p.kernel_mode = o ? o->kernel : 0;
 }
 
 extern "C" {

@@ -104,6 +104,33 @@ void PrgIndex::flatten()
         f.slot_off[s] = f.rec_off[i];
         f.slot_cnt[s] = f.rec_off[i + 1] - f.rec_off[i];
     }
+    // Bloom filter of index k-mer codes for the LDS-prefiltered sketch kernel
+    constexpr uint32_t MAX_WBITS = 14; // 16384 words = 64 KB of LDS
+    const size_t entries = 2 * recs.size();
+    if (k <= 15 && entries > 0 && entries <= 3 * (size_t(1) << MAX_WBITS)) {
+        uint32_t wbits = 8;
+        while (wbits < MAX_WBITS && (size_t(1) << wbits) * 5 < entries * 4) ++wbits; // <= 1.25 entries per word
+        f.bloom_wbits = wbits;
+        f.bloom.assign(size_t(1) << wbits, 0);
+        auto add = [&](uint32_t code) {
+            const uint32_t h = code * 0x9E3779B1u;
+            f.bloom[h >> (32 - wbits)] |= (1u << (h & 31)) | (1u << ((h >> 5) & 31));
+        };
+        for (size_t p = 0; p < prgs.size(); ++p) {
+            const auto& nodes = kgs[p].nodes;
+            for (size_t i = 1; i + 1 < nodes.size(); ++i) {
+                const std::string s = kpath_sequence(prgs[p], nodes[i].path);
+                uint32_t fw = 0, rc = 0;
+                for (int j = 0; j < k; ++j) {
+                    const uint32_t c = (uint32_t)nt4((unsigned char)s[(size_t)j]);
+                    fw = (fw << 2) | c;
+                    rc = (rc >> 2) | ((3 - c) << (2 * (k - 1)));
+                }
+                add(fw);
+                add(rc);
+            }
+        }
+    }
 }
 
 void PrgIndex::save(const std::string& prg_file) const

@@ -78,6 +78,9 @@ struct ClusterArgs {
 uint32_t sketch_tile_eval(int halo);
 uint32_t sketch_n_tiles(uint64_t n_bases, int halo);
 hipError_t launch_sketch_probe(const SketchArgs& a, bool wide_hash, hipStream_t stream);
+// filtered form (k <= 15, w <= 16): bloom = 2^bloom_wbits words of index k-mer codes
+uint32_t filter_n_tiles(uint64_t n_bases);
+hipError_t launch_sketch_filter(const SketchArgs& a, const uint32_t* bloom, uint32_t bloom_wbits, int n_cus, hipStream_t stream);
 size_t sort_temp_bytes(uint32_t n);
 size_t scan_temp_bytes(uint32_t n);
 hipError_t sort_hits(void* temp, size_t temp_bytes, const uint64_t* key_in, uint64_t* key_out, const uint32_t* val_in,

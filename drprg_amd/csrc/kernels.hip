@@ -81,12 +81,13 @@ __device__ inline uint32_t encode_base(uint32_t c)
 __device__ inline uint32_t encode4(uint32_t word)
 {
     const uint32_t u = word & 0xDFDFDFDFu; // upper case
-    uint32_t x = (u >> 1) & 0x03030303u;
-    x ^= (x >> 1) & 0x01010101u;
-    // bit 7 of nz(v) is set in every non-zero byte of v (exact, no carry between bytes)
-    auto nz = [](uint32_t v) { return ((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v; };
-    const uint32_t bad = nz(u ^ 0x41414141u) & nz(u ^ 0x43434343u) & nz(u ^ 0x47474747u) & nz(u ^ 0x54545454u) & 0x80808080u;
-    return x | (bad >> 5); // 0x80 >> 5 = 4: the "not ACGT" flag
+    const uint32_t sel = (u >> 1) & 0x03030303u; // A0 C1 T2 G3: a byte-wise index into two 4-entry tables
+    // v_perm_b32 as a 4-entry byte LUT: selector bytes 0..3 pick bytes of the second operand
+    const uint32_t code = __builtin_amdgcn_perm(0u, 0x02030100u, sel);   // -> A0 C1 G2 T3
+    const uint32_t expect = __builtin_amdgcn_perm(0u, 0x47544341u, sel); // the letter that index stands for
+    const uint32_t diff = u ^ expect; // a byte is a valid base iff it equals the letter of its index
+    const uint32_t bad = (((diff & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | diff) & 0x80808080u; // bit 7 set in every non-zero byte
+    return code | (bad >> 5); // 0x80 >> 5 = 4: the "not ACGT" flag
 }
 
 // read holding global base position gp, searched upwards from read `lo` (offsets[lo] <= gp)
@@ -347,6 +348,279 @@ __global__ __launch_bounds__(SK_THREADS) void sketch_probe_kernel(SketchArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
+// K1 + K2, filtered form: persistent workgroups + LDS Bloom prefilter on k-mer codes
+// ---------------------------------------------------------------------------------------------
+// A read minimizer can only produce a hit if its k-mer is an index k-mer (either orientation).  So instead of
+// hashing every k-mer, each position's 2-bit code is tested against a Bloom filter of the index k-mer codes that
+// lives in LDS for the lifetime of a persistent workgroup; only candidates get the exact treatment: canonical hash,
+// exact table lookup, and -- for true index k-mers -- the window-minimizer test over the 2w-1 neighbouring hashes.
+// Results are identical to sketch_probe_kernel (the Bloom filter has no false negatives); k <= 15, w <= 16.
+constexpr int FT_THREADS = 512;
+constexpr int FT_G = 16;
+constexpr int FT_NPOS = FT_THREADS * FT_G;   // 8192 positions per tile
+constexpr int FT_HALO = 16;                  // >= w-1
+constexpr int FT_EVAL = FT_NPOS - 2 * FT_HALO;
+constexpr int FT_CODES = FT_NPOS + 48;       // staged bases
+constexpr int FT_WORDS = FT_CODES / 16;      // 515 packed words
+constexpr int FT_CAND_CAP = FT_THREADS;      // one candidate per thread per round
+constexpr int FT_VER_HITS = 32;              // hits verified per pass
+constexpr int FT_VER_W = 31;                 // 2*16-1 neighbour slots
+
+__global__ void tile_first_read_ft_kernel(const uint64_t* __restrict__ offsets, uint32_t n_reads, uint32_t n_tiles,
+    uint32_t* __restrict__ out)
+{
+    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_tiles) return;
+    int64_t lo_pos = (int64_t)b * FT_EVAL - FT_HALO;
+    if (lo_pos < 0) lo_pos = 0;
+    uint32_t lo = 0, hi = n_reads;
+    while (lo < hi) {
+        uint32_t mid = lo + ((hi - lo) >> 1);
+        if ((int64_t)offsets[mid] < lo_pos) lo = mid + 1; else hi = mid;
+    }
+    out[b] = lo;
+}
+
+// 16 ASCII bases -> 32-bit packed 2-bit codes (first base in the top bits) + 16-bit "not ACGT" mask (bit i = base i)
+__device__ inline void pack16(const uint4& in, uint32_t& packed, uint32_t& nmask)
+{
+    const uint32_t e0 = encode4(in.x), e1 = encode4(in.y), e2 = encode4(in.z), e3 = encode4(in.w);
+    // gather the four 2-bit fields of a dword into one byte, first base highest: (x * 0x40100401) >> 24
+    const uint32_t p0 = ((e0 & 0x03030303u) * 0x40100401u) >> 24, p1 = ((e1 & 0x03030303u) * 0x40100401u) >> 24;
+    const uint32_t p2 = ((e2 & 0x03030303u) * 0x40100401u) >> 24, p3 = ((e3 & 0x03030303u) * 0x40100401u) >> 24;
+    packed = (p0 << 24) | (p1 << 16) | (p2 << 8) | p3;
+    nmask = 0;
+    if ((e0 | e1 | e2 | e3) & 0x04040404u) { // rare
+        // (flags * 0x01020408) >> 24 gathers the flag of byte i into bit i
+        auto m4 = [](uint32_t e) { return ((((e >> 2) & 0x01010101u) * 0x01020408u) >> 24) & 0xFu; };
+        nmask = m4(e0) | (m4(e1) << 4) | (m4(e2) << 8) | (m4(e3) << 12);
+    }
+}
+
+// reverse complement of a k-mer code (2 bits per base, k <= 16)
+__device__ inline uint32_t revcomp_code(uint32_t f, int k)
+{
+    uint32_t x = __brev(f);                                    // bit reversal also swaps the two bits of every base
+    x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);   // swap them back
+    return (~x) >> (32 - 2 * k);                               // complement, right-align
+}
+
+struct FtShared {
+    uint32_t pack[FT_WORDS + 1];
+    uint16_t nmask[FT_WORDS + 1];
+    uint32_t start[(FT_CODES + 31) / 32 + 1]; // bit per staged base: a read starts here
+    uint16_t cand[FT_CAND_CAP];
+    uint32_t hit_slot[FT_CAND_CAP];
+    uint16_t hit_pos[FT_CAND_CAP]; // bit 15 = strand of the read k-mer
+    uint32_t ver[FT_VER_HITS][FT_VER_W];
+    uint32_t ncand, nhit;
+};
+
+__global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a, const uint32_t* __restrict__ bloom,
+    uint32_t bloom_wbits, uint32_t n_tiles)
+{
+    using Tr = HashTraits<uint32_t>;
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_bloom[];
+    __shared__ FtShared sh;
+
+    const int tid = threadIdx.x;
+    const int k = a.k, w = a.w;
+    const uint32_t kmask = (1u << (2 * k)) - 1;
+    const uint32_t kbits = (1u << k) - 1; // k consecutive base flags
+    const int64_t n_bases = (int64_t)a.n_bases;
+    const uint32_t tmask = (1u << a.table_bits) - 1;
+    const uint32_t* __restrict__ slot_key = reinterpret_cast<const uint32_t*>(a.slot_key);
+    const int base0 = tid * FT_G;
+
+    for (uint32_t i = tid; i < (1u << bloom_wbits); i += FT_THREADS) s_bloom[i] = bloom[i];
+
+    auto load_tile = [&](uint32_t tile, uint4& main, uint4& extra) {
+        const int64_t origin = (int64_t)tile * FT_EVAL - FT_HALO;
+        auto ld = [&](int v) -> uint4 {
+            const int64_t g = origin + (int64_t)v * 16;
+            if (g >= 0 && g + 16 <= n_bases) return *reinterpret_cast<const uint4*>(a.bases + g);
+            uint32_t t4[4];
+            for (int q = 0; q < 4; ++q) {
+                uint32_t wd = 0;
+                for (int b = 0; b < 4; ++b) {
+                    const int64_t gg = g + q * 4 + b;
+                    wd |= (uint32_t)((gg >= 0 && gg < n_bases) ? a.bases[gg] : (uint8_t)'N') << (8 * b);
+                }
+                t4[q] = wd;
+            }
+            return make_uint4(t4[0], t4[1], t4[2], t4[3]);
+        };
+        main = ld(tid);
+        if (tid < FT_WORDS - FT_THREADS) extra = ld(FT_THREADS + tid);
+    };
+
+    // k-mer at tile position p: g = canonical hash + 1, or 0 if it holds an N or straddles two reads
+    auto kmer_at = [&](int p, uint32_t& f_out, bool& strand) -> uint32_t {
+        const int v = p >> 4, o = p & 15;
+        const uint32_t f = __funnelshift_l(sh.pack[v + 1], sh.pack[v], 2 * o) >> (32 - 2 * k);
+        f_out = f;
+        const uint32_t nm = (uint32_t)sh.nmask[v] | ((uint32_t)sh.nmask[v + 1] << 16);
+        if ((nm >> o) & kbits) return 0;
+        const int q = p + 1; // read starts at p+1 .. p+k-1 split the k-mer
+        const uint32_t st = __funnelshift_r(sh.start[q >> 5], sh.start[(q >> 5) + 1], q & 31);
+        if (st & (kbits >> 1)) return 0;
+        const uint32_t hf = Tr::mix(f, kmask), hr = Tr::mix(revcomp_code(f, k), kmask);
+        strand = hf <= hr;
+        return (hf < hr ? hf : hr) + 1;
+    };
+
+    uint4 cur = make_uint4(0, 0, 0, 0), cur_x = cur, nxt = cur, nxt_x = cur;
+    uint32_t tile = blockIdx.x;
+    if (tile < n_tiles) load_tile(tile, cur, cur_x);
+    __syncthreads(); // bloom filter in place
+
+    for (; tile < n_tiles; tile += gridDim.x) {
+        const int64_t origin = (int64_t)tile * FT_EVAL - FT_HALO;
+        const uint32_t first_read = a.tile_first_read[tile];
+        const uint32_t next_tile = tile + gridDim.x;
+
+        // ---- pack this tile into LDS ----
+        {
+            uint32_t pk, nm;
+            pack16(cur, pk, nm);
+            sh.pack[tid] = pk;
+            sh.nmask[tid] = (uint16_t)nm;
+            if (tid < FT_WORDS - FT_THREADS) {
+                pack16(cur_x, pk, nm);
+                sh.pack[FT_THREADS + tid] = pk;
+                sh.nmask[FT_THREADS + tid] = (uint16_t)nm;
+            }
+            for (int i = tid; i < (FT_CODES + 31) / 32 + 1; i += FT_THREADS) sh.start[i] = 0;
+            if (tid == 0) {
+                sh.pack[FT_WORDS] = 0;
+                sh.nmask[FT_WORDS] = 0xFFFF;
+            }
+        }
+        __syncthreads();
+        {
+            const int64_t end_pos = origin + FT_CODES;
+            for (uint32_t r = first_read + tid; r < a.n_reads; r += FT_THREADS) {
+                const int64_t o = (int64_t)a.offsets[r];
+                if (o >= end_pos) break;
+                const int oc = (int)(o - origin);
+                atomicOr(&sh.start[oc >> 5], 1u << (oc & 31));
+            }
+        }
+        // prefetch: the next tile's bases stay in flight under the Bloom phase (issued after this tile's own
+        // offset loads, because vector-memory results return in issue order)
+        if (next_tile < n_tiles) load_tile(next_tile, nxt, nxt_x);
+        // ---- Bloom test of my 16 positions ----
+        uint32_t cand = 0;
+        if (base0 >= FT_HALO && base0 < FT_NPOS - FT_HALO) {
+            const uint32_t w0 = sh.pack[tid], w1 = sh.pack[tid + 1];
+            const int sh_k = 32 - 2 * k, sh_w = 32 - (int)bloom_wbits;
+#pragma unroll
+            for (int j = 0; j < FT_G; ++j) {
+                const uint32_t f = __funnelshift_l(w1, w0, 2 * j) >> sh_k;
+                const uint32_t hsh = f * 0x9E3779B1u;
+                const uint32_t word = s_bloom[hsh >> sh_w];
+                cand |= ((word >> (hsh & 31)) & (word >> ((hsh >> 5) & 31)) & 1u) << j;
+            }
+        }
+        // ---- rounds: compact candidates, exact lookup, window test, emit ----
+        while (true) {
+            if (tid == 0) {
+                sh.ncand = 0;
+                sh.nhit = 0;
+            }
+            __syncthreads(); // also orders the start bitmap before its first use
+            if (cand) {
+                const int j = __ffs(cand) - 1;
+                cand &= cand - 1;
+                sh.cand[atomicAdd(&sh.ncand, 1u)] = (uint16_t)(base0 + j);
+            }
+            const int more = __syncthreads_or(cand != 0);
+            const uint32_t ncand = sh.ncand;
+            // exact: is the candidate's canonical hash an index key?
+            if ((uint32_t)tid < ncand) {
+                const int p = sh.cand[tid];
+                uint32_t f;
+                bool strand = false;
+                const uint32_t g = kmer_at(p, f, strand);
+                if (g) {
+                    const uint32_t h = g - 1;
+                    uint32_t s = table_slot_dev((uint64_t)h, a.table_bits);
+                    bool found = false;
+                    while (true) {
+                        const uint32_t key = slot_key[s];
+                        if (key == h) { found = true; break; }
+                        if (key == Tr::EMPTY) break;
+                        s = (s + 1) & tmask;
+                    }
+                    if (found) {
+                        const uint32_t at = atomicAdd(&sh.nhit, 1u);
+                        sh.hit_slot[at] = s;
+                        sh.hit_pos[at] = (uint16_t)(p | (strand ? 0x8000 : 0));
+                    }
+                }
+            }
+            __syncthreads();
+            const uint32_t nhit = sh.nhit;
+            const int span = 2 * w - 1;
+            for (uint32_t c0 = 0; c0 < nhit; c0 += FT_VER_HITS) {
+                const uint32_t nchunk = nhit - c0 < (uint32_t)FT_VER_HITS ? nhit - c0 : (uint32_t)FT_VER_HITS;
+                for (uint32_t t = tid; t < nchunk * (uint32_t)span; t += FT_THREADS) {
+                    const uint32_t hi = t / (uint32_t)span;
+                    const int d = (int)(t - hi * span);
+                    const int p = (int)(sh.hit_pos[c0 + hi] & 0x7FFF) + d - (w - 1);
+                    uint32_t f;
+                    bool st;
+                    sh.ver[hi][d] = kmer_at(p, f, st);
+                }
+                __syncthreads();
+                if ((uint32_t)tid < nchunk) {
+                    const uint32_t* v = sh.ver[tid];
+                    const uint32_t g = v[w - 1];
+                    int got = 0;
+                    const int need = w - 1;
+                    for (int d = 1; d <= need; ++d) { // neighbours >= g on the left ...
+                        const uint32_t x = v[w - 1 - d];
+                        if (x == 0 || x < g) break;
+                        ++got;
+                    }
+                    for (int d = 1; got < need && d <= need; ++d) { // ... and on the right
+                        const uint32_t x = v[w - 1 + d];
+                        if (x == 0 || x < g) break;
+                        ++got;
+                    }
+                    if (got >= need) { // a window of w valid k-mers around p has no smaller hash: p is a minimizer
+                        const int p = sh.hit_pos[c0 + tid] & 0x7FFF;
+                        const uint32_t strand = sh.hit_pos[c0 + tid] >> 15;
+                        const uint2 rec = a.slot_rec[sh.hit_slot[c0 + tid]];
+                        const uint64_t gp = (uint64_t)(origin + p);
+                        const uint32_t read = find_read_from(a.offsets, a.n_reads, first_read ? first_read - 1 : 0, gp);
+                        const uint64_t pos = gp - a.offsets[read];
+                        const unsigned long long at = atomicAdd(a.n_hits, (unsigned long long)rec.y);
+                        atomicAdd(a.n_minimizers, 1ull);
+                        if (at + rec.y > a.hit_capacity || pos >= (1ull << HIT_POS_BITS)) {
+                            atomicOr(a.overflow, pos >= (1ull << HIT_POS_BITS) ? 2u : 1u);
+                        } else {
+                            for (uint32_t q = 0; q < rec.y; ++q) {
+                                const uint32_t kn = a.rec_knode[rec.x + q];
+                                const uint32_t prg = a.rec_prg[rec.x + q];
+                                const uint32_t rev = ((kn & 1u) == strand) ? 0u : 1u;
+                                a.hit_key[at + q] = pack_hit_key(read, prg, rev, (uint32_t)pos);
+                                a.hit_val[at + q] = kn >> 1;
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+            if (!more) break;
+        }
+        __syncthreads(); // everyone is done with this tile's LDS before it is overwritten
+        cur = nxt;
+        cur_x = nxt_x;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // K3: clustering on the sorted hit list
 // ---------------------------------------------------------------------------------------------
 // a hit opens a new cluster when read / prg / strand change or the read-position gap exceeds max_diff
@@ -501,6 +775,33 @@ hipError_t launch_sketch_probe(const SketchArgs& a, bool wide_hash, hipStream_t 
         hipLaunchKernelGGL((sketch_probe_kernel<uint32_t, 15, 14>), g, b, 0, stream, a);
     else
         hipLaunchKernelGGL((sketch_probe_kernel<uint32_t, 0, 0>), g, b, 0, stream, a);
+    return hipGetLastError();
+}
+
+uint32_t filter_n_tiles(uint64_t n_bases) { return (uint32_t)((n_bases + FT_EVAL - 1) / FT_EVAL); }
+
+hipError_t launch_sketch_filter(const SketchArgs& a, const uint32_t* bloom, uint32_t bloom_wbits, int n_cus, hipStream_t stream)
+{
+    if (a.n_bases == 0) return hipSuccess;
+    const uint32_t n_tiles = filter_n_tiles(a.n_bases);
+    hipLaunchKernelGGL(tile_first_read_ft_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, stream, a.offsets, a.n_reads,
+        n_tiles, a.tile_first_read);
+    HIP_TRY(hipGetLastError());
+    const size_t dyn = sizeof(uint32_t) << bloom_wbits;
+    static size_t configured = 0;
+    if (dyn > configured) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&sketch_filter_kernel),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+        configured = dyn;
+    }
+    // persistent grid: as many workgroups as stay resident (LDS-limited), never more than there are tiles
+    const size_t lds_per_wg = dyn + sizeof(FtShared) + 64;
+    uint32_t per_cu = (uint32_t)((160 * 1024) / lds_per_wg);
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 4) per_cu = 4;
+    uint32_t grid = (uint32_t)n_cus * per_cu;
+    if (grid > n_tiles) grid = n_tiles;
+    hipLaunchKernelGGL(sketch_filter_kernel, dim3(grid), dim3(FT_THREADS), dyn, stream, a, bloom, bloom_wbits, n_tiles);
     return hipGetLastError();
 }
 

@@ -40,6 +40,7 @@ Mapper::Mapper(const FlatIndex& idx, const MapParams& p, int device) : device_(d
     n_prgs_ = (uint32_t)idx.min_path_len.size();
     n_knodes_ = idx.total_knodes();
     table_bits_ = idx.table_bits;
+    bloom_wbits_ = idx.bloom_wbits;
     if (n_prgs_ > dev::MAX_PRGS) throw Error(DRPRG_EOVERFLOW, "more than " + std::to_string(dev::MAX_PRGS) + " PRGs");
     set_params(p);
 
@@ -77,6 +78,13 @@ Mapper::Mapper(const FlatIndex& idx, const MapParams& p, int device) : device_(d
     HIPCHK(hipMemcpy(d_rec_prg_, rp.data(), nrec * sizeof(uint16_t), hipMemcpyHostToDevice));
     dmalloc(d_min_path_len_, (size_t)n_prgs_);
     HIPCHK(hipMemcpy(d_min_path_len_, idx.min_path_len.data(), n_prgs_ * sizeof(uint32_t), hipMemcpyHostToDevice));
+    bloom_wbits_ = idx.bloom_wbits;
+    if (bloom_wbits_) {
+        dmalloc(d_bloom_, idx.bloom.size());
+        HIPCHK(hipMemcpy(d_bloom_, idx.bloom.data(), idx.bloom.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    HIPCHK(hipDeviceGetAttribute(&n_cus_, hipDeviceAttributeMultiprocessorCount, device_));
+    set_params(p); // again: the kernel choice depends on the filter being available
     dmalloc(d_covg_, 2 * (size_t)n_knodes_);
     dmalloc(d_prg_reads_, (size_t)n_prgs_);
     dmalloc(d_counters_, (size_t)C_N);
@@ -96,7 +104,7 @@ Mapper::~Mapper()
     dfree(d_key_a_); dfree(d_key_b_); dfree(d_val_a_); dfree(d_val_b_);
     dfree(d_head_); dfree(d_scan_); dfree(d_cstart_); dfree(d_order_); dfree(d_clusters_);
     if (d_temp_) (void)hipFree(d_temp_);
-    dfree(d_bases_); dfree(d_offsets_); dfree(d_tile_first_);
+    dfree(d_bases_); dfree(d_offsets_); dfree(d_tile_first_); dfree(d_bloom_);
     if (h_counters_) (void)hipHostFree(h_counters_);
     if (h_bases_) (void)hipHostFree(h_bases_);
     if (h_offsets_) (void)hipHostFree(h_offsets_);
@@ -112,6 +120,10 @@ void Mapper::set_params(const MapParams& p)
     params_ = p;
     wide_hash_ = p.k > 15;
     halo_ = std::max(16, ((p.w - 1 + 15) / 16) * 16);
+    const bool filter_ok = bloom_wbits_ != 0 && p.k <= 15 && p.w <= 16;
+    if (p.kernel_mode == 2 && !filter_ok)
+        throw Error(DRPRG_EINVAL, "the Bloom-prefiltered kernel needs k <= 15, w <= 16 and an index small enough for an LDS filter");
+    use_filter_ = p.kernel_mode == 2 || (p.kernel_mode == 0 && filter_ok);
 }
 
 void Mapper::reset_coverage()
@@ -145,7 +157,7 @@ void Mapper::run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32
     uint32_t* covg, uint32_t* prg_reads, hipStream_t stream)
 {
     ensure_workspace(std::max<uint64_t>(1u << 20, n_bases / 64));
-    const uint32_t n_tiles = dev::sketch_n_tiles(n_bases, halo_);
+    const uint32_t n_tiles = std::max(dev::sketch_n_tiles(n_bases, halo_), dev::filter_n_tiles(n_bases));
     if (n_tiles > tile_cap_) {
         dfree(d_tile_first_);
         tile_cap_ = n_tiles + n_tiles / 4 + 16;
@@ -175,7 +187,8 @@ void Mapper::run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32
         a.n_minimizers = &d_counters_[C_MINIMIZERS];
         a.overflow = reinterpret_cast<uint32_t*>(&d_counters_[C_OVERFLOW]);
         if (timing_) HIPCHK(hipEventRecord(ev0_, stream));
-        HIPCHK(dev::launch_sketch_probe(a, wide_hash_, stream));
+        if (use_filter_) HIPCHK(dev::launch_sketch_filter(a, d_bloom_, bloom_wbits_, n_cus_, stream));
+        else HIPCHK(dev::launch_sketch_probe(a, wide_hash_, stream));
         if (timing_) HIPCHK(hipEventRecord(ev1_, stream));
         HIPCHK(hipMemcpyAsync(h_counters_, d_counters_, C_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));

@@ -67,6 +67,10 @@ private:
     uint32_t* d_rec_knode_ = nullptr;
     uint16_t* d_rec_prg_ = nullptr;
     uint32_t* d_min_path_len_ = nullptr;
+    uint32_t* d_bloom_ = nullptr;
+    uint32_t bloom_wbits_ = 0;
+    int n_cus_ = 256;
+    bool use_filter_ = false;
     // accumulators
     uint32_t* d_covg_ = nullptr;
     uint32_t* d_prg_reads_ = nullptr;

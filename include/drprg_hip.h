@@ -34,6 +34,7 @@ typedef struct drprg_hip_map_opts {
     int32_t illumina;          /* -I */
     uint64_t genome_size;      /* -g (drprg passes 4411532) */
     double genotyping_error_rate; /* <=0: 0.01 */
+    int32_t kernel;            /* 0 auto; 1 direct sketch kernel; 2 Bloom-prefiltered kernel (k<=15, w<=16, small index) */
 } drprg_hip_map_opts;
 
 /* Replaces Pandora::index_with (`pandora index -t T -w W -k K <prg>`, /root/reference/src/lib.rs:479-510):

@@ -1,4 +1,7 @@
-"""HIP path vs CPU oracle, bit-exact, through the C ABI (pytest -m gpu)."""
+"""HIP path vs CPU oracle, bit-exact, through the C ABI (pytest -m gpu).
+
+Both forms of the sketch kernel are checked: kernel=1 is the direct sketch (every k-mer hashed), kernel=2 the
+persistent Bloom-prefiltered form (k <= 15, w <= 16); they must give the identical coverage vector."""
 import numpy as np
 import pytest
 
@@ -7,16 +10,16 @@ from util import cluster_fraction, map_params
 pytestmark = pytest.mark.gpu
 
 
-def _ctx(tmp_path, panel, w, k, illumina, genome_size=20000):
+def _ctx(tmp_path, panel, w, k, illumina, genome_size=20000, kernel=0):
     from drprg_amd import Context
     prg = str(tmp_path / "dr.prg")
     panel.write(prg, str(tmp_path / "genes.fa"))
     ctx = Context(prg, w, k, device=0, from_files=False)
-    ctx.set_opts(illumina=illumina, genome_size=genome_size)
+    ctx.set_opts(illumina=illumina, genome_size=genome_size, kernel=kernel)
     return ctx
 
 
-def _compare(ctx, oracle, bases, offsets, w, k, illumina):
+def _compare(ctx, oracle, bases, offsets, w, k, illumina, kernel):
     idx = ctx.export_index()
     md, er = map_params(k, illumina)
     ocov, oprg, ocnt = oracle.map_reads(bases, offsets, idx, w, k, md, cluster_fraction(er, k), 10)
@@ -24,7 +27,8 @@ def _compare(ctx, oracle, bases, offsets, w, k, illumina):
     ctx.map_host(bases, offsets)
     gcov, gprg = ctx.coverage()
     gcnt = ctx.counters()
-    assert gcnt["minimizers"] == ocnt["minimizers"]
+    if kernel == 1:  # the filtered kernel only counts the minimizers that are index keys
+        assert gcnt["minimizers"] == ocnt["minimizers"]
     assert gcnt["hits"] == ocnt["hits"]
     assert gcnt["clusters_kept"] == ocnt["clusters_kept"]
     assert gcnt["hits_kept"] == ocnt["hits_kept"]
@@ -33,38 +37,44 @@ def _compare(ctx, oracle, bases, offsets, w, k, illumina):
     return ocnt
 
 
-@pytest.mark.parametrize("w,k", [(11, 15), (14, 15), (5, 9), (19, 21), (1, 15), (11, 31)])
-def test_short_reads_bit_exact(tmp_path, oracle, w, k):
+CASES = [(11, 15, 1), (11, 15, 2), (14, 15, 1), (14, 15, 2), (5, 9, 1), (5, 9, 2), (16, 13, 2), (19, 21, 1), (1, 15, 1),
+         (1, 15, 2), (11, 31, 1)]
+
+
+@pytest.mark.parametrize("w,k,kernel", CASES)
+def test_short_reads_bit_exact(tmp_path, oracle, w, k, kernel):
     from drprg_amd import synth
     panel = synth.small_panel(seed=w * 100 + k)
-    ctx = _ctx(tmp_path, panel, w, k, True)
+    ctx = _ctx(tmp_path, panel, w, k, True, kernel=kernel)
     gen = synth.HaplotypeGenomes(panel, genome_size=20000, n_hap=4, seed=3)
     bases, offs = synth.sample_short_reads(gen, 20000, seed=5)
-    cnt = _compare(ctx, oracle, bases, offs, w, k, True)
+    cnt = _compare(ctx, oracle, bases, offs, w, k, True, kernel)
     assert cnt["clusters_kept"] > 0
 
 
-def test_long_reads_bit_exact(tmp_path, oracle):
+@pytest.mark.parametrize("kernel", [1, 2])
+def test_long_reads_bit_exact(tmp_path, oracle, kernel):
     from drprg_amd import synth
     panel = synth.small_panel(seed=11, n_loci=6, length=1500)
-    ctx = _ctx(tmp_path, panel, 11, 15, False)
+    ctx = _ctx(tmp_path, panel, 11, 15, False, kernel=kernel)
     gen = synth.HaplotypeGenomes(panel, genome_size=60000, n_hap=4, seed=3)
     bases, offs = synth.sample_long_reads(gen, 1500, seed=3)
-    cnt = _compare(ctx, oracle, bases, offs, 11, 15, False)
+    cnt = _compare(ctx, oracle, bases, offs, 11, 15, False, kernel)
     assert cnt["clusters_kept"] > 0
 
 
-def test_ragged_and_degenerate_inputs(tmp_path, oracle):
+@pytest.mark.parametrize("kernel", [1, 2])
+def test_ragged_and_degenerate_inputs(tmp_path, oracle, kernel):
     """empty reads, reads shorter than k, N runs, lower case, read boundaries at tile edges"""
     from drprg_amd import synth
     panel = synth.small_panel(seed=2)
-    ctx = _ctx(tmp_path, panel, 11, 15, True)
+    ctx = _ctx(tmp_path, panel, 11, 15, True, kernel=kernel)
     rng = np.random.default_rng(0)
     gen = synth.HaplotypeGenomes(panel, genome_size=20000, n_hap=2, seed=3)
     g = gen.haps[0]
     reads = []
-    for i in range(6000):
-        L = int(rng.choice([0, 1, 14, 15, 24, 25, 26, 40, 150, 151, 300, 4064, 4096, 5000]))
+    for i in range(12000):
+        L = int(rng.choice([0, 1, 14, 15, 24, 25, 26, 40, 150, 151, 300, 4064, 4096, 5000, 8160, 8192]))
         s = int(rng.integers(0, len(g) - L))
         r = g[s:s + L].copy()
         if L and rng.random() < 0.3:
@@ -75,13 +85,31 @@ def test_ragged_and_degenerate_inputs(tmp_path, oracle):
     offs = np.zeros(len(reads) + 1, np.uint64)
     offs[1:] = np.cumsum([len(r) for r in reads])
     bases = np.concatenate(reads)
-    _compare(ctx, oracle, bases, offs, 11, 15, True)
+    _compare(ctx, oracle, bases, offs, 11, 15, True, kernel)
     # empty batch and a batch of only empty reads
     ctx.reset()
     ctx.map_host(np.zeros(0, np.uint8), np.zeros(1, np.uint64))
     ctx.map_host(np.zeros(0, np.uint8), np.zeros(5, np.uint64))
     cov, _ = ctx.coverage()
     assert cov.sum() == 0
+
+
+def test_dense_panel_reads(tmp_path, oracle):
+    """amplicon-like input: every read lies in the panel, so almost every tile position is a Bloom candidate"""
+    from drprg_amd import synth
+    panel = synth.small_panel(seed=6, n_loci=3, length=900)
+    rng = np.random.default_rng(1)
+    reads = []
+    for i in range(6000):
+        hap = np.frombuffer(synth.sample_haplotype(rng, panel.trees[i % 3]).encode(), np.uint8)
+        s = int(rng.integers(0, len(hap) - 150))
+        reads.append(hap[s:s + 150])
+    offs = np.arange(len(reads) + 1, dtype=np.uint64) * np.uint64(150)
+    bases = np.concatenate(reads)
+    for kernel in (1, 2):
+        ctx = _ctx(tmp_path, panel, 11, 15, True, kernel=kernel)
+        cnt = _compare(ctx, oracle, bases, offs, 11, 15, True, kernel)
+        assert cnt["clusters_kept"] > 5000
 
 
 def test_batches_accumulate(tmp_path, oracle):
@@ -100,3 +128,10 @@ def test_batches_accumulate(tmp_path, oracle):
         ctx.map_host(b, o)
     three, _ = ctx.coverage()
     assert np.array_equal(one, three)
+
+
+def test_filter_kernel_refuses_unsupported_parameters(tmp_path):
+    from drprg_amd import DependencyError, synth
+    panel = synth.small_panel(seed=4)
+    with pytest.raises(DependencyError):
+        _ctx(tmp_path, panel, 11, 21, True, kernel=2)
