@@ -1,0 +1,94 @@
+// device_common.h -- device-side helpers shared by the kernels of the hot path (hash, base encoding, read lookup).
+#pragma once
+#include "kernels.h"
+#include <hip/hip_runtime.h>
+
+namespace drprg {
+namespace dev {
+
+#define HIP_TRY(x)                                                                                   \
+    do {                                                                                             \
+        hipError_t e_ = (x);                                                                         \
+        if (e_ != hipSuccess) return e_;                                                             \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// hash
+// ---------------------------------------------------------------------------------------------
+template <typename HT> struct HashTraits;
+template <> struct HashTraits<uint32_t> {
+    static constexpr uint32_t EMPTY = 0xFFFFFFFFu; // never a hash: this path serves k <= 15 (30 bits)
+    // minimap hash64 restricted to <= 30 bits: every intermediate is taken mod 2^(2k), so 32-bit
+    // arithmetic is exact; the final (key + key<<31) term vanishes below 31 bits.
+    __device__ static inline uint32_t mix(uint32_t key, uint32_t mask)
+    {
+        key = (~key + (key << 21)) & mask;
+        key = key ^ (key >> 24);
+        key = (key + (key << 3) + (key << 8)) & mask;
+        key = key ^ (key >> 14);
+        key = (key + (key << 2) + (key << 4)) & mask;
+        key = key ^ (key >> 28);
+        return key;
+    }
+};
+template <> struct HashTraits<uint64_t> {
+    static constexpr uint64_t EMPTY = ~0ULL; // k <= 31: hashes stay below 2^62
+    __device__ static inline uint64_t mix(uint64_t key, uint64_t mask)
+    {
+        key = (~key + (key << 21)) & mask;
+        key = key ^ (key >> 24);
+        key = (key + (key << 3) + (key << 8)) & mask;
+        key = key ^ (key >> 14);
+        key = (key + (key << 2) + (key << 4)) & mask;
+        key = key ^ (key >> 28);
+        key = (key + (key << 31)) & mask;
+        return key;
+    }
+};
+
+__device__ inline uint32_t table_slot_dev(uint64_t key, uint32_t bits)
+{
+    return (uint32_t)((key * 0x9E3779B97F4A7C15ULL) >> (64 - bits));
+}
+
+// ASCII -> code byte: bits 0-1 base (A0 C1 G2 T3), bit 2 = not ACGT
+__device__ inline uint32_t encode_base(uint32_t c)
+{
+    uint32_t u = c & 0xDFu; // upper case
+    uint32_t x = (u >> 1) & 3u;
+    x ^= x >> 1;
+    bool ok = (u == 'A') | (u == 'C') | (u == 'G') | (u == 'T');
+    return ok ? x : 4u;
+}
+// four bases at once (SWAR): same mapping on every byte of a dword
+__device__ inline uint32_t encode4(uint32_t word)
+{
+    const uint32_t u = word & 0xDFDFDFDFu; // upper case
+    const uint32_t sel = (u >> 1) & 0x03030303u; // A0 C1 T2 G3: a byte-wise index into two 4-entry tables
+    // v_perm_b32 as a 4-entry byte LUT: selector bytes 0..3 pick bytes of the second operand
+    const uint32_t code = __builtin_amdgcn_perm(0u, 0x02030100u, sel);   // -> A0 C1 G2 T3
+    const uint32_t expect = __builtin_amdgcn_perm(0u, 0x47544341u, sel); // the letter that index stands for
+    const uint32_t diff = u ^ expect; // a byte is a valid base iff it equals the letter of its index
+    const uint32_t bad = (((diff & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | diff) & 0x80808080u; // bit 7 set in every non-zero byte
+    return code | (bad >> 5); // 0x80 >> 5 = 4: the "not ACGT" flag
+}
+
+// read holding global base position gp, searched upwards from read `lo` (offsets[lo] <= gp)
+__device__ inline uint32_t find_read_from(const uint64_t* __restrict__ offsets, uint32_t n_reads, uint32_t lo, uint64_t gp)
+{
+    uint32_t step = 1, hi = lo + 1;
+    while (hi < n_reads && offsets[hi] <= gp) { // gallop
+        lo = hi;
+        step <<= 1;
+        hi = (n_reads - lo > step) ? lo + step : n_reads;
+    }
+    // invariant: offsets[lo] <= gp < offsets[hi]  (offsets[n_reads] = n_bases > gp)
+    while (hi - lo > 1) {
+        uint32_t mid = lo + ((hi - lo) >> 1);
+        if (offsets[mid] <= gp) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+} // namespace dev
+} // namespace drprg

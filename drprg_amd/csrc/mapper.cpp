@@ -85,6 +85,7 @@ Mapper::Mapper(const FlatIndex& idx, const MapParams& p, int device) : device_(d
     }
     HIPCHK(hipDeviceGetAttribute(&n_cus_, hipDeviceAttributeMultiprocessorCount, device_));
     set_params(p); // again: the kernel choice depends on the filter being available
+    dmalloc(d_raw_count_, (size_t)n_cus_ * 4 + 16);
     dmalloc(d_covg_, 2 * (size_t)n_knodes_);
     dmalloc(d_prg_reads_, (size_t)n_prgs_);
     dmalloc(d_counters_, (size_t)C_N);
@@ -104,7 +105,7 @@ Mapper::~Mapper()
     dfree(d_key_a_); dfree(d_key_b_); dfree(d_val_a_); dfree(d_val_b_);
     dfree(d_head_); dfree(d_scan_); dfree(d_cstart_); dfree(d_order_); dfree(d_clusters_);
     if (d_temp_) (void)hipFree(d_temp_);
-    dfree(d_bases_); dfree(d_offsets_); dfree(d_tile_first_); dfree(d_bloom_);
+    dfree(d_bases_); dfree(d_offsets_); dfree(d_tile_first_); dfree(d_bloom_); dfree(d_raw_count_);
     if (h_counters_) (void)hipHostFree(h_counters_);
     if (h_bases_) (void)hipHostFree(h_bases_);
     if (h_offsets_) (void)hipHostFree(h_offsets_);
@@ -187,7 +188,8 @@ void Mapper::run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32
         a.n_minimizers = &d_counters_[C_MINIMIZERS];
         a.overflow = reinterpret_cast<uint32_t*>(&d_counters_[C_OVERFLOW]);
         if (timing_) HIPCHK(hipEventRecord(ev0_, stream));
-        if (use_filter_) HIPCHK(dev::launch_sketch_filter(a, d_bloom_, bloom_wbits_, n_cus_, stream));
+        if (use_filter_)
+            HIPCHK(dev::launch_sketch_filter(a, d_bloom_, bloom_wbits_, n_cus_, d_key_b_, d_val_b_, hit_capacity_, d_raw_count_, stream));
         else HIPCHK(dev::launch_sketch_probe(a, wide_hash_, stream));
         if (timing_) HIPCHK(hipEventRecord(ev1_, stream));
         HIPCHK(hipMemcpyAsync(h_counters_, d_counters_, C_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
@@ -200,8 +202,16 @@ void Mapper::run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32
         }
         uint32_t ovf = (uint32_t)h_counters_[C_OVERFLOW];
         if (ovf & 2u) throw Error(DRPRG_EOVERFLOW, "a read is longer than 2^" + std::to_string(dev::HIT_POS_BITS) + " bases");
+        if (ovf & 4u) { // a workgroup's raw-hit slice of the filtered kernel was too small: double the workspace
+            if (attempt > 6) throw Error(DRPRG_EOVERFLOW, "raw-hit buffer overflow after regrow");
+            unsigned long long restored = last_minimizers_;
+            HIPCHK(hipMemcpyAsync(&d_counters_[C_MINIMIZERS], &restored, sizeof(restored), hipMemcpyHostToDevice, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            ensure_workspace(hit_capacity_ * 2);
+            continue;
+        }
         if (h_counters_[C_HITS] > hit_capacity_) {
-            if (attempt > 0) throw Error(DRPRG_EOVERFLOW, "hit buffer overflow after regrow");
+            if (attempt > 6) throw Error(DRPRG_EOVERFLOW, "hit buffer overflow after regrow");
             // undo the minimizer count of the aborted pass, grow, and re-run the sketch
             unsigned long long restored = last_minimizers_;
             HIPCHK(hipMemcpyAsync(&d_counters_[C_MINIMIZERS], &restored, sizeof(restored), hipMemcpyHostToDevice, stream));

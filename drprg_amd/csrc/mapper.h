@@ -68,6 +68,7 @@ private:
     uint16_t* d_rec_prg_ = nullptr;
     uint32_t* d_min_path_len_ = nullptr;
     uint32_t* d_bloom_ = nullptr;
+    uint32_t* d_raw_count_ = nullptr;
     uint32_t bloom_wbits_ = 0;
     int n_cus_ = 256;
     bool use_filter_ = false;
