@@ -114,7 +114,7 @@ void PrgIndex::flatten()
         f.bloom.assign(size_t(1) << wbits, 0);
         auto add = [&](uint32_t code) {
             const uint32_t h = code * 0x9E3779B1u;
-            f.bloom[h >> (32 - wbits)] |= (1u << (h & 31)) | (1u << ((h >> 5) & 31));
+            f.bloom[h >> (32 - wbits)] |= (1u << (h & 31)) | (1u << ((h >> 5) & 31)) | (1u << ((h >> 10) & 31));
         };
         for (size_t p = 0; p < prgs.size(); ++p) {
             const auto& nodes = kgs[p].nodes;

@@ -189,7 +189,7 @@ void Mapper::run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32
         a.overflow = reinterpret_cast<uint32_t*>(&d_counters_[C_OVERFLOW]);
         if (timing_) HIPCHK(hipEventRecord(ev0_, stream));
         if (use_filter_)
-            HIPCHK(dev::launch_sketch_filter(a, d_bloom_, bloom_wbits_, n_cus_, d_key_b_, d_val_b_, hit_capacity_, d_raw_count_, stream));
+            HIPCHK(dev::launch_sketch_filter(a, d_bloom_, bloom_wbits_, n_cus_, d_key_b_, d_val_b_, d_head_, hit_capacity_, d_raw_count_, stream));
         else HIPCHK(dev::launch_sketch_probe(a, wide_hash_, stream));
         if (timing_) HIPCHK(hipEventRecord(ev1_, stream));
         HIPCHK(hipMemcpyAsync(h_counters_, d_counters_, C_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));

@@ -16,6 +16,7 @@
 #include "device_common.h"
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 
 namespace drprg {
 namespace dev {
@@ -27,8 +28,8 @@ constexpr int FT_HALO = 16;                  // >= w-1
 constexpr int FT_EVAL = FT_NPOS - 2 * FT_HALO;
 constexpr int FT_CODES = FT_NPOS + 48;       // staged bases
 constexpr int FT_WORDS = FT_CODES / 16;      // 515 packed words
-constexpr int FT_CAND_CAP = 4 * FT_THREADS;  // up to four candidates per thread per round
-constexpr int FT_VER_HITS = 64;              // candidates verified per pass
+constexpr int FT_CAND_CAP = 2 * FT_THREADS;  // up to two candidates per thread per round
+constexpr int FT_VER_HITS = 32;              // candidates verified per pass
 constexpr int FT_VER_W = 31;                 // 2*16-1 neighbour slots
 constexpr int FT_START_WORDS = (FT_CODES + 31) / 32 + 1;
 
@@ -76,10 +77,15 @@ struct FtShared {
     uint16_t nmask[FT_WORDS + 1];
     uint32_t start[FT_START_WORDS]; // bit per staged base: a read starts here
     uint16_t cand[FT_CAND_CAP];
-    uint32_t ver[FT_VER_HITS][FT_VER_W];
     uint32_t ncand;
+    uint32_t more; // some thread still holds candidates for another round
     uint32_t nraw; // raw hits appended by this workgroup so far (may exceed its slice: overflow)
 };
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, which would stall every wave
+// on the next tile's prefetch (global loads still in flight on purpose); LDS operations of a wave complete in
+// order, so lgkmcnt(0) + s_barrier is enough for LDS visibility inside the workgroup.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 struct FilterArgs {
     const uint32_t* bloom;
@@ -87,8 +93,10 @@ struct FilterArgs {
     uint32_t n_tiles;
     uint64_t* raw_pos;   // [grid][raw_slice]: global base position | strand << 63
     uint32_t* raw_hash;  // canonical hash of the minimizer
+    uint32_t* raw_hint;  // a read at or before the one holding the position (start of the read search)
     uint32_t* raw_count; // [grid]
     uint32_t raw_slice;
+    uint32_t debug; // ablation switches for profiling (DRPRG_FT_DEBUG): 1 = skip the Bloom test, 2 = skip verification
 };
 
 __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a, FilterArgs fa)
@@ -146,6 +154,7 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
         return (hf < hr ? hf : hr) + 1;
     };
 
+    unsigned long long dbg_cands = 0;
     uint4 cur = make_uint4(0, 0, 0, 0), cur_x = cur, nxt = cur, nxt_x = cur;
     int64_t cur_off = INT64_MAX, nxt_off = INT64_MAX;
     uint32_t tile = blockIdx.x, first_read = 0;
@@ -197,7 +206,7 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
         }
         // ---- Bloom test of my 16 positions ----
         uint32_t cand = 0;
-        if (base0 >= FT_HALO && base0 < FT_NPOS - FT_HALO) {
+        if (!(fa.debug & 1u) && base0 >= FT_HALO && base0 < FT_NPOS - FT_HALO) {
             const uint32_t w0 = sh.pack[tid], w1 = sh.pack[tid + 1];
             const int sh_k = 32 - 2 * k, sh_w = 32 - (int)fa.bloom_wbits;
 #pragma unroll
@@ -205,17 +214,21 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
                 const uint32_t f = __funnelshift_l(w1, w0, 2 * j) >> sh_k;
                 const uint32_t hsh = f * 0x9E3779B1u;
                 const uint32_t word = s_bloom[hsh >> sh_w];
-                cand |= ((word >> (hsh & 31)) & (word >> ((hsh >> 5) & 31)) & 1u) << j;
+                cand |= ((word >> (hsh & 31)) & (word >> ((hsh >> 5) & 31)) & (word >> ((hsh >> 10) & 31)) & 1u) << j;
             }
         }
         // ---- rounds (almost always one): compact candidates, window test from LDS, append raw hits ----
         const int span = 2 * w - 1;
+        if (fa.debug & 2u) cand = 0;
         while (true) {
-            if (tid == 0) sh.ncand = 0;
-            __syncthreads(); // also orders the start bitmap before its first use
+            if (tid == 0) {
+                sh.ncand = 0;
+                sh.more = 0;
+            }
+            lds_barrier(); // also orders the start bitmap before its first use
             if (cand) {
                 int np = __popc(cand);
-                if (np > 4) np = 4;
+                if (np > 2) np = 2;
                 uint32_t at = atomicAdd(&sh.ncand, (uint32_t)np);
                 for (int i = 0; i < np; ++i) {
                     const int j = __ffs(cand) - 1;
@@ -223,49 +236,46 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
                     sh.cand[at++] = (uint16_t)(base0 + j);
                 }
             }
-            const int more = __syncthreads_or(cand != 0);
+            if (cand) sh.more = 1;
+            lds_barrier();
+            const uint32_t more = sh.more;
             const uint32_t ncand = sh.ncand;
-            for (uint32_t c0 = 0; c0 < ncand; c0 += FT_VER_HITS) {
-                const uint32_t nchunk = ncand - c0 < (uint32_t)FT_VER_HITS ? ncand - c0 : (uint32_t)FT_VER_HITS;
-                for (uint32_t t = tid; t < nchunk * (uint32_t)span; t += FT_THREADS) {
-                    const uint32_t hi = t / (uint32_t)span;
-                    const int d = (int)(t - hi * span);
-                    bool st;
-                    sh.ver[hi][d] = kmer_at((int)sh.cand[c0 + hi] + d - (w - 1), st);
-                }
-                __syncthreads();
-                if ((uint32_t)tid < nchunk) {
-                    const uint32_t* v = sh.ver[tid];
-                    const uint32_t g = v[w - 1];
-                    const int need = w - 1;
-                    int got = g ? 0 : -1000000;
-                    for (int d = 1; d <= need; ++d) { // neighbours >= g on the left ...
-                        const uint32_t x = v[w - 1 - d];
-                        if (x == 0 || x < g) break;
-                        ++got;
-                    }
-                    for (int d = 1; got < need && d <= need; ++d) { // ... and on the right
-                        const uint32_t x = v[w - 1 + d];
-                        if (x == 0 || x < g) break;
-                        ++got;
-                    }
-                    if (got >= need) { // a window of w valid k-mers around p has no smaller hash: p is a read minimizer
-                        const int p = sh.cand[c0 + tid];
-                        bool strand = false;
-                        (void)kmer_at(p, strand);
+            dbg_cands += ncand;
+            // Window test, half a wave per candidate: lane d of the half evaluates neighbour d (d = w-1 is the candidate
+            // itself); a ballot of "valid and >= the candidate's hash" gives the run of such neighbours on either side.
+            {
+                const int lane = tid & 63, half = lane >> 5, d = lane & 31;
+                for (uint32_t cb = (uint32_t)(tid >> 6) * 2; cb < ncand; cb += (FT_THREADS / 64) * 2) {
+                    const uint32_t c = cb + (uint32_t)half;
+                    const bool active = c < ncand && d < span;
+                    const int p = c < ncand ? (int)sh.cand[c] : FT_HALO;
+                    bool strand = false;
+                    const uint32_t g = active ? kmer_at(p + d - (w - 1), strand) : 0u;
+                    const uint32_t gc = (uint32_t)__shfl((int)g, half * 32 + (w - 1));
+                    const uint64_t ball = __ballot(active && g != 0 && g >= gc);
+                    const uint32_t m = half ? (uint32_t)(ball >> 32) : (uint32_t)ball;
+                    const uint32_t lmask = (1u << (w - 1)) - 1;       // bits 0 .. w-2: left neighbours, bit w-2 nearest
+                    const uint32_t lzero = ~m & lmask;
+                    const int left = lzero ? (w - 2) - (31 - __clz((int)lzero)) : (w - 1);
+                    const uint32_t rzero = ~(m >> w);                 // bit 0: nearest right neighbour
+                    int right = __ffs((int)rzero) - 1;
+                    if (right > w - 1) right = w - 1;
+                    // a window of w valid k-mers around p without a smaller hash exists: p is a read minimizer
+                    if (d == w - 1 && c < ncand && gc != 0 && left + right >= w - 1) {
                         const uint32_t idx = atomicAdd(&sh.nraw, 1u);
                         if (idx < fa.raw_slice) {
                             const size_t at = (size_t)blockIdx.x * fa.raw_slice + idx;
                             fa.raw_pos[at] = (uint64_t)(origin + p) | ((uint64_t)strand << 63);
                             fa.raw_hash[at] = g - 1;
+                            fa.raw_hint[at] = first_read ? first_read - 1 : 0;
                         }
                     }
                 }
-                __syncthreads();
             }
+            lds_barrier(); // the candidate list is reused by the next round
             if (!more) break;
         }
-        __syncthreads(); // everyone is done with this tile's LDS before it is overwritten
+        lds_barrier(); // everyone is done with this tile's LDS before it is overwritten
         cur = nxt;
         cur_x = nxt_x;
         cur_off = nxt_off;
@@ -273,48 +283,67 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
     }
     if (tid == 0) {
         fa.raw_count[blockIdx.x] = sh.nraw;
+        if (fa.debug & 4u) atomicAdd(a.n_minimizers, dbg_cands | ((unsigned long long)sh.nraw << 40));
         if (sh.nraw > fa.raw_slice) atomicOr(a.overflow, 4u);
     }
 }
 
-// raw hits -> hits: exact table lookup, read lookup, one (key,val) per index record
-__global__ void expand_hits_kernel(SketchArgs a, FilterArgs fa)
+// raw hits -> hits: exact table lookup, read lookup, one (key,val) per index record.
+// 1-D grid-stride over the concatenation of the workgroups' slices (prefix sums of raw_count kept in LDS).
+constexpr int EX_MAX_WG = 1024 + 16;
+__global__ __launch_bounds__(256) void expand_hits_kernel(SketchArgs a, FilterArgs fa, uint32_t n_wg)
 {
     using Tr = HashTraits<uint32_t>;
-    const uint32_t blk = blockIdx.y;
-    uint32_t n = fa.raw_count[blk];
-    if (n > fa.raw_slice) n = fa.raw_slice;
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const size_t at_raw = (size_t)blk * fa.raw_slice + i;
-    const uint64_t rp = fa.raw_pos[at_raw];
-    const uint32_t strand = (uint32_t)(rp >> 63);
-    const uint64_t gp = rp & ~(1ull << 63);
-    const uint32_t h = fa.raw_hash[at_raw];
+    __shared__ uint32_t s_prefix[EX_MAX_WG + 1];
+    if (threadIdx.x == 0) {
+        uint32_t acc = 0;
+        for (uint32_t b = 0; b < n_wg; ++b) {
+            s_prefix[b] = acc;
+            const uint32_t n = fa.raw_count[b];
+            acc += n < fa.raw_slice ? n : fa.raw_slice;
+        }
+        s_prefix[n_wg] = acc;
+    }
+    __syncthreads();
+    const uint32_t total = s_prefix[n_wg];
     const uint32_t* __restrict__ slot_key = reinterpret_cast<const uint32_t*>(a.slot_key);
     const uint32_t tmask = (1u << a.table_bits) - 1;
-    uint32_t s = table_slot_dev((uint64_t)h, a.table_bits);
-    while (true) {
-        const uint32_t key = slot_key[s];
-        if (key == h) break;
-        if (key == Tr::EMPTY) return; // a Bloom false positive
-        s = (s + 1) & tmask;
-    }
-    atomicAdd(a.n_minimizers, 1ull);
-    const uint2 rec = a.slot_rec[s];
-    const uint32_t read = find_read_from(a.offsets, a.n_reads, 0, gp);
-    const uint64_t pos = gp - a.offsets[read];
-    const unsigned long long at = atomicAdd(a.n_hits, (unsigned long long)rec.y);
-    if (at + rec.y > a.hit_capacity || pos >= (1ull << HIT_POS_BITS)) {
-        atomicOr(a.overflow, pos >= (1ull << HIT_POS_BITS) ? 2u : 1u);
-        return;
-    }
-    for (uint32_t q = 0; q < rec.y; ++q) {
-        const uint32_t kn = a.rec_knode[rec.x + q];
-        const uint32_t prg = a.rec_prg[rec.x + q];
-        const uint32_t rev = ((kn & 1u) == strand) ? 0u : 1u;
-        a.hit_key[at + q] = pack_hit_key(read, prg, rev, (uint32_t)pos);
-        a.hit_val[at + q] = kn >> 1;
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+        uint32_t lo = 0, hi = n_wg; // s_prefix[lo] <= t < s_prefix[hi]
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (s_prefix[mid] <= t) lo = mid; else hi = mid;
+        }
+        const size_t at_raw = (size_t)lo * fa.raw_slice + (t - s_prefix[lo]);
+        const uint64_t rp = fa.raw_pos[at_raw];
+        const uint32_t strand = (uint32_t)(rp >> 63);
+        const uint64_t gp = rp & ~(1ull << 63);
+        const uint32_t h = fa.raw_hash[at_raw];
+        uint32_t s = table_slot_dev((uint64_t)h, a.table_bits);
+        bool found = false;
+        while (true) {
+            const uint32_t key = slot_key[s];
+            if (key == h) { found = true; break; }
+            if (key == Tr::EMPTY) break; // a Bloom false positive
+            s = (s + 1) & tmask;
+        }
+        if (!found) continue;
+        atomicAdd(a.n_minimizers, 1ull);
+        const uint2 rec = a.slot_rec[s];
+        const uint32_t read = find_read_from(a.offsets, a.n_reads, fa.raw_hint[at_raw], gp);
+        const uint64_t pos = gp - a.offsets[read];
+        const unsigned long long at = atomicAdd(a.n_hits, (unsigned long long)rec.y);
+        if (at + rec.y > a.hit_capacity || pos >= (1ull << HIT_POS_BITS)) {
+            atomicOr(a.overflow, pos >= (1ull << HIT_POS_BITS) ? 2u : 1u);
+            continue;
+        }
+        for (uint32_t q = 0; q < rec.y; ++q) {
+            const uint32_t kn = a.rec_knode[rec.x + q];
+            const uint32_t prg = a.rec_prg[rec.x + q];
+            const uint32_t rev = ((kn & 1u) == strand) ? 0u : 1u;
+            a.hit_key[at + q] = pack_hit_key(read, prg, rev, (uint32_t)pos);
+            a.hit_val[at + q] = kn >> 1;
+        }
     }
 }
 
@@ -323,7 +352,8 @@ uint32_t filter_n_tiles(uint64_t n_bases) { return (uint32_t)((n_bases + FT_EVAL
 uint32_t filter_grid(uint32_t bloom_wbits, int n_cus, uint32_t n_tiles)
 {
     // persistent grid: as many workgroups as stay resident (LDS-limited), never more than there are tiles
-    const size_t lds_per_wg = (sizeof(uint32_t) << bloom_wbits) + sizeof(FtShared) + 64;
+    // (LDS is handed out in granules; leave a margin so that the resident count is not over-estimated)
+    const size_t lds_per_wg = (sizeof(uint32_t) << bloom_wbits) + sizeof(FtShared) + 2048;
     uint32_t per_cu = (uint32_t)((160 * 1024) / lds_per_wg);
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 4) per_cu = 4;
@@ -333,7 +363,7 @@ uint32_t filter_grid(uint32_t bloom_wbits, int n_cus, uint32_t n_tiles)
 }
 
 hipError_t launch_sketch_filter(const SketchArgs& a, const uint32_t* bloom, uint32_t bloom_wbits, int n_cus, uint64_t* raw_pos,
-    uint32_t* raw_hash, uint64_t raw_capacity, uint32_t* raw_count, hipStream_t stream)
+    uint32_t* raw_hash, uint32_t* raw_hint, uint64_t raw_capacity, uint32_t* raw_count, hipStream_t stream)
 {
     if (a.n_bases == 0) return hipSuccess;
     const uint32_t n_tiles = filter_n_tiles(a.n_bases);
@@ -354,11 +384,13 @@ hipError_t launch_sketch_filter(const SketchArgs& a, const uint32_t* bloom, uint
     fa.n_tiles = n_tiles;
     fa.raw_pos = raw_pos;
     fa.raw_hash = raw_hash;
+    fa.raw_hint = raw_hint;
     fa.raw_count = raw_count;
     fa.raw_slice = (uint32_t)std::min<uint64_t>(raw_capacity / grid, 0x7FFFFFFFull);
+    if (const char* dbg = std::getenv("DRPRG_FT_DEBUG")) fa.debug = (uint32_t)std::atoi(dbg);
     hipLaunchKernelGGL(sketch_filter_kernel, dim3(grid), dim3(FT_THREADS), dyn, stream, a, fa);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(expand_hits_kernel, dim3((fa.raw_slice + 255) / 256, grid), dim3(256), 0, stream, a, fa);
+    hipLaunchKernelGGL(expand_hits_kernel, dim3((uint32_t)n_cus * 8), dim3(256), 0, stream, a, fa, grid);
     return hipGetLastError();
 }
 
