@@ -151,6 +151,13 @@ def main():
         alg_bytes = n_bases + 8 * n_reads + table_bytes + 8 * ctx.n_knodes
         avg_ms = k_ms / max(k_launches, 1)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        kernel_name = {1: "sketch_probe_kernel", 2: "sketch_filter_kernel"}.get(ctx.counters().get("kernel"), "?")
+        # HBM bytes per launch of that kernel from rocprofv3 PMC counters (separate --pmc passes, FETCH_SIZE doubled as
+        # the microarch guide prescribes for wide coalesced loads on gfx950): measured offline, committed under profiles/
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")
+        if args.workload == "mtb" and n_reads == 10_000_000 and os.path.exists(tfile):
+            traffic = json.load(open(tfile)).get(kernel_name, {}).get("hbm_bytes_per_launch")
         out = {
             "metric": "reads/sec (+ achieved HBM GB/s) predicting on mtb index, 1/2/4/8 GPUs",
             "value": value,
@@ -173,8 +180,8 @@ def main():
                 "coverage_checksum": checksum,
             },
             "roofline": {
-                "bound": "hbm", "kernel": "sketch_probe_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
+                "bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": avg_ms, "launches_timed": k_launches,
             },
         }

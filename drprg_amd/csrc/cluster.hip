@@ -110,14 +110,35 @@ __global__ void cluster_filter_kernel(ClusterArgs a)
 }
 
 // per surviving cluster: pangraph node read count; per hit of a surviving cluster: coverage += 1
-__global__ void cluster_count_kernel(ClusterArgs a)
+// Only a few PRGs receive all the clusters, so per-cluster global atomics would serialise on a handful of
+// addresses: histogram in LDS, then one global atomic per touched PRG and per counter per workgroup.
+__global__ __launch_bounds__(256) void cluster_count_kernel(ClusterArgs a, uint32_t n_prgs)
 {
-    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= *a.d_n_clusters) return;
-    if (a.clusters[c].state == 0) return;
-    atomicAdd(&a.prg_reads[a.clusters[c].prg_rev >> 1], 1u);
-    atomicAdd(a.n_clusters_kept, 1ull);
-    atomicAdd(a.n_hits_kept, (unsigned long long)a.clusters[c].n);
+    __shared__ uint32_t s_prg[MAX_PRGS];
+    __shared__ uint32_t s_kept;
+    __shared__ unsigned long long s_hits;
+    const uint32_t n_clusters = *a.d_n_clusters;
+    const uint32_t per_wg = (n_clusters + gridDim.x - 1) / gridDim.x;
+    const uint32_t begin = blockIdx.x * per_wg;
+    const uint32_t end = begin + per_wg < n_clusters ? begin + per_wg : n_clusters;
+    if (begin >= end) return;
+    for (uint32_t i = threadIdx.x; i < n_prgs; i += blockDim.x) s_prg[i] = 0;
+    if (threadIdx.x == 0) { s_kept = 0; s_hits = 0; }
+    __syncthreads();
+    for (uint32_t c = begin + threadIdx.x; c < end; c += blockDim.x) {
+        const ClusterRec r = a.clusters[c];
+        if (r.state == 0) continue;
+        atomicAdd(&s_prg[r.prg_rev >> 1], 1u);
+        atomicAdd(&s_kept, 1u);
+        atomicAdd(&s_hits, (unsigned long long)r.n);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_prgs; i += blockDim.x)
+        if (s_prg[i]) atomicAdd(&a.prg_reads[i], s_prg[i]);
+    if (threadIdx.x == 0 && s_kept) {
+        atomicAdd(a.n_clusters_kept, (unsigned long long)s_kept);
+        atomicAdd(a.n_hits_kept, s_hits);
+    }
 }
 
 __global__ void accumulate_kernel(ClusterArgs a, uint32_t n_hits)
@@ -167,7 +188,7 @@ hipError_t launch_cluster_starts(const uint32_t* head, const uint32_t* scan, uin
     return hipGetLastError();
 }
 
-hipError_t launch_cluster_pipeline(const ClusterArgs& a, uint32_t n_hits, hipStream_t stream)
+hipError_t launch_cluster_pipeline(const ClusterArgs& a, uint32_t n_hits, uint32_t n_prgs, hipStream_t stream)
 {
     const int B = 128;
     dim3 gc((n_hits + B - 1) / B); // n_clusters <= n_hits; the true count is read on the device
@@ -175,7 +196,7 @@ hipError_t launch_cluster_pipeline(const ClusterArgs& a, uint32_t n_hits, hipStr
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(cluster_filter_kernel, gc, dim3(B), 0, stream, a);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(cluster_count_kernel, gc, dim3(B), 0, stream, a);
+    hipLaunchKernelGGL(cluster_count_kernel, dim3(256), dim3(256), 0, stream, a, n_prgs);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(accumulate_kernel, dim3((n_hits + 255) / 256), dim3(256), 0, stream, a, n_hits);
     return hipGetLastError();

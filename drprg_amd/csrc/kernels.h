@@ -75,16 +75,21 @@ struct ClusterArgs {
     unsigned long long* n_hits_kept;
 };
 
+// optional HIP events recorded on the launch stream immediately around the dominant kernel of a launch sequence
+struct KernelTimer {
+    hipEvent_t begin = nullptr, end = nullptr;
+};
+
 uint32_t sketch_tile_eval(int halo);
 uint32_t sketch_n_tiles(uint64_t n_bases, int halo);
-hipError_t launch_sketch_probe(const SketchArgs& a, bool wide_hash, hipStream_t stream);
+hipError_t launch_sketch_probe(const SketchArgs& a, bool wide_hash, hipStream_t stream, KernelTimer timer = {});
 // filtered form (k <= 15, w <= 16): bloom = 2^bloom_wbits words of index k-mer codes
 uint32_t filter_n_tiles(uint64_t n_bases);
 uint32_t filter_grid(uint32_t bloom_wbits, int n_cus, uint32_t n_tiles);
 // raw_pos / raw_hash: scratch of raw_capacity entries (split into one slice per workgroup); raw_count: one u32 per
 // workgroup (>= filter_grid entries).  Overflow bit 2 (value 4) in a.overflow: a slice was too small.
 hipError_t launch_sketch_filter(const SketchArgs& a, const uint32_t* bloom, uint32_t bloom_wbits, int n_cus, uint64_t* raw_pos,
-    uint32_t* raw_hash, uint32_t* raw_hint, uint64_t raw_capacity, uint32_t* raw_count, hipStream_t stream);
+    uint32_t* raw_hash, uint32_t* raw_hint, uint64_t raw_capacity, uint32_t* raw_count, hipStream_t stream, KernelTimer timer = {});
 size_t sort_temp_bytes(uint32_t n);
 size_t scan_temp_bytes(uint32_t n);
 hipError_t sort_hits(void* temp, size_t temp_bytes, const uint64_t* key_in, uint64_t* key_out, const uint32_t* val_in,
@@ -92,7 +97,7 @@ hipError_t sort_hits(void* temp, size_t temp_bytes, const uint64_t* key_in, uint
 hipError_t launch_cluster_flags(const uint64_t* key, uint32_t n, int max_diff, uint32_t* head, uint32_t* scan, void* temp,
     size_t temp_bytes, hipStream_t stream);
 hipError_t launch_cluster_starts(const uint32_t* head, const uint32_t* scan, uint32_t n, uint32_t* cstart, hipStream_t stream);
-hipError_t launch_cluster_pipeline(const ClusterArgs& a, uint32_t n_hits, hipStream_t stream);
+hipError_t launch_cluster_pipeline(const ClusterArgs& a, uint32_t n_hits, uint32_t n_prgs, hipStream_t stream);
 
 } // namespace dev
 } // namespace drprg

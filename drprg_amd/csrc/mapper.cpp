@@ -162,7 +162,7 @@ void Mapper::run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32
     if (n_tiles > tile_cap_) {
         dfree(d_tile_first_);
         tile_cap_ = n_tiles + n_tiles / 4 + 16;
-        dmalloc(d_tile_first_, (size_t)tile_cap_);
+        dmalloc(d_tile_first_, 2 * (size_t)tile_cap_); // filtered kernel: [first read | number of read starts] per tile
     }
     for (int attempt = 0;; ++attempt) {
         HIPCHK(hipMemsetAsync(&d_counters_[C_HITS], 0, sizeof(unsigned long long), stream));
@@ -187,14 +187,18 @@ void Mapper::run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32
         a.n_hits = &d_counters_[C_HITS];
         a.n_minimizers = &d_counters_[C_MINIMIZERS];
         a.overflow = reinterpret_cast<uint32_t*>(&d_counters_[C_OVERFLOW]);
-        if (timing_) HIPCHK(hipEventRecord(ev0_, stream));
+        dev::KernelTimer timer;
+        if (timing_) { // events bracket the dominant kernel only (sketch_filter_kernel / sketch_probe_kernel)
+            timer.begin = ev0_;
+            timer.end = ev1_;
+        }
         if (use_filter_)
-            HIPCHK(dev::launch_sketch_filter(a, d_bloom_, bloom_wbits_, n_cus_, d_key_b_, d_val_b_, d_head_, hit_capacity_, d_raw_count_, stream));
-        else HIPCHK(dev::launch_sketch_probe(a, wide_hash_, stream));
-        if (timing_) HIPCHK(hipEventRecord(ev1_, stream));
+            HIPCHK(dev::launch_sketch_filter(a, d_bloom_, bloom_wbits_, n_cus_, d_key_b_, d_val_b_, d_head_, hit_capacity_,
+                d_raw_count_, stream, timer));
+        else HIPCHK(dev::launch_sketch_probe(a, wide_hash_, stream, timer));
         HIPCHK(hipMemcpyAsync(h_counters_, d_counters_, C_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
-        if (timing_) {
+        if (timing_ && n_bases > 0) {
             float ms = 0;
             HIPCHK(hipEventElapsedTime(&ms, ev0_, ev1_));
             sketch_ms_ += ms;
@@ -245,7 +249,7 @@ void Mapper::run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32
     c.prg_reads = prg_reads;
     c.n_clusters_kept = &d_counters_[C_CLUSTERS_KEPT];
     c.n_hits_kept = &d_counters_[C_HITS_KEPT];
-    HIPCHK(dev::launch_cluster_pipeline(c, n_hits, stream));
+    HIPCHK(dev::launch_cluster_pipeline(c, n_hits, n_prgs_, stream));
 }
 
 void Mapper::map_device(const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n_reads, uint64_t n_bases,
@@ -316,6 +320,7 @@ MapCounters Mapper::counters()
     m.hits = tot_hits_;
     m.clusters_kept = c[C_CLUSTERS_KEPT];
     m.hits_kept = c[C_HITS_KEPT];
+    m.kernel = use_filter_ ? 2 : 1;
     return m;
 }
 

@@ -11,6 +11,7 @@ namespace drprg {
 
 struct MapCounters {
     uint64_t reads = 0, bases = 0, minimizers = 0, hits = 0, clusters_kept = 0, hits_kept = 0;
+    uint64_t kernel = 0; // sketch kernel in use: 1 direct (sketch_probe_kernel), 2 Bloom-prefiltered (sketch_filter_kernel)
 };
 
 class Mapper {

@@ -46,6 +46,14 @@ __global__ void tile_first_read_ft_kernel(const uint64_t* __restrict__ offsets, 
         if ((int64_t)offsets[mid] < lo_pos) lo = mid + 1; else hi = mid;
     }
     out[b] = lo;
+    // number of reads that start inside the staged range of the tile (so that exactly those offsets are loaded)
+    const int64_t end_pos = (int64_t)b * FT_EVAL - FT_HALO + FT_CODES;
+    uint32_t lo2 = lo, hi2 = n_reads;
+    while (lo2 < hi2) {
+        uint32_t mid = lo2 + ((hi2 - lo2) >> 1);
+        if ((int64_t)offsets[mid] < end_pos) lo2 = mid + 1; else hi2 = mid;
+    }
+    out[n_tiles + b] = lo2 - lo;
 }
 
 // 16 ASCII bases -> 32-bit packed 2-bit codes (first base in the top bits) + 16-bit "not ACGT" mask (bit i = base i)
@@ -135,11 +143,6 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
         main = ld(tid);
         if (tid < FT_WORDS - FT_THREADS) extra = ld(FT_THREADS + tid);
     };
-    auto load_offset = [&](uint32_t first) -> int64_t {
-        const uint64_t r = (uint64_t)first + (uint64_t)tid;
-        return r < a.n_reads ? (int64_t)a.offsets[r] : INT64_MAX;
-    };
-
     // k-mer at tile position p: canonical hash + 1, or 0 if it holds an N or straddles two reads
     auto kmer_at = [&](int p, bool& strand) -> uint32_t {
         const int v = p >> 4, o = p & 15;
@@ -155,29 +158,47 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
     };
 
     unsigned long long dbg_cands = 0;
-    uint4 cur = make_uint4(0, 0, 0, 0), cur_x = cur, nxt = cur, nxt_x = cur;
-    int64_t cur_off = INT64_MAX, nxt_off = INT64_MAX;
-    uint32_t tile = blockIdx.x, first_read = 0;
-    if (tile < n_tiles) {
-        first_read = a.tile_first_read[tile];
-        load_tile(tile, cur, cur_x);
-        cur_off = load_offset(first_read);
-    }
+    // register ring: the tile being processed plus three tiles in flight (Little's law: ~48 KB per CU must be
+    // outstanding to keep HBM busy; one tile is 8 KB per workgroup)
+    struct Pending {
+        uint4 main, extra;
+        int64_t off;
+        uint2 fc; // first read starting in the tile's staged range, number of reads starting there
+    };
+    const uint32_t gs = gridDim.x; // tile stride of this persistent workgroup
+    auto fetch = [&](uint32_t t, uint2 fc, Pending& p) {
+        p.fc = fc;
+        p.off = INT64_MAX;
+        if (t < n_tiles) {
+            load_tile(t, p.main, p.extra);
+            if ((uint32_t)tid < fc.y) p.off = (int64_t)a.offsets[(uint64_t)fc.x + tid];
+        }
+    };
+    auto first_of = [&](uint32_t t) -> uint2 {
+        return t < n_tiles ? make_uint2(a.tile_first_read[t], a.tile_first_read[n_tiles + t]) : make_uint2(0u, 0u);
+    };
+    Pending cur {}, p1 {}, p2 {}, p3 {};
+    uint32_t tile = blockIdx.x;
+    fetch(tile, first_of(tile), cur);
+    fetch(tile + gs, first_of(tile + gs), p1);
+    fetch(tile + 2 * gs, first_of(tile + 2 * gs), p2);
+    uint2 first3 = first_of(tile + 3 * gs);
     __syncthreads(); // Bloom filter in place
 
-    for (; tile < n_tiles; tile += gridDim.x) {
+    for (; tile < n_tiles; tile += gs) {
         const int64_t origin = (int64_t)tile * FT_EVAL - FT_HALO;
-        const uint32_t next_tile = tile + gridDim.x;
-        const uint32_t first_next = next_tile < n_tiles ? a.tile_first_read[next_tile] : 0;
+        const uint32_t first_read = cur.fc.x, n_starts = cur.fc.y;
+        const int64_t cur_off = cur.off;
+        const uint2 first4 = first_of(tile + 4 * gs); // scalar loads, consumed in the next iteration
 
         // ---- pack this tile into LDS ----
         {
             uint32_t pk, nm;
-            pack16(cur, pk, nm);
+            pack16(cur.main, pk, nm);
             sh.pack[tid] = pk;
             sh.nmask[tid] = (uint16_t)nm;
             if (tid < FT_WORDS - FT_THREADS) {
-                pack16(cur_x, pk, nm);
+                pack16(cur.extra, pk, nm);
                 sh.pack[FT_THREADS + tid] = pk;
                 sh.nmask[FT_THREADS + tid] = (uint16_t)nm;
             }
@@ -187,23 +208,19 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
                 sh.nmask[FT_WORDS] = 0xFFFF;
             }
         }
-        __syncthreads();
+        lds_barrier(); // not __syncthreads(): the ring's global loads must stay in flight
         // ---- read starts of this tile -> bitmap (first offset per thread was prefetched) ----
         {
-            const int64_t end_pos = origin + FT_CODES;
-            int64_t o = cur_off;
-            for (uint64_t r = (uint64_t)first_read + tid; o < end_pos;) {
+            for (uint32_t i = tid; i < n_starts; i += FT_THREADS) {
+                // beyond the first 512 starts (very short reads only) the offsets are loaded here
+                const int64_t o = i < FT_THREADS ? cur_off : (int64_t)a.offsets[(uint64_t)first_read + i];
                 const int oc = (int)(o - origin);
                 atomicOr(&sh.start[oc >> 5], 1u << (oc & 31));
-                r += FT_THREADS; // more than 512 reads start in this tile: very short reads only
-                o = r < a.n_reads ? (int64_t)a.offsets[r] : INT64_MAX;
             }
         }
-        // ---- prefetch the next tile: its loads stay in flight while this tile is processed from LDS ----
-        if (next_tile < n_tiles) {
-            load_tile(next_tile, nxt, nxt_x);
-            nxt_off = load_offset(first_next);
-        }
+        // ---- prefetch: tile + 3*grid joins the ring; its loads stay in flight while tiles are processed from LDS
+        // (issued after this tile's own offset loads, because vector-memory results return in issue order) ----
+        fetch(tile + 3 * gs, first3, p3);
         // ---- Bloom test of my 16 positions ----
         uint32_t cand = 0;
         if (!(fa.debug & 1u) && base0 >= FT_HALO && base0 < FT_NPOS - FT_HALO) {
@@ -276,10 +293,10 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
             if (!more) break;
         }
         lds_barrier(); // everyone is done with this tile's LDS before it is overwritten
-        cur = nxt;
-        cur_x = nxt_x;
-        cur_off = nxt_off;
-        first_read = first_next;
+        cur = p1;
+        p1 = p2;
+        p2 = p3;
+        first3 = first4;
     }
     if (tid == 0) {
         fa.raw_count[blockIdx.x] = sh.nraw;
@@ -289,61 +306,100 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
 }
 
 // raw hits -> hits: exact table lookup, read lookup, one (key,val) per index record.
-// 1-D grid-stride over the concatenation of the workgroups' slices (prefix sums of raw_count kept in LDS).
-constexpr int EX_MAX_WG = 1024 + 16;
+// Every workgroup takes a contiguous range of the concatenated raw slices; output space is reserved once per
+// 256-thread batch (LDS prefix + one global atomic per workgroup per batch), not once per wave.
+constexpr int EX_MAX_WG = 1024;
 __global__ __launch_bounds__(256) void expand_hits_kernel(SketchArgs a, FilterArgs fa, uint32_t n_wg)
 {
     using Tr = HashTraits<uint32_t>;
     __shared__ uint32_t s_prefix[EX_MAX_WG + 1];
-    if (threadIdx.x == 0) {
-        uint32_t acc = 0;
-        for (uint32_t b = 0; b < n_wg; ++b) {
-            s_prefix[b] = acc;
-            const uint32_t n = fa.raw_count[b];
-            acc += n < fa.raw_slice ? n : fa.raw_slice;
+    __shared__ uint32_t s_cnt, s_found;
+    __shared__ unsigned long long s_base;
+    const int tid = threadIdx.x;
+    // inclusive scan of the (clamped) slice counts: 4 entries per thread, then a block scan
+    {
+        uint32_t v[4], run = 0;
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t b = (uint32_t)tid * 4 + i;
+            const uint32_t n = b < n_wg ? fa.raw_count[b] : 0u;
+            v[i] = run;
+            run += n < fa.raw_slice ? n : fa.raw_slice;
         }
-        s_prefix[n_wg] = acc;
+        __shared__ uint32_t s_part[256];
+        s_part[tid] = run;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            const uint32_t add = tid >= off ? s_part[tid - off] : 0u;
+            __syncthreads();
+            s_part[tid] += add;
+            __syncthreads();
+        }
+        const uint32_t before = tid ? s_part[tid - 1] : 0u;
+        for (int i = 0; i < 4; ++i) s_prefix[tid * 4 + i] = before + v[i];
+        if (tid == 255) s_prefix[EX_MAX_WG] = s_part[255];
+        __syncthreads();
     }
-    __syncthreads();
-    const uint32_t total = s_prefix[n_wg];
+    const uint32_t total = s_prefix[EX_MAX_WG];
     const uint32_t* __restrict__ slot_key = reinterpret_cast<const uint32_t*>(a.slot_key);
     const uint32_t tmask = (1u << a.table_bits) - 1;
-    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
-        uint32_t lo = 0, hi = n_wg; // s_prefix[lo] <= t < s_prefix[hi]
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (s_prefix[mid] <= t) lo = mid; else hi = mid;
+    const uint32_t per_wg = (total + gridDim.x - 1) / gridDim.x;
+    const uint32_t t_begin = blockIdx.x * per_wg;
+    const uint32_t t_end = t_begin + per_wg < total ? t_begin + per_wg : total;
+    for (uint32_t t0 = t_begin; t0 < t_end; t0 += 256) {
+        const uint32_t t = t0 + tid;
+        uint32_t cnt = 0, slot = 0, strand = 0, hint = 0;
+        uint64_t gp = 0;
+        if (t < t_end) {
+            uint32_t lo = 0, hi = EX_MAX_WG; // s_prefix[lo] <= t < s_prefix[hi]
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (s_prefix[mid] <= t) lo = mid; else hi = mid;
+            }
+            const size_t at_raw = (size_t)lo * fa.raw_slice + (t - s_prefix[lo]);
+            const uint64_t rp = fa.raw_pos[at_raw];
+            strand = (uint32_t)(rp >> 63);
+            gp = rp & ~(1ull << 63);
+            hint = fa.raw_hint[at_raw];
+            const uint32_t h = fa.raw_hash[at_raw];
+            uint32_t s = table_slot_dev((uint64_t)h, a.table_bits);
+            while (true) {
+                const uint32_t key = slot_key[s];
+                if (key == h) { slot = s; cnt = a.slot_rec[s].y; break; }
+                if (key == Tr::EMPTY) break; // a Bloom false positive
+                s = (s + 1) & tmask;
+            }
         }
-        const size_t at_raw = (size_t)lo * fa.raw_slice + (t - s_prefix[lo]);
-        const uint64_t rp = fa.raw_pos[at_raw];
-        const uint32_t strand = (uint32_t)(rp >> 63);
-        const uint64_t gp = rp & ~(1ull << 63);
-        const uint32_t h = fa.raw_hash[at_raw];
-        uint32_t s = table_slot_dev((uint64_t)h, a.table_bits);
-        bool found = false;
-        while (true) {
-            const uint32_t key = slot_key[s];
-            if (key == h) { found = true; break; }
-            if (key == Tr::EMPTY) break; // a Bloom false positive
-            s = (s + 1) & tmask;
+        if (tid == 0) { s_cnt = 0; s_found = 0; }
+        __syncthreads();
+        uint32_t my_off = 0;
+        if (cnt) {
+            my_off = atomicAdd(&s_cnt, cnt);
+            atomicAdd(&s_found, 1u);
         }
-        if (!found) continue;
-        atomicAdd(a.n_minimizers, 1ull);
-        const uint2 rec = a.slot_rec[s];
-        const uint32_t read = find_read_from(a.offsets, a.n_reads, fa.raw_hint[at_raw], gp);
-        const uint64_t pos = gp - a.offsets[read];
-        const unsigned long long at = atomicAdd(a.n_hits, (unsigned long long)rec.y);
-        if (at + rec.y > a.hit_capacity || pos >= (1ull << HIT_POS_BITS)) {
-            atomicOr(a.overflow, pos >= (1ull << HIT_POS_BITS) ? 2u : 1u);
-            continue;
+        __syncthreads();
+        if (tid == 0 && s_cnt) {
+            s_base = atomicAdd(a.n_hits, (unsigned long long)s_cnt);
+            atomicAdd(a.n_minimizers, (unsigned long long)s_found);
         }
-        for (uint32_t q = 0; q < rec.y; ++q) {
-            const uint32_t kn = a.rec_knode[rec.x + q];
-            const uint32_t prg = a.rec_prg[rec.x + q];
-            const uint32_t rev = ((kn & 1u) == strand) ? 0u : 1u;
-            a.hit_key[at + q] = pack_hit_key(read, prg, rev, (uint32_t)pos);
-            a.hit_val[at + q] = kn >> 1;
+        __syncthreads();
+        if (cnt) {
+            const uint32_t read = find_read_from(a.offsets, a.n_reads, hint, gp);
+            const uint64_t pos = gp - a.offsets[read];
+            const unsigned long long at = s_base + my_off;
+            if (at + cnt > a.hit_capacity || pos >= (1ull << HIT_POS_BITS)) {
+                atomicOr(a.overflow, pos >= (1ull << HIT_POS_BITS) ? 2u : 1u);
+            } else {
+                const uint2 rec = a.slot_rec[slot];
+                for (uint32_t q = 0; q < rec.y; ++q) {
+                    const uint32_t kn = a.rec_knode[rec.x + q];
+                    const uint32_t prg = a.rec_prg[rec.x + q];
+                    const uint32_t rev = ((kn & 1u) == strand) ? 0u : 1u;
+                    a.hit_key[at + q] = pack_hit_key(read, prg, rev, (uint32_t)pos);
+                    a.hit_val[at + q] = kn >> 1;
+                }
+            }
         }
+        __syncthreads();
     }
 }
 
@@ -359,11 +415,12 @@ uint32_t filter_grid(uint32_t bloom_wbits, int n_cus, uint32_t n_tiles)
     if (per_cu > 4) per_cu = 4;
     uint32_t grid = (uint32_t)n_cus * per_cu;
     if (grid > n_tiles) grid = n_tiles;
+    if (grid > (uint32_t)EX_MAX_WG) grid = EX_MAX_WG; // expand_hits_kernel keeps one prefix entry per workgroup in LDS
     return grid ? grid : 1;
 }
 
 hipError_t launch_sketch_filter(const SketchArgs& a, const uint32_t* bloom, uint32_t bloom_wbits, int n_cus, uint64_t* raw_pos,
-    uint32_t* raw_hash, uint32_t* raw_hint, uint64_t raw_capacity, uint32_t* raw_count, hipStream_t stream)
+    uint32_t* raw_hash, uint32_t* raw_hint, uint64_t raw_capacity, uint32_t* raw_count, hipStream_t stream, KernelTimer timer)
 {
     if (a.n_bases == 0) return hipSuccess;
     const uint32_t n_tiles = filter_n_tiles(a.n_bases);
@@ -388,8 +445,10 @@ hipError_t launch_sketch_filter(const SketchArgs& a, const uint32_t* bloom, uint
     fa.raw_count = raw_count;
     fa.raw_slice = (uint32_t)std::min<uint64_t>(raw_capacity / grid, 0x7FFFFFFFull);
     if (const char* dbg = std::getenv("DRPRG_FT_DEBUG")) fa.debug = (uint32_t)std::atoi(dbg);
+    if (timer.begin) HIP_TRY(hipEventRecord(timer.begin, stream));
     hipLaunchKernelGGL(sketch_filter_kernel, dim3(grid), dim3(FT_THREADS), dyn, stream, a, fa);
     HIP_TRY(hipGetLastError());
+    if (timer.end) HIP_TRY(hipEventRecord(timer.end, stream));
     hipLaunchKernelGGL(expand_hits_kernel, dim3((uint32_t)n_cus * 8), dim3(256), 0, stream, a, fa, grid);
     return hipGetLastError();
 }

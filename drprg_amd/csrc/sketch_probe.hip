@@ -273,7 +273,7 @@ uint32_t sketch_n_tiles(uint64_t n_bases, int halo)
     return (uint32_t)((n_bases + t_eval - 1) / t_eval);
 }
 
-hipError_t launch_sketch_probe(const SketchArgs& a, bool wide_hash, hipStream_t stream)
+hipError_t launch_sketch_probe(const SketchArgs& a, bool wide_hash, hipStream_t stream, KernelTimer timer)
 {
     if (a.n_bases == 0) return hipSuccess;
     const uint32_t grid = sketch_n_tiles(a.n_bases, a.halo); // positions past n_bases-k are invalid inside the kernel
@@ -281,6 +281,7 @@ hipError_t launch_sketch_probe(const SketchArgs& a, bool wide_hash, hipStream_t 
         (int)sketch_tile_eval(a.halo), a.halo, grid, a.tile_first_read);
     HIP_TRY(hipGetLastError());
     const dim3 g(grid), b(SK_THREADS);
+    if (timer.begin) HIP_TRY(hipEventRecord(timer.begin, stream));
     if (wide_hash)
         hipLaunchKernelGGL((sketch_probe_kernel<uint64_t, 0, 0>), g, b, 0, stream, a);
     else if (a.k == 15 && a.w == 11)
@@ -289,7 +290,9 @@ hipError_t launch_sketch_probe(const SketchArgs& a, bool wide_hash, hipStream_t 
         hipLaunchKernelGGL((sketch_probe_kernel<uint32_t, 15, 14>), g, b, 0, stream, a);
     else
         hipLaunchKernelGGL((sketch_probe_kernel<uint32_t, 0, 0>), g, b, 0, stream, a);
-    return hipGetLastError();
+    HIP_TRY(hipGetLastError());
+    if (timer.end) HIP_TRY(hipEventRecord(timer.end, stream));
+    return hipSuccess;
 }
 
 } // namespace dev

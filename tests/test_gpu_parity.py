@@ -135,3 +135,48 @@ def test_filter_kernel_refuses_unsupported_parameters(tmp_path):
     panel = synth.small_panel(seed=4)
     with pytest.raises(DependencyError):
         _ctx(tmp_path, panel, 11, 21, True, kernel=2)
+
+
+def test_cli_map_end_to_end(tmp_path, oracle):
+    """configs[0]-style plumbing: the drop-in `pandora` executable with the argv drprg builds
+    (/root/reference/src/lib.rs:594-618), FASTQ(.gz) in, pandora_genotyped.vcf out; same VCF as the in-process path
+    fed with the oracle's coverage."""
+    import os
+    import subprocess
+    from drprg_amd import Context, synth
+    from drprg_amd._lib import PANDORA_EXE
+    w, k = 11, 15
+    panel = synth.small_panel(seed=33)
+    prg, genes = str(tmp_path / "dr.prg"), str(tmp_path / "genes.fa")
+    panel.write(prg, genes)
+    gen = synth.HaplotypeGenomes(panel, genome_size=4411532 // 100, n_hap=4, seed=3)
+    bases, offs = synth.sample_short_reads(gen, 10000, seed=1)
+    fq = str(tmp_path / "reads.fq.gz")
+    synth.write_fastq(fq, bases, offs, gz=True)
+    r = subprocess.run([PANDORA_EXE, "index", "-t", "2", "-w", str(w), "-k", str(k), prg], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = tmp_path / "out"
+    argv = [PANDORA_EXE, "map", "--genotype", "--local", "--gt-conf", "0", "-v", "-o", str(out), "-g", "4411532", "--max-covg",
+            "4294967295", "--vcf-refs", genes, "-t", "1", "-w", str(w), "-k", str(k), "-c", "10", "-I", prg, fq]
+    r = subprocess.run(argv, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    vcf = out / "pandora_genotyped.vcf"
+    assert vcf.exists()
+    # discover: must leave a parsable denovo_paths.txt with zero loci (/root/reference/src/lib.rs:648-697)
+    q = tmp_path / "query.tsv"
+    q.write_text(f"sample\t{fq}\n")
+    r = subprocess.run([PANDORA_EXE, "discover", "-g", "4411532", "--max-covg", "4294967295", "-v", "-o", str(tmp_path / "disc"),
+                        "-t", "1", "-w", str(w), "-k", str(k), "-c", "10", "-I", prg, str(q)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    from drprg_amd import Pandora
+    assert Pandora.list_prgs_with_novel_variants(str(tmp_path / "disc" / "denovo_paths.txt")) == []
+    # reference VCF: host genotyper on the oracle's coverage of the same reads
+    ctx = Context(prg, w, k, device=-1, from_files=True)
+    ctx.set_opts(illumina=True, genome_size=4411532)
+    md, er = map_params(k, True)
+    covg, prg_reads, _ = oracle.map_reads(bases, offs, ctx.export_index(), w, k, md, cluster_fraction(er, k), 10)
+    ctx.set_coverage(covg, prg_reads, int(offs[-1]))
+    ref = str(tmp_path / "ref.vcf")
+    ctx.genotype(genes, ref)
+    strip = lambda p: [l for l in open(p) if not l.startswith("##fileDate")]
+    assert strip(vcf) == strip(ref)
