@@ -140,8 +140,28 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # size-independent parity properties at full size: additivity checksum across two halves
+    # size-independent parity properties at full size (the oracle cannot map 10M reads in seconds):
+    # (1) sharding invariance: coverage(whole shard) == coverage(first half) + coverage(second half), bit for bit;
+    # (2) the two sketch kernels (direct / Bloom-prefiltered) give the identical vector.
     checksum = int(covg.to(torch.int64).sum().item())
+    full = covg.clone()
+    half = max(8, (n_reads // 2) // 8 * 8)  # keeps the second half's base pointer 16-byte aligned for any read length
+    split = torch.zeros_like(covg)
+    sp = torch.zeros_like(prg_reads)
+    torch.cuda.synchronize()
+    ctx.map_device(bases.data_ptr(), offsets.data_ptr(), half, half * args.read_len, split.data_ptr(), sp.data_ptr(), stream.cuda_stream)
+    ctx.map_device(bases.data_ptr() + half * args.read_len, offsets[half:].sub(half * args.read_len).contiguous().data_ptr(),
+                   n_reads - half, (n_reads - half) * args.read_len, split.data_ptr(), sp.data_ptr(), stream.cuda_stream)
+    torch.cuda.synchronize()
+    shard_invariant = bool(torch.equal(full, split)) if world == 1 else None
+    kernels_agree = None
+    if world == 1 and ctx.counters().get("kernel") == 2:
+        ctx.set_opts(illumina=True, min_cluster_size=10, genome_size=synth.MTB_GENOME_SIZE, kernel=1)
+        direct = torch.zeros_like(covg)
+        ctx.map_device(bases.data_ptr(), offsets.data_ptr(), n_reads, n_bases, direct.data_ptr(), sp.data_ptr(), stream.cuda_stream)
+        torch.cuda.synchronize()
+        kernels_agree = bool(torch.equal(full, direct))
+        ctx.set_opts(illumina=True, min_cluster_size=10, genome_size=synth.MTB_GENOME_SIZE, kernel=0)
 
     if rank == 0:
         total_reads = n_reads * world * args.steps
@@ -177,7 +197,8 @@ def main():
                 "reads_per_gpu": n_reads, "read_len": args.read_len, "w": W, "k": K, "loci": ctx.n_prgs,
                 "index_keys": ctx.n_keys, "kmer_nodes": ctx.n_knodes, "sharding": f"reads x{world}",
                 "collective": "all_reduce(u32 coverage) per step" if world > 1 else "none",
-                "coverage_checksum": checksum,
+                "coverage_checksum": checksum, "full_size_shard_invariance": shard_invariant,
+                "full_size_direct_vs_filtered_kernel_identical": kernels_agree,
             },
             "roofline": {
                 "bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
