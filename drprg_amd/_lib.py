@@ -25,6 +25,23 @@ class MapOpts(C.Structure):
     ]
 
 
+class AnnotateOpts(C.Structure):
+    """struct drprg_hip_annotate_opts; defaults = the CLI defaults of `drprg predict`
+    (/root/reference/src/filter.rs:12-16, src/minor.rs:11-17)"""
+    _fields_ = [
+        ("min_covg", C.c_int32), ("max_covg", C.c_int32),
+        ("min_strand_bias", C.c_float), ("min_gt_conf", C.c_float), ("min_frs", C.c_float),
+        ("max_indel", C.c_int32),
+        ("maf", C.c_float), ("max_gaps", C.c_float), ("max_called_gaps", C.c_float), ("max_gaps_diff", C.c_float),
+        ("minor_min_covg", C.c_int32), ("minor_min_strand_bias", C.c_float),
+        ("ignore_synonymous", C.c_int32), ("id_seed", C.c_uint64),
+    ]
+
+    @classmethod
+    def cli_defaults(cls, illumina=False):
+        return cls(3, 2 ** 31 - 1, 0.01, 0.0, 0.0, -1, 0.1 if illumina else 1.0, 0.5, 0.39, 0.2, 3, 0.01, 0, 0)
+
+
 # name -> (restype, argtypes); every symbol include/drprg_hip.h declares
 SIGNATURES = {
     "drprg_hip_index": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int]),
@@ -49,6 +66,9 @@ SIGNATURES = {
     "drprg_hip_index_export": (C.c_int, [C.c_void_p] + [C.c_void_p] * 7),
     "drprg_hip_prg_nodes": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32),
                                       C.POINTER(C.c_uint32)]),
+    "drprg_hip_annotate": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(AnnotateOpts), C.c_char_p, C.c_size_t]),
+    "drprg_hip_report_json": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_char_p,
+                                        C.c_size_t]),
     "drprg_hip_kernel_timing": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
 }
 

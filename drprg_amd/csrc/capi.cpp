@@ -4,6 +4,7 @@
 #include "genotype.h"
 #include "mapper.h"
 #include <cstring>
+#include <functional>
 #include <memory>
 
 using namespace drprg;
@@ -310,6 +311,74 @@ int drprg_hip_kernel_timing(drprg_hip_ctx* ctx, int enable, int reset, double* m
     if (launches) *launches = m.sketch_launches();
     if (reset) m.reset_kernel_timing();
     API_END(ctx)
+}
+
+} // extern "C"
+
+// ---- post-VCF stage ------------------------------------------------------------------------------------
+#include "report.h"
+
+static int report_guard(char* err, size_t err_len, const std::function<void()>& fn)
+{
+    auto put = [&](const char* m) {
+        if (err && err_len) {
+            std::strncpy(err, m, err_len - 1);
+            err[err_len - 1] = 0;
+        }
+    };
+    try {
+        fn();
+    } catch (const Error& e) {
+        put(e.what());
+        return e.code;
+    } catch (const std::exception& e) {
+        put(e.what());
+        return DRPRG_EIO;
+    }
+    return DRPRG_OK;
+}
+
+extern "C" {
+
+int drprg_hip_annotate(const char* index_dir, const char* pandora_vcf, const char* out_vcf, const drprg_hip_annotate_opts* o,
+    char* err, size_t err_len)
+{
+    if (!index_dir || !pandora_vcf || !out_vcf || !o) return DRPRG_EINVAL;
+    return report_guard(err, err_len, [&]() {
+        report::AnnotateOpts a;
+        a.filter.min_covg = o->min_covg;
+        a.filter.max_covg = o->max_covg;
+        a.filter.min_strand_bias = o->min_strand_bias;
+        a.filter.min_gt_conf = o->min_gt_conf;
+        a.filter.min_frs = o->min_frs;
+        a.filter.has_max_indel = o->max_indel >= 0;
+        a.filter.max_indel = o->max_indel;
+        a.minor.maf = o->maf;
+        a.minor.max_gaps = o->max_gaps;
+        a.minor.max_called_gaps = o->max_called_gaps;
+        a.minor.max_gaps_diff = o->max_gaps_diff;
+        a.minor.minor_min_covg = o->minor_min_covg;
+        a.minor.minor_min_strand_bias = o->minor_min_strand_bias;
+        a.ignore_synonymous = o->ignore_synonymous != 0;
+        a.id_seed = o->id_seed;
+        report::annotate_vcf(report::IndexFiles { index_dir }, pandora_vcf, out_vcf, a);
+    });
+}
+
+int drprg_hip_report_json(const char* index_dir, const char* annotated_vcf, const char* out_json, const char* sample, int padding,
+    const char* index_version, char* err, size_t err_len)
+{
+    if (!index_dir || !annotated_vcf || !out_json) return DRPRG_EINVAL;
+    return report_guard(err, err_len, [&]() {
+        report::IndexFiles idx { index_dir };
+        std::string version = index_version ? index_version : "";
+        if (padding < 0 || !index_version) {
+            report::IndexConfig c = report::read_config(idx.config());
+            if (padding < 0) padding = c.padding;
+            if (!index_version) version = c.version;
+        }
+        report::vcf_to_json(idx, annotated_vcf, out_json, sample ? sample : "sample", padding, version);
+    });
 }
 
 } // extern "C"

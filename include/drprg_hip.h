@@ -97,6 +97,31 @@ int drprg_hip_index_export(const drprg_hip_ctx* ctx, uint64_t* keys, uint32_t* r
 int drprg_hip_prg_nodes(const drprg_hip_ctx* ctx, uint32_t prg, uint32_t* starts, uint32_t* ends, uint32_t cap,
     uint32_t* n_nodes, uint32_t* n_sites);
 
+/* ---- post-VCF stage (host only; SURVEY.md section 8f NEXT-1) ------------------------------------------------
+ * Options of Filterer (/root/reference/src/filter.rs:165-197) and MinorAllele (/root/reference/src/minor.rs:19-49)
+ * with the CLI defaults of `drprg predict`; a disabled filter is min_covg < 0, max_covg = INT32_MAX,
+ * min_strand_bias / min_gt_conf / min_frs < 0, max_indel < 0. */
+typedef struct drprg_hip_annotate_opts {
+    int32_t min_covg, max_covg;
+    float min_strand_bias, min_gt_conf, min_frs;
+    int32_t max_indel;
+    float maf, max_gaps, max_called_gaps, max_gaps_diff;
+    int32_t minor_min_covg;
+    float minor_min_strand_bias;
+    int32_t ignore_synonymous;
+    uint64_t id_seed; /* 0: random 8-hex record IDs like the reference's Uuid::new_v4()[..8] */
+} drprg_hip_annotate_opts;
+
+/* Replaces Predict::predict_from_pandora_vcf (/root/reference/src/predict.rs:420-544): pandora VCF -> filtered,
+ * annotated VCF (FILTER, PDP/OGT/VARID/PREDICT INFO).  index_dir holds .config.toml, genes.fa, panel.bcf, rules.csv.
+ * Deviation: the output is VCF text, not BCF.  err receives the message on failure (may be NULL). */
+int drprg_hip_annotate(const char* index_dir, const char* pandora_vcf, const char* out_vcf,
+    const drprg_hip_annotate_opts* opts, char* err, size_t err_len);
+/* Replaces Predict::vcf_to_json (/root/reference/src/predict.rs:716-1086).  padding < 0 / index_version NULL: taken from
+ * <index_dir>/.config.toml. */
+int drprg_hip_report_json(const char* index_dir, const char* annotated_vcf, const char* out_json, const char* sample,
+    int padding, const char* index_version, char* err, size_t err_len);
+
 /* HIP-event timing of the sketch+probe kernel on the launch stream (bench.py roofline).
  * enable != 0 starts/keeps timing; ms_total / launches may be NULL; reset != 0 clears the sums. */
 int drprg_hip_kernel_timing(drprg_hip_ctx* ctx, int enable, int reset, double* ms_total, uint64_t* launches);
