@@ -16,7 +16,13 @@ LIB  := drprg_amd/lib/libdrprg_hip.so
 BIN  := drprg_amd/bin/pandora
 ORACLE := oracle/liboracle.so
 
-all: $(LIB) $(BIN) $(ORACLE)
+DRPRG := drprg_amd/bin/drprg
+
+all: $(LIB) $(BIN) $(DRPRG) $(ORACLE)
+
+$(DRPRG): $(SRC)/drprg_main.cpp $(LIB)
+	@mkdir -p $(dir $@)
+	$(HIPCC) $(CXXFLAGS) -o $@ $< -Ldrprg_amd/lib -ldrprg_hip -Wl,-rpath,'$$ORIGIN/../lib'
 
 $(OBJD)/%.o: $(SRC)/%.cpp $(wildcard $(SRC)/*.h) include/drprg_hip.h
 	@mkdir -p $(OBJD)

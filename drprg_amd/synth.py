@@ -256,3 +256,58 @@ def write_fastq(path, bases, offsets, gz=False):
         for i in range(len(offsets) - 1):
             s = bases[int(offsets[i]):int(offsets[i + 1])].tobytes()
             fh.write(b"@r%d\n" % i + s + b"\n+\n" + b"I" * len(s) + b"\n")
+
+
+# ---- an mtb-like panel built from a real index directory (genes.fa + panel.bcf) -------------------------------
+def panel_from_index_dir(index_dir, max_alts=4, min_gap=2, lead=30):
+    """PRGs whose first-allele path is the genes.fa sequence and whose sites are the (non-overlapping) records of
+    panel.bcf.  Returns (Panel, sites) where sites[gene] = [(record id, pos, ref, alts)]."""
+    import os
+    from .bcf_lite import read_bcf
+    genes = []
+    name, seq = None, []
+    for line in open(os.path.join(index_dir, "genes.fa")):
+        if line.startswith(">"):
+            if name:
+                genes.append((name, "".join(seq).upper()))
+            name, seq = line[1:].split()[0], []
+        else:
+            seq.append(line.strip())
+    if name:
+        genes.append((name, "".join(seq).upper()))
+    by_gene = {}
+    for r in read_bcf(os.path.join(index_dir, "panel.bcf")):
+        by_gene.setdefault(r["chrom"], []).append(r)
+    names, trees, sites = [], [], {}
+    for gname, gseq in genes:
+        recs = sorted(by_gene.get(gname, []), key=lambda r: (r["pos"], len(r["ref"])))
+        segs, cur, chosen = [], 0, []
+        for r in recs:
+            if r["pos"] < max(cur + min_gap, lead) or r["pos"] + len(r["ref"]) > len(gseq) - lead:
+                continue
+            if gseq[r["pos"]:r["pos"] + len(r["ref"])] != r["ref"] or len(r["ref"]) > 12:
+                continue
+            alts = [a for a in dict.fromkeys(r["alts"]) if a != r["ref"] and set(a) <= set("ACGT")][:max_alts]
+            if not alts:
+                continue
+            segs.append(gseq[cur:r["pos"]])
+            segs.append(Site([[r["ref"]]] + [[a] for a in alts]))
+            cur = r["pos"] + len(r["ref"])
+            chosen.append((r["id"], r["pos"], r["ref"], alts))
+        segs.append(gseq[cur:])
+        names.append(gname)
+        trees.append(segs)
+        sites[gname] = chosen
+    return Panel(names, trees), sites
+
+
+def haplotype_with(segs, choose):
+    """sequence of a locus where site number i (in order) takes allele choose(i) (0 = reference allele)"""
+    s, i = "", 0
+    for seg in segs:
+        if isinstance(seg, str):
+            s += seg
+        else:
+            s += "".join(x for x in seg.alleles[choose(i)] if isinstance(x, str))
+            i += 1
+    return s

@@ -1,0 +1,105 @@
+"""`drprg predict` end to end on the GPU box: reads -> hot path -> pandora_genotyped.vcf -> annotated VCF -> JSON,
+on an mtb-like index built from the reference's test index files (tests/golden/downstream: genes.fa, panel.bcf,
+rules.csv, .config.toml) with the panel variants as PRG sites."""
+import json
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from util import GOLDEN, ROOT
+
+pytestmark = pytest.mark.gpu
+DS = os.path.join(GOLDEN, "downstream")
+BIN = os.path.join(ROOT, "drprg_amd", "bin")
+
+
+def _make_index(tmp_path):
+    from drprg_amd import synth
+    idx = tmp_path / "idx"
+    idx.mkdir()
+    for f in (".config.toml", "genes.fa", "genes.fa.fai", "panel.bcf", "panel.bcf.csi", "rules.csv"):
+        shutil.copy(os.path.join(DS, f), idx / f)
+    (idx / "msas").mkdir()
+    panel, sites = synth.panel_from_index_dir(str(idx))
+    panel.write(str(idx / "dr.prg"))
+    r = subprocess.run([os.path.join(BIN, "pandora"), "index", "-t", "4", "-w", "11", "-k", "15", str(idx / "dr.prg")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return idx, panel, sites
+
+
+def _reads(panel, choose, n_reads, seed):
+    from drprg_amd import synth
+    rng = np.random.default_rng(seed)
+    spacer = synth.random_seq(rng, 300)
+    genome = spacer + spacer.join(synth.haplotype_with(t, lambda i, g=gi: choose(g, i)) for gi, t in enumerate(panel.trees)) + spacer
+    g = np.frombuffer(genome.encode(), np.uint8)
+    starts = rng.integers(0, len(g) - 150, size=n_reads)
+    block = g[starts[:, None] + np.arange(150)]
+    rev = rng.random(n_reads) < 0.5
+    block[rev] = synth._COMP[block[rev][:, ::-1]]
+    return block.reshape(-1), np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(150)
+
+
+def _predict(tmp_path, idx, bases, offs, name):
+    from drprg_amd import synth
+    fq = str(tmp_path / f"{name}.fq")
+    synth.write_fastq(fq, bases, offs)
+    out = tmp_path / f"out_{name}"
+    r = subprocess.run([os.path.join(BIN, "drprg"), "predict", "-x", str(idx), "-i", fq, "-o", str(out), "-s", name, "-I", "-v"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    for f in ("pandora_genotyped.vcf", f"{name}.drprg.vcf", f"{name}.drprg.json", "discover/denovo_paths.txt"):
+        assert (out / f).exists(), f
+    return json.load(open(out / f"{name}.drprg.json")), out
+
+
+def test_reference_sample_is_susceptible_and_resistant_sample_is_called(tmp_path):
+    idx, panel, sites = _make_index(tmp_path)
+    gene_ix = {g: i for i, g in enumerate(panel.names)}
+    # wild type: every site takes the reference allele -> every drug S, no evidence, all 18 genes present
+    bases, offs = _reads(panel, lambda g, i: 0, 14000, seed=1)
+    wt, _ = _predict(tmp_path, idx, bases, offs, "wt")
+    assert wt["sample"] == "wt" and wt["genes"]["absent"] == [] and len(wt["genes"]["present"]) == 18
+    assert all(v["predict"] == "S" and v["evidence"] == [] for v in wt["susceptibility"].values()), wt["susceptibility"]
+    assert wt["version"]["index"] == "mtb-20230308"
+    # mutant: one panel variant in rrs and one in katG take their first alternate allele
+    want = {}
+    for gene in ("rrs", "katG", "gyrA"):
+        k = len(sites[gene]) // 2
+        want[gene] = (k, sites[gene][k][0])
+    bases, offs = _reads(panel, lambda g, i: 1 if any(gene_ix[gn] == g and i == k for gn, (k, _) in want.items()) else 0,
+                         14000, seed=2)
+    mut, out = _predict(tmp_path, idx, bases, offs, "mut")
+    evid = {(e["gene"], e["variant"]) for v in mut["susceptibility"].values() if v["predict"] == "R" for e in v["evidence"]}
+    for gene, (k, vid) in want.items():
+        assert any(g == gene for g, _ in evid), (gene, vid, evid)
+    resistant = {d for d, v in mut["susceptibility"].items() if v["predict"] == "R"}
+    assert resistant and resistant != set(mut["susceptibility"])
+    # the genotyped VCF calls the alternate allele at exactly the mutated sites
+    alt_calls = set()
+    for line in open(out / "pandora_genotyped.vcf"):
+        if line.startswith("#"):
+            continue
+        t = line.split("\t")
+        if t[9].split(":")[0] not in ("0", "."):
+            alt_calls.add((t[0], int(t[1])))
+    expect_calls = {(gene, sites[gene][k][1] + 1) for gene, (k, _) in want.items()}
+    assert expect_calls <= alt_calls and len(alt_calls) <= len(expect_calls) + 2, (alt_calls, expect_calls)
+
+
+def test_absent_gene_is_reported(tmp_path):
+    idx, panel, sites = _make_index(tmp_path)
+    pnca = panel.names.index("pncA")
+    from drprg_amd import synth
+    # a sample without pncA: gene absence -> Pyrazinamide R with the gene_absent evidence (rules.csv: absence,pncA,,,Pyrazinamide)
+    trees = [t for i, t in enumerate(panel.trees) if i != pnca]
+    sub = synth.Panel([n for i, n in enumerate(panel.names) if i != pnca], trees)
+    bases, offs = _reads(sub, lambda g, i: 0, 14000, seed=3)
+    res, _ = _predict(tmp_path, idx, bases, offs, "nopnca")
+    assert res["genes"]["absent"] == ["pncA"]
+    pza = res["susceptibility"]["Pyrazinamide"]
+    assert pza["predict"] == "R" and pza["evidence"][0]["variant"] == "gene_absent" and pza["evidence"][0]["gene"] == "pncA"
