@@ -90,5 +90,36 @@ __device__ inline uint32_t find_read_from(const uint64_t* __restrict__ offsets, 
     return lo;
 }
 
+// read holding global base position gp, searched outwards from `guess` (any read index): gallops down or up, then
+// bisects.  With near-uniform read lengths and guess = gp * n_reads / n_bases this costs two or three loads.
+__device__ inline uint32_t find_read_near(const uint64_t* __restrict__ offsets, uint32_t n_reads, uint32_t guess, uint64_t gp)
+{
+    uint32_t lo = guess < n_reads ? guess : n_reads - 1, hi;
+    if (offsets[lo] <= gp) {
+        uint32_t step = 1;
+        hi = lo + 1;
+        while (hi < n_reads && offsets[hi] <= gp) {
+            lo = hi;
+            step <<= 1;
+            hi = (n_reads - lo > step) ? lo + step : n_reads;
+        }
+    } else {
+        uint32_t step = 1;
+        hi = lo;
+        while (true) {
+            lo = hi > step ? hi - step : 0;
+            if (offsets[lo] <= gp) break;
+            hi = lo;
+            step <<= 1;
+        }
+    }
+    // invariant: offsets[lo] <= gp < offsets[hi]  (offsets[n_reads] = n_bases > gp)
+    while (hi - lo > 1) {
+        uint32_t mid = lo + ((hi - lo) >> 1);
+        if (offsets[mid] <= gp) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
 } // namespace dev
 } // namespace drprg

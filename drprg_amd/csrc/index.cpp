@@ -115,6 +115,8 @@ void PrgIndex::flatten()
         auto add = [&](uint32_t code) {
             const uint32_t h = code * 0x9E3779B1u;
             f.bloom[h >> (32 - wbits)] |= (1u << (h & 31)) | (1u << ((h >> 5) & 31)) | (1u << ((h >> 10) & 31));
+            const uint32_t h2 = code * 0x85EBCA6Bu; // second level: an independent word, tested only for level-1 survivors
+            f.bloom[h2 >> (32 - wbits)] |= (1u << (h2 & 31)) | (1u << ((h2 >> 5) & 31)) | (1u << ((h2 >> 10) & 31));
         };
         for (size_t p = 0; p < prgs.size(); ++p) {
             const auto& nodes = kgs[p].nodes;

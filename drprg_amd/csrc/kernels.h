@@ -86,10 +86,10 @@ hipError_t launch_sketch_probe(const SketchArgs& a, bool wide_hash, hipStream_t 
 // filtered form (k <= 15, w <= 16): bloom = 2^bloom_wbits words of index k-mer codes
 uint32_t filter_n_tiles(uint64_t n_bases);
 uint32_t filter_grid(uint32_t bloom_wbits, int n_cus, uint32_t n_tiles);
-// raw_pos / raw_hash: scratch of raw_capacity entries (split into one slice per workgroup); raw_count: one u32 per
+// raw_pos: scratch of raw_capacity candidate positions (split into one slice per workgroup); raw_count: one u32 per
 // workgroup (>= filter_grid entries).  Overflow bit 2 (value 4) in a.overflow: a slice was too small.
 hipError_t launch_sketch_filter(const SketchArgs& a, const uint32_t* bloom, uint32_t bloom_wbits, int n_cus, uint64_t* raw_pos,
-    uint32_t* raw_hash, uint32_t* raw_hint, uint64_t raw_capacity, uint32_t* raw_count, hipStream_t stream, KernelTimer timer = {});
+    uint64_t raw_capacity, uint32_t* raw_count, hipStream_t stream, KernelTimer timer = {});
 size_t sort_temp_bytes(uint32_t n);
 size_t scan_temp_bytes(uint32_t n);
 hipError_t sort_hits(void* temp, size_t temp_bytes, const uint64_t* key_in, uint64_t* key_out, const uint32_t* val_in,

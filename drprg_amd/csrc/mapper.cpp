@@ -193,8 +193,7 @@ void Mapper::run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32
             timer.end = ev1_;
         }
         if (use_filter_)
-            HIPCHK(dev::launch_sketch_filter(a, d_bloom_, bloom_wbits_, n_cus_, d_key_b_, d_val_b_, d_head_, hit_capacity_,
-                d_raw_count_, stream, timer));
+            HIPCHK(dev::launch_sketch_filter(a, d_bloom_, bloom_wbits_, n_cus_, d_key_b_, hit_capacity_, d_raw_count_, stream, timer));
         else HIPCHK(dev::launch_sketch_probe(a, wide_hash_, stream, timer));
         HIPCHK(hipMemcpyAsync(h_counters_, d_counters_, C_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));

@@ -1,18 +1,22 @@
 // sketch_filter.hip -- K1+K2 in their fast form: persistent workgroups + an LDS-resident Bloom prefilter.
 //
 // A read minimizer can only produce a hit if its k-mer is an index k-mer (in either orientation).  So instead of
-// hashing every k-mer of every read (sketch_probe.hip: ~86 VALU instructions per base, two 15-op hashes each),
-// this kernel tests each position's 2-bit k-mer *code* against a Bloom filter of the index k-mer codes that stays
-// in LDS for the lifetime of a persistent workgroup.  Only candidates get the exact treatment -- canonical hashes
-// of the 2w-1 neighbouring k-mers and the window-minimizer test -- and the survivors are written, without any
-// global atomic, to a per-workgroup slice of a raw-hit buffer.  A second, fully parallel kernel
-// (expand_hits_kernel) does the exact table lookup, finds the read of each raw hit and emits the (key,val) hits
-// the cluster pipeline sorts.  The Bloom filter has no false negatives, so the result is identical to the direct
-// kernel (tests/test_gpu_parity.py checks both against the oracle).  Serves k <= 15, w <= 16 and indexes whose
-// filter fits 64 KB of LDS; everything else takes the direct kernel.
+// hashing every k-mer of every read (sketch_probe.hip: ~86 VALU instructions per base, two 15-op hashes each):
 //
-// Nothing in the per-tile loop waits on global memory: the next tile's bases, its first-read index and its read
-// offsets are prefetched into registers while the current tile is processed from LDS.
+//   sketch_filter_kernel   streams the concatenated base buffer through persistent workgroups, packs it to 2 bits
+//                          per base in LDS and tests each position's k-mer *code* against a Bloom filter of the
+//                          index k-mer codes that stays in LDS for the lifetime of the workgroup; the positions that
+//                          pass (index k-mers + ~0.5 % false positives) are appended, without any global atomic, to
+//                          the workgroup's slice of a candidate buffer.  Nothing in its loop waits on global memory:
+//                          three tiles of bases are in flight in a register ring.
+//   verify_expand_kernel   one thread per candidate, no barriers on the critical path: canonical hash from the raw
+//                          bases -> exact table lookup (false positives end here) -> read lookup -> window-minimizer
+//                          test over the 2w-1 neighbouring k-mers inside the read -> one (key,val) hit per index
+//                          record, with output space reserved once per 256-thread batch.
+//
+// The Bloom filter has no false negatives and every survivor is re-derived exactly from the bases, so the result is
+// identical to the direct kernel (tests/test_gpu_parity.py checks both against the oracle).  Serves k <= 15, w <= 16
+// and indexes whose filter fits 64 KB of LDS; everything else takes the direct kernel.
 #include "device_common.h"
 #include <algorithm>
 #include <cstdint>
@@ -23,50 +27,146 @@ namespace dev {
 
 constexpr int FT_THREADS = 512;
 constexpr int FT_G = 16;
-constexpr int FT_NPOS = FT_THREADS * FT_G;   // 8192 positions per tile
-constexpr int FT_HALO = 16;                  // >= w-1
-constexpr int FT_EVAL = FT_NPOS - 2 * FT_HALO;
-constexpr int FT_CODES = FT_NPOS + 48;       // staged bases
-constexpr int FT_WORDS = FT_CODES / 16;      // 515 packed words
-constexpr int FT_CAND_CAP = 2 * FT_THREADS;  // up to two candidates per thread per round
-constexpr int FT_VER_HITS = 32;              // candidates verified per pass
-constexpr int FT_VER_W = 31;                 // 2*16-1 neighbour slots
-constexpr int FT_START_WORDS = (FT_CODES + 31) / 32 + 1;
+constexpr int FT_NPOS = FT_THREADS * FT_G; // 8192 positions (= bases) per tile, tiles do not overlap
+constexpr int FT_WORDS = FT_THREADS + 1;   // packed words staged per tile: 16 bases each, one extra for the k-1 tail
 
-__global__ void tile_first_read_ft_kernel(const uint64_t* __restrict__ offsets, uint32_t n_reads, uint32_t n_tiles,
-    uint32_t* __restrict__ out)
+// 16 ASCII bases -> 32-bit packed 2-bit codes, first base in the top bits (a non-ACGT byte packs to an arbitrary
+// code: it can only create a false candidate, which verify_expand_kernel rejects from the raw bases)
+__device__ inline uint32_t pack16(const uint4& in)
 {
-    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= n_tiles) return;
-    int64_t lo_pos = (int64_t)b * FT_EVAL - FT_HALO;
-    if (lo_pos < 0) lo_pos = 0;
-    uint32_t lo = 0, hi = n_reads;
-    while (lo < hi) {
-        uint32_t mid = lo + ((hi - lo) >> 1);
-        if ((int64_t)offsets[mid] < lo_pos) lo = mid + 1; else hi = mid;
-    }
-    out[b] = lo;
-    // number of reads that start inside the staged range of the tile (so that exactly those offsets are loaded)
-    const int64_t end_pos = (int64_t)b * FT_EVAL - FT_HALO + FT_CODES;
-    uint32_t lo2 = lo, hi2 = n_reads;
-    while (lo2 < hi2) {
-        uint32_t mid = lo2 + ((hi2 - lo2) >> 1);
-        if ((int64_t)offsets[mid] < end_pos) lo2 = mid + 1; else hi2 = mid;
-    }
-    out[n_tiles + b] = lo2 - lo;
+    const uint32_t e0 = encode4(in.x) & 0x03030303u, e1 = encode4(in.y) & 0x03030303u;
+    const uint32_t e2 = encode4(in.z) & 0x03030303u, e3 = encode4(in.w) & 0x03030303u;
+    // gather the four 2-bit fields of a dword into one byte, first base highest: (x * 0x40100401) >> 24
+    return (((e0 * 0x40100401u) >> 24) << 24) | (((e1 * 0x40100401u) >> 24) << 16) | (((e2 * 0x40100401u) >> 24) << 8)
+        | ((e3 * 0x40100401u) >> 24);
 }
 
-// 16 ASCII bases -> 32-bit packed 2-bit codes (first base in the top bits) + 16-bit "not ACGT" mask (bit i = base i)
-__device__ inline void pack16(const uint4& in, uint32_t& packed, uint32_t& nmask)
+struct FilterArgs {
+    const uint32_t* bloom;
+    uint32_t bloom_wbits;
+    uint32_t n_tiles;
+    uint64_t* raw_pos;   // [grid][raw_slice]: global base position of a candidate k-mer
+    uint32_t* raw_count; // [grid]
+    uint32_t raw_slice;
+    uint32_t debug; // ablation switch for profiling (DRPRG_FT_DEBUG): 1 = skip the Bloom test
+};
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, which would stall every wave
+// on the prefetch ring (global loads in flight on purpose); LDS operations of a wave complete in order, so
+// lgkmcnt(0) + s_barrier is enough for LDS visibility inside the workgroup.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a, FilterArgs fa)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_bloom[];
+    __shared__ uint32_t s_pack[2][FT_WORDS + 1]; // double buffered: one barrier per tile
+    __shared__ uint32_t s_nraw;
+
+    const int tid = threadIdx.x;
+    const int k = a.k;
+    const int64_t n_bases = (int64_t)a.n_bases;
+    const uint32_t n_tiles = fa.n_tiles;
+    const int sh_k = 32 - 2 * k, sh_w = 32 - (int)fa.bloom_wbits;
+
+    for (uint32_t i = tid; i < (1u << fa.bloom_wbits); i += FT_THREADS) s_bloom[i] = fa.bloom[i];
+    if (tid == 0) s_nraw = 0;
+
+    auto load16 = [&](int64_t g) -> uint4 { // 16 bases at global position g (a multiple of 16)
+        if (g + 16 <= n_bases) return *reinterpret_cast<const uint4*>(a.bases + g);
+        uint32_t t4[4];
+        for (int q = 0; q < 4; ++q) {
+            uint32_t wd = 0;
+            for (int b = 0; b < 4; ++b) {
+                const int64_t gg = g + q * 4 + b;
+                wd |= (uint32_t)(gg < n_bases ? a.bases[gg] : (uint8_t)'N') << (8 * b);
+            }
+            t4[q] = wd;
+        }
+        return make_uint4(t4[0], t4[1], t4[2], t4[3]);
+    };
+    struct Pending {
+        uint4 main, extra;
+    };
+    auto fetch = [&](uint32_t t, Pending& p) {
+        if (t < n_tiles) {
+            const int64_t origin = (int64_t)t * FT_NPOS;
+            p.main = load16(origin + (int64_t)tid * 16);
+            if (tid == 0) p.extra = load16(origin + FT_NPOS);
+        }
+    };
+    // register ring: the tile being processed plus three tiles in flight (Little's law: ~48 KB per CU must be
+    // outstanding to keep HBM busy; one tile is 8 KB per workgroup, two workgroups per CU)
+    const uint32_t gs = gridDim.x;
+    Pending cur {}, p1 {}, p2 {}, p3 {};
+    uint32_t tile = blockIdx.x;
+    fetch(tile, cur);
+    fetch(tile + gs, p1);
+    fetch(tile + 2 * gs, p2);
+    __syncthreads(); // Bloom filter in place
+
+    int buf = 0;
+    for (; tile < n_tiles; tile += gs, buf ^= 1) {
+        fetch(tile + 3 * gs, p3); // stays in flight for three iterations
+        uint32_t* pack = s_pack[buf];
+        pack[tid] = pack16(cur.main);
+        if (tid == 0) pack[FT_THREADS] = pack16(cur.extra);
+        lds_barrier(); // not __syncthreads(): the ring's global loads must stay in flight
+        // ---- Bloom test of my 16 positions ----
+        uint32_t cand = 0;
+        if (!(fa.debug & 1u)) {
+            const uint32_t w0 = pack[tid], w1 = pack[tid + 1];
+#pragma unroll
+            for (int j = 0; j < FT_G; ++j) {
+                const uint32_t f = __funnelshift_l(w1, w0, 2 * j) >> sh_k;
+                const uint32_t hsh = f * 0x9E3779B1u;
+                const uint32_t word = s_bloom[hsh >> sh_w];
+                cand |= ((word >> (hsh & 31)) & (word >> ((hsh >> 5) & 31)) & (word >> ((hsh >> 10) & 31)) & 1u) << j;
+            }
+            // second level, only for the ~1.5 % that passed: three more bits in a second word (independent hash of the
+            // same code); together the two levels let through the index k-mers plus ~0.02 % false positives
+            uint32_t c1 = cand;
+            cand = 0;
+            while (c1) {
+                const int j = __ffs(c1) - 1;
+                c1 &= c1 - 1;
+                const uint32_t f = __funnelshift_l(w1, w0, 2 * j) >> sh_k;
+                const uint32_t h2 = f * 0x85EBCA6Bu;
+                const uint32_t word = s_bloom[h2 >> sh_w];
+                cand |= ((word >> (h2 & 31)) & (word >> ((h2 >> 5) & 31)) & (word >> ((h2 >> 10) & 31)) & 1u) << j;
+            }
+        }
+        // ---- append candidate positions to this workgroup's slice (plain stores, LDS cursor) ----
+        if (cand) {
+            const int np = __popc(cand);
+            uint32_t at = atomicAdd(&s_nraw, (uint32_t)np);
+            const uint64_t base = (uint64_t)tile * FT_NPOS + (uint64_t)tid * FT_G;
+            uint64_t* out = fa.raw_pos + (size_t)blockIdx.x * fa.raw_slice;
+            while (cand) {
+                const int j = __ffs(cand) - 1;
+                cand &= cand - 1;
+                if (at < fa.raw_slice) out[at] = base + (uint64_t)j;
+                ++at;
+            }
+        }
+        cur = p1;
+        p1 = p2;
+        p2 = p3;
+    }
+    lds_barrier();
+    if (tid == 0) {
+        fa.raw_count[blockIdx.x] = s_nraw;
+        if (s_nraw > fa.raw_slice) atomicOr(a.overflow, 4u);
+    }
+}
+
+// 16 ASCII bases -> packed codes + 16-bit "not ACGT" mask (bit i = base i)
+__device__ inline void pack16n(const uint4& in, uint32_t& packed, uint32_t& nmask)
 {
     const uint32_t e0 = encode4(in.x), e1 = encode4(in.y), e2 = encode4(in.z), e3 = encode4(in.w);
-    // gather the four 2-bit fields of a dword into one byte, first base highest: (x * 0x40100401) >> 24
-    const uint32_t p0 = ((e0 & 0x03030303u) * 0x40100401u) >> 24, p1 = ((e1 & 0x03030303u) * 0x40100401u) >> 24;
-    const uint32_t p2 = ((e2 & 0x03030303u) * 0x40100401u) >> 24, p3 = ((e3 & 0x03030303u) * 0x40100401u) >> 24;
-    packed = (p0 << 24) | (p1 << 16) | (p2 << 8) | p3;
+    packed = ((((e0 & 0x03030303u) * 0x40100401u) >> 24) << 24) | ((((e1 & 0x03030303u) * 0x40100401u) >> 24) << 16)
+        | ((((e2 & 0x03030303u) * 0x40100401u) >> 24) << 8) | (((e3 & 0x03030303u) * 0x40100401u) >> 24);
     nmask = 0;
-    if ((e0 | e1 | e2 | e3) & 0x04040404u) { // rare
-        // (flags * 0x01020408) >> 24 gathers the flag of byte i into bit i
+    if ((e0 | e1 | e2 | e3) & 0x04040404u) { // rare; (flags * 0x01020408) >> 24 gathers the flag of byte i into bit i
         auto m4 = [](uint32_t e) { return ((((e >> 2) & 0x01010101u) * 0x01020408u) >> 24) & 0xFu; };
         nmask = m4(e0) | (m4(e1) << 4) | (m4(e2) << 8) | (m4(e3) << 12);
     }
@@ -80,243 +180,54 @@ __device__ inline uint32_t revcomp_code(uint32_t f, int k)
     return (~x) >> (32 - 2 * k);                               // complement, right-align
 }
 
-struct FtShared {
-    uint32_t pack[FT_WORDS + 1];
-    uint16_t nmask[FT_WORDS + 1];
-    uint32_t start[FT_START_WORDS]; // bit per staged base: a read starts here
-    uint16_t cand[FT_CAND_CAP];
-    uint32_t ncand;
-    uint32_t more; // some thread still holds candidates for another round
-    uint32_t nraw; // raw hits appended by this workgroup so far (may exceed its slice: overflow)
-};
-
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, which would stall every wave
-// on the next tile's prefetch (global loads still in flight on purpose); LDS operations of a wave complete in
-// order, so lgkmcnt(0) + s_barrier is enough for LDS visibility inside the workgroup.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-struct FilterArgs {
-    const uint32_t* bloom;
-    uint32_t bloom_wbits;
-    uint32_t n_tiles;
-    uint64_t* raw_pos;   // [grid][raw_slice]: global base position | strand << 63
-    uint32_t* raw_hash;  // canonical hash of the minimizer
-    uint32_t* raw_hint;  // a read at or before the one holding the position (start of the read search)
-    uint32_t* raw_count; // [grid]
-    uint32_t raw_slice;
-    uint32_t debug; // ablation switches for profiling (DRPRG_FT_DEBUG): 1 = skip the Bloom test, 2 = skip verification
-};
-
-__global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a, FilterArgs fa)
+// canonical hash + 1 of the k-mer starting at bases[p] (k <= 15), 0 if it holds a non-ACGT base.  Two aligned 16-byte
+// loads cover any 15-mer; the byte loop only serves the last bytes of the buffer.
+__device__ inline uint32_t kmer_hash_at(const uint8_t* __restrict__ bases, int64_t n_bases, int64_t p, int k, uint32_t kmask,
+    bool& strand)
 {
-    using Tr = HashTraits<uint32_t>;
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_bloom[];
-    __shared__ FtShared sh;
-
-    const int tid = threadIdx.x;
-    const int k = a.k, w = a.w;
-    const uint32_t kmask = (1u << (2 * k)) - 1;
-    const uint32_t kbits = (1u << k) - 1; // k consecutive base flags
-    const int64_t n_bases = (int64_t)a.n_bases;
-    const int base0 = tid * FT_G;
-    const uint32_t n_tiles = fa.n_tiles;
-
-    for (uint32_t i = tid; i < (1u << fa.bloom_wbits); i += FT_THREADS) s_bloom[i] = fa.bloom[i];
-    if (tid == 0) sh.nraw = 0;
-
-    auto load_tile = [&](uint32_t tile, uint4& main, uint4& extra) {
-        const int64_t origin = (int64_t)tile * FT_EVAL - FT_HALO;
-        auto ld = [&](int v) -> uint4 {
-            const int64_t g = origin + (int64_t)v * 16;
-            if (g >= 0 && g + 16 <= n_bases) return *reinterpret_cast<const uint4*>(a.bases + g);
-            uint32_t t4[4];
-            for (int q = 0; q < 4; ++q) {
-                uint32_t wd = 0;
-                for (int b = 0; b < 4; ++b) {
-                    const int64_t gg = g + q * 4 + b;
-                    wd |= (uint32_t)((gg >= 0 && gg < n_bases) ? a.bases[gg] : (uint8_t)'N') << (8 * b);
-                }
-                t4[q] = wd;
-            }
-            return make_uint4(t4[0], t4[1], t4[2], t4[3]);
-        };
-        main = ld(tid);
-        if (tid < FT_WORDS - FT_THREADS) extra = ld(FT_THREADS + tid);
-    };
-    // k-mer at tile position p: canonical hash + 1, or 0 if it holds an N or straddles two reads
-    auto kmer_at = [&](int p, bool& strand) -> uint32_t {
-        const int v = p >> 4, o = p & 15;
-        const uint32_t f = __funnelshift_l(sh.pack[v + 1], sh.pack[v], 2 * o) >> (32 - 2 * k);
-        const uint32_t nm = (uint32_t)sh.nmask[v] | ((uint32_t)sh.nmask[v + 1] << 16);
-        if ((nm >> o) & kbits) return 0;
-        const int q = p + 1; // a read starting at p+1 .. p+k-1 splits the k-mer
-        const uint32_t st = __funnelshift_r(sh.start[q >> 5], sh.start[(q >> 5) + 1], q & 31);
-        if (st & (kbits >> 1)) return 0;
-        const uint32_t hf = Tr::mix(f, kmask), hr = Tr::mix(revcomp_code(f, k), kmask);
-        strand = hf <= hr;
-        return (hf < hr ? hf : hr) + 1;
-    };
-
-    unsigned long long dbg_cands = 0;
-    // register ring: the tile being processed plus three tiles in flight (Little's law: ~48 KB per CU must be
-    // outstanding to keep HBM busy; one tile is 8 KB per workgroup)
-    struct Pending {
-        uint4 main, extra;
-        int64_t off;
-        uint2 fc; // first read starting in the tile's staged range, number of reads starting there
-    };
-    const uint32_t gs = gridDim.x; // tile stride of this persistent workgroup
-    auto fetch = [&](uint32_t t, uint2 fc, Pending& p) {
-        p.fc = fc;
-        p.off = INT64_MAX;
-        if (t < n_tiles) {
-            load_tile(t, p.main, p.extra);
-            if ((uint32_t)tid < fc.y) p.off = (int64_t)a.offsets[(uint64_t)fc.x + tid];
+    uint32_t f;
+    const int64_t a0 = p & ~(int64_t)15;
+    if (a0 + 32 <= n_bases) {
+        const uint4 A = *reinterpret_cast<const uint4*>(bases + a0), B = *reinterpret_cast<const uint4*>(bases + a0 + 16);
+        uint32_t pa, pb, na, nb;
+        pack16n(A, pa, na);
+        pack16n(B, pb, nb);
+        const int o = (int)(p - a0);
+        if (((na | (nb << 16)) >> o) & ((1u << k) - 1)) return 0;
+        f = __funnelshift_l(pb, pa, 2 * o) >> (32 - 2 * k);
+    } else {
+        uint32_t bad = 0;
+        f = 0;
+        for (int i = 0; i < k; ++i) {
+            const uint32_t c = encode_base(bases[p + i]);
+            bad |= c;
+            f = (f << 2) | (c & 3u);
         }
-    };
-    auto first_of = [&](uint32_t t) -> uint2 {
-        return t < n_tiles ? make_uint2(a.tile_first_read[t], a.tile_first_read[n_tiles + t]) : make_uint2(0u, 0u);
-    };
-    Pending cur {}, p1 {}, p2 {}, p3 {};
-    uint32_t tile = blockIdx.x;
-    fetch(tile, first_of(tile), cur);
-    fetch(tile + gs, first_of(tile + gs), p1);
-    fetch(tile + 2 * gs, first_of(tile + 2 * gs), p2);
-    uint2 first3 = first_of(tile + 3 * gs);
-    __syncthreads(); // Bloom filter in place
-
-    for (; tile < n_tiles; tile += gs) {
-        const int64_t origin = (int64_t)tile * FT_EVAL - FT_HALO;
-        const uint32_t first_read = cur.fc.x, n_starts = cur.fc.y;
-        const int64_t cur_off = cur.off;
-        const uint2 first4 = first_of(tile + 4 * gs); // scalar loads, consumed in the next iteration
-
-        // ---- pack this tile into LDS ----
-        {
-            uint32_t pk, nm;
-            pack16(cur.main, pk, nm);
-            sh.pack[tid] = pk;
-            sh.nmask[tid] = (uint16_t)nm;
-            if (tid < FT_WORDS - FT_THREADS) {
-                pack16(cur.extra, pk, nm);
-                sh.pack[FT_THREADS + tid] = pk;
-                sh.nmask[FT_THREADS + tid] = (uint16_t)nm;
-            }
-            for (int i = tid; i < FT_START_WORDS; i += FT_THREADS) sh.start[i] = 0;
-            if (tid == 0) {
-                sh.pack[FT_WORDS] = 0;
-                sh.nmask[FT_WORDS] = 0xFFFF;
-            }
-        }
-        lds_barrier(); // not __syncthreads(): the ring's global loads must stay in flight
-        // ---- read starts of this tile -> bitmap (first offset per thread was prefetched) ----
-        {
-            for (uint32_t i = tid; i < n_starts; i += FT_THREADS) {
-                // beyond the first 512 starts (very short reads only) the offsets are loaded here
-                const int64_t o = i < FT_THREADS ? cur_off : (int64_t)a.offsets[(uint64_t)first_read + i];
-                const int oc = (int)(o - origin);
-                atomicOr(&sh.start[oc >> 5], 1u << (oc & 31));
-            }
-        }
-        // ---- prefetch: tile + 3*grid joins the ring; its loads stay in flight while tiles are processed from LDS
-        // (issued after this tile's own offset loads, because vector-memory results return in issue order) ----
-        fetch(tile + 3 * gs, first3, p3);
-        // ---- Bloom test of my 16 positions ----
-        uint32_t cand = 0;
-        if (!(fa.debug & 1u) && base0 >= FT_HALO && base0 < FT_NPOS - FT_HALO) {
-            const uint32_t w0 = sh.pack[tid], w1 = sh.pack[tid + 1];
-            const int sh_k = 32 - 2 * k, sh_w = 32 - (int)fa.bloom_wbits;
-#pragma unroll
-            for (int j = 0; j < FT_G; ++j) {
-                const uint32_t f = __funnelshift_l(w1, w0, 2 * j) >> sh_k;
-                const uint32_t hsh = f * 0x9E3779B1u;
-                const uint32_t word = s_bloom[hsh >> sh_w];
-                cand |= ((word >> (hsh & 31)) & (word >> ((hsh >> 5) & 31)) & (word >> ((hsh >> 10) & 31)) & 1u) << j;
-            }
-        }
-        // ---- rounds (almost always one): compact candidates, window test from LDS, append raw hits ----
-        const int span = 2 * w - 1;
-        if (fa.debug & 2u) cand = 0;
-        while (true) {
-            if (tid == 0) {
-                sh.ncand = 0;
-                sh.more = 0;
-            }
-            lds_barrier(); // also orders the start bitmap before its first use
-            if (cand) {
-                int np = __popc(cand);
-                if (np > 2) np = 2;
-                uint32_t at = atomicAdd(&sh.ncand, (uint32_t)np);
-                for (int i = 0; i < np; ++i) {
-                    const int j = __ffs(cand) - 1;
-                    cand &= cand - 1;
-                    sh.cand[at++] = (uint16_t)(base0 + j);
-                }
-            }
-            if (cand) sh.more = 1;
-            lds_barrier();
-            const uint32_t more = sh.more;
-            const uint32_t ncand = sh.ncand;
-            dbg_cands += ncand;
-            // Window test, half a wave per candidate: lane d of the half evaluates neighbour d (d = w-1 is the candidate
-            // itself); a ballot of "valid and >= the candidate's hash" gives the run of such neighbours on either side.
-            {
-                const int lane = tid & 63, half = lane >> 5, d = lane & 31;
-                for (uint32_t cb = (uint32_t)(tid >> 6) * 2; cb < ncand; cb += (FT_THREADS / 64) * 2) {
-                    const uint32_t c = cb + (uint32_t)half;
-                    const bool active = c < ncand && d < span;
-                    const int p = c < ncand ? (int)sh.cand[c] : FT_HALO;
-                    bool strand = false;
-                    const uint32_t g = active ? kmer_at(p + d - (w - 1), strand) : 0u;
-                    const uint32_t gc = (uint32_t)__shfl((int)g, half * 32 + (w - 1));
-                    const uint64_t ball = __ballot(active && g != 0 && g >= gc);
-                    const uint32_t m = half ? (uint32_t)(ball >> 32) : (uint32_t)ball;
-                    const uint32_t lmask = (1u << (w - 1)) - 1;       // bits 0 .. w-2: left neighbours, bit w-2 nearest
-                    const uint32_t lzero = ~m & lmask;
-                    const int left = lzero ? (w - 2) - (31 - __clz((int)lzero)) : (w - 1);
-                    const uint32_t rzero = ~(m >> w);                 // bit 0: nearest right neighbour
-                    int right = __ffs((int)rzero) - 1;
-                    if (right > w - 1) right = w - 1;
-                    // a window of w valid k-mers around p without a smaller hash exists: p is a read minimizer
-                    if (d == w - 1 && c < ncand && gc != 0 && left + right >= w - 1) {
-                        const uint32_t idx = atomicAdd(&sh.nraw, 1u);
-                        if (idx < fa.raw_slice) {
-                            const size_t at = (size_t)blockIdx.x * fa.raw_slice + idx;
-                            fa.raw_pos[at] = (uint64_t)(origin + p) | ((uint64_t)strand << 63);
-                            fa.raw_hash[at] = g - 1;
-                            fa.raw_hint[at] = first_read ? first_read - 1 : 0;
-                        }
-                    }
-                }
-            }
-            lds_barrier(); // the candidate list is reused by the next round
-            if (!more) break;
-        }
-        lds_barrier(); // everyone is done with this tile's LDS before it is overwritten
-        cur = p1;
-        p1 = p2;
-        p2 = p3;
-        first3 = first4;
+        if (bad & 4u) return 0;
     }
-    if (tid == 0) {
-        fa.raw_count[blockIdx.x] = sh.nraw;
-        if (fa.debug & 4u) atomicAdd(a.n_minimizers, dbg_cands | ((unsigned long long)sh.nraw << 40));
-        if (sh.nraw > fa.raw_slice) atomicOr(a.overflow, 4u);
-    }
+    const uint32_t hf = HashTraits<uint32_t>::mix(f, kmask), hr = HashTraits<uint32_t>::mix(revcomp_code(f, k), kmask);
+    strand = hf <= hr;
+    return (hf < hr ? hf : hr) + 1;
 }
 
-// raw hits -> hits: exact table lookup, read lookup, one (key,val) per index record.
-// Every workgroup takes a contiguous range of the concatenated raw slices; output space is reserved once per
-// 256-thread batch (LDS prefix + one global atomic per workgroup per batch), not once per wave.
 constexpr int EX_MAX_WG = 1024;
-__global__ __launch_bounds__(256) void expand_hits_kernel(SketchArgs a, FilterArgs fa, uint32_t n_wg)
+constexpr int EX_THREADS = 256;
+
+struct ExFound { // a candidate whose canonical hash is an index key
+    int64_t gp, r0, r1; // position, start and end of its read (global base coordinates)
+    uint32_t slot, read, g, strand, cnt;
+};
+
+__global__ __launch_bounds__(EX_THREADS) void verify_expand_kernel(SketchArgs a, FilterArgs fa, uint32_t n_wg)
 {
     using Tr = HashTraits<uint32_t>;
     __shared__ uint32_t s_prefix[EX_MAX_WG + 1];
-    __shared__ uint32_t s_cnt, s_found;
+    __shared__ uint32_t s_part[EX_THREADS];
+    __shared__ ExFound s_found[EX_THREADS];
+    __shared__ uint32_t s_nfound, s_cnt, s_nmin;
     __shared__ unsigned long long s_base;
     const int tid = threadIdx.x;
-    // inclusive scan of the (clamped) slice counts: 4 entries per thread, then a block scan
+    // exclusive prefix sums of the (clamped) slice counts: 4 entries per thread, then a block scan
     {
         uint32_t v[4], run = 0;
         for (int i = 0; i < 4; ++i) {
@@ -325,10 +236,9 @@ __global__ __launch_bounds__(256) void expand_hits_kernel(SketchArgs a, FilterAr
             v[i] = run;
             run += n < fa.raw_slice ? n : fa.raw_slice;
         }
-        __shared__ uint32_t s_part[256];
         s_part[tid] = run;
         __syncthreads();
-        for (int off = 1; off < 256; off <<= 1) {
+        for (int off = 1; off < EX_THREADS; off <<= 1) {
             const uint32_t add = tid >= off ? s_part[tid - off] : 0u;
             __syncthreads();
             s_part[tid] += add;
@@ -336,66 +246,107 @@ __global__ __launch_bounds__(256) void expand_hits_kernel(SketchArgs a, FilterAr
         }
         const uint32_t before = tid ? s_part[tid - 1] : 0u;
         for (int i = 0; i < 4; ++i) s_prefix[tid * 4 + i] = before + v[i];
-        if (tid == 255) s_prefix[EX_MAX_WG] = s_part[255];
+        if (tid == EX_THREADS - 1) s_prefix[EX_MAX_WG] = s_part[EX_THREADS - 1];
         __syncthreads();
     }
     const uint32_t total = s_prefix[EX_MAX_WG];
     const uint32_t* __restrict__ slot_key = reinterpret_cast<const uint32_t*>(a.slot_key);
     const uint32_t tmask = (1u << a.table_bits) - 1;
+    const int k = a.k, w = a.w;
+    const uint32_t kmask = (1u << (2 * k)) - 1;
+    const int64_t n_bases = (int64_t)a.n_bases;
     const uint32_t per_wg = (total + gridDim.x - 1) / gridDim.x;
     const uint32_t t_begin = blockIdx.x * per_wg;
     const uint32_t t_end = t_begin + per_wg < total ? t_begin + per_wg : total;
-    for (uint32_t t0 = t_begin; t0 < t_end; t0 += 256) {
+    const int lane = tid & 63, half = lane >> 5, d = lane & 31;
+    const double reads_per_base = (double)a.n_reads / (double)(a.n_bases ? a.n_bases : 1);
+    for (uint32_t t0 = t_begin; t0 < t_end; t0 += EX_THREADS) {
+        if (tid == 0) { s_nfound = 0; s_cnt = 0; s_nmin = 0; }
+        __syncthreads();
+        // ---- phase 1, one lane per candidate: canonical hash from the raw bases, exact table lookup, read lookup ----
         const uint32_t t = t0 + tid;
-        uint32_t cnt = 0, slot = 0, strand = 0, hint = 0;
-        uint64_t gp = 0;
         if (t < t_end) {
             uint32_t lo = 0, hi = EX_MAX_WG; // s_prefix[lo] <= t < s_prefix[hi]
             while (hi - lo > 1) {
                 const uint32_t mid = (lo + hi) >> 1;
                 if (s_prefix[mid] <= t) lo = mid; else hi = mid;
             }
-            const size_t at_raw = (size_t)lo * fa.raw_slice + (t - s_prefix[lo]);
-            const uint64_t rp = fa.raw_pos[at_raw];
-            strand = (uint32_t)(rp >> 63);
-            gp = rp & ~(1ull << 63);
-            hint = fa.raw_hint[at_raw];
-            const uint32_t h = fa.raw_hash[at_raw];
-            uint32_t s = table_slot_dev((uint64_t)h, a.table_bits);
-            while (true) {
-                const uint32_t key = slot_key[s];
-                if (key == h) { slot = s; cnt = a.slot_rec[s].y; break; }
-                if (key == Tr::EMPTY) break; // a Bloom false positive
-                s = (s + 1) & tmask;
+            const int64_t gp = (int64_t)fa.raw_pos[(size_t)lo * fa.raw_slice + (t - s_prefix[lo])];
+            bool st = false;
+            const uint32_t g = gp + k <= n_bases ? kmer_hash_at(a.bases, n_bases, gp, k, kmask, st) : 0u;
+            if (g) { // Bloom false positives end at the exact lookup
+                const uint32_t h = g - 1;
+                uint32_t s = table_slot_dev((uint64_t)h, a.table_bits);
+                bool found = false;
+                while (true) {
+                    const uint32_t key = slot_key[s];
+                    if (key == h) { found = true; break; }
+                    if (key == Tr::EMPTY) break;
+                    s = (s + 1) & tmask;
+                }
+                if (found) {
+                    // interpolated first guess: exact for fixed-length reads, a short gallop otherwise
+                    const uint32_t guess = (uint32_t)((double)gp * reads_per_base);
+                    const uint32_t rlo = find_read_near(a.offsets, a.n_reads, guess, (uint64_t)gp);
+                    const int64_t r0 = (int64_t)a.offsets[rlo], r1 = (int64_t)a.offsets[rlo + 1];
+                    if (gp + k <= r1) { // the k-mer lies inside one read
+                        ExFound e;
+                        e.gp = gp; e.r0 = r0; e.r1 = r1;
+                        e.slot = s; e.read = rlo; e.g = g; e.strand = st ? 1u : 0u; e.cnt = 0;
+                        s_found[atomicAdd(&s_nfound, 1u)] = e;
+                    }
+                }
             }
         }
-        if (tid == 0) { s_cnt = 0; s_found = 0; }
         __syncthreads();
-        uint32_t my_off = 0;
-        if (cnt) {
-            my_off = atomicAdd(&s_cnt, cnt);
-            atomicAdd(&s_found, 1u);
+        // ---- phase 2, half a wave per index k-mer: lane d evaluates neighbour d - (w-1); a ballot of "inside the read,
+        // no N, hash >= the candidate's" gives the runs on either side; a window of w such k-mers makes it a minimizer ----
+        const uint32_t nfound = s_nfound;
+        for (uint32_t cb = (uint32_t)(tid >> 6) * 2; cb < nfound; cb += (EX_THREADS / 64) * 2) {
+            const uint32_t c = cb + (uint32_t)half;
+            const bool have = c < nfound;
+            const ExFound e = s_found[have ? c : 0];
+            const int64_t q = e.gp + d - (w - 1);
+            uint32_t x = 0;
+            bool s2;
+            if (have && d < 2 * w - 1 && d != w - 1 && q >= e.r0 && q + k <= e.r1) x = kmer_hash_at(a.bases, n_bases, q, k, kmask, s2);
+            const uint64_t ball = __ballot(x != 0 && x >= e.g);
+            const uint32_t m = half ? (uint32_t)(ball >> 32) : (uint32_t)ball;
+            const uint32_t lmask = (1u << (w - 1)) - 1;   // bits 0 .. w-2: left neighbours, bit w-2 nearest
+            const uint32_t lzero = ~m & lmask;
+            const int left = lzero ? (w - 2) - (31 - __clz((int)lzero)) : (w - 1);
+            const uint32_t rzero = ~(m >> w);             // bit 0: nearest right neighbour
+            int right = __ffs((int)rzero) - 1;
+            if (right > w - 1) right = w - 1;
+            if (have && d == w - 1 && left + right >= w - 1) {
+                const uint32_t cnt = a.slot_rec[e.slot].y;
+                s_found[c].cnt = cnt;
+                atomicAdd(&s_cnt, cnt);
+                atomicAdd(&s_nmin, 1u);
+            }
         }
         __syncthreads();
+        // ---- phase 3: reserve output once per batch, emit one (key,val) per index record ----
         if (tid == 0 && s_cnt) {
             s_base = atomicAdd(a.n_hits, (unsigned long long)s_cnt);
-            atomicAdd(a.n_minimizers, (unsigned long long)s_found);
+            atomicAdd(a.n_minimizers, (unsigned long long)s_nmin);
+            s_cnt = 0; // reused as the running offset below
         }
         __syncthreads();
-        if (cnt) {
-            const uint32_t read = find_read_from(a.offsets, a.n_reads, hint, gp);
-            const uint64_t pos = gp - a.offsets[read];
-            const unsigned long long at = s_base + my_off;
-            if (at + cnt > a.hit_capacity || pos >= (1ull << HIT_POS_BITS)) {
+        if ((uint32_t)tid < nfound && s_found[tid].cnt) {
+            const ExFound e = s_found[tid];
+            const unsigned long long at = s_base + atomicAdd(&s_cnt, e.cnt);
+            const uint64_t pos = (uint64_t)(e.gp - e.r0);
+            if (at + e.cnt > a.hit_capacity || pos >= (1ull << HIT_POS_BITS)) {
                 atomicOr(a.overflow, pos >= (1ull << HIT_POS_BITS) ? 2u : 1u);
             } else {
-                const uint2 rec = a.slot_rec[slot];
-                for (uint32_t q = 0; q < rec.y; ++q) {
-                    const uint32_t kn = a.rec_knode[rec.x + q];
-                    const uint32_t prg = a.rec_prg[rec.x + q];
-                    const uint32_t rev = ((kn & 1u) == strand) ? 0u : 1u;
-                    a.hit_key[at + q] = pack_hit_key(read, prg, rev, (uint32_t)pos);
-                    a.hit_val[at + q] = kn >> 1;
+                const uint2 rec = a.slot_rec[e.slot];
+                for (uint32_t qq = 0; qq < rec.y; ++qq) {
+                    const uint32_t kn = a.rec_knode[rec.x + qq];
+                    const uint32_t prg = a.rec_prg[rec.x + qq];
+                    const uint32_t rev = ((kn & 1u) == e.strand) ? 0u : 1u;
+                    a.hit_key[at + qq] = pack_hit_key(e.read, prg, rev, (uint32_t)pos);
+                    a.hit_val[at + qq] = kn >> 1;
                 }
             }
         }
@@ -403,30 +354,27 @@ __global__ __launch_bounds__(256) void expand_hits_kernel(SketchArgs a, FilterAr
     }
 }
 
-uint32_t filter_n_tiles(uint64_t n_bases) { return (uint32_t)((n_bases + FT_EVAL - 1) / FT_EVAL); }
+uint32_t filter_n_tiles(uint64_t n_bases) { return (uint32_t)((n_bases + FT_NPOS - 1) / FT_NPOS); }
 
 uint32_t filter_grid(uint32_t bloom_wbits, int n_cus, uint32_t n_tiles)
 {
     // persistent grid: as many workgroups as stay resident (LDS-limited), never more than there are tiles
     // (LDS is handed out in granules; leave a margin so that the resident count is not over-estimated)
-    const size_t lds_per_wg = (sizeof(uint32_t) << bloom_wbits) + sizeof(FtShared) + 2048;
+    const size_t lds_per_wg = (sizeof(uint32_t) << bloom_wbits) + 2 * (FT_WORDS + 1) * sizeof(uint32_t) + 2048;
     uint32_t per_cu = (uint32_t)((160 * 1024) / lds_per_wg);
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 4) per_cu = 4;
     uint32_t grid = (uint32_t)n_cus * per_cu;
     if (grid > n_tiles) grid = n_tiles;
-    if (grid > (uint32_t)EX_MAX_WG) grid = EX_MAX_WG; // expand_hits_kernel keeps one prefix entry per workgroup in LDS
+    if (grid > (uint32_t)EX_MAX_WG) grid = EX_MAX_WG; // verify_expand_kernel keeps one prefix entry per workgroup in LDS
     return grid ? grid : 1;
 }
 
 hipError_t launch_sketch_filter(const SketchArgs& a, const uint32_t* bloom, uint32_t bloom_wbits, int n_cus, uint64_t* raw_pos,
-    uint32_t* raw_hash, uint32_t* raw_hint, uint64_t raw_capacity, uint32_t* raw_count, hipStream_t stream, KernelTimer timer)
+    uint64_t raw_capacity, uint32_t* raw_count, hipStream_t stream, KernelTimer timer)
 {
     if (a.n_bases == 0) return hipSuccess;
     const uint32_t n_tiles = filter_n_tiles(a.n_bases);
-    hipLaunchKernelGGL(tile_first_read_ft_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, stream, a.offsets, a.n_reads,
-        n_tiles, a.tile_first_read);
-    HIP_TRY(hipGetLastError());
     const size_t dyn = sizeof(uint32_t) << bloom_wbits;
     static size_t configured = 0;
     if (dyn > configured) {
@@ -440,8 +388,6 @@ hipError_t launch_sketch_filter(const SketchArgs& a, const uint32_t* bloom, uint
     fa.bloom_wbits = bloom_wbits;
     fa.n_tiles = n_tiles;
     fa.raw_pos = raw_pos;
-    fa.raw_hash = raw_hash;
-    fa.raw_hint = raw_hint;
     fa.raw_count = raw_count;
     fa.raw_slice = (uint32_t)std::min<uint64_t>(raw_capacity / grid, 0x7FFFFFFFull);
     if (const char* dbg = std::getenv("DRPRG_FT_DEBUG")) fa.debug = (uint32_t)std::atoi(dbg);
@@ -449,7 +395,7 @@ hipError_t launch_sketch_filter(const SketchArgs& a, const uint32_t* bloom, uint
     hipLaunchKernelGGL(sketch_filter_kernel, dim3(grid), dim3(FT_THREADS), dyn, stream, a, fa);
     HIP_TRY(hipGetLastError());
     if (timer.end) HIP_TRY(hipEventRecord(timer.end, stream));
-    hipLaunchKernelGGL(expand_hits_kernel, dim3((uint32_t)n_cus * 8), dim3(256), 0, stream, a, fa, grid);
+    hipLaunchKernelGGL(verify_expand_kernel, dim3((uint32_t)n_cus * 8), dim3(256), 0, stream, a, fa, grid);
     return hipGetLastError();
 }
 
