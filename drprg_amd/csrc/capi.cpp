@@ -2,6 +2,7 @@
 #include "../../include/drprg_hip.h"
 #include "fastx.h"
 #include "genotype.h"
+#include "ingest.h"
 #include "mapper.h"
 #include <cstring>
 #include <functional>
@@ -19,6 +20,7 @@ struct drprg_hip_ctx {
     std::vector<uint32_t> covg, prg_reads;
     bool host_coverage_valid = false;
     uint64_t total_bases = 0;
+    int threads = 4; // parser threads of drprg_hip_map_fastx
     uint32_t ginfo[4] = { 0, 0, 0, 0 };
 };
 
@@ -127,14 +129,32 @@ int drprg_hip_map_fastx(drprg_hip_ctx* ctx, const char* reads_path)
     API_BEGIN(ctx)
     if (!reads_path) throw Error(DRPRG_EINVAL, "null reads path");
     Mapper& m = need_mapper(ctx);
-    FastxReader rd(reads_path);
-    ReadBatch batch;
-    while (rd.next_batch(batch, 8u << 20, 1ull << 30)) {
-        m.map_host(batch.bases.data(), batch.offsets.data(), batch.n_reads());
-        ctx->total_bases += batch.bases.size();
-    }
     ctx->host_coverage_valid = false;
+    // multi-threaded ingest into pinned blocks (ingest.cpp); multi-line FASTQ falls back to the serial reader
+    IngestHooks hooks;
+    hooks.alloc = [](size_t n) { return Mapper::pinned_alloc(n); };
+    hooks.release = [](void* p) { Mapper::pinned_free(p); };
+    hooks.submit = [&](const PinnedBatch& b) { m.map_host(b.bases, b.offsets, b.n_reads); };
+    try {
+        IngestStats st = ingest_fastx(reads_path, ctx->threads, hooks);
+        ctx->total_bases += st.bases;
+    } catch (const Error& e) {
+        if (e.code != DRPRG_EAGAIN_SERIAL) throw;
+        FastxReader rd(reads_path);
+        ReadBatch batch;
+        while (rd.next_batch(batch, 8u << 20, 1ull << 30)) {
+            m.map_host(batch.bases.data(), batch.offsets.data(), batch.n_reads());
+            ctx->total_bases += batch.bases.size();
+        }
+    }
     API_END(ctx)
+}
+
+int drprg_hip_set_threads(drprg_hip_ctx* ctx, int threads)
+{
+    if (!ctx) return DRPRG_EINVAL;
+    ctx->threads = threads > 0 ? threads : 1;
+    return DRPRG_OK;
 }
 
 int drprg_hip_map_host(drprg_hip_ctx* ctx, const uint8_t* bases, const uint64_t* offsets, uint64_t n_reads)
@@ -382,3 +402,33 @@ int drprg_hip_report_json(const char* index_dir, const char* annotated_vcf, cons
 }
 
 } // extern "C"
+
+// ---- ingest self-check (host only) ---------------------------------------------------------------------------
+extern "C" int drprg_hip_parse_fastx(const char* reads_path, int threads, uint64_t out[4], char* err, size_t err_len)
+{
+    if (!reads_path || !out) return DRPRG_EINVAL;
+    return report_guard(err, err_len, [&]() {
+        uint64_t sum = 0, n_reads = 0, n_bases = 0, batches = 0;
+        auto digest = [&](const uint8_t* bases, const uint64_t* offsets, uint64_t n) {
+            for (uint64_t i = 0; i < n; ++i) { // order-independent: sum of FNV-1a hashes of the reads
+                uint64_t h = 1469598103934665603ull;
+                for (uint64_t j = offsets[i]; j < offsets[i + 1]; ++j) h = (h ^ bases[j]) * 1099511628211ull;
+                sum += h;
+            }
+            n_reads += n;
+            n_bases += offsets[n];
+            ++batches;
+        };
+        IngestHooks hooks;
+        hooks.submit = [&](const PinnedBatch& b) { digest(b.bases, b.offsets, b.n_reads); };
+        try {
+            ingest_fastx(reads_path, threads, hooks);
+        } catch (const Error& e) {
+            if (e.code != DRPRG_EAGAIN_SERIAL) throw;
+            FastxReader rd(reads_path);
+            ReadBatch batch;
+            while (rd.next_batch(batch, 1u << 20, 1ull << 28)) digest(batch.bases.data(), batch.offsets.data(), batch.n_reads());
+        }
+        out[0] = n_reads; out[1] = n_bases; out[2] = sum; out[3] = batches;
+    });
+}

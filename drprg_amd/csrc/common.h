@@ -26,6 +26,7 @@ enum : int {
     DRPRG_ENODEV = -19,
     DRPRG_EOVERFLOW = -75,
     DRPRG_EFORMAT = -84,
+    DRPRG_EAGAIN_SERIAL = -11, // internal: the parallel ingest hands the file to the serial reader (nothing was mapped yet)
 };
 
 inline uint64_t kmer_mask(int k) { return k >= 32 ? ~0ULL : ((1ULL << (2 * k)) - 1); }

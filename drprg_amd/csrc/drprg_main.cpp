@@ -177,7 +177,6 @@ int main(int argc, char** argv)
     if (sample.empty()) sample = file_prefix(input);
     int device = 0;
     if (const char* d = std::getenv("DRPRG_HIP_DEVICE")) device = std::atoi(d);
-    (void)threads;
 
     const std::string prg = index + "/dr.prg";
     drprg_hip_ctx* ctx = drprg_hip_open(prg.c_str(), w, k, device);
@@ -187,6 +186,7 @@ int main(int argc, char** argv)
     mo.min_cluster_size = min_cluster;
     mo.genome_size = 4411532; // MTB_GENOME_SIZE, /root/reference/src/lib.rs:36
     if (int rc = drprg_hip_set_opts(ctx, &mo)) die(drprg_hip_last_error(ctx), -rc);
+    drprg_hip_set_threads(ctx, threads);
     if (verbose) std::fprintf(stderr, "[drprg-hip] mapping %s against %s (k=%d w=%d) on device %d\n", input.c_str(), index.c_str(), k, w, device);
     // discover + map share one pass over the reads; no de novo loci are reported (the PRG is used unchanged)
     {

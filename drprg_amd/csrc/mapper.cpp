@@ -114,6 +114,18 @@ Mapper::~Mapper()
     if (stream_) (void)hipStreamDestroy(stream_);
 }
 
+void* Mapper::pinned_alloc(size_t bytes)
+{
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+
+void Mapper::pinned_free(void* p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
 void Mapper::set_params(const MapParams& p)
 {
     if (p.k < 1 || p.k > 31) throw Error(DRPRG_EINVAL, "k must be in [1,31]");

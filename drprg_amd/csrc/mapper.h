@@ -37,6 +37,10 @@ public:
     // Map a host batch (copies through pinned staging buffers, then map_device on the own accumulators).
     void map_host(const uint8_t* bases, const uint64_t* offsets, uint64_t n_reads);
 
+    // page-locked host memory for ingest blocks (H2D copies from it run at DMA speed)
+    static void* pinned_alloc(size_t bytes);
+    static void pinned_free(void* p);
+
     void reset_coverage();
     // own accumulators
     uint32_t* d_covg() const { return d_covg_; }

@@ -121,6 +121,7 @@ drprg_hip_ctx* open_ctx(const Args& a)
     o.min_cluster_size = a.min_cluster_size;
     o.genome_size = a.genome_size;
     if (int rc = drprg_hip_set_opts(ctx, &o)) die(drprg_hip_last_error(ctx), -rc);
+    drprg_hip_set_threads(ctx, a.threads);
     return ctx;
 }
 

@@ -255,7 +255,7 @@ def write_fastq_fixed(path, bases, read_len, chunk=1 << 20):
     with open(path, "wb") as fh:
         for lo in range(0, n, chunk):
             m = min(chunk, n - lo)
-            rec = np.empty((m, 11 + read_len + 1 + 2 + read_len + 1), dtype=np.uint8)
+            rec = np.empty((m, 12 + read_len + 1 + 2 + read_len + 1), dtype=np.uint8)
             rec[:, 0:2] = np.frombuffer(b"@r", np.uint8)
             idx = np.arange(lo, lo + m)
             for d in range(9):
