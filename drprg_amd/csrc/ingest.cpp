@@ -18,9 +18,11 @@ namespace drprg {
 
 namespace {
 
-constexpr size_t SLICE_BYTES = 96u << 20; // text handed to one parser task
-constexpr size_t BLOCK_BASES = 64u << 20; // pinned block: bases capacity ...
-constexpr size_t BLOCK_READS = 4u << 20;  // ... and read capacity (flushed early when either fills up)
+// A slice of FASTQ text is about half bases, so one slice normally fills one block (one H2D copy + one launch
+// sequence per slice).  Pinning memory is slow (~10 GB/s), hence small blocks, allocated only by workers that get work.
+constexpr size_t SLICE_BYTES = 32u << 20; // text handed to one parser task
+constexpr size_t BLOCK_BASES = 24u << 20; // pinned block: bases capacity ...
+constexpr size_t BLOCK_READS = 1u << 20;  // ... and read capacity (flushed early when either fills up)
 
 struct Block {
     uint8_t* bases = nullptr;
@@ -259,10 +261,10 @@ IngestStats ingest_fastx(const std::string& path, int threads, const IngestHooks
     auto worker = [&]() {
         Block blk;
         try {
-            blk = sh.new_block();
             Slice s;
             while (queue.pop(s)) {
                 if (sh.failed) continue; // drain
+                if (!blk.bases) blk = sh.new_block();
                 parse_slice(s.begin, s.end, fastq, blk, sh);
             }
             if (!sh.failed) sh.submit(blk);
@@ -297,7 +299,8 @@ IngestStats ingest_fastx(const std::string& path, int threads, const IngestHooks
                 return st;
             }
             if (fastq) require_four_line_fastq(text, end);
-            for (int t = 0; t < threads; ++t) pool.emplace_back(worker);
+            const int n_workers = (int)std::min<size_t>((size_t)threads, map_len / SLICE_BYTES + 1);
+            for (int t = 0; t < n_workers; ++t) pool.emplace_back(worker);
             const char* cur = text;
             while (cur < end && !sh.failed) {
                 const char* cut = end;
