@@ -54,6 +54,11 @@ inline int nt4(unsigned char c)
     }
 }
 
+// Multipliers of the two Bloom-filter levels shared by FlatIndex::build (index.cpp) and sketch_filter_kernel
+// (sketch_filter.hip, where the layout is described); level 1 is a 24 x 24 bit multiply.
+constexpr uint32_t BLOOM_C1 = 0x9E3779u;
+constexpr uint32_t BLOOM_C2 = 0x85EBCA6Bu;
+
 // canonical hash of a k-mer given as a string of exactly k ACGT characters.
 // strand = true when the forward k-mer hashes <= its reverse complement.
 inline bool canonical_kmer_hash(const char* s, int k, uint64_t& h, bool& strand)

@@ -112,10 +112,15 @@ void PrgIndex::flatten()
         while (wbits < MAX_WBITS && (size_t(1) << wbits) * 5 < entries * 4) ++wbits; // <= 1.25 entries per word
         f.bloom_wbits = wbits;
         f.bloom.assign(size_t(1) << wbits, 0);
+        // layout: see sketch_filter.hip.  The code is the kernel's own packing: letter = bits 2:1 of the ASCII base
+        // (A 0, C 1, T 2, G 3; complement = letter ^ 2), first base in the lowest bits.
+        const uint32_t wmask = (1u << wbits) - 1;
+        const uint32_t kmask = (1u << (2 * k)) - 1; // k <= 15
         auto add = [&](uint32_t code) {
-            const uint32_t h = code * 0x9E3779B1u;
-            f.bloom[h >> (32 - wbits)] |= (1u << (h & 31)) | (1u << ((h >> 5) & 31)) | (1u << ((h >> 10) & 31));
-            const uint32_t h2 = code * 0x85EBCA6Bu; // second level: an independent word, tested only for level-1 survivors
+            const uint32_t x = code & kmask & 0xFFFFFFu; // level 1: the first min(k,12) bases, 24 x 24 bit multiply
+            const uint32_t h = (uint32_t)((uint64_t)x * BLOOM_C1);
+            f.bloom[(h >> 18) & wmask] |= (1u << (31 - (h & 31))) | (1u << (31 - ((h >> 8) & 31))) | (1u << (31 - ((x >> 16) & 31)));
+            const uint32_t h2 = code * BLOOM_C2; // level 2: an independent word, tested only for level-1 survivors
             f.bloom[h2 >> (32 - wbits)] |= (1u << (h2 & 31)) | (1u << ((h2 >> 5) & 31)) | (1u << ((h2 >> 10) & 31));
         };
         for (size_t p = 0; p < prgs.size(); ++p) {
@@ -124,9 +129,9 @@ void PrgIndex::flatten()
                 const std::string s = kpath_sequence(prgs[p], nodes[i].path);
                 uint32_t fw = 0, rc = 0;
                 for (int j = 0; j < k; ++j) {
-                    const uint32_t c = (uint32_t)nt4((unsigned char)s[(size_t)j]);
-                    fw = (fw << 2) | c;
-                    rc = (rc >> 2) | ((3 - c) << (2 * (k - 1)));
+                    const uint32_t c = ((uint32_t)(unsigned char)s[(size_t)j] >> 1) & 3u;
+                    fw |= c << (2 * j);
+                    rc |= (c ^ 2u) << (2 * (k - 1 - j));
                 }
                 add(fw);
                 add(rc);

@@ -29,8 +29,8 @@ struct FlatIndex {
     uint32_t table_bits = 0;
     std::vector<uint64_t> slot_key;
     std::vector<uint32_t> slot_off, slot_cnt;
-    // Bloom filter over the 2-bit codes of every index k-mer in both orientations (k <= 15 only), 3 bits per entry in
-    // one 32-bit word: word = (code*0x9E3779B1) >> (32-bloom_wbits), bits = hash & 31, (hash >> 5) & 31, (hash >> 10) & 31.
+    // Bloom filter over the 2-bit codes of every index k-mer in both orientations (k <= 15 only): two levels, each
+    // 3 bits in one 32-bit word of the same array (layout at the top of sketch_filter_kernel, sketch_filter.hip).
     // bloom_wbits == 0: no filter (k > 15, or too many keys for an LDS-resident filter).
     uint32_t bloom_wbits = 0;
     std::vector<uint32_t> bloom;

@@ -170,11 +170,11 @@ void Mapper::run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32
     uint32_t* covg, uint32_t* prg_reads, hipStream_t stream)
 {
     ensure_workspace(std::max<uint64_t>(1u << 20, n_bases / 64));
-    const uint32_t n_tiles = std::max(dev::sketch_n_tiles(n_bases, halo_), dev::filter_n_tiles(n_bases));
-    if (n_tiles > tile_cap_) {
+    const uint32_t n_tiles = use_filter_ ? 0u : dev::sketch_n_tiles(n_bases, halo_);
+    if (n_tiles > tile_cap_) { // direct kernel only: first read of every tile
         dfree(d_tile_first_);
         tile_cap_ = n_tiles + n_tiles / 4 + 16;
-        dmalloc(d_tile_first_, 2 * (size_t)tile_cap_); // filtered kernel: [first read | number of read starts] per tile
+        dmalloc(d_tile_first_, (size_t)tile_cap_);
     }
     for (int attempt = 0;; ++attempt) {
         HIPCHK(hipMemsetAsync(&d_counters_[C_HITS], 0, sizeof(unsigned long long), stream));

@@ -1,14 +1,15 @@
-// sketch_filter.hip -- K1+K2 in their fast form: persistent workgroups + an LDS-resident Bloom prefilter.
+// sketch_filter.hip -- K1+K2 in their fast form: persistent waves + an LDS-resident Bloom prefilter.
 //
 // A read minimizer can only produce a hit if its k-mer is an index k-mer (in either orientation).  So instead of
 // hashing every k-mer of every read (sketch_probe.hip: ~86 VALU instructions per base, two 15-op hashes each):
 //
-//   sketch_filter_kernel   streams the concatenated base buffer through persistent workgroups, packs it to 2 bits
-//                          per base in LDS and tests each position's k-mer *code* against a Bloom filter of the
-//                          index k-mer codes that stays in LDS for the lifetime of the workgroup; the positions that
-//                          pass (index k-mers + ~0.5 % false positives) are appended, without any global atomic, to
-//                          the workgroup's slice of a candidate buffer.  Nothing in its loop waits on global memory:
-//                          three tiles of bases are in flight in a register ring.
+//   sketch_filter_kernel   streams the concatenated base buffer through persistent waves, packs it to 2 bits per base
+//                          in registers and tests each position's k-mer *code* against a Bloom filter of the index
+//                          k-mer codes that stays in LDS for the lifetime of the workgroup; the positions that pass
+//                          (index k-mers + ~0.02 % false positives) are appended, without any global atomic, to the
+//                          workgroup's slice of a candidate buffer.  The loop has no barrier and waits on nothing but
+//                          its own loads: three tiles of bases are in flight per wave in a register ring, the right
+//                          neighbour's packed word arrives through a DPP wave shift.
 //   verify_expand_kernel   one thread per candidate, no barriers on the critical path: canonical hash from the raw
 //                          bases -> exact table lookup (false positives end here) -> read lookup -> window-minimizer
 //                          test over the 2w-1 neighbouring k-mers inside the read -> one (key,val) hit per index
@@ -17,6 +18,7 @@
 // The Bloom filter has no false negatives and every survivor is re-derived exactly from the bases, so the result is
 // identical to the direct kernel (tests/test_gpu_parity.py checks both against the oracle).  Serves k <= 15, w <= 16
 // and indexes whose filter fits 64 KB of LDS; everything else takes the direct kernel.
+#include "common.h"
 #include "device_common.h"
 #include <algorithm>
 #include <cstdint>
@@ -25,51 +27,59 @@
 namespace drprg {
 namespace dev {
 
-constexpr int FT_THREADS = 512;
-constexpr int FT_G = 16;
-constexpr int FT_NPOS = FT_THREADS * FT_G; // 8192 positions (= bases) per tile, tiles do not overlap
-constexpr int FT_WORDS = FT_THREADS + 1;   // packed words staged per tile: 16 bases each, one extra for the k-1 tail
+constexpr int FT_THREADS = 1024;
+constexpr int FT_WAVES = FT_THREADS / 64;
+constexpr int FT_G = 16;                // positions per lane
+constexpr int FT_WPOS = 63 * FT_G;      // positions per wave tile: lane 63's word is only lane 62's right neighbour
+constexpr int FT_BLOOM_WORDS = 1 << 14; // static LDS: the filter sits at LDS address 0, so a hash is an address
 
-// 16 ASCII bases -> 32-bit packed 2-bit codes, first base in the top bits (a non-ACGT byte packs to an arbitrary
-// code: it can only create a false candidate, which verify_expand_kernel rejects from the raw bases)
-__device__ inline uint32_t pack16(const uint4& in)
+// 16 ASCII bases -> 32 bits, 2 per base, first base in the lowest bits.  The 2-bit letter is bits 2:1 of the ASCII code
+// (A 0, C 1, T 2, G 3, either case; anything else aliases one of them: it can only create a false candidate, which
+// verify_expand_kernel rejects from the raw bases).  One multiply gathers the four fields of a dword into its top byte.
+__device__ inline uint32_t pack16le(const uint4& in)
 {
-    const uint32_t e0 = encode4(in.x) & 0x03030303u, e1 = encode4(in.y) & 0x03030303u;
-    const uint32_t e2 = encode4(in.z) & 0x03030303u, e3 = encode4(in.w) & 0x03030303u;
-    // gather the four 2-bit fields of a dword into one byte, first base highest: (x * 0x40100401) >> 24
-    return (((e0 * 0x40100401u) >> 24) << 24) | (((e1 * 0x40100401u) >> 24) << 16) | (((e2 * 0x40100401u) >> 24) << 8)
-        | ((e3 * 0x40100401u) >> 24);
+    constexpr uint32_t M = (1u << 23) | (1u << 17) | (1u << 11) | (1u << 5);
+    const uint32_t p0 = (in.x & 0x06060606u) * M, p1 = (in.y & 0x06060606u) * M;
+    const uint32_t p2 = (in.z & 0x06060606u) * M, p3 = (in.w & 0x06060606u) * M;
+    // byte 3 of p0..p3 -> bytes 0..3
+    return __builtin_amdgcn_perm(p1, p0, 0x0c0c0703u) | __builtin_amdgcn_perm(p3, p2, 0x07030c0cu);
 }
 
 struct FilterArgs {
     const uint32_t* bloom;
     uint32_t bloom_wbits;
-    uint32_t n_tiles;
+    uint32_t n_tiles;    // wave tiles of FT_WPOS positions
     uint64_t* raw_pos;   // [grid][raw_slice]: global base position of a candidate k-mer
     uint32_t* raw_count; // [grid]
     uint32_t raw_slice;
     uint32_t debug; // ablation switch for profiling (DRPRG_FT_DEBUG): 1 = skip the Bloom test
 };
 
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, which would stall every wave
-// on the prefetch ring (global loads in flight on purpose); LDS operations of a wave complete in order, so
-// lgkmcnt(0) + s_barrier is enough for LDS visibility inside the workgroup.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
+// Bloom filter layout (built by FlatIndex, index.cpp; both orientations of every index k-mer are entered):
+//   code   = little-endian 2-bit letters of the k-mer (pack16le alphabet), 2k bits
+//   level 1, keyed on the first min(k,12) bases: x = code & 0xFFFFFF, h = (x * BLOOM_C1) mod 2^32,
+//            word (h >> 18) & (words-1), bits 31-(h & 31), 31-((h >> 8) & 31), 31-((x >> 16) & 31)
+//   level 2, keyed on the whole code: h2 = code * BLOOM_C2, word h2 >> (32-wbits), bits h2 & 31, (h2>>5) & 31, (h2>>10) & 31
+// Level 1 costs 7 VALU + 1 LDS instruction per position (24-bit multiply, byte-select shifts, 3-input AND, funnel-shift
+// accumulate); level 2 runs only for the ~1.5 % level-1 survivors.
+template <bool SHORT_K> // SHORT_K: k < 12, the level-1 key must be masked to 2k bits
 __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a, FilterArgs fa)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_bloom[];
-    __shared__ uint32_t s_pack[2][FT_WORDS + 1]; // double buffered: one barrier per tile
-    __shared__ uint32_t s_nraw;
+    __shared__ uint32_t s_bloom[FT_BLOOM_WORDS];
+    extern __shared__ uint32_t s_nraw[]; // one cursor, behind the filter
 
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int k = a.k;
     const int64_t n_bases = (int64_t)a.n_bases;
     const uint32_t n_tiles = fa.n_tiles;
-    const int sh_k = 32 - 2 * k, sh_w = 32 - (int)fa.bloom_wbits;
+    const uint32_t n_words = 1u << fa.bloom_wbits;
+    const uint32_t amask = (n_words - 1) << 2; // byte address of the level-1 word = (h >> 16) & amask
+    const uint32_t kmask = (k < 16) ? ((1u << (2 * k)) - 1) : 0xFFFFFFFFu;
+    const uint32_t kmask24 = kmask & 0xFFFFFFu;
+    const int sh_w = 32 - (int)fa.bloom_wbits;
 
-    for (uint32_t i = tid; i < (1u << fa.bloom_wbits); i += FT_THREADS) s_bloom[i] = fa.bloom[i];
-    if (tid == 0) s_nraw = 0;
+    for (uint32_t i = tid; i < n_words; i += FT_THREADS) s_bloom[i] = fa.bloom[i];
+    if (tid == 0) s_nraw[0] = 0;
 
     auto load16 = [&](int64_t g) -> uint4 { // 16 bases at global position g (a multiple of 16)
         if (g + 16 <= n_bases) return *reinterpret_cast<const uint4*>(a.bases + g);
@@ -84,53 +94,49 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
         }
         return make_uint4(t4[0], t4[1], t4[2], t4[3]);
     };
-    struct Pending {
-        uint4 main, extra;
+    auto fetch = [&](uint32_t t, uint4& p) {
+        if (t < n_tiles) p = load16((int64_t)t * FT_WPOS + (int64_t)lane * 16);
     };
-    auto fetch = [&](uint32_t t, Pending& p) {
-        if (t < n_tiles) {
-            const int64_t origin = (int64_t)t * FT_NPOS;
-            p.main = load16(origin + (int64_t)tid * 16);
-            if (tid == 0) p.extra = load16(origin + FT_NPOS);
-        }
-    };
-    // register ring: the tile being processed plus three tiles in flight (Little's law: ~48 KB per CU must be
-    // outstanding to keep HBM busy; one tile is 8 KB per workgroup, two workgroups per CU)
-    const uint32_t gs = gridDim.x;
-    Pending cur {}, p1 {}, p2 {}, p3 {};
-    uint32_t tile = blockIdx.x;
+    // register ring: the tile being processed plus three in flight (Little's law: ~48 KB per CU must be outstanding
+    // to keep HBM busy; a wave tile is 1 KB, 32 waves per CU)
+    const uint32_t stride = gridDim.x * FT_WAVES;
+    uint32_t tile = blockIdx.x * FT_WAVES + (uint32_t)(tid >> 6);
+    uint4 cur {}, p1 {}, p2 {}, p3 {};
     fetch(tile, cur);
-    fetch(tile + gs, p1);
-    fetch(tile + 2 * gs, p2);
-    __syncthreads(); // Bloom filter in place
+    fetch(tile + stride, p1);
+    fetch(tile + 2 * stride, p2);
+    __syncthreads(); // Bloom filter in place; the only barrier before the end
 
-    int buf = 0;
-    for (; tile < n_tiles; tile += gs, buf ^= 1) {
-        fetch(tile + 3 * gs, p3); // stays in flight for three iterations
-        uint32_t* pack = s_pack[buf];
-        pack[tid] = pack16(cur.main);
-        if (tid == 0) pack[FT_THREADS] = pack16(cur.extra);
-        lds_barrier(); // not __syncthreads(): the ring's global loads must stay in flight
-        // ---- Bloom test of my 16 positions ----
+    uint64_t* out = fa.raw_pos + (size_t)blockIdx.x * fa.raw_slice;
+    for (; tile < n_tiles; tile += stride) {
+        fetch(tile + 3 * stride, p3); // stays in flight for three iterations
+        const uint32_t w0 = pack16le(cur);
+        const uint32_t w1 = __builtin_amdgcn_update_dpp(0u, w0, 0x130 /* wave_shl:1: lane i <- lane i+1 */, 0xF, 0xF, false);
         uint32_t cand = 0;
         if (!(fa.debug & 1u)) {
-            const uint32_t w0 = pack[tid], w1 = pack[tid + 1];
+            // ---- level 1 over my 16 positions; position j ends up in bit j of cand ----
 #pragma unroll
-            for (int j = 0; j < FT_G; ++j) {
-                const uint32_t f = __funnelshift_l(w1, w0, 2 * j) >> sh_k;
-                const uint32_t hsh = f * 0x9E3779B1u;
-                const uint32_t word = s_bloom[hsh >> sh_w];
-                cand |= ((word >> (hsh & 31)) & (word >> ((hsh >> 5) & 31)) & (word >> ((hsh >> 10) & 31)) & 1u) << j;
+            for (int j = FT_G - 1; j >= 0; --j) {
+                uint32_t x = j ? __builtin_amdgcn_alignbit(w1, w0, 2 * j) : w0; // code in the low bits, later bases above
+                if (SHORT_K) x &= kmask24;
+                const uint32_t h = __umul24(x, BLOOM_C1);
+                const uint32_t word = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(s_bloom) + ((h >> 16) & amask));
+                uint32_t t2; // word << h[12:8]: the byte select is free, the compiler does not find it
+                asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD"
+                    : "=v"(t2)
+                    : "v"(h), "v"(word));
+                const uint32_t t = (word << (h & 31)) & t2 & (word << ((x >> 16) & 0xFF)); // bit 31 = all three bits set
+                cand = __builtin_amdgcn_alignbit(cand, t, 31);                             // cand = cand << 1 | t >> 31
             }
-            // second level, only for the ~1.5 % that passed: three more bits in a second word (independent hash of the
-            // same code); together the two levels let through the index k-mers plus ~0.02 % false positives
+            if (lane == 63) cand = 0;
+            // ---- level 2, only for the survivors: three more bits in a second word, keyed on the whole code ----
             uint32_t c1 = cand;
             cand = 0;
             while (c1) {
                 const int j = __ffs(c1) - 1;
                 c1 &= c1 - 1;
-                const uint32_t f = __funnelshift_l(w1, w0, 2 * j) >> sh_k;
-                const uint32_t h2 = f * 0x85EBCA6Bu;
+                const uint32_t f = __funnelshift_r(w0, w1, 2 * j) & kmask;
+                const uint32_t h2 = f * BLOOM_C2;
                 const uint32_t word = s_bloom[h2 >> sh_w];
                 cand |= ((word >> (h2 & 31)) & (word >> ((h2 >> 5) & 31)) & (word >> ((h2 >> 10) & 31)) & 1u) << j;
             }
@@ -138,9 +144,8 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
         // ---- append candidate positions to this workgroup's slice (plain stores, LDS cursor) ----
         if (cand) {
             const int np = __popc(cand);
-            uint32_t at = atomicAdd(&s_nraw, (uint32_t)np);
-            const uint64_t base = (uint64_t)tile * FT_NPOS + (uint64_t)tid * FT_G;
-            uint64_t* out = fa.raw_pos + (size_t)blockIdx.x * fa.raw_slice;
+            uint32_t at = atomicAdd(&s_nraw[0], (uint32_t)np);
+            const uint64_t base = (uint64_t)tile * FT_WPOS + (uint64_t)lane * FT_G;
             while (cand) {
                 const int j = __ffs(cand) - 1;
                 cand &= cand - 1;
@@ -152,10 +157,10 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
         p1 = p2;
         p2 = p3;
     }
-    lds_barrier();
+    __syncthreads();
     if (tid == 0) {
-        fa.raw_count[blockIdx.x] = s_nraw;
-        if (s_nraw > fa.raw_slice) atomicOr(a.overflow, 4u);
+        fa.raw_count[blockIdx.x] = s_nraw[0];
+        if (s_nraw[0] > fa.raw_slice) atomicOr(a.overflow, 4u);
     }
 }
 
@@ -354,18 +359,16 @@ __global__ __launch_bounds__(EX_THREADS) void verify_expand_kernel(SketchArgs a,
     }
 }
 
-uint32_t filter_n_tiles(uint64_t n_bases) { return (uint32_t)((n_bases + FT_NPOS - 1) / FT_NPOS); }
+uint32_t filter_n_tiles(uint64_t n_bases) { return (uint32_t)((n_bases + FT_WPOS - 1) / FT_WPOS); }
 
 uint32_t filter_grid(uint32_t bloom_wbits, int n_cus, uint32_t n_tiles)
 {
-    // persistent grid: as many workgroups as stay resident (LDS-limited), never more than there are tiles
-    // (LDS is handed out in granules; leave a margin so that the resident count is not over-estimated)
-    const size_t lds_per_wg = (sizeof(uint32_t) << bloom_wbits) + 2 * (FT_WORDS + 1) * sizeof(uint32_t) + 2048;
-    uint32_t per_cu = (uint32_t)((160 * 1024) / lds_per_wg);
-    if (per_cu < 1) per_cu = 1;
-    if (per_cu > 4) per_cu = 4;
-    uint32_t grid = (uint32_t)n_cus * per_cu;
-    if (grid > n_tiles) grid = n_tiles;
+    // persistent grid: the two workgroups per CU that stay resident (64 KB of LDS and 1024 threads each), never more
+    // waves than there are wave tiles
+    (void)bloom_wbits;
+    uint32_t grid = (uint32_t)n_cus * 2;
+    const uint32_t need = (n_tiles + FT_WAVES - 1) / FT_WAVES;
+    if (grid > need) grid = need;
     if (grid > (uint32_t)EX_MAX_WG) grid = EX_MAX_WG; // verify_expand_kernel keeps one prefix entry per workgroup in LDS
     return grid ? grid : 1;
 }
@@ -374,13 +377,15 @@ hipError_t launch_sketch_filter(const SketchArgs& a, const uint32_t* bloom, uint
     uint64_t raw_capacity, uint32_t* raw_count, hipStream_t stream, KernelTimer timer)
 {
     if (a.n_bases == 0) return hipSuccess;
+    if ((1u << bloom_wbits) > (uint32_t)FT_BLOOM_WORDS) return hipErrorInvalidValue;
     const uint32_t n_tiles = filter_n_tiles(a.n_bases);
-    const size_t dyn = sizeof(uint32_t) << bloom_wbits;
-    static size_t configured = 0;
-    if (dyn > configured) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&sketch_filter_kernel),
-            hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-        configured = dyn;
+    const size_t dyn = 16; // the candidate cursor, behind the static filter
+    const bool short_k = a.k < 12;
+    auto kernel = short_k ? &sketch_filter_kernel<true> : &sketch_filter_kernel<false>;
+    static bool configured[2] = { false, false };
+    if (!configured[short_k]) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+        configured[short_k] = true;
     }
     const uint32_t grid = filter_grid(bloom_wbits, n_cus, n_tiles);
     FilterArgs fa {};
@@ -392,7 +397,7 @@ hipError_t launch_sketch_filter(const SketchArgs& a, const uint32_t* bloom, uint
     fa.raw_slice = (uint32_t)std::min<uint64_t>(raw_capacity / grid, 0x7FFFFFFFull);
     if (const char* dbg = std::getenv("DRPRG_FT_DEBUG")) fa.debug = (uint32_t)std::atoi(dbg);
     if (timer.begin) HIP_TRY(hipEventRecord(timer.begin, stream));
-    hipLaunchKernelGGL(sketch_filter_kernel, dim3(grid), dim3(FT_THREADS), dyn, stream, a, fa);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(FT_THREADS), dyn, stream, a, fa);
     HIP_TRY(hipGetLastError());
     if (timer.end) HIP_TRY(hipEventRecord(timer.end, stream));
     hipLaunchKernelGGL(verify_expand_kernel, dim3((uint32_t)n_cus * 8), dim3(256), 0, stream, a, fa, grid);
