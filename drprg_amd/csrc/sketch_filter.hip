@@ -10,10 +10,10 @@
 //                          workgroup's slice of a candidate buffer.  The loop has no barrier and waits on nothing but
 //                          its own loads: three tiles of bases are in flight per wave in a register ring, the right
 //                          neighbour's packed word arrives through a DPP wave shift.
-//   verify_expand_kernel   one thread per candidate, no barriers on the critical path: canonical hash from the raw
-//                          bases -> exact table lookup (false positives end here) -> read lookup -> window-minimizer
-//                          test over the 2w-1 neighbouring k-mers inside the read -> one (key,val) hit per index
-//                          record, with output space reserved once per 256-thread batch.
+//   verify_expand_kernel   one lane per candidate, start to finish: canonical hash from the raw bases -> exact table
+//                          lookup (false positives end here) -> read lookup -> window-minimizer test over the 2w-1
+//                          neighbouring k-mers inside the read, hashed one by one out of a register shift register
+//                          -> one (key,val) hit per index record, output space reserved once per 256 candidates.
 //
 // The Bloom filter has no false negatives and every survivor is re-derived exactly from the bases, so the result is
 // identical to the direct kernel (tests/test_gpu_parity.py checks both against the oracle).  Serves k <= 15, w <= 16
@@ -185,58 +185,45 @@ __device__ inline uint32_t revcomp_code(uint32_t f, int k)
     return (~x) >> (32 - 2 * k);                               // complement, right-align
 }
 
-// canonical hash + 1 of the k-mer starting at bases[p] (k <= 15), 0 if it holds a non-ACGT base.  Two aligned 16-byte
-// loads cover any 15-mer; the byte loop only serves the last bytes of the buffer.
-__device__ inline uint32_t kmer_hash_at(const uint8_t* __restrict__ bases, int64_t n_bases, int64_t p, int k, uint32_t kmask,
-    bool& strand)
+constexpr int EX_MAX_WG = 1024;
+constexpr int EX_THREADS = 1024;
+
+// 16 bases at global position g (a multiple of 16); bytes past the end of the buffer read as 'N'
+__device__ inline uint4 load16_guarded(const uint8_t* __restrict__ bases, int64_t n_bases, int64_t g)
 {
-    uint32_t f;
-    const int64_t a0 = p & ~(int64_t)15;
-    if (a0 + 32 <= n_bases) {
-        const uint4 A = *reinterpret_cast<const uint4*>(bases + a0), B = *reinterpret_cast<const uint4*>(bases + a0 + 16);
-        uint32_t pa, pb, na, nb;
-        pack16n(A, pa, na);
-        pack16n(B, pb, nb);
-        const int o = (int)(p - a0);
-        if (((na | (nb << 16)) >> o) & ((1u << k) - 1)) return 0;
-        f = __funnelshift_l(pb, pa, 2 * o) >> (32 - 2 * k);
-    } else {
-        uint32_t bad = 0;
-        f = 0;
-        for (int i = 0; i < k; ++i) {
-            const uint32_t c = encode_base(bases[p + i]);
-            bad |= c;
-            f = (f << 2) | (c & 3u);
+    if (g + 16 <= n_bases) return *reinterpret_cast<const uint4*>(bases + g);
+    uint32_t t4[4];
+    for (int q = 0; q < 4; ++q) {
+        uint32_t wd = 0;
+        for (int b = 0; b < 4; ++b) {
+            const int64_t gg = g + q * 4 + b;
+            wd |= (uint32_t)(gg < n_bases ? bases[gg] : (uint8_t)'N') << (8 * b);
         }
-        if (bad & 4u) return 0;
+        t4[q] = wd;
     }
-    const uint32_t hf = HashTraits<uint32_t>::mix(f, kmask), hr = HashTraits<uint32_t>::mix(revcomp_code(f, k), kmask);
-    strand = hf <= hr;
-    return (hf < hr ? hf : hr) + 1;
+    return make_uint4(t4[0], t4[1], t4[2], t4[3]);
 }
 
-constexpr int EX_MAX_WG = 1024;
-constexpr int EX_THREADS = 256;
-
-struct ExFound { // a candidate whose canonical hash is an index key
-    int64_t gp, r0, r1; // position, start and end of its read (global base coordinates)
-    uint32_t slot, read, g, strand, cnt;
-};
-
+// One lane per candidate, start to finish: the 64 bases around it are packed into registers once (2 bits per base,
+// first base highest), the candidate's canonical hash goes to the exact table lookup (Bloom false positives end there),
+// then the 2w-1 neighbouring k-mers are hashed one after the other out of a 96-bit shift register -- a third of the
+// instructions of giving every neighbour its own lane, each of which had to load and pack its own bases.  It is a read
+// minimizer iff the run of neighbours with hash >= its own (inside the read, no N) reaches w-1 across both sides.
+// Output space is reserved once per 256 candidates.
 __global__ __launch_bounds__(EX_THREADS) void verify_expand_kernel(SketchArgs a, FilterArgs fa, uint32_t n_wg)
 {
     using Tr = HashTraits<uint32_t>;
     __shared__ uint32_t s_prefix[EX_MAX_WG + 1];
     __shared__ uint32_t s_part[EX_THREADS];
-    __shared__ ExFound s_found[EX_THREADS];
-    __shared__ uint32_t s_nfound, s_cnt, s_nmin;
+    __shared__ uint32_t s_cnt, s_nmin;
     __shared__ unsigned long long s_base;
     const int tid = threadIdx.x;
-    // exclusive prefix sums of the (clamped) slice counts: 4 entries per thread, then a block scan
+    // exclusive prefix sums of the (clamped) slice counts: EX_PER entries per thread, then a block scan
     {
-        uint32_t v[4], run = 0;
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t b = (uint32_t)tid * 4 + i;
+        constexpr int EX_PER = EX_MAX_WG / EX_THREADS;
+        uint32_t v[EX_PER], run = 0;
+        for (int i = 0; i < EX_PER; ++i) {
+            const uint32_t b = (uint32_t)tid * EX_PER + i;
             const uint32_t n = b < n_wg ? fa.raw_count[b] : 0u;
             v[i] = run;
             run += n < fa.raw_slice ? n : fa.raw_slice;
@@ -250,26 +237,26 @@ __global__ __launch_bounds__(EX_THREADS) void verify_expand_kernel(SketchArgs a,
             __syncthreads();
         }
         const uint32_t before = tid ? s_part[tid - 1] : 0u;
-        for (int i = 0; i < 4; ++i) s_prefix[tid * 4 + i] = before + v[i];
+        for (int i = 0; i < EX_PER; ++i) s_prefix[tid * EX_PER + i] = before + v[i];
         if (tid == EX_THREADS - 1) s_prefix[EX_MAX_WG] = s_part[EX_THREADS - 1];
+        if (tid == 0) { s_cnt = 0; s_nmin = 0; }
         __syncthreads();
     }
     const uint32_t total = s_prefix[EX_MAX_WG];
     const uint32_t* __restrict__ slot_key = reinterpret_cast<const uint32_t*>(a.slot_key);
     const uint32_t tmask = (1u << a.table_bits) - 1;
     const int k = a.k, w = a.w;
+    const int sh_k = 32 - 2 * k;
     const uint32_t kmask = (1u << (2 * k)) - 1;
     const int64_t n_bases = (int64_t)a.n_bases;
     const uint32_t per_wg = (total + gridDim.x - 1) / gridDim.x;
     const uint32_t t_begin = blockIdx.x * per_wg;
     const uint32_t t_end = t_begin + per_wg < total ? t_begin + per_wg : total;
-    const int lane = tid & 63, half = lane >> 5, d = lane & 31;
     const double reads_per_base = (double)a.n_reads / (double)(a.n_bases ? a.n_bases : 1);
     for (uint32_t t0 = t_begin; t0 < t_end; t0 += EX_THREADS) {
-        if (tid == 0) { s_nfound = 0; s_cnt = 0; s_nmin = 0; }
-        __syncthreads();
-        // ---- phase 1, one lane per candidate: canonical hash from the raw bases, exact table lookup, read lookup ----
         const uint32_t t = t0 + tid;
+        uint32_t cnt = 0, my_off = 0, slot = 0, read = 0, strand = 0;
+        uint64_t pos = 0;
         if (t < t_end) {
             uint32_t lo = 0, hi = EX_MAX_WG; // s_prefix[lo] <= t < s_prefix[hi]
             while (hi - lo > 1) {
@@ -277,86 +264,116 @@ __global__ __launch_bounds__(EX_THREADS) void verify_expand_kernel(SketchArgs a,
                 if (s_prefix[mid] <= t) lo = mid; else hi = mid;
             }
             const int64_t gp = (int64_t)fa.raw_pos[(size_t)lo * fa.raw_slice + (t - s_prefix[lo])];
-            bool st = false;
-            const uint32_t g = gp + k <= n_bases ? kmer_hash_at(a.bases, n_bases, gp, k, kmask, st) : 0u;
-            if (g) { // Bloom false positives end at the exact lookup
-                const uint32_t h = g - 1;
-                uint32_t s = table_slot_dev((uint64_t)h, a.table_bits);
+            if (gp + k <= n_bases) {
+                // ---- the 64 bases [a0, a0+64) hold the candidate and all its neighbours (w <= 16, k <= 15) ----
+                const int64_t a0 = (gp > 15 ? gp - 15 : 0) & ~(int64_t)15;
+                uint32_t r0w, r1w, r2w, r3w, n0, n1, n2, n3;
+                pack16n(load16_guarded(a.bases, n_bases, a0), r0w, n0);
+                pack16n(load16_guarded(a.bases, n_bases, a0 + 16), r1w, n1);
+                pack16n(load16_guarded(a.bases, n_bases, a0 + 32), r2w, n2);
+                pack16n(load16_guarded(a.bases, n_bases, a0 + 48), r3w, n3);
+                uint64_t bad = (uint64_t)(n0 | (n1 << 16)) | ((uint64_t)(n2 | (n3 << 16)) << 32); // bit i: base a0+i is not ACGT
+                if (bad) { // -> bit i: the k-mer starting at a0+i holds such a base
+                    uint64_t m = bad;
+                    for (int i = 1; i < k; ++i) m |= bad >> i;
+                    bad = m;
+                }
+                // ---- the candidate's own canonical hash, exact lookup ----
+                const int oc = (int)(gp - a0); // 0..30
+                uint32_t g = 0;
+                if (!((bad >> oc) & 1u)) {
+                    const uint32_t h0 = (oc & 16) ? r1w : r0w, h1 = (oc & 16) ? r2w : r1w;
+                    const uint32_t f = __funnelshift_l(h1, h0, 2 * (oc & 15)) >> sh_k;
+                    const uint32_t hf = Tr::mix(f, kmask), hr = Tr::mix(revcomp_code(f, k), kmask);
+                    strand = hf <= hr ? 1u : 0u;
+                    g = (hf < hr ? hf : hr) + 1;
+                }
                 bool found = false;
-                while (true) {
-                    const uint32_t key = slot_key[s];
-                    if (key == h) { found = true; break; }
-                    if (key == Tr::EMPTY) break;
-                    s = (s + 1) & tmask;
+                if (g) {
+                    const uint32_t h = g - 1;
+                    uint32_t s = table_slot_dev((uint64_t)h, a.table_bits);
+                    while (true) {
+                        const uint32_t key = slot_key[s];
+                        if (key == h) { found = true; break; }
+                        if (key == Tr::EMPTY) break;
+                        s = (s + 1) & tmask;
+                    }
+                    slot = s;
                 }
                 if (found) {
                     // interpolated first guess: exact for fixed-length reads, a short gallop otherwise
                     const uint32_t guess = (uint32_t)((double)gp * reads_per_base);
-                    const uint32_t rlo = find_read_near(a.offsets, a.n_reads, guess, (uint64_t)gp);
-                    const int64_t r0 = (int64_t)a.offsets[rlo], r1 = (int64_t)a.offsets[rlo + 1];
+                    read = find_read_near(a.offsets, a.n_reads, guess, (uint64_t)gp);
+                    const int64_t r0 = (int64_t)a.offsets[read], r1 = (int64_t)a.offsets[read + 1];
                     if (gp + k <= r1) { // the k-mer lies inside one read
-                        ExFound e;
-                        e.gp = gp; e.r0 = r0; e.r1 = r1;
-                        e.slot = s; e.read = rlo; e.g = g; e.strand = st ? 1u : 0u; e.cnt = 0;
-                        s_found[atomicAdd(&s_nfound, 1u)] = e;
+                        // ---- scan q = q_first .. q_first + 2w-2; steps outside [gp-(w-1), gp+(w-1)] or the read are invalid ----
+                        const int64_t q_lo = gp - (w - 1);
+                        const int64_t q_first = q_lo > a0 ? q_lo : a0; // a0 <= max(q_lo, 0)
+                        const int of = (int)(q_first - a0);            // 0..30
+                        const int64_t v_lo = r0 > q_first ? r0 : q_first;
+                        const int64_t v_hi = (r1 - k) < (gp + w - 1) ? (r1 - k) : (gp + w - 1);
+                        const int i_lo = (int)(v_lo - q_first), i_hi = (int)(v_hi - q_first), ic = (int)(gp - q_first);
+                        // align the shift register on q_first: 48 bases in three words cover 2w-1 + k-1 <= 45
+                        if (of & 16) { r0w = r1w; r1w = r2w; r2w = r3w; r3w = 0; }
+                        const int s2 = 2 * (of & 15);
+                        r0w = __funnelshift_l(r1w, r0w, s2);
+                        r1w = __funnelshift_l(r2w, r1w, s2);
+                        r2w = __funnelshift_l(r3w, r2w, s2);
+                        bad >>= of;
+                        uint32_t streak = 0, right = 0, alive = 1;
+                        for (int i = 0; i < 2 * w - 1; ++i) {
+                            const uint32_t f = r0w >> sh_k;
+                            r0w = __funnelshift_l(r1w, r0w, 2);
+                            r1w = __funnelshift_l(r2w, r1w, 2);
+                            r2w <<= 2;
+                            const uint32_t hf = Tr::mix(f, kmask), hr = Tr::mix(revcomp_code(f, k), kmask);
+                            const uint32_t x = (hf < hr ? hf : hr) + 1;
+                            const bool ok = i >= i_lo && i <= i_hi && !((uint32_t)bad & 1u) && x >= g;
+                            bad >>= 1;
+                            if (i < ic) streak = ok ? streak + 1 : 0;
+                            else if (i > ic) {
+                                alive = ok ? alive : 0u;
+                                right += alive;
+                            }
+                        }
+                        if ((int)(streak + right) >= w - 1) {
+                            cnt = a.slot_rec[slot].y;
+                            pos = (uint64_t)(gp - r0);
+                        }
                     }
                 }
             }
         }
-        __syncthreads();
-        // ---- phase 2, half a wave per index k-mer: lane d evaluates neighbour d - (w-1); a ballot of "inside the read,
-        // no N, hash >= the candidate's" gives the runs on either side; a window of w such k-mers makes it a minimizer ----
-        const uint32_t nfound = s_nfound;
-        for (uint32_t cb = (uint32_t)(tid >> 6) * 2; cb < nfound; cb += (EX_THREADS / 64) * 2) {
-            const uint32_t c = cb + (uint32_t)half;
-            const bool have = c < nfound;
-            const ExFound e = s_found[have ? c : 0];
-            const int64_t q = e.gp + d - (w - 1);
-            uint32_t x = 0;
-            bool s2;
-            if (have && d < 2 * w - 1 && d != w - 1 && q >= e.r0 && q + k <= e.r1) x = kmer_hash_at(a.bases, n_bases, q, k, kmask, s2);
-            const uint64_t ball = __ballot(x != 0 && x >= e.g);
-            const uint32_t m = half ? (uint32_t)(ball >> 32) : (uint32_t)ball;
-            const uint32_t lmask = (1u << (w - 1)) - 1;   // bits 0 .. w-2: left neighbours, bit w-2 nearest
-            const uint32_t lzero = ~m & lmask;
-            const int left = lzero ? (w - 2) - (31 - __clz((int)lzero)) : (w - 1);
-            const uint32_t rzero = ~(m >> w);             // bit 0: nearest right neighbour
-            int right = __ffs((int)rzero) - 1;
-            if (right > w - 1) right = w - 1;
-            if (have && d == w - 1 && left + right >= w - 1) {
-                const uint32_t cnt = a.slot_rec[e.slot].y;
-                s_found[c].cnt = cnt;
-                atomicAdd(&s_cnt, cnt);
-                atomicAdd(&s_nmin, 1u);
-            }
+        // ---- reserve output once per batch ----
+        if (cnt) {
+            my_off = atomicAdd(&s_cnt, cnt);
+            atomicAdd(&s_nmin, 1u);
         }
         __syncthreads();
-        // ---- phase 3: reserve output once per batch, emit one (key,val) per index record ----
+        // (atomics on one address retire at ~12 ns each device-wide: one per 1024 candidates, not one per wave)
         if (tid == 0 && s_cnt) {
             s_base = atomicAdd(a.n_hits, (unsigned long long)s_cnt);
-            atomicAdd(a.n_minimizers, (unsigned long long)s_nmin);
-            s_cnt = 0; // reused as the running offset below
+            s_cnt = 0; // the next batch adds only after the barrier below
         }
         __syncthreads();
-        if ((uint32_t)tid < nfound && s_found[tid].cnt) {
-            const ExFound e = s_found[tid];
-            const unsigned long long at = s_base + atomicAdd(&s_cnt, e.cnt);
-            const uint64_t pos = (uint64_t)(e.gp - e.r0);
-            if (at + e.cnt > a.hit_capacity || pos >= (1ull << HIT_POS_BITS)) {
+        if (cnt) {
+            const unsigned long long at = s_base + my_off;
+            if (at + cnt > a.hit_capacity || pos >= (1ull << HIT_POS_BITS)) {
                 atomicOr(a.overflow, pos >= (1ull << HIT_POS_BITS) ? 2u : 1u);
             } else {
-                const uint2 rec = a.slot_rec[e.slot];
+                const uint2 rec = a.slot_rec[slot];
                 for (uint32_t qq = 0; qq < rec.y; ++qq) {
                     const uint32_t kn = a.rec_knode[rec.x + qq];
                     const uint32_t prg = a.rec_prg[rec.x + qq];
-                    const uint32_t rev = ((kn & 1u) == e.strand) ? 0u : 1u;
-                    a.hit_key[at + qq] = pack_hit_key(e.read, prg, rev, (uint32_t)pos);
+                    const uint32_t rev = ((kn & 1u) == strand) ? 0u : 1u;
+                    a.hit_key[at + qq] = pack_hit_key(read, prg, rev, (uint32_t)pos);
                     a.hit_val[at + qq] = kn >> 1;
                 }
             }
         }
-        __syncthreads();
     }
+    __syncthreads();
+    if (tid == 0 && s_nmin) atomicAdd(a.n_minimizers, (unsigned long long)s_nmin);
 }
 
 uint32_t filter_n_tiles(uint64_t n_bases) { return (uint32_t)((n_bases + FT_WPOS - 1) / FT_WPOS); }
@@ -400,7 +417,7 @@ hipError_t launch_sketch_filter(const SketchArgs& a, const uint32_t* bloom, uint
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(FT_THREADS), dyn, stream, a, fa);
     HIP_TRY(hipGetLastError());
     if (timer.end) HIP_TRY(hipEventRecord(timer.end, stream));
-    hipLaunchKernelGGL(verify_expand_kernel, dim3((uint32_t)n_cus * 8), dim3(256), 0, stream, a, fa, grid);
+    hipLaunchKernelGGL(verify_expand_kernel, dim3((uint32_t)n_cus * 2), dim3(EX_THREADS), 0, stream, a, fa, grid);
     return hipGetLastError();
 }
 
