@@ -86,10 +86,23 @@ hipError_t launch_sketch_probe(const SketchArgs& a, bool wide_hash, hipStream_t 
 // filtered form (k <= 15, w <= 16): bloom = 2^bloom_wbits words of index k-mer codes
 uint32_t filter_n_tiles(uint64_t n_bases);
 uint32_t filter_grid(uint32_t bloom_wbits, int n_cus, uint32_t n_tiles);
-// raw_pos: scratch of raw_capacity candidate positions (split into one slice per workgroup); raw_count: one u32 per
-// workgroup (>= filter_grid entries).  Overflow bit 2 (value 4) in a.overflow: a slice was too small.
-hipError_t launch_sketch_filter(const SketchArgs& a, const uint32_t* bloom, uint32_t bloom_wbits, int n_cus, uint64_t* raw_pos,
-    uint64_t raw_capacity, uint32_t* raw_count, hipStream_t stream, KernelTimer timer = {});
+// Scratch of the filtered launch sequence.  raw_pos: raw_capacity candidate positions (one slice per filter wave);
+// cand_info / cand_pos1: raw_capacity entries each; small: filter_small_words() u32; max_len: device scalar that
+// receives the length of the longest read holding a minimizer hit.  Overflow bit 2 (value 4) in a.overflow: a slice
+// was too small.  The hits are written ordered by (read, position); a.n_hits receives their number.
+struct FilterBuffers {
+    uint64_t* raw_pos;
+    uint64_t* cand_info;
+    uint32_t* cand_pos1;
+    uint64_t raw_capacity;
+    uint32_t* small;
+    unsigned long long* max_len;
+};
+size_t filter_small_words();
+hipError_t launch_sketch_filter(const SketchArgs& a, const uint32_t* bloom, uint32_t bloom_wbits, int n_cus, const FilterBuffers& b,
+    hipStream_t stream, KernelTimer timer = {});
+// hits ordered by (read, pos) -> ordered by (read, prg, strand, pos), in place; meant for short reads
+hipError_t launch_read_sort(uint64_t* key, uint32_t* val, uint32_t n, hipStream_t stream);
 size_t sort_temp_bytes(uint32_t n);
 size_t scan_temp_bytes(uint32_t n);
 hipError_t sort_hits(void* temp, size_t temp_bytes, const uint64_t* key_in, uint64_t* key_out, const uint32_t* val_in,

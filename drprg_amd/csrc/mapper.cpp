@@ -27,7 +27,9 @@ template <typename T> static void dfree(T*& p)
 }
 
 // counter slots
-enum { C_HITS = 0, C_MINIMIZERS = 1, C_CLUSTERS_KEPT = 2, C_HITS_KEPT = 3, C_OVERFLOW = 4, C_N = 8 };
+enum { C_HITS = 0, C_MINIMIZERS = 1, C_CLUSTERS_KEPT = 2, C_HITS_KEPT = 3, C_OVERFLOW = 4, C_MAXLEN = 5, C_N = 8 };
+// reads up to this length get their hits reordered per read (read_sort_kernel); longer ones take the radix sort
+constexpr uint64_t READ_SORT_MAX_LEN = 512;
 
 Mapper::Mapper(const FlatIndex& idx, const MapParams& p, int device) : device_(device)
 {
@@ -85,7 +87,7 @@ Mapper::Mapper(const FlatIndex& idx, const MapParams& p, int device) : device_(d
     }
     HIPCHK(hipDeviceGetAttribute(&n_cus_, hipDeviceAttributeMultiprocessorCount, device_));
     set_params(p); // again: the kernel choice depends on the filter being available
-    dmalloc(d_raw_count_, (size_t)n_cus_ * 4 + 16);
+    dmalloc(d_filter_small_, dev::filter_small_words());
     dmalloc(d_covg_, 2 * (size_t)n_knodes_);
     dmalloc(d_prg_reads_, (size_t)n_prgs_);
     dmalloc(d_counters_, (size_t)C_N);
@@ -105,7 +107,8 @@ Mapper::~Mapper()
     dfree(d_key_a_); dfree(d_key_b_); dfree(d_val_a_); dfree(d_val_b_);
     dfree(d_head_); dfree(d_scan_); dfree(d_cstart_); dfree(d_order_); dfree(d_clusters_);
     if (d_temp_) (void)hipFree(d_temp_);
-    dfree(d_bases_); dfree(d_offsets_); dfree(d_tile_first_); dfree(d_bloom_); dfree(d_raw_count_);
+    dfree(d_bases_); dfree(d_offsets_); dfree(d_tile_first_); dfree(d_bloom_); dfree(d_filter_small_);
+    dfree(d_raw_pos_); dfree(d_cand_info_); dfree(d_cand_pos1_);
     if (h_counters_) (void)hipHostFree(h_counters_);
     if (h_bases_) (void)hipHostFree(h_bases_);
     if (h_offsets_) (void)hipHostFree(h_offsets_);
@@ -166,10 +169,20 @@ void Mapper::ensure_workspace(uint64_t cap)
     HIPCHK(hipMalloc(&d_temp_, temp_bytes_ ? temp_bytes_ : 1));
 }
 
+void Mapper::ensure_raw_workspace(uint64_t cap)
+{
+    if (cap <= raw_capacity_) return;
+    if (cap >= (1ull << 31)) throw Error(DRPRG_EOVERFLOW, "more than 2^31 candidate k-mers in one batch; map smaller batches");
+    dfree(d_raw_pos_); dfree(d_cand_info_); dfree(d_cand_pos1_);
+    raw_capacity_ = cap;
+    dmalloc(d_raw_pos_, cap); dmalloc(d_cand_info_, cap); dmalloc(d_cand_pos1_, cap);
+}
+
 void Mapper::run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads, uint64_t n_bases,
     uint32_t* covg, uint32_t* prg_reads, hipStream_t stream)
 {
     ensure_workspace(std::max<uint64_t>(1u << 20, n_bases / 64));
+    if (use_filter_) ensure_raw_workspace(std::max<uint64_t>(1u << 20, n_bases / 64));
     const uint32_t n_tiles = use_filter_ ? 0u : dev::sketch_n_tiles(n_bases, halo_);
     if (n_tiles > tile_cap_) { // direct kernel only: first read of every tile
         dfree(d_tile_first_);
@@ -204,9 +217,10 @@ void Mapper::run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32
             timer.begin = ev0_;
             timer.end = ev1_;
         }
-        if (use_filter_)
-            HIPCHK(dev::launch_sketch_filter(a, d_bloom_, bloom_wbits_, n_cus_, d_key_b_, hit_capacity_, d_raw_count_, stream, timer));
-        else HIPCHK(dev::launch_sketch_probe(a, wide_hash_, stream, timer));
+        if (use_filter_) {
+            dev::FilterBuffers fb { d_raw_pos_, d_cand_info_, d_cand_pos1_, raw_capacity_, d_filter_small_, &d_counters_[C_MAXLEN] };
+            HIPCHK(dev::launch_sketch_filter(a, d_bloom_, bloom_wbits_, n_cus_, fb, stream, timer));
+        } else HIPCHK(dev::launch_sketch_probe(a, wide_hash_, stream, timer));
         HIPCHK(hipMemcpyAsync(h_counters_, d_counters_, C_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
         if (timing_ && n_bases > 0) {
@@ -217,12 +231,12 @@ void Mapper::run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32
         }
         uint32_t ovf = (uint32_t)h_counters_[C_OVERFLOW];
         if (ovf & 2u) throw Error(DRPRG_EOVERFLOW, "a read is longer than 2^" + std::to_string(dev::HIT_POS_BITS) + " bases");
-        if (ovf & 4u) { // a workgroup's raw-hit slice of the filtered kernel was too small: double the workspace
-            if (attempt > 6) throw Error(DRPRG_EOVERFLOW, "raw-hit buffer overflow after regrow");
+        if (ovf & 4u) { // a wave's candidate slice of the filtered kernel was too small: grow the candidate workspace
+            if (attempt > 8) throw Error(DRPRG_EOVERFLOW, "candidate buffer overflow after regrow");
             unsigned long long restored = last_minimizers_;
             HIPCHK(hipMemcpyAsync(&d_counters_[C_MINIMIZERS], &restored, sizeof(restored), hipMemcpyHostToDevice, stream));
             HIPCHK(hipStreamSynchronize(stream));
-            ensure_workspace(hit_capacity_ * 2);
+            ensure_raw_workspace(raw_capacity_ * 4);
             continue;
         }
         if (h_counters_[C_HITS] > hit_capacity_) {
@@ -240,12 +254,19 @@ void Mapper::run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32
     const uint32_t n_hits = (uint32_t)h_counters_[C_HITS];
     tot_hits_ += n_hits;
     if (n_hits == 0) return;
-    HIPCHK(dev::sort_hits(d_temp_, temp_bytes_, d_key_a_, d_key_b_, d_val_a_, d_val_b_, n_hits, stream));
-    HIPCHK(dev::launch_cluster_flags(d_key_b_, n_hits, params_.max_diff, d_head_, d_scan_, d_temp_, temp_bytes_, stream));
+    // the filtered sequence leaves the hits ordered by (read, pos): short reads only need a per-read reorder
+    const uint64_t* s_key = d_key_b_;
+    const uint32_t* s_val = d_val_b_;
+    if (use_filter_ && h_counters_[C_MAXLEN] <= READ_SORT_MAX_LEN) {
+        HIPCHK(dev::launch_read_sort(d_key_a_, d_val_a_, n_hits, stream));
+        s_key = d_key_a_;
+        s_val = d_val_a_;
+    } else HIPCHK(dev::sort_hits(d_temp_, temp_bytes_, d_key_a_, d_key_b_, d_val_a_, d_val_b_, n_hits, stream));
+    HIPCHK(dev::launch_cluster_flags(s_key, n_hits, params_.max_diff, d_head_, d_scan_, d_temp_, temp_bytes_, stream));
     HIPCHK(dev::launch_cluster_starts(d_head_, d_scan_, n_hits, d_cstart_, stream));
     dev::ClusterArgs c {};
-    c.key = d_key_b_;
-    c.val = d_val_b_;
+    c.key = s_key;
+    c.val = s_val;
     c.scan = d_scan_;
     c.cstart = d_cstart_;
     c.d_n_clusters = d_scan_ + (n_hits - 1);

@@ -57,6 +57,7 @@ public:
 
 private:
     void ensure_workspace(uint64_t hit_capacity);
+    void ensure_raw_workspace(uint64_t raw_capacity);
     void run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads, uint64_t n_bases,
         uint32_t* d_covg, uint32_t* d_prg_reads, hipStream_t stream);
 
@@ -73,7 +74,7 @@ private:
     uint16_t* d_rec_prg_ = nullptr;
     uint32_t* d_min_path_len_ = nullptr;
     uint32_t* d_bloom_ = nullptr;
-    uint32_t* d_raw_count_ = nullptr;
+    uint32_t* d_filter_small_ = nullptr; // slice / workgroup counters of the filtered launch sequence
     uint32_t bloom_wbits_ = 0;
     int n_cus_ = 256;
     bool use_filter_ = false;
@@ -90,6 +91,10 @@ private:
     uint32_t *d_val_a_ = nullptr, *d_val_b_ = nullptr;
     uint32_t *d_head_ = nullptr, *d_scan_ = nullptr, *d_cstart_ = nullptr, *d_order_ = nullptr;
     dev::ClusterRec* d_clusters_ = nullptr;
+    // candidate workspace of the filtered sequence
+    uint64_t raw_capacity_ = 0;
+    uint64_t *d_raw_pos_ = nullptr, *d_cand_info_ = nullptr;
+    uint32_t* d_cand_pos1_ = nullptr;
     void* d_temp_ = nullptr;
     uint32_t* d_tile_first_ = nullptr;
     uint32_t tile_cap_ = 0;
