@@ -257,11 +257,9 @@ void Mapper::run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32
     // the filtered sequence leaves the hits ordered by (read, pos): short reads only need a per-read reorder
     const uint64_t* s_key = d_key_b_;
     const uint32_t* s_val = d_val_b_;
-    if (use_filter_ && h_counters_[C_MAXLEN] <= READ_SORT_MAX_LEN) {
-        HIPCHK(dev::launch_read_sort(d_key_a_, d_val_a_, n_hits, stream));
-        s_key = d_key_a_;
-        s_val = d_val_a_;
-    } else HIPCHK(dev::sort_hits(d_temp_, temp_bytes_, d_key_a_, d_key_b_, d_val_a_, d_val_b_, n_hits, stream));
+    if (use_filter_ && h_counters_[C_MAXLEN] <= READ_SORT_MAX_LEN)
+        HIPCHK(dev::launch_read_sort(d_key_a_, d_val_a_, d_key_b_, d_val_b_, n_hits, stream));
+    else HIPCHK(dev::sort_hits(d_temp_, temp_bytes_, d_key_a_, d_key_b_, d_val_a_, d_val_b_, n_hits, stream));
     HIPCHK(dev::launch_cluster_flags(s_key, n_hits, params_.max_diff, d_head_, d_scan_, d_temp_, temp_bytes_, stream));
     HIPCHK(dev::launch_cluster_starts(d_head_, d_scan_, n_hits, d_cstart_, stream));
     dev::ClusterArgs c {};

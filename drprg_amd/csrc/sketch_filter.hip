@@ -36,7 +36,7 @@ namespace dev {
 
 constexpr int FT_THREADS = 1024;
 constexpr int FT_WAVES = FT_THREADS / 64;
-constexpr int FT_G = 16;                // positions per lane
+constexpr int FT_G = 32;                // positions per lane
 constexpr int FT_WPOS = 63 * FT_G;      // positions per wave tile: lane 63's word is only lane 62's right neighbour
 constexpr int FT_BLOOM_WORDS = 1 << 14; // static LDS: the filter sits at LDS address 0, so a hash is an address
 constexpr int EX_THREADS = 256;
@@ -100,7 +100,13 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
 
     const uint32_t gw = blockIdx.x * FT_WAVES + (uint32_t)(tid >> 6); // this wave's slice
     uint32_t tile = gw * fw.tiles_per_wave;
-    const uint32_t tile_end = tile + fw.tiles_per_wave < fw.n_tiles ? tile + fw.tiles_per_wave : fw.n_tiles;
+    uint32_t tile_end = tile + fw.tiles_per_wave < fw.n_tiles ? tile + fw.tiles_per_wave : fw.n_tiles;
+    uint32_t step = 1;
+    if (fw.debug & 2u) { // timing experiment only (breaks the candidate order): tiles interleaved across waves
+        tile = gw;
+        tile_end = fw.n_tiles;
+        step = fw.n_slices;
+    }
 
     auto load16 = [&](int64_t g) -> uint4 { // 16 bases at global position g (a multiple of 16)
         if (g + 16 <= n_bases) return *reinterpret_cast<const uint4*>(a.bases + g);
@@ -115,29 +121,34 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
         }
         return make_uint4(t4[0], t4[1], t4[2], t4[3]);
     };
-    auto fetch = [&](uint32_t t, uint4& p) {
-        if (t < tile_end) p = load16((int64_t)t * FT_WPOS + (int64_t)lane * 16);
+    struct Pair { // the 32 bases of one lane in one tile
+        uint4 a, b;
     };
-    // register ring: the tile being processed plus three in flight (Little's law: ~48 KB per CU must be outstanding
-    // to keep HBM busy; a wave tile is 1 KB, 32 waves per CU)
-    uint4 cur {}, p1 {}, p2 {}, p3 {};
-    fetch(tile, cur);
-    fetch(tile + 1, p1);
-    fetch(tile + 2, p2);
-    __syncthreads(); // Bloom filter in place; the only barrier
-
+    // Tiles whose 64 x 32 bytes lie inside the buffer are loaded without any guard, so that the compiler can count the
+    // loads in flight (a guarded byte path inside the loop forces s_waitcnt vmcnt(0) everywhere); the one or two
+    // tiles at the very end of the buffer take the guarded path after the pipelined loop.
+    const uint32_t n_full = n_bases >= 64 * FT_G ? (uint32_t)((n_bases - 64 * FT_G) / FT_WPOS) + 1 : 0u;
+    const uint32_t full_end = tile_end < n_full ? tile_end : n_full;
+    auto fetch = [&](uint32_t t, Pair& p) { // unconditional (a prefetch past the wave's range re-reads its last full tile)
+        const uint32_t tc = t < full_end ? t : full_end - 1;
+        const uint8_t* g = a.bases + (int64_t)tc * FT_WPOS + (int64_t)lane * FT_G;
+        p.a = *reinterpret_cast<const uint4*>(g);
+        p.b = *reinterpret_cast<const uint4*>(g + 16);
+    };
     uint64_t* out = fw.raw_pos + (size_t)gw * fw.raw_slice;
     uint32_t wcur = 0; // candidates of this wave so far (wave-uniform)
-    for (; tile < tile_end; ++tile) {
-        fetch(tile + 3, p3); // stays in flight for three iterations
-        const uint32_t w0 = pack16le(cur);
-        const uint32_t w1 = __builtin_amdgcn_update_dpp(0u, w0, 0x130 /* wave_shl:1: lane i <- lane i+1 */, 0xF, 0xF, false);
+
+    // one tile: my 32 positions start in words wa, wb; wc (the first word of lane+1) completes the last k-mers
+    auto process = [&](uint32_t t, const Pair& p) {
+        const uint32_t wa = pack16le(p.a), wb = pack16le(p.b);
+        const uint32_t wc = __builtin_amdgcn_update_dpp(0u, wa, 0x130 /* wave_shl:1: lane i <- lane i+1 */, 0xF, 0xF, false);
         uint32_t cand = 0;
         if (!(fw.debug & 1u)) {
-            // ---- level 1 over my 16 positions; position j ends up in bit j of cand ----
+            // ---- level 1 over my 32 positions; position j ends up in bit j of cand ----
 #pragma unroll
             for (int j = FT_G - 1; j >= 0; --j) {
-                uint32_t x = j ? __builtin_amdgcn_alignbit(w1, w0, 2 * j) : w0; // code in the low bits, later bases above
+                const uint32_t lo = j < 16 ? wa : wb, hi = j < 16 ? wb : wc;
+                uint32_t x = (j & 15) ? __builtin_amdgcn_alignbit(hi, lo, 2 * (j & 15)) : lo; // code in the low bits, later bases above
                 if (SHORT_K) x &= kmask24;
                 const uint32_t h = __umul24(x, BLOOM_C1);
                 const uint32_t word = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(s_bloom) + ((h >> 16) & amask));
@@ -145,8 +156,8 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
                 asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD"
                     : "=v"(t2)
                     : "v"(h), "v"(word));
-                const uint32_t t = (word << (h & 31)) & t2 & (word << ((x >> 16) & 0xFF)); // bit 31 = all three bits set
-                cand = __builtin_amdgcn_alignbit(cand, t, 31);                             // cand = cand << 1 | t >> 31
+                const uint32_t tt = (word << (h & 31)) & t2 & (word << ((x >> 16) & 0xFF)); // bit 31 = all three bits set
+                cand = __builtin_amdgcn_alignbit(cand, tt, 31);                             // cand = cand << 1 | tt >> 31
             }
             if (lane == 63) cand = 0;
             // ---- level 2, only for the survivors: three more bits in a second word, keyed on the whole code ----
@@ -155,20 +166,21 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
             while (c1) {
                 const int j = __ffs(c1) - 1;
                 c1 &= c1 - 1;
-                const uint32_t f = __funnelshift_r(w0, w1, 2 * j) & kmask;
+                const uint32_t lo = j < 16 ? wa : wb, hi = j < 16 ? wb : wc;
+                const uint32_t f = __funnelshift_r(lo, hi, 2 * (j & 15)) & kmask;
                 const uint32_t h2 = f * BLOOM_C2;
                 const uint32_t word = s_bloom[h2 >> sh_w];
                 cand |= ((word >> (h2 & 31)) & (word >> ((h2 >> 5) & 31)) & (word >> ((h2 >> 10) & 31)) & 1u) << j;
             }
         }
-        // ---- append in (lane, bit) = position order; about one candidate per tile survives ----
+        // ---- append in (lane, bit) = position order; about two candidates per tile survive ----
         uint64_t m = __ballot(cand != 0);
         while (m) {
             const int l = __ffsll((unsigned long long)m) - 1;
             m &= m - 1;
             const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cand, l);
             if (lane == l) {
-                const uint64_t base = (uint64_t)tile * FT_WPOS + (uint64_t)lane * FT_G;
+                const uint64_t base = (uint64_t)t * FT_WPOS + (uint64_t)lane * FT_G;
                 uint32_t cc = c, at = wcur;
                 while (cc) {
                     const int j = __ffs(cc) - 1;
@@ -179,9 +191,36 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
             }
             wcur += (uint32_t)__popc(c);
         }
-        cur = p1;
-        p1 = p2;
-        p2 = p3;
+    };
+
+    // register ring, unrolled so that no tile is copied between registers: the tile being processed plus two in
+    // flight (2 KB each per wave; Little's law asks for ~48 KB outstanding per CU, 32 waves give 128 KB)
+    Pair r0 {}, r1 {}, r2 {};
+    const bool pipelined = tile < full_end; // wave-uniform
+    if (pipelined) {
+        fetch(tile, r0);
+        fetch(tile + step, r1);
+    }
+    __syncthreads(); // Bloom filter in place; the only barrier
+    while (tile < full_end) {
+        fetch(tile + 2 * step, r2);
+        process(tile, r0);
+        tile += step;
+        if (tile >= full_end) break;
+        fetch(tile + 2 * step, r0);
+        process(tile, r1);
+        tile += step;
+        if (tile >= full_end) break;
+        fetch(tile + 2 * step, r1);
+        process(tile, r2);
+        tile += step;
+    }
+    for (; tile < tile_end; tile += step) { // the end of the buffer, guarded loads
+        const int64_t g = (int64_t)tile * FT_WPOS + (int64_t)lane * FT_G;
+        Pair p;
+        p.a = load16(g);
+        p.b = load16(g + 16);
+        process(tile, p);
     }
     if (lane == 0) {
         fw.slice_count[gw] = wcur;
@@ -531,34 +570,32 @@ __global__ __launch_bounds__(EX_THREADS) void expand_kernel(SketchArgs a, Filter
     }
 }
 
-// Hits ordered by (read, pos) -> ordered by (read, prg, strand, pos): the thread of the first hit of a read
-// insertion-sorts the read's hits in place (stable).  A short read has a few dozen hits, nearly always in one
-// (prg, strand) group already; long reads take the global radix sort instead (Mapper::run_batch).
-__global__ void read_sort_kernel(uint64_t* __restrict__ key, uint32_t* __restrict__ val, uint32_t n)
+// Hits ordered by (read, pos) -> ordered by (read, prg, strand, pos), out of place and stable: every hit counts the
+// hits of its own read that sort before it (a short read has a few dozen, contiguous in memory and nearly always in
+// one (prg, strand) group already) and moves to read start + rank.  Long reads take the global radix sort instead
+// (Mapper::run_batch).
+__global__ void read_sort_kernel(const uint64_t* __restrict__ key, const uint32_t* __restrict__ val, uint64_t* __restrict__ key_out,
+    uint32_t* __restrict__ val_out, uint32_t n)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t read = hit_read(key[i]);
-    if (i > 0 && hit_read(key[i - 1]) == read) return;
-    uint64_t prev = key[i];
-    for (uint32_t j = i + 1; j < n; ++j) {
+    const uint64_t ki = key[i];
+    const uint32_t read = hit_read(ki);
+    uint32_t before = 0, j = i;
+    while (j > 0) { // earlier hits of the read precede on ties
+        const uint64_t kj = key[j - 1];
+        if (hit_read(kj) != read) break;
+        before += kj <= ki ? 1u : 0u;
+        --j;
+    }
+    const uint32_t start = j;
+    for (j = i + 1; j < n; ++j) {
         const uint64_t kj = key[j];
         if (hit_read(kj) != read) break;
-        if (kj >= prev) { // already in place
-            prev = kj;
-            continue;
-        }
-        const uint32_t vj = val[j];
-        uint32_t p = j;
-        while (p > i && key[p - 1] > kj) {
-            key[p] = key[p - 1];
-            val[p] = val[p - 1];
-            --p;
-        }
-        key[p] = kj;
-        val[p] = vj;
-        // prev (the largest so far) moved to j
+        before += kj < ki ? 1u : 0u;
     }
+    key_out[start + before] = ki;
+    val_out[start + before] = val[i];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -617,10 +654,10 @@ hipError_t launch_sketch_filter(const SketchArgs& a, const uint32_t* bloom, uint
     return hipGetLastError();
 }
 
-hipError_t launch_read_sort(uint64_t* key, uint32_t* val, uint32_t n, hipStream_t stream)
+hipError_t launch_read_sort(const uint64_t* key, const uint32_t* val, uint64_t* key_out, uint32_t* val_out, uint32_t n, hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(read_sort_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, key, val, n);
+    hipLaunchKernelGGL(read_sort_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, key, val, key_out, val_out, n);
     return hipGetLastError();
 }
 
