@@ -56,6 +56,7 @@ inline int nt4(unsigned char c)
 
 // Multipliers of the two Bloom-filter levels shared by FlatIndex::build (index.cpp) and sketch_filter_kernel
 // (sketch_filter.hip, where the layout is described); level 1 is a 24 x 24 bit multiply.
+constexpr uint32_t BLOOM_C0 = 0xC2B2AFu; // level 0, also 24 x 24 bit
 constexpr uint32_t BLOOM_C1 = 0x9E3779u;
 constexpr uint32_t BLOOM_C2 = 0x85EBCA6Bu;
 

@@ -108,20 +108,37 @@ void PrgIndex::flatten()
     constexpr uint32_t MAX_WBITS = 14; // 16384 words = 64 KB of LDS
     const size_t entries = 2 * recs.size();
     if (k <= 15 && entries > 0 && entries <= 3 * (size_t(1) << MAX_WBITS)) {
+        // level 0 (k = 15 and a small index only): a second array of 2^15 words keyed on the 12-mers at offsets 0..3 of
+        // every index k-mer, so that the kernel probes one 12-mer per four read positions (the 12-mer at 4g+3 lies
+        // inside every 15-mer that starts at 4g..4g+3).  Levels 1+2 then get 32 KB: 160 KB of LDS in all.
+        constexpr uint32_t L0_WBITS = 15;
+        const bool level0 = k == 15 && 4 * entries * 3 <= (size_t(32) << L0_WBITS) / 2;
+        const uint32_t max_wbits = level0 ? MAX_WBITS - 1 : MAX_WBITS;
         uint32_t wbits = 8;
-        while (wbits < MAX_WBITS && (size_t(1) << wbits) * 5 < entries * 4) ++wbits; // <= 1.25 entries per word
+        while (wbits < max_wbits && (size_t(1) << wbits) * 5 < entries * 4) ++wbits; // <= 1.25 entries per word
         f.bloom_wbits = wbits;
         f.bloom.assign(size_t(1) << wbits, 0);
         // layout: see sketch_filter.hip.  The code is the kernel's own packing: letter = bits 2:1 of the ASCII base
         // (A 0, C 1, T 2, G 3; complement = letter ^ 2), first base in the lowest bits.
         const uint32_t wmask = (1u << wbits) - 1;
         const uint32_t kmask = (1u << (2 * k)) - 1; // k <= 15
+        if (level0) {
+            f.bloom0_wbits = L0_WBITS;
+            f.bloom0.assign(size_t(1) << L0_WBITS, 0);
+        }
+        const uint32_t wmask0 = (1u << L0_WBITS) - 1;
         auto add = [&](uint32_t code) {
             const uint32_t x = code & kmask & 0xFFFFFFu; // level 1: the first min(k,12) bases, 24 x 24 bit multiply
             const uint32_t h = (uint32_t)((uint64_t)x * BLOOM_C1);
             f.bloom[(h >> 18) & wmask] |= (1u << (31 - (h & 31))) | (1u << (31 - ((h >> 8) & 31))) | (1u << (31 - ((x >> 16) & 31)));
             const uint32_t h2 = code * BLOOM_C2; // level 2: an independent word, tested only for level-1 survivors
             f.bloom[h2 >> (32 - wbits)] |= (1u << (h2 & 31)) | (1u << ((h2 >> 5) & 31)) | (1u << ((h2 >> 10) & 31));
+            if (level0)
+                for (int o = 0; o < 4; ++o) {
+                    const uint32_t y = (code >> (2 * o)) & 0xFFFFFFu;
+                    const uint32_t g = (uint32_t)((uint64_t)y * BLOOM_C0);
+                    f.bloom0[(g >> 17) & wmask0] |= (1u << (31 - (g & 31))) | (1u << (31 - ((g >> 8) & 31))) | (1u << (31 - ((y >> 16) & 31)));
+                }
         };
         for (size_t p = 0; p < prgs.size(); ++p) {
             const auto& nodes = kgs[p].nodes;

@@ -34,6 +34,9 @@ struct FlatIndex {
     // bloom_wbits == 0: no filter (k > 15, or too many keys for an LDS-resident filter).
     uint32_t bloom_wbits = 0;
     std::vector<uint32_t> bloom;
+    // level 0 of that filter (k = 15, small indexes): the 12-mers at offsets 0..3 of every index k-mer; 0 = absent
+    uint32_t bloom0_wbits = 0;
+    std::vector<uint32_t> bloom0;
     uint32_t total_knodes() const { return knode_base.empty() ? 0 : knode_base.back(); }
 };
 

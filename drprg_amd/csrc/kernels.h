@@ -49,7 +49,8 @@ struct SketchArgs {
     uint64_t hit_capacity;
     unsigned long long* n_hits;
     unsigned long long* n_minimizers;
-    uint32_t* overflow; // bit 0: hit buffer too small, bit 1: read longer than 2^HIT_POS_BITS
+    uint32_t* overflow; // bit 0: hit buffer too small, bit 1: read longer than 2^HIT_POS_BITS, bit 2: candidate slice
+                        // too small, bit 3: dynamic LDS does not start at address 0 (sketch_filter_kernel)
 };
 
 struct ClusterRec {
@@ -85,7 +86,14 @@ uint32_t sketch_n_tiles(uint64_t n_bases, int halo);
 hipError_t launch_sketch_probe(const SketchArgs& a, bool wide_hash, hipStream_t stream, KernelTimer timer = {});
 // filtered form (k <= 15, w <= 16): bloom = 2^bloom_wbits words of index k-mer codes
 uint32_t filter_n_tiles(uint64_t n_bases);
-uint32_t filter_grid(uint32_t bloom_wbits, int n_cus, uint32_t n_tiles);
+uint32_t filter_grid(bool level0, int n_cus, uint32_t n_tiles);
+// device copies of FlatIndex::bloom / bloom0 (bloom0 == nullptr: no level 0)
+struct BloomTables {
+    const uint32_t* bloom;
+    uint32_t bloom_wbits;
+    const uint32_t* bloom0;
+    uint32_t bloom0_wbits;
+};
 // Scratch of the filtered launch sequence.  raw_pos: raw_capacity candidate positions (one slice per filter wave);
 // cand_info / cand_pos1: raw_capacity entries each; small: filter_small_words() u32; max_len: device scalar that
 // receives the length of the longest read holding a minimizer hit.  Overflow bit 2 (value 4) in a.overflow: a slice
@@ -99,8 +107,8 @@ struct FilterBuffers {
     unsigned long long* max_len;
 };
 size_t filter_small_words();
-hipError_t launch_sketch_filter(const SketchArgs& a, const uint32_t* bloom, uint32_t bloom_wbits, int n_cus, const FilterBuffers& b,
-    hipStream_t stream, KernelTimer timer = {});
+hipError_t launch_sketch_filter(const SketchArgs& a, const BloomTables& bt, int n_cus, const FilterBuffers& b, hipStream_t stream,
+    KernelTimer timer = {});
 // hits ordered by (read, pos) -> ordered by (read, prg, strand, pos), out of place; meant for short reads
 hipError_t launch_read_sort(const uint64_t* key, const uint32_t* val, uint64_t* key_out, uint32_t* val_out, uint32_t n, hipStream_t stream);
 size_t sort_temp_bytes(uint32_t n);

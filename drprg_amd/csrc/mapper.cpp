@@ -85,6 +85,11 @@ Mapper::Mapper(const FlatIndex& idx, const MapParams& p, int device) : device_(d
         dmalloc(d_bloom_, idx.bloom.size());
         HIPCHK(hipMemcpy(d_bloom_, idx.bloom.data(), idx.bloom.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
+    bloom0_wbits_ = bloom_wbits_ ? idx.bloom0_wbits : 0;
+    if (bloom0_wbits_) {
+        dmalloc(d_bloom0_, idx.bloom0.size());
+        HIPCHK(hipMemcpy(d_bloom0_, idx.bloom0.data(), idx.bloom0.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     HIPCHK(hipDeviceGetAttribute(&n_cus_, hipDeviceAttributeMultiprocessorCount, device_));
     set_params(p); // again: the kernel choice depends on the filter being available
     dmalloc(d_filter_small_, dev::filter_small_words());
@@ -107,7 +112,7 @@ Mapper::~Mapper()
     dfree(d_key_a_); dfree(d_key_b_); dfree(d_val_a_); dfree(d_val_b_);
     dfree(d_head_); dfree(d_scan_); dfree(d_cstart_); dfree(d_order_); dfree(d_clusters_);
     if (d_temp_) (void)hipFree(d_temp_);
-    dfree(d_bases_); dfree(d_offsets_); dfree(d_tile_first_); dfree(d_bloom_); dfree(d_filter_small_);
+    dfree(d_bases_); dfree(d_offsets_); dfree(d_tile_first_); dfree(d_bloom_); dfree(d_bloom0_); dfree(d_filter_small_);
     dfree(d_raw_pos_); dfree(d_cand_info_); dfree(d_cand_pos1_);
     if (h_counters_) (void)hipHostFree(h_counters_);
     if (h_bases_) (void)hipHostFree(h_bases_);
@@ -219,7 +224,8 @@ void Mapper::run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32
         }
         if (use_filter_) {
             dev::FilterBuffers fb { d_raw_pos_, d_cand_info_, d_cand_pos1_, raw_capacity_, d_filter_small_, &d_counters_[C_MAXLEN] };
-            HIPCHK(dev::launch_sketch_filter(a, d_bloom_, bloom_wbits_, n_cus_, fb, stream, timer));
+            dev::BloomTables bt { d_bloom_, bloom_wbits_, d_bloom0_, bloom0_wbits_ };
+            HIPCHK(dev::launch_sketch_filter(a, bt, n_cus_, fb, stream, timer));
         } else HIPCHK(dev::launch_sketch_probe(a, wide_hash_, stream, timer));
         HIPCHK(hipMemcpyAsync(h_counters_, d_counters_, C_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
@@ -230,6 +236,7 @@ void Mapper::run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32
             sketch_launches_ += 1;
         }
         uint32_t ovf = (uint32_t)h_counters_[C_OVERFLOW];
+        if (ovf & 8u) throw Error(DRPRG_EIO, "sketch_filter_kernel: dynamic LDS does not start at address 0");
         if (ovf & 2u) throw Error(DRPRG_EOVERFLOW, "a read is longer than 2^" + std::to_string(dev::HIT_POS_BITS) + " bases");
         if (ovf & 4u) { // a wave's candidate slice of the filtered kernel was too small: grow the candidate workspace
             if (attempt > 8) throw Error(DRPRG_EOVERFLOW, "candidate buffer overflow after regrow");

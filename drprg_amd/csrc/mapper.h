@@ -76,6 +76,8 @@ private:
     uint32_t* d_bloom_ = nullptr;
     uint32_t* d_filter_small_ = nullptr; // slice / workgroup counters of the filtered launch sequence
     uint32_t bloom_wbits_ = 0;
+    uint32_t* d_bloom0_ = nullptr; // level 0 of the filter (k = 15, small indexes)
+    uint32_t bloom0_wbits_ = 0;
     int n_cus_ = 256;
     bool use_filter_ = false;
     // accumulators

@@ -11,7 +11,8 @@
 //                          own slice of a candidate buffer (cursor in a scalar register: no atomics, no barriers).
 //                          Three tiles of bases are in flight per wave in a register ring, the right neighbour's
 //                          packed word arrives through a DPP wave shift.
-//   cand_scan_kernel       one workgroup: exclusive scan of the slice counts -> the candidates become one ordered list.
+//   cand_scan_kernel       one workgroup: exclusive scan of the slice counts; cand_gather_kernel copies the slices into
+//                          one dense, ordered candidate list.
 //   verify_count_kernel    one lane per candidate, start to finish, no barrier and no atomic: canonical hash from the
 //                          raw bases -> exact table lookup (false positives end here) -> read lookup -> window-minimizer
 //                          test over the 2w-1 neighbouring k-mers inside the read, hashed one by one out of a register
@@ -38,7 +39,8 @@ constexpr int FT_THREADS = 1024;
 constexpr int FT_WAVES = FT_THREADS / 64;
 constexpr int FT_G = 32;                // positions per lane
 constexpr int FT_WPOS = 63 * FT_G;      // positions per wave tile: lane 63's word is only lane 62's right neighbour
-constexpr int FT_BLOOM_WORDS = 1 << 14; // static LDS: the filter sits at LDS address 0, so a hash is an address
+constexpr int FT_BLOOM_WORDS = 1 << 14; // levels 1+2 of the filter, at most (64 KB of LDS)
+constexpr int FT_L0_WORDS = 1 << 15;    // level 0 (128 KB; levels 1+2 then get 32 KB: all 160 KB of a CU)
 constexpr int EX_THREADS = 256;
 constexpr int SCAN_THREADS = 1024;
 constexpr int MAX_SLICES = SCAN_THREADS * 8; // one slice per filter wave
@@ -60,6 +62,8 @@ __device__ inline uint32_t pack16le(const uint4& in)
 struct FilterWork {
     const uint32_t* bloom;
     uint32_t bloom_wbits;
+    const uint32_t* bloom0;  // level 0 (nullptr / 0: absent)
+    uint32_t bloom0_wbits;
     uint32_t n_tiles;        // wave tiles of FT_WPOS positions
     uint32_t tiles_per_wave; // wave g owns tiles [g * tiles_per_wave, (g+1) * tiles_per_wave)
     uint32_t n_slices;       // filter waves
@@ -80,23 +84,45 @@ struct FilterWork {
 //   level 1, keyed on the first min(k,12) bases: x = code & 0xFFFFFF, h = (x * BLOOM_C1) mod 2^32,
 //            word (h >> 18) & (words-1), bits 31-(h & 31), 31-((h >> 8) & 31), 31-((x >> 16) & 31)
 //   level 2, keyed on the whole code: h2 = code * BLOOM_C2, word h2 >> (32-wbits), bits h2 & 31, (h2>>5) & 31, (h2>>10) & 31
-// Level 1 costs 7 VALU + 1 LDS instruction per position (24-bit multiply, byte-select shifts, 3-input AND, funnel-shift
-// accumulate); level 2 runs only for the ~1 % level-1 survivors.
-template <bool SHORT_K> // SHORT_K: k < 12, the level-1 key must be masked to 2k bits
+//   level 0 (own array, k = 15 and small indexes), keyed on the 12-mers at offsets 0..3 of the k-mer: like level 1 with
+//            BLOOM_C0; probed once per four read positions
+// A level-0/1 probe costs 7 VALU + 1 LDS instruction (24-bit multiply, byte-select shifts, 3-input AND, funnel-shift
+// accumulate).  Without level 0 every position pays one; with it every fourth does, level 1 runs for the ~5 % of the
+// groups that pass, level 2 for the ~1 % level-1 survivors.
+//
+// The filter lives in dynamic LDS, which starts at LDS address 0 (the kernel has no static LDS): a masked hash is the
+// address of its word, read through an address-space-3 pointer made from the integer.
+typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
+__device__ __forceinline__ uint32_t lds_at(uint32_t byte_addr) { return *(lds_cu32*)(uintptr_t)byte_addr; }
+// bit 31 of the result: all three filter bits of (h, x) are set in word
+__device__ __forceinline__ uint32_t bloom_test(uint32_t word, uint32_t h, uint32_t x)
+{
+    uint32_t t2; // word << h[12:8]: the byte select is free, the compiler does not find it
+    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(t2) : "v"(h), "v"(word));
+    return (word << (h & 31)) & t2 & (word << ((x >> 16) & 0xFF));
+}
+
+// SHORT_K: k < 12, the level-1 key must be masked to 2k bits.  LEVEL0: the level-0 array is present (k = 15).
+template <bool SHORT_K, bool LEVEL0>
 __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a, FilterWork fw)
 {
-    __shared__ uint32_t s_bloom[FT_BLOOM_WORDS];
+    extern __shared__ uint32_t s_dyn[]; // [level 0: FT_L0_WORDS] [levels 1+2: 2^bloom_wbits words]
+    constexpr uint32_t L12_BASE = LEVEL0 ? FT_L0_WORDS * 4u : 0u;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int k = a.k;
     const int64_t n_bases = (int64_t)a.n_bases;
     const uint32_t n_words = 1u << fw.bloom_wbits;
-    const uint32_t amask = (n_words - 1) << 2; // byte address of the level-1 word = (h >> 16) & amask
+    const uint32_t amask = (n_words - 1) << 2; // byte offset of the level-1 word = (h >> 16) & amask
+    const uint32_t amask0 = ((1u << fw.bloom0_wbits) - 1) << 2;
     const uint32_t kmask = (k < 16) ? ((1u << (2 * k)) - 1) : 0xFFFFFFFFu;
     const uint32_t kmask24 = kmask & 0xFFFFFFu;
     const int sh_w = 32 - (int)fw.bloom_wbits;
 
-    for (uint32_t i = tid; i < n_words; i += FT_THREADS) s_bloom[i] = fw.bloom[i];
+    if (LEVEL0)
+        for (uint32_t i = tid; i < (1u << fw.bloom0_wbits); i += FT_THREADS) s_dyn[i] = fw.bloom0[i];
+    for (uint32_t i = tid; i < n_words; i += FT_THREADS) s_dyn[L12_BASE / 4 + i] = fw.bloom[i];
+    if (tid == 0 && (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)s_dyn != 0u) atomicOr(a.overflow, 8u);
 
     const uint32_t gw = blockIdx.x * FT_WAVES + (uint32_t)(tid >> 6); // this wave's slice
     uint32_t tile = gw * fw.tiles_per_wave;
@@ -144,32 +170,57 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
         const uint32_t wc = __builtin_amdgcn_update_dpp(0u, wa, 0x130 /* wave_shl:1: lane i <- lane i+1 */, 0xF, 0xF, false);
         uint32_t cand = 0;
         if (!(fw.debug & 1u)) {
-            // ---- level 1 over my 32 positions; position j ends up in bit j of cand ----
+            uint32_t c1 = 0; // level-1 survivors, position j in bit j
+            if (LEVEL0) {
+                // ---- level 0: one 12-mer per four positions (the one at 4g+3 lies inside every 15-mer starting at
+                // 4g..4g+3); group g ends up in bit g of grp ----
+                uint32_t grp = 0, xs[FT_G / 4], hs[FT_G / 4], ws[FT_G / 4];
 #pragma unroll
-            for (int j = FT_G - 1; j >= 0; --j) {
-                const uint32_t lo = j < 16 ? wa : wb, hi = j < 16 ? wb : wc;
-                uint32_t x = (j & 15) ? __builtin_amdgcn_alignbit(hi, lo, 2 * (j & 15)) : lo; // code in the low bits, later bases above
-                if (SHORT_K) x &= kmask24;
-                const uint32_t h = __umul24(x, BLOOM_C1);
-                const uint32_t word = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(s_bloom) + ((h >> 16) & amask));
-                uint32_t t2; // word << h[12:8]: the byte select is free, the compiler does not find it
-                asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD"
-                    : "=v"(t2)
-                    : "v"(h), "v"(word));
-                const uint32_t tt = (word << (h & 31)) & t2 & (word << ((x >> 16) & 0xFF)); // bit 31 = all three bits set
-                cand = __builtin_amdgcn_alignbit(cand, tt, 31);                             // cand = cand << 1 | tt >> 31
+                for (int g = 0; g < FT_G / 4; ++g) { // all eight LDS reads in flight before the first test
+                    const int j = 4 * g + 3;
+                    const uint32_t lo = j < 16 ? wa : wb, hi = j < 16 ? wb : wc;
+                    xs[g] = __builtin_amdgcn_alignbit(hi, lo, 2 * (j & 15));
+                    hs[g] = __umul24(xs[g], BLOOM_C0);
+                    ws[g] = lds_at((hs[g] >> 15) & amask0);
+                }
+#pragma unroll
+                for (int g = FT_G / 4 - 1; g >= 0; --g) grp = __builtin_amdgcn_alignbit(grp, bloom_test(ws[g], hs[g], xs[g]), 31);
+                if (lane == 63) grp = 0;
+                // ---- level 1 on the four positions of every surviving group (~5 % of the groups) ----
+                while (grp) {
+                    const int g = __ffs(grp) - 1;
+                    grp &= grp - 1;
+                    const uint32_t lo = g < 4 ? wa : wb, hi = g < 4 ? wb : wc;
+                    const uint32_t u0 = __funnelshift_r(lo, hi, (8 * g) & 31); // the 16 bases from position 4g
+                    uint32_t nib = 0;
+#pragma unroll
+                    for (int q = 3; q >= 0; --q) {
+                        const uint32_t x = u0 >> (2 * q);
+                        const uint32_t h = __umul24(x, BLOOM_C1);
+                        nib = __builtin_amdgcn_alignbit(nib, bloom_test(lds_at(L12_BASE + ((h >> 16) & amask)), h, x), 31);
+                    }
+                    c1 |= nib << (4 * g);
+                }
+            } else {
+                // ---- level 1 over my 32 positions ----
+#pragma unroll
+                for (int j = FT_G - 1; j >= 0; --j) {
+                    const uint32_t lo = j < 16 ? wa : wb, hi = j < 16 ? wb : wc;
+                    uint32_t x = (j & 15) ? __builtin_amdgcn_alignbit(hi, lo, 2 * (j & 15)) : lo; // code in the low bits, later bases above
+                    if (SHORT_K) x &= kmask24;
+                    const uint32_t h = __umul24(x, BLOOM_C1);
+                    c1 = __builtin_amdgcn_alignbit(c1, bloom_test(lds_at(L12_BASE + ((h >> 16) & amask)), h, x), 31); // c1 = c1 << 1 | bit
+                }
+                if (lane == 63) c1 = 0;
             }
-            if (lane == 63) cand = 0;
             // ---- level 2, only for the survivors: three more bits in a second word, keyed on the whole code ----
-            uint32_t c1 = cand;
-            cand = 0;
             while (c1) {
                 const int j = __ffs(c1) - 1;
                 c1 &= c1 - 1;
                 const uint32_t lo = j < 16 ? wa : wb, hi = j < 16 ? wb : wc;
                 const uint32_t f = __funnelshift_r(lo, hi, 2 * (j & 15)) & kmask;
                 const uint32_t h2 = f * BLOOM_C2;
-                const uint32_t word = s_bloom[h2 >> sh_w];
+                const uint32_t word = lds_at(L12_BASE + ((h2 >> sh_w) << 2));
                 cand |= ((word >> (h2 & 31)) & (word >> ((h2 >> 5) & 31)) & (word >> ((h2 >> 10) & 31)) & 1u) << j;
             }
         }
@@ -342,15 +393,15 @@ __device__ inline void candidate_range(const FilterWork& fw, uint32_t wg, uint32
     t_begin = b < total ? (uint32_t)b : total;
     t_end = b + per_wg < total ? (uint32_t)(b + per_wg) : total;
 }
-// last slice s in [lo, hi] with cand_prefix[s] <= t (empty slices are skipped by construction)
-__device__ inline uint32_t slice_of(const uint32_t* __restrict__ prefix, uint32_t lo, uint32_t hi, uint32_t t)
+
+// slices -> one dense, ordered candidate list (cand_info[t] holds the position until verify_count_kernel replaces it)
+__global__ __launch_bounds__(64) void cand_gather_kernel(FilterWork fw)
 {
-    ++hi; // prefix[lo] <= t < prefix[hi]
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (prefix[mid] <= t) lo = mid; else hi = mid;
-    }
-    return lo;
+    const uint32_t s = blockIdx.x;
+    const uint32_t n = fw.cand_prefix[s + 1] - fw.cand_prefix[s];
+    const uint64_t* __restrict__ src = fw.raw_pos + (size_t)s * fw.raw_slice;
+    uint64_t* __restrict__ dst = fw.cand_info + fw.cand_prefix[s];
+    for (uint32_t i = threadIdx.x; i < n; i += 64) dst[i] = src[i];
 }
 
 // One lane per candidate, start to finish: the 64 bases around it are packed into registers once (2 bits per base,
@@ -365,12 +416,6 @@ __global__ __launch_bounds__(EX_THREADS) void verify_count_kernel(SketchArgs a, 
     const int tid = threadIdx.x;
     uint32_t t_begin, t_end;
     candidate_range(fw, blockIdx.x, gridDim.x, t_begin, t_end);
-    const uint32_t* __restrict__ prefix = fw.cand_prefix;
-    uint32_t s_lo = 0, s_hi = 0;
-    if (t_begin < t_end) {
-        s_lo = slice_of(prefix, 0, fw.n_slices - 1, t_begin);
-        s_hi = slice_of(prefix, s_lo, fw.n_slices - 1, t_end - 1);
-    }
     const uint32_t* __restrict__ slot_key = reinterpret_cast<const uint32_t*>(a.slot_key);
     const uint32_t tmask = (1u << a.table_bits) - 1;
     const int k = a.k, w = a.w;
@@ -380,8 +425,7 @@ __global__ __launch_bounds__(EX_THREADS) void verify_count_kernel(SketchArgs a, 
     const double reads_per_base = (double)a.n_reads / (double)(a.n_bases ? a.n_bases : 1);
     uint32_t my_hits = 0, my_nmin = 0, my_maxlen = 0;
     for (uint32_t t = t_begin + tid; t < t_end; t += EX_THREADS) {
-        const uint32_t s = slice_of(prefix, s_lo, s_hi, t);
-        const int64_t gp = (int64_t)fw.raw_pos[(size_t)s * fw.raw_slice + (t - prefix[s])];
+        const int64_t gp = (int64_t)fw.cand_info[t]; // position now, (slot, strand, read) when this lane is done
         uint32_t pos1 = 0, slot = 0, read = 0, strand = 0;
         if (gp + k <= n_bases) {
             // ---- the 64 bases [a0, a0+64) hold the candidate and all its neighbours (w <= 16, k <= 15) ----
@@ -574,23 +618,37 @@ __global__ __launch_bounds__(EX_THREADS) void expand_kernel(SketchArgs a, Filter
 // hits of its own read that sort before it (a short read has a few dozen, contiguous in memory and nearly always in
 // one (prg, strand) group already) and moves to read start + rank.  Long reads take the global radix sort instead
 // (Mapper::run_batch).
-__global__ void read_sort_kernel(const uint64_t* __restrict__ key, const uint32_t* __restrict__ val, uint64_t* __restrict__ key_out,
+constexpr int RS_THREADS = 256, RS_HALO = 64;
+__global__ __launch_bounds__(RS_THREADS) void read_sort_kernel(const uint64_t* __restrict__ key, const uint32_t* __restrict__ val, uint64_t* __restrict__ key_out,
     uint32_t* __restrict__ val_out, uint32_t n)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    // the keys of the block and RS_HALO neighbours on either side are staged in LDS: the walk over a read's hits is a
+    // chain of dependent loads, and from global memory that latency is the whole cost of the kernel
+    __shared__ uint64_t s_key[RS_THREADS + 2 * RS_HALO];
+    const int64_t first = (int64_t)blockIdx.x * RS_THREADS - RS_HALO; // global index of s_key[0]
+    for (int q = threadIdx.x; q < RS_THREADS + 2 * RS_HALO; q += RS_THREADS) {
+        const int64_t g = first + q;
+        s_key[q] = (g >= 0 && g < (int64_t)n) ? key[g] : 0ull;
+    }
+    __syncthreads();
+    const uint32_t i = blockIdx.x * RS_THREADS + threadIdx.x;
     if (i >= n) return;
-    const uint64_t ki = key[i];
+    auto at = [&](uint32_t g) -> uint64_t { // 0 <= g < n
+        const int64_t q = (int64_t)g - first;
+        return (q >= 0 && q < RS_THREADS + 2 * RS_HALO) ? s_key[q] : key[g];
+    };
+    const uint64_t ki = s_key[threadIdx.x + RS_HALO];
     const uint32_t read = hit_read(ki);
     uint32_t before = 0, j = i;
     while (j > 0) { // earlier hits of the read precede on ties
-        const uint64_t kj = key[j - 1];
+        const uint64_t kj = at(j - 1);
         if (hit_read(kj) != read) break;
         before += kj <= ki ? 1u : 0u;
         --j;
     }
     const uint32_t start = j;
     for (j = i + 1; j < n; ++j) {
-        const uint64_t kj = key[j];
+        const uint64_t kj = at(j);
         if (hit_read(kj) != read) break;
         before += kj < ki ? 1u : 0u;
     }
@@ -603,12 +661,11 @@ __global__ void read_sort_kernel(const uint64_t* __restrict__ key, const uint32_
 // ---------------------------------------------------------------------------------------------
 uint32_t filter_n_tiles(uint64_t n_bases) { return (uint32_t)((n_bases + FT_WPOS - 1) / FT_WPOS); }
 
-uint32_t filter_grid(uint32_t bloom_wbits, int n_cus, uint32_t n_tiles)
+uint32_t filter_grid(bool level0, int n_cus, uint32_t n_tiles)
 {
-    // persistent grid: the two workgroups per CU that stay resident (64 KB of LDS and 1024 threads each), never more
-    // waves than there are wave tiles
-    (void)bloom_wbits;
-    uint32_t grid = (uint32_t)n_cus * 2;
+    // persistent grid: the workgroups that stay resident (1024 threads each; 64 KB of LDS: two per CU, 128 KB with
+    // level 0: one per CU), never more waves than there are wave tiles
+    uint32_t grid = (uint32_t)n_cus * (level0 ? 1 : 2);
     const uint32_t need = (n_tiles + FT_WAVES - 1) / FT_WAVES;
     if (grid > need) grid = need;
     if (grid > (uint32_t)(MAX_SLICES / FT_WAVES)) grid = MAX_SLICES / FT_WAVES;
@@ -617,16 +674,22 @@ uint32_t filter_grid(uint32_t bloom_wbits, int n_cus, uint32_t n_tiles)
 
 size_t filter_small_words() { return (size_t)MAX_SLICES * 2 + 1 + 4 * (size_t)MAX_EX_WG; }
 
-hipError_t launch_sketch_filter(const SketchArgs& a, const uint32_t* bloom, uint32_t bloom_wbits, int n_cus, const FilterBuffers& b,
-    hipStream_t stream, KernelTimer timer)
+hipError_t launch_sketch_filter(const SketchArgs& a, const BloomTables& bt, int n_cus, const FilterBuffers& b, hipStream_t stream,
+    KernelTimer timer)
 {
     if (a.n_bases == 0) return hipSuccess;
-    if ((1u << bloom_wbits) > (uint32_t)FT_BLOOM_WORDS) return hipErrorInvalidValue;
+    if ((1u << bt.bloom_wbits) > (uint32_t)FT_BLOOM_WORDS) return hipErrorInvalidValue;
+    if (bt.bloom0 && (1u << bt.bloom0_wbits) != (uint32_t)FT_L0_WORDS) return hipErrorInvalidValue;
     FilterWork fw {};
-    fw.bloom = bloom;
-    fw.bloom_wbits = bloom_wbits;
+    if (const char* dbg = std::getenv("DRPRG_FT_DEBUG")) fw.debug = (uint32_t)std::atoi(dbg); // 1 no filter test, 2 strided tiles, 4 no level 0
+    const bool level0 = bt.bloom0 != nullptr && a.k == 15 && ((size_t)4 << bt.bloom_wbits) + (size_t)FT_L0_WORDS * 4 <= 160 * 1024
+        && !(fw.debug & 4u);
+    fw.bloom = bt.bloom;
+    fw.bloom_wbits = bt.bloom_wbits;
+    fw.bloom0 = level0 ? bt.bloom0 : nullptr;
+    fw.bloom0_wbits = level0 ? bt.bloom0_wbits : 0;
     fw.n_tiles = filter_n_tiles(a.n_bases);
-    const uint32_t grid = filter_grid(bloom_wbits, n_cus, fw.n_tiles);
+    const uint32_t grid = filter_grid(level0, n_cus, fw.n_tiles);
     fw.n_slices = grid * FT_WAVES;
     fw.tiles_per_wave = (fw.n_tiles + fw.n_slices - 1) / fw.n_slices;
     fw.raw_slice = (uint32_t)std::min<uint64_t>(b.raw_capacity / fw.n_slices, 0x7FFFFFFFull / fw.n_slices);
@@ -641,13 +704,25 @@ hipError_t launch_sketch_filter(const SketchArgs& a, const uint32_t* bloom, uint
     fw.wg_base = fw.wg_maxlen + MAX_EX_WG;
     fw.ex_grid = std::min<uint32_t>((uint32_t)n_cus * 8, MAX_EX_WG);
     fw.max_len = b.max_len;
-    if (const char* dbg = std::getenv("DRPRG_FT_DEBUG")) fw.debug = (uint32_t)std::atoi(dbg);
     if (timer.begin) HIP_TRY(hipEventRecord(timer.begin, stream));
-    if (a.k < 12) hipLaunchKernelGGL(sketch_filter_kernel<true>, dim3(grid), dim3(FT_THREADS), 0, stream, a, fw);
-    else hipLaunchKernelGGL(sketch_filter_kernel<false>, dim3(grid), dim3(FT_THREADS), 0, stream, a, fw);
+    {
+        using Kernel = void (*)(SketchArgs, FilterWork);
+        const int which = level0 ? 2 : (a.k < 12 ? 1 : 0);
+        const Kernel kernel = which == 2 ? &sketch_filter_kernel<false, true>
+            : which == 1                 ? &sketch_filter_kernel<true, false>
+                                         : &sketch_filter_kernel<false, false>;
+        const size_t dyn = (level0 ? (size_t)FT_L0_WORDS * 4 : 0) + ((size_t)4 << bt.bloom_wbits);
+        static size_t configured[3] = { 0, 0, 0 };
+        if (dyn > configured[which]) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+            configured[which] = dyn;
+        }
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(FT_THREADS), dyn, stream, a, fw);
+    }
     HIP_TRY(hipGetLastError());
     if (timer.end) HIP_TRY(hipEventRecord(timer.end, stream));
     hipLaunchKernelGGL(cand_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, fw);
+    hipLaunchKernelGGL(cand_gather_kernel, dim3(fw.n_slices), dim3(64), 0, stream, fw);
     hipLaunchKernelGGL(verify_count_kernel, dim3(fw.ex_grid), dim3(EX_THREADS), 0, stream, a, fw);
     hipLaunchKernelGGL(hit_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, a, fw);
     hipLaunchKernelGGL(expand_kernel, dim3(fw.ex_grid), dim3(EX_THREADS), 0, stream, a, fw);
@@ -657,7 +732,7 @@ hipError_t launch_sketch_filter(const SketchArgs& a, const uint32_t* bloom, uint
 hipError_t launch_read_sort(const uint64_t* key, const uint32_t* val, uint64_t* key_out, uint32_t* val_out, uint32_t n, hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(read_sort_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, key, val, key_out, val_out, n);
+    hipLaunchKernelGGL(read_sort_kernel, dim3((n + RS_THREADS - 1) / RS_THREADS), dim3(RS_THREADS), 0, stream, key, val, key_out, val_out, n);
     return hipGetLastError();
 }
 
