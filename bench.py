@@ -104,20 +104,19 @@ def main():
     bases, offsets = gpu_sample_reads(torch, hap_pad, hap_lens, n_reads, args.read_len, 2 + rank, device)
     n_bases = int(bases.numel())
     del hap_pad
-    covg = torch.zeros(2 * ctx.n_knodes, dtype=torch.int32, device=device)
-    prg_reads = torch.zeros(ctx.n_prgs, dtype=torch.int32, device=device)
+    # the reduced vector: per-node coverage and per-PRG cluster counts in one buffer (one memset, one all-reduce)
+    acc = torch.zeros(2 * ctx.n_knodes + ctx.n_prgs, dtype=torch.int32, device=device)
+    covg, prg_reads = acc[: 2 * ctx.n_knodes], acc[2 * ctx.n_knodes:]
     stream = torch.cuda.Stream(device)  # the hot path and the collective run on this stream
     torch.cuda.synchronize()
 
     def step():
         with torch.cuda.stream(stream):
-            covg.zero_()
-            prg_reads.zero_()
+            acc.zero_()
             ctx.map_device(bases.data_ptr(), offsets.data_ptr(), n_reads, n_bases, covg.data_ptr(), prg_reads.data_ptr(),
                            stream.cuda_stream)
             if world > 1:
-                dist.all_reduce(covg)
-                dist.all_reduce(prg_reads)
+                dist.all_reduce(acc)
 
     def barrier():
         torch.cuda.synchronize()

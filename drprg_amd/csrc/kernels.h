@@ -109,8 +109,10 @@ struct FilterBuffers {
 size_t filter_small_words();
 hipError_t launch_sketch_filter(const SketchArgs& a, const BloomTables& bt, int n_cus, const FilterBuffers& b, hipStream_t stream,
     KernelTimer timer = {});
-// hits ordered by (read, pos) -> ordered by (read, prg, strand, pos), out of place; meant for short reads
-hipError_t launch_read_sort(const uint64_t* key, const uint32_t* val, uint64_t* key_out, uint32_t* val_out, uint32_t n, hipStream_t stream);
+// hits ordered by (read, pos) -> ordered by (read, prg, strand, pos), in place; meant for short reads.  scratch: u32
+// words (>= n) for the list of reads that need reordering; count: zeroed device scalar
+hipError_t launch_read_sort(uint64_t* key, uint32_t* val, uint32_t n, uint32_t* scratch, uint64_t scratch_words, unsigned long long* count,
+    hipStream_t stream);
 size_t sort_temp_bytes(uint32_t n);
 size_t scan_temp_bytes(uint32_t n);
 hipError_t sort_hits(void* temp, size_t temp_bytes, const uint64_t* key_in, uint64_t* key_out, const uint32_t* val_in,

@@ -27,7 +27,7 @@ template <typename T> static void dfree(T*& p)
 }
 
 // counter slots
-enum { C_HITS = 0, C_MINIMIZERS = 1, C_CLUSTERS_KEPT = 2, C_HITS_KEPT = 3, C_OVERFLOW = 4, C_MAXLEN = 5, C_N = 8 };
+enum { C_HITS = 0, C_MINIMIZERS = 1, C_CLUSTERS_KEPT = 2, C_HITS_KEPT = 3, C_OVERFLOW = 4, C_MAXLEN = 5, C_UNSORTED = 6, C_N = 8 };
 // reads up to this length get their hits reordered per read (read_sort_kernel); longer ones take the radix sort
 constexpr uint64_t READ_SORT_MAX_LEN = 512;
 
@@ -186,6 +186,7 @@ void Mapper::ensure_raw_workspace(uint64_t cap)
 void Mapper::run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads, uint64_t n_bases,
     uint32_t* covg, uint32_t* prg_reads, hipStream_t stream)
 {
+    if (n_bases == 0) return; // only empty reads: no k-mers, no hits
     ensure_workspace(std::max<uint64_t>(1u << 20, n_bases / 64));
     if (use_filter_) ensure_raw_workspace(std::max<uint64_t>(1u << 20, n_bases / 64));
     const uint32_t n_tiles = use_filter_ ? 0u : dev::sketch_n_tiles(n_bases, halo_);
@@ -195,8 +196,10 @@ void Mapper::run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32
         dmalloc(d_tile_first_, (size_t)tile_cap_);
     }
     for (int attempt = 0;; ++attempt) {
-        HIPCHK(hipMemsetAsync(&d_counters_[C_HITS], 0, sizeof(unsigned long long), stream));
-        HIPCHK(hipMemsetAsync(&d_counters_[C_OVERFLOW], 0, sizeof(unsigned long long), stream));
+        if (!use_filter_) // the filtered sequence stores the hit count, the direct kernel adds to it
+            HIPCHK(hipMemsetAsync(&d_counters_[C_HITS], 0, sizeof(unsigned long long), stream));
+        // overflow flags, longest read (stored later by the filtered sequence), list length of the per-read reorder
+        HIPCHK(hipMemsetAsync(&d_counters_[C_OVERFLOW], 0, 3 * sizeof(unsigned long long), stream));
         dev::SketchArgs a {};
         a.bases = d_bases;
         a.offsets = d_offsets;
@@ -264,9 +267,11 @@ void Mapper::run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32
     // the filtered sequence leaves the hits ordered by (read, pos): short reads only need a per-read reorder
     const uint64_t* s_key = d_key_b_;
     const uint32_t* s_val = d_val_b_;
-    if (use_filter_ && h_counters_[C_MAXLEN] <= READ_SORT_MAX_LEN)
-        HIPCHK(dev::launch_read_sort(d_key_a_, d_val_a_, d_key_b_, d_val_b_, n_hits, stream));
-    else HIPCHK(dev::sort_hits(d_temp_, temp_bytes_, d_key_a_, d_key_b_, d_val_a_, d_val_b_, n_hits, stream));
+    if (use_filter_ && h_counters_[C_MAXLEN] <= READ_SORT_MAX_LEN) {
+        HIPCHK(dev::launch_read_sort(d_key_a_, d_val_a_, n_hits, d_order_, hit_capacity_, &d_counters_[C_UNSORTED], stream));
+        s_key = d_key_a_;
+        s_val = d_val_a_;
+    } else HIPCHK(dev::sort_hits(d_temp_, temp_bytes_, d_key_a_, d_key_b_, d_val_a_, d_val_b_, n_hits, stream));
     HIPCHK(dev::launch_cluster_flags(s_key, n_hits, params_.max_diff, d_head_, d_scan_, d_temp_, temp_bytes_, stream));
     HIPCHK(dev::launch_cluster_starts(d_head_, d_scan_, n_hits, d_cstart_, stream));
     dev::ClusterArgs c {};

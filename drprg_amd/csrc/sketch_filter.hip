@@ -482,7 +482,8 @@ __global__ __launch_bounds__(EX_THREADS) void verify_count_kernel(SketchArgs a, 
                     r0w = __funnelshift_l(r1w, r0w, s2);
                     r1w = __funnelshift_l(r2w, r1w, s2);
                     r2w = __funnelshift_l(r3w, r2w, s2);
-                    bad >>= of;
+                    // steps that can count at all: inside the read and the window, no N in the k-mer (bit i = step i)
+                    const uint32_t valid = ((2u << i_hi) - 1u) & ~((1u << i_lo) - 1u) & ~(uint32_t)(bad >> of);
                     uint32_t streak = 0, right = 0, alive = 1;
                     for (int i = 0; i < 2 * w - 1; ++i) {
                         const uint32_t f = r0w >> sh_k;
@@ -491,8 +492,7 @@ __global__ __launch_bounds__(EX_THREADS) void verify_count_kernel(SketchArgs a, 
                         r2w <<= 2;
                         const uint32_t hf = Tr::mix(f, kmask), hr = Tr::mix(revcomp_code(f, k), kmask);
                         const uint32_t x = (hf < hr ? hf : hr) + 1;
-                        const bool ok = i >= i_lo && i <= i_hi && !((uint32_t)bad & 1u) && x >= g;
-                        bad >>= 1;
+                        const bool ok = ((valid >> i) & 1u) && x >= g;
                         if (i < ic) streak = ok ? streak + 1 : 0;
                         else if (i > ic) {
                             alive = ok ? alive : 0u;
@@ -614,46 +614,70 @@ __global__ __launch_bounds__(EX_THREADS) void expand_kernel(SketchArgs a, Filter
     }
 }
 
-// Hits ordered by (read, pos) -> ordered by (read, prg, strand, pos), out of place and stable: every hit counts the
-// hits of its own read that sort before it (a short read has a few dozen, contiguous in memory and nearly always in
-// one (prg, strand) group already) and moves to read start + rank.  Long reads take the global radix sort instead
-// (Mapper::run_batch).
-constexpr int RS_THREADS = 256, RS_HALO = 64;
-__global__ __launch_bounds__(RS_THREADS) void read_sort_kernel(const uint64_t* __restrict__ key, const uint32_t* __restrict__ val, uint64_t* __restrict__ key_out,
-    uint32_t* __restrict__ val_out, uint32_t n)
+// Hits ordered by (read, pos) -> ordered by (read, prg, strand, pos).  A short read's hits nearly always lie in one
+// (prg, strand) group, i.e. they are in order already: read_inversion_kernel lists the few reads that are not (one
+// thread per adjacent pair, the first inversion of a read reports it) and read_fix_kernel reorders just those, in
+// place and stable.  Long reads take the global radix sort instead (Mapper::run_batch).
+__global__ void read_inversion_kernel(const uint64_t* __restrict__ key, uint32_t n, uint2* __restrict__ list, uint32_t cap,
+    unsigned long long* __restrict__ count)
 {
-    // the keys of the block and RS_HALO neighbours on either side are staged in LDS: the walk over a read's hits is a
-    // chain of dependent loads, and from global memory that latency is the whole cost of the kernel
-    __shared__ uint64_t s_key[RS_THREADS + 2 * RS_HALO];
-    const int64_t first = (int64_t)blockIdx.x * RS_THREADS - RS_HALO; // global index of s_key[0]
-    for (int q = threadIdx.x; q < RS_THREADS + 2 * RS_HALO; q += RS_THREADS) {
-        const int64_t g = first + q;
-        s_key[q] = (g >= 0 && g < (int64_t)n) ? key[g] : 0ull;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i + 1 >= n) return;
+    const uint64_t a = key[i], b = key[i + 1];
+    const uint32_t read = hit_read(a);
+    if (hit_read(b) != read || a <= b) return;
+    // rare from here on: [s, e) = the hits of this read; an earlier inversion in it means another thread reports it
+    uint32_t s = i;
+    while (s > 0 && hit_read(key[s - 1]) == read) {
+        if (key[s - 1] > key[s]) return;
+        --s;
     }
-    __syncthreads();
-    const uint32_t i = blockIdx.x * RS_THREADS + threadIdx.x;
-    if (i >= n) return;
-    auto at = [&](uint32_t g) -> uint64_t { // 0 <= g < n
-        const int64_t q = (int64_t)g - first;
-        return (q >= 0 && q < RS_THREADS + 2 * RS_HALO) ? s_key[q] : key[g];
-    };
-    const uint64_t ki = s_key[threadIdx.x + RS_HALO];
-    const uint32_t read = hit_read(ki);
-    uint32_t before = 0, j = i;
-    while (j > 0) { // earlier hits of the read precede on ties
-        const uint64_t kj = at(j - 1);
-        if (hit_read(kj) != read) break;
-        before += kj <= ki ? 1u : 0u;
-        --j;
+    uint32_t e = i + 2;
+    while (e < n && hit_read(key[e]) == read) ++e;
+    const unsigned long long at = atomicAdd(count, 1ull);
+    if (at < cap) list[at] = make_uint2(s, e - s); // cap >= n / 2 >= the number of reads with two hits
+}
+
+constexpr int RS_THREADS = 256, RS_MAX = 1024;
+__global__ __launch_bounds__(RS_THREADS) void read_fix_kernel(uint64_t* __restrict__ key, uint32_t* __restrict__ val,
+    const uint2* __restrict__ list, const unsigned long long* __restrict__ count)
+{
+    __shared__ uint64_t s_key[RS_MAX];
+    __shared__ uint32_t s_val[RS_MAX];
+    const uint32_t n_list = (uint32_t)*count;
+    for (uint32_t r = blockIdx.x; r < n_list; r += gridDim.x) {
+        const uint32_t start = list[r].x, len = list[r].y;
+        if (len > RS_MAX) { // not expected for short reads; correct but serial
+            if (threadIdx.x == 0)
+                for (uint32_t j = start + 1; j < start + len; ++j) {
+                    const uint64_t kj = key[j];
+                    const uint32_t vj = val[j];
+                    uint32_t p = j;
+                    while (p > start && key[p - 1] > kj) {
+                        key[p] = key[p - 1];
+                        val[p] = val[p - 1];
+                        --p;
+                    }
+                    key[p] = kj;
+                    val[p] = vj;
+                }
+            continue;
+        }
+        for (uint32_t t = threadIdx.x; t < len; t += RS_THREADS) {
+            s_key[t] = key[start + t];
+            s_val[t] = val[start + t];
+        }
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t < len; t += RS_THREADS) {
+            const uint64_t kt = s_key[t];
+            uint32_t before = 0;
+            for (uint32_t j = 0; j < t; ++j) before += s_key[j] <= kt ? 1u : 0u; // earlier hits precede on ties
+            for (uint32_t j = t + 1; j < len; ++j) before += s_key[j] < kt ? 1u : 0u;
+            key[start + before] = kt;
+            val[start + before] = s_val[t];
+        }
+        __syncthreads();
     }
-    const uint32_t start = j;
-    for (j = i + 1; j < n; ++j) {
-        const uint64_t kj = at(j);
-        if (hit_read(kj) != read) break;
-        before += kj < ki ? 1u : 0u;
-    }
-    key_out[start + before] = ki;
-    val_out[start + before] = val[i];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -729,10 +753,14 @@ hipError_t launch_sketch_filter(const SketchArgs& a, const BloomTables& bt, int 
     return hipGetLastError();
 }
 
-hipError_t launch_read_sort(const uint64_t* key, const uint32_t* val, uint64_t* key_out, uint32_t* val_out, uint32_t n, hipStream_t stream)
+hipError_t launch_read_sort(uint64_t* key, uint32_t* val, uint32_t n, uint32_t* scratch, uint64_t scratch_words, unsigned long long* count,
+    hipStream_t stream)
 {
-    if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(read_sort_kernel, dim3((n + RS_THREADS - 1) / RS_THREADS), dim3(RS_THREADS), 0, stream, key, val, key_out, val_out, n);
+    if (n < 2) return hipSuccess;
+    uint2* list = reinterpret_cast<uint2*>(scratch);
+    hipLaunchKernelGGL(read_inversion_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, key, n, list, (uint32_t)(scratch_words / 2), count);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(read_fix_kernel, dim3(128), dim3(RS_THREADS), 0, stream, key, val, list, count);
     return hipGetLastError();
 }
 
