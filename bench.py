@@ -59,15 +59,118 @@ def gpu_sample_reads(torch, hap_pad, hap_lens, n_reads, read_len, seed, device, 
     return out, offsets
 
 
+def gpu_sample_long_reads(torch, hap_pad, hap_lens, n_reads, seed, device, mean_len=4000, sigma=0.5, min_len=500, max_len=50000,
+                          err=0.05, chunk_bases=1 << 25):
+    """Same distribution as drprg_amd.synth.sample_long_reads (lognormal lengths, 5 % errors split 40/30/30
+    substitution/insertion/deletion), generated on the device chunk by chunk (plumbing only)."""
+    import math
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    n_hap, max_hap = hap_pad.shape
+    flat = hap_pad.reshape(-1)
+    comp = torch.zeros(256, dtype=torch.uint8, device=device)
+    for a, b in zip(b"ACGTN", b"TGCAN"):
+        comp[a] = b
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+    mu = math.log(mean_len) - sigma * sigma / 2
+    z = torch.randn(n_reads, generator=g, device=device, dtype=torch.float64)
+    lens = torch.exp(mu + sigma * z).clamp(min_len, max_len).to(torch.int64)
+    hap = torch.randint(0, n_hap, (n_reads,), generator=g, device=device)
+    lens = torch.minimum(lens, hap_lens[hap] - 1)
+    start = (torch.rand(n_reads, generator=g, device=device, dtype=torch.float64) * (hap_lens[hap] - lens).to(torch.float64)).to(torch.int64)
+    rev = torch.rand(n_reads, generator=g, device=device) < 0.5
+    src_off = torch.zeros(n_reads + 1, dtype=torch.int64, device=device)
+    src_off[1:] = torch.cumsum(lens, 0)
+    bounds = [0]  # chunks of whole reads holding ~chunk_bases source bases
+    so = src_off.cpu().numpy()
+    while bounds[-1] < n_reads:
+        nxt = int(np.searchsorted(so, so[bounds[-1]] + chunk_bases, side="right")) - 1
+        bounds.append(min(n_reads, max(nxt, bounds[-1] + 1)))
+    pieces, out_lens = [], torch.empty(n_reads, dtype=torch.int64, device=device)
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        ln = lens[lo:hi]
+        m = int(ln.sum().item())
+        rid = torch.repeat_interleave(torch.arange(hi - lo, device=device), ln)
+        i_in = torch.arange(m, device=device) - (src_off[lo:hi] - src_off[lo])[rid]
+        r = rev[lo:hi][rid]
+        src = torch.where(r, start[lo:hi][rid] + ln[rid] - 1 - i_in, start[lo:hi][rid] + i_in)
+        t = flat[hap[lo:hi][rid] * max_hap + src]
+        t = torch.where(r, comp[t.long()], t)
+        u = torch.rand(m, generator=g, device=device)
+        counts = torch.ones(m, dtype=torch.int64, device=device)
+        counts[u < err * 0.3] = 0
+        ins = (u >= err * 0.3) & (u < err * 0.6)
+        counts[ins] = 2
+        sub = (u >= err * 0.6) & (u < err)
+        rnd = acgt[torch.randint(0, 4, (m,), generator=g, device=device)]
+        t = torch.where(sub, rnd, t)
+        out = torch.repeat_interleave(t, counts)
+        idx = torch.cumsum(counts, 0)[ins] - 1
+        out[idx] = acgt[torch.randint(0, 4, (int(idx.numel()),), generator=g, device=device)]
+        out_lens[lo:hi] = torch.zeros(hi - lo, dtype=torch.int64, device=device).index_add_(0, rid, counts)
+        pieces.append(out)
+        del rid, i_in, r, src, t, u, counts, ins, sub, rnd, idx
+    offsets = torch.zeros(n_reads + 1, dtype=torch.int64, device=device)
+    offsets[1:] = torch.cumsum(out_lens, 0)
+    return torch.cat(pieces), offsets
+
+
+WORKLOADS = {
+    # name: (BASELINE.json config, description, default reads per GPU, illumina)
+    "mtb": ("configs[1]", "10M synthetic 150 bp Illumina reads vs mtb-like PRG index", 10_000_000, True),
+    "nanopore": ("configs[2]", "2M synthetic Nanopore reads (mean 4 kb, 5% error) vs mtb-like PRG index", 2_000_000, False),
+    "big": ("configs[4]", "10M synthetic 150 bp reads vs 500-locus / 50k-variant synthetic PRG index", 10_000_000, True),
+}
+
+
+def map_range(ctx, bases, offsets, lo, hi, covg, prg_reads, stream, torch):
+    """reads [lo, hi) of the batch through the hot path (a 16-byte aligned copy of that range when lo > 0)"""
+    b0, b1 = int(offsets[lo].item()), int(offsets[hi].item())
+    if lo == 0:
+        sub_b, sub_o = bases, offsets
+    else:
+        sub_b = bases[b0:b1].clone()
+        sub_o = (offsets[lo:hi + 1] - b0).contiguous()
+    torch.cuda.synchronize()  # the copies above ran on torch's current stream, the hot path runs on `stream`
+    ctx.map_device(sub_b.data_ptr(), sub_o.data_ptr(), hi - lo, b1 - b0, covg.data_ptr(), prg_reads.data_ptr(), stream.cuda_stream)
+    torch.cuda.synchronize()
+
+
+def full_size_checks(torch, ctx, opts, bases, offsets, n_reads, covg, prg_reads, stream):
+    """Size-independent parity properties at full size (the oracle cannot map the whole batch in seconds):
+    (1) sharding invariance: coverage(whole shard) == coverage(first half) + coverage(second half), bit for bit;
+    (2) the two sketch kernels (direct / Bloom-prefiltered) give the identical vector."""
+    full = covg.clone()
+    split = torch.zeros_like(covg)
+    sp = torch.zeros_like(prg_reads)
+    torch.cuda.synchronize()
+    half = n_reads // 2
+    map_range(ctx, bases, offsets, 0, half, split, sp, stream, torch)
+    map_range(ctx, bases, offsets, half, n_reads, split, sp, stream, torch)
+    shard_invariant = bool(torch.equal(full, split))
+    kernels_agree = None
+    if ctx.counters().get("kernel") == 2:
+        ctx.set_opts(kernel=1, **opts)
+        direct = torch.zeros_like(covg)
+        map_range(ctx, bases, offsets, 0, n_reads, direct, sp, stream, torch)
+        kernels_agree = bool(torch.equal(full, direct))
+        ctx.set_opts(kernel=0, **opts)
+    return shard_invariant, kernels_agree
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--reads-per-gpu", type=int, default=10_000_000)
+    ap.add_argument("--workload", default="mtb", choices=sorted(WORKLOADS),
+                    help="mtb = configs[1] (the bench line); nanopore = configs[2]; big = configs[4]'s index")
+    ap.add_argument("--reads-per-gpu", type=int, default=0, help="0 = the workload's size")
     ap.add_argument("--read-len", type=int, default=150)
-    ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="reads timed on the CPU oracle (0 = skip)")
-    ap.add_argument("--workload", default="mtb", choices=["mtb", "big"], help="mtb = configs[1]; big = configs[4] index")
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="reads timed on the CPU oracle (0 = skip, -1 = ~10 s worth)")
+    ap.add_argument("--no-checks", action="store_true",
+                    help="skip the full-size property checks after the timed region (profiling runs: every launch is then a "
+                         "timed full-size one, so rocprofv3 per-kernel averages compare directly with avg_launch_ms)")
     args = ap.parse_args()
 
     import torch
@@ -89,21 +192,27 @@ def main():
     from drprg_amd import Context, synth
 
     W, K = 11, 15
-    panel = synth.mtb_like_panel() if args.workload == "mtb" else synth.big_panel()
+    cfg_name, cfg_desc, default_reads, illumina = WORKLOADS[args.workload]
+    panel = synth.big_panel() if args.workload == "big" else synth.mtb_like_panel()
     tmp = tempfile.mkdtemp(prefix=f"drprg_bench_r{rank}_")
     prg = os.path.join(tmp, "dr.prg")
     panel.write(prg, os.path.join(tmp, "genes.fa"))
     ctx = Context(prg, W, K, device=local_rank, from_files=False, threads=8)
-    ctx.set_opts(illumina=True, min_cluster_size=10, genome_size=synth.MTB_GENOME_SIZE)
+    opts = dict(illumina=illumina, min_cluster_size=10, genome_size=synth.MTB_GENOME_SIZE)
+    ctx.set_opts(**opts)
 
     # synthetic reads, generated on the device; every rank samples a different shard (seed + rank)
     genomes = synth.HaplotypeGenomes(panel, n_hap=8)
     hap_pad = torch.from_numpy(genomes.padded()).to(device)
     hap_lens = torch.from_numpy(genomes.lens).to(device)
-    n_reads = args.reads_per_gpu
-    bases, offsets = gpu_sample_reads(torch, hap_pad, hap_lens, n_reads, args.read_len, 2 + rank, device)
+    n_reads = args.reads_per_gpu or default_reads
+    if args.workload == "nanopore":
+        bases, offsets = gpu_sample_long_reads(torch, hap_pad, hap_lens, n_reads, 3 + rank, device)
+    else:
+        bases, offsets = gpu_sample_reads(torch, hap_pad, hap_lens, n_reads, args.read_len, 2 + rank, device)
     n_bases = int(bases.numel())
     del hap_pad
+    torch.cuda.empty_cache()
     # the reduced vector: per-node coverage and per-PRG cluster counts in one buffer (one memset, one all-reduce)
     acc = torch.zeros(2 * ctx.n_knodes + ctx.n_prgs, dtype=torch.int32, device=device)
     covg, prg_reads = acc[: 2 * ctx.n_knodes], acc[2 * ctx.n_knodes:]
@@ -139,28 +248,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # size-independent parity properties at full size (the oracle cannot map 10M reads in seconds):
-    # (1) sharding invariance: coverage(whole shard) == coverage(first half) + coverage(second half), bit for bit;
-    # (2) the two sketch kernels (direct / Bloom-prefiltered) give the identical vector.
     checksum = int(covg.to(torch.int64).sum().item())
-    full = covg.clone()
-    half = max(8, (n_reads // 2) // 8 * 8)  # keeps the second half's base pointer 16-byte aligned for any read length
-    split = torch.zeros_like(covg)
-    sp = torch.zeros_like(prg_reads)
-    torch.cuda.synchronize()
-    ctx.map_device(bases.data_ptr(), offsets.data_ptr(), half, half * args.read_len, split.data_ptr(), sp.data_ptr(), stream.cuda_stream)
-    ctx.map_device(bases.data_ptr() + half * args.read_len, offsets[half:].sub(half * args.read_len).contiguous().data_ptr(),
-                   n_reads - half, (n_reads - half) * args.read_len, split.data_ptr(), sp.data_ptr(), stream.cuda_stream)
-    torch.cuda.synchronize()
-    shard_invariant = bool(torch.equal(full, split)) if world == 1 else None
-    kernels_agree = None
-    if world == 1 and ctx.counters().get("kernel") == 2:
-        ctx.set_opts(illumina=True, min_cluster_size=10, genome_size=synth.MTB_GENOME_SIZE, kernel=1)
-        direct = torch.zeros_like(covg)
-        ctx.map_device(bases.data_ptr(), offsets.data_ptr(), n_reads, n_bases, direct.data_ptr(), sp.data_ptr(), stream.cuda_stream)
-        torch.cuda.synchronize()
-        kernels_agree = bool(torch.equal(full, direct))
-        ctx.set_opts(illumina=True, min_cluster_size=10, genome_size=synth.MTB_GENOME_SIZE, kernel=0)
+    counters = ctx.counters()
+    shard_invariant = kernels_agree = None
+    if world == 1 and not args.no_checks:
+        shard_invariant, kernels_agree = full_size_checks(torch, ctx, opts, bases, offsets, n_reads, covg, prg_reads, stream)
 
     if rank == 0:
         total_reads = n_reads * world * args.steps
@@ -170,13 +262,13 @@ def main():
         alg_bytes = n_bases + 8 * n_reads + table_bytes + 8 * ctx.n_knodes
         avg_ms = k_ms / max(k_launches, 1)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        kernel_name = {1: "sketch_probe_kernel", 2: "sketch_filter_kernel"}.get(ctx.counters().get("kernel"), "?")
+        kernel_name = {1: "sketch_probe_kernel", 2: "sketch_filter_kernel"}.get(counters.get("kernel"), "?")
         # HBM bytes per launch of that kernel from rocprofv3 PMC counters (separate --pmc passes, FETCH_SIZE doubled as
         # the microarch guide prescribes for wide coalesced loads on gfx950): measured offline, committed under profiles/
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
-        if args.workload == "mtb" and n_reads == 10_000_000 and os.path.exists(tfile):
-            traffic = json.load(open(tfile)).get(kernel_name, {}).get("hbm_bytes_per_launch")
+        if n_reads == default_reads and os.path.exists(tfile):
+            traffic = json.load(open(tfile)).get(args.workload, {}).get(kernel_name, {}).get("hbm_bytes_per_launch")
         out = {
             "metric": "reads/sec (+ achieved HBM GB/s) predicting on mtb index, 1/2/4/8 GPUs",
             "value": value,
@@ -191,11 +283,13 @@ def main():
             "dtype": "u32",
             "data": "synthetic",
             "config": {
-                "workload": ("configs[1]: 10M synthetic 150 bp Illumina reads vs mtb-like PRG index" if args.workload == "mtb"
-                             else "configs[4]: 500-locus / 50k-variant synthetic PRG index"),
-                "reads_per_gpu": n_reads, "read_len": args.read_len, "w": W, "k": K, "loci": ctx.n_prgs,
-                "index_keys": ctx.n_keys, "kmer_nodes": ctx.n_knodes, "sharding": f"reads x{world}",
+                "workload": f"{cfg_name}: {cfg_desc}",
+                "reads_per_gpu": n_reads, "bases_per_gpu": n_bases, "mean_read_len": n_bases / max(n_reads, 1), "w": W, "k": K,
+                "loci": ctx.n_prgs, "index_keys": ctx.n_keys, "kmer_nodes": ctx.n_knodes, "sharding": f"reads x{world}",
                 "collective": "all_reduce(u32 coverage) per step" if world > 1 else "none",
+                "bases_per_s": n_bases * world * args.steps / elapsed,
+                "hits_per_batch": counters.get("hits", 0) // (args.warmup + args.steps),
+                "clusters_kept_per_batch": counters.get("clusters_kept", 0) // (args.warmup + args.steps),
                 "coverage_checksum": checksum, "full_size_shard_invariance": shard_invariant,
                 "full_size_direct_vs_filtered_kernel_identical": kernels_agree,
             },
@@ -206,14 +300,16 @@ def main():
             },
         }
         # CPU baseline: the oracle (single-threaded port of the same path) on a bounded sample, rank 0, N=1 semantics
-        if args.cpu_sample > 0:
+        if args.cpu_sample != 0:
             from util import Oracle, cluster_fraction, map_params
             orc = Oracle()
-            ns = min(args.cpu_sample, n_reads)
-            hb = bases[:ns * args.read_len].cpu().numpy()
+            ns = args.cpu_sample if args.cpu_sample > 0 else max(1, int(2_000_000 * 150 / max(n_bases / n_reads, 1)))
+            ns = min(ns, n_reads)
+            nb = int(offsets[ns].item())
+            hb = bases[:nb].cpu().numpy()
             ho = offsets[:ns + 1].cpu().numpy().astype(np.uint64)
             idx = ctx.export_index()
-            md, er = map_params(K, True)
+            md, er = map_params(K, illumina)
             t1 = time.perf_counter()
             ocov, _, _ = orc.map_reads(hb, ho, idx, W, K, md, cluster_fraction(er, K), 10)
             cpu_s = time.perf_counter() - t1
@@ -221,12 +317,10 @@ def main():
             c2 = torch.zeros_like(covg)
             p2 = torch.zeros_like(prg_reads)
             torch.cuda.synchronize()
-            ctx.map_device(bases.data_ptr(), offsets.data_ptr(), ns, ns * args.read_len, c2.data_ptr(), p2.data_ptr(),
-                           stream.cuda_stream)
-            torch.cuda.synchronize()
+            map_range(ctx, bases, offsets, 0, ns, c2, p2, stream, torch)
             parity = bool(np.array_equal(c2.cpu().numpy().view(np.uint32), ocov))
             out["cpu_baseline"] = {"value": ns / cpu_s, "unit": "reads/s", "cores": 1, "kind": "port",
-                                   "sample": f"first {ns} reads of rank 0's shard, oracle/oracle.c single thread, {cpu_s:.1f}s",
+                                   "sample": f"first {ns} reads ({nb} bases) of rank 0's shard, oracle/oracle.c single thread, {cpu_s:.1f}s",
                                    "host_cores_available": os.cpu_count(), "parity_vs_hip_on_sample": parity}
         print(json.dumps(out), flush=True)
     ctx.close()

@@ -1,19 +1,8 @@
-# usage: bash tools/pmc.sh <tag> "<COUNTER list, one rocprofv3 pass each>"
+# usage: bash tools/pmc.sh <tag> <workload> <COUNTER> [<COUNTER> ...]     (one rocprofv3 --pmc pass per counter)
+# every launch of the run is a timed full-size one (--no-checks), so per-launch = sum / launches
 cd /tmp && export TMPDIR=/tmp
-tag=$1; shift
+tag=$1; wl=$2; shift; shift
 for c in "$@"; do
-  rocprofv3 --pmc $c --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$tag -o $(echo $c | tr ' ' '_') -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --cpu-sample 0 > /dev/null 2>&1
+  rocprofv3 --pmc $c --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$tag -o $c -- python3 $GRAFT_REPO_ROOT/bench.py --workload $wl --steps 3 --warmup 1 --cpu-sample 0 --no-checks > /dev/null 2>&1
 done
-python3 - <<'PY'
-import csv,glob,os,collections
-root=os.environ['GRAFT_REPO_ROOT']+'/gpurun_out/pmc_'+os.environ.get('TAG','')
-for f in sorted(glob.glob(os.environ['GRAFT_REPO_ROOT']+'/gpurun_out/pmc_*/*counter_collection.csv')):
-    acc=collections.defaultdict(lambda:[0,0])
-    for r in csv.DictReader(open(f)):
-        k=r['Kernel_Name']
-        if 'sketch_filter' in k or 'verify_count' in k:
-            key=(k.split('(')[0][-40:], r['Counter_Name'])
-            acc[key][0]+=float(r['Counter_Value']); acc[key][1]+=1
-    for (k,c),(v,n) in sorted(acc.items()):
-        print(f"{k:42s} {c:28s} per-launch {v/n:16.0f}  (n={n})")
-PY
+python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py $GRAFT_REPO_ROOT/gpurun_out/pmc_$tag
