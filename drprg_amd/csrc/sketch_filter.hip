@@ -282,46 +282,6 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
 // ---------------------------------------------------------------------------------------------
 // scans
 // ---------------------------------------------------------------------------------------------
-__device__ inline uint32_t wave_inclusive_scan(uint32_t v)
-{
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t n = __shfl_up(v, off);
-        if (lane >= off) v += n;
-    }
-    return v;
-}
-__device__ inline uint32_t wave_max(uint32_t v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const uint32_t n = __shfl_xor(v, off);
-        v = n > v ? n : v;
-    }
-    return v;
-}
-
-// exclusive scan over the workgroup (NW waves); s_w: NW + 1 words of LDS; returns the exclusive prefix, total in *total.
-// Two barriers; s_w may be reused after the call returns on every thread.
-template <int NW> __device__ inline uint32_t block_exclusive_scan(uint32_t v, uint32_t* s_w, uint32_t* total)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t incl = wave_inclusive_scan(v);
-    __syncthreads(); // s_w free again (previous call)
-    if (lane == 63) s_w[wave] = incl;
-    __syncthreads();
-    uint32_t base = 0, sum = 0;
-#pragma unroll
-    for (int i = 0; i < NW; ++i) {
-        const uint32_t x = s_w[i];
-        if (i < wave) base += x;
-        sum += x;
-    }
-    *total = sum;
-    return base + incl - v;
-}
-
 // one workgroup: cand_prefix = exclusive scan of min(slice_count, raw_slice)
 __global__ __launch_bounds__(SCAN_THREADS) void cand_scan_kernel(FilterWork fw)
 {

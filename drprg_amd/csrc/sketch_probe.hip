@@ -63,6 +63,8 @@ __global__ __launch_bounds__(SK_THREADS) void sketch_probe_kernel(SketchArgs a)
     __shared__ uint16_t s_strand[SK_THREADS];
     __shared__ uint16_t s_mins[SK_NPOS];
     __shared__ uint32_t s_nmin;
+    __shared__ uint32_t s_scan[SK_THREADS / 64 + 1];
+    __shared__ unsigned long long s_base;
     uint8_t* s_code = reinterpret_cast<uint8_t*>(s_code4);
 
     const int tid = threadIdx.x;
@@ -228,9 +230,14 @@ __global__ __launch_bounds__(SK_THREADS) void sketch_probe_kernel(SketchArgs a)
     __syncthreads();
 
     // ---- phase 2b: probe the index with the compacted minimizer list ----
+    // Found slots replace the hash in s_hash (same thread, same word); the hits of the whole tile then take ONE global
+    // reservation (a per-minimizer atomic on the hit counter serialises on a single L2 address once millions of
+    // minimizers hit, as they do with a large index).
     const uint32_t nmin = s_nmin;
     const uint32_t tmask = (1u << a.table_bits) - 1;
     const HT* __restrict__ slot_key = reinterpret_cast<const HT*>(a.slot_key);
+    constexpr HT NOT_FOUND = (HT)~(HT)0;
+    uint32_t mine = 0;
     for (uint32_t i = tid; i < nmin; i += SK_THREADS) {
         const int j = s_mins[i];
         const HT h = s_hash[hpad(j)] - 1;
@@ -242,15 +249,28 @@ __global__ __launch_bounds__(SK_THREADS) void sketch_probe_kernel(SketchArgs a)
             if (key == Tr::EMPTY) break;
             s = (s + 1) & tmask;
         }
-        if (!found) continue;
+        s_hash[hpad(j)] = found ? (HT)s : NOT_FOUND;
+        if (found) mine += a.slot_rec[s].y;
+    }
+    uint32_t total;
+    const uint32_t before = block_exclusive_scan<SK_THREADS / 64>(mine, s_scan, &total);
+    if (tid == 0) s_base = total ? atomicAdd(a.n_hits, (unsigned long long)total) : 0ull;
+    __syncthreads();
+    unsigned long long at = s_base + before;
+    for (uint32_t i = tid; i < nmin; i += SK_THREADS) {
+        const int j = s_mins[i];
+        const HT sv = s_hash[hpad(j)];
+        if (sv == NOT_FOUND) continue;
+        const uint32_t s = (uint32_t)sv;
         const uint2 rec = a.slot_rec[s];
         // a hit: locate the read and emit one hit per index record
         const uint64_t gp = (uint64_t)(origin + j);
         const uint32_t read = find_read_from(a.offsets, a.n_reads, first_read ? first_read - 1 : 0, gp);
         const uint64_t pos = gp - a.offsets[read];
         const uint32_t strand = (s_strand[j / SK_G] >> (j % SK_G)) & 1u;
-        const unsigned long long at = atomicAdd(a.n_hits, (unsigned long long)rec.y);
-        if (at + rec.y > a.hit_capacity || pos >= (1ull << HIT_POS_BITS)) {
+        const unsigned long long mine_at = at;
+        at += rec.y;
+        if (mine_at + rec.y > a.hit_capacity || pos >= (1ull << HIT_POS_BITS)) {
             atomicOr(a.overflow, pos >= (1ull << HIT_POS_BITS) ? 2u : 1u);
             continue;
         }
@@ -258,8 +278,8 @@ __global__ __launch_bounds__(SK_THREADS) void sketch_probe_kernel(SketchArgs a)
             const uint32_t kn = a.rec_knode[rec.x + q]; // (global knode << 1) | strand
             const uint32_t prg = a.rec_prg[rec.x + q];
             const uint32_t rev = ((kn & 1u) == strand) ? 0u : 1u; // forward hits sort first
-            a.hit_key[at + q] = pack_hit_key(read, prg, rev, (uint32_t)pos);
-            a.hit_val[at + q] = kn >> 1;
+            a.hit_key[mine_at + q] = pack_hit_key(read, prg, rev, (uint32_t)pos);
+            a.hit_val[mine_at + q] = kn >> 1;
         }
     }
     if (tid == 0 && nmin) atomicAdd(a.n_minimizers, (unsigned long long)nmin);
