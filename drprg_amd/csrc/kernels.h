@@ -102,13 +102,59 @@ struct FilterBuffers {
     uint64_t* raw_pos;
     uint64_t* cand_info;
     uint32_t* cand_pos1;
+    uint4* cand_rec; // raw_capacity entries
     uint64_t raw_capacity;
     uint32_t* small;
     unsigned long long* max_len;
 };
+// device view of the workspace of one filtered launch sequence (filled by launch_sketch_filter)
+struct FilterWork {
+    const uint32_t* bloom;
+    uint32_t bloom_wbits;
+    const uint32_t* bloom0;  // level 0 (nullptr / 0: absent)
+    uint32_t bloom0_wbits;
+    uint32_t n_tiles;        // wave tiles of FT_WPOS positions
+    uint32_t tiles_per_wave; // wave g owns tiles [g * tiles_per_wave, (g+1) * tiles_per_wave)
+    uint32_t n_slices;       // filter waves
+    uint32_t raw_slice;      // capacity of one slice
+    uint64_t* raw_pos;       // [n_slices][raw_slice]: global base position of a candidate k-mer, ascending per slice
+    uint32_t* slice_count;   // [n_slices] (may exceed raw_slice: overflow)
+    uint32_t* cand_prefix;   // [n_slices + 1]: exclusive scan of the clamped counts
+    uint64_t* cand_info;     // [candidates]: slot << 32 | strand << 31 | read
+    uint32_t* cand_pos1;     // [candidates]: read position + 1 of a minimizer, 0 = not a minimizer
+    uint4* cand_rec;         // [candidates]: what read_cluster_kernel needs of a minimizer: first index record, number of
+                             // records, group << 16 | size threshold, coverage index of the first record (0,0,.. = not a minimizer)
+    uint32_t ex_grid;        // workgroups of verify_count_kernel / expand_kernel
+    uint32_t *wg_hits, *wg_nmin, *wg_maxlen, *wg_base; // [ex_grid]
+    unsigned long long* max_len; // longest read that holds a minimizer hit (this batch)
+    uint32_t debug;          // ablation switch for profiling (DRPRG_FT_DEBUG): 1 = skip the Bloom test
+};
+constexpr uint32_t READ_NONE = 0x7FFFFFFFu; // "read" of a candidate that lies past the last whole k-mer of the buffer
+
+// per-read clustering straight from the candidate list (read_cluster_kernel)
+struct ReadClusterArgs {
+    const uint32_t* prg_min_path_len;
+    double fraction;
+    uint32_t min_cluster_size;
+    int max_diff;
+    uint32_t n_prgs;
+    uint32_t* covg;
+    uint32_t* prg_reads;
+    unsigned long long* n_clusters_kept;
+    unsigned long long* n_hits_kept;
+    unsigned long long* n_complex; // reads left to the generic pipeline (their candidates keep cand_pos1 != 0)
+    uint32_t* chunk_counter;       // zeroed device scalar: work distribution of read_cluster_kernel
+};
 size_t filter_small_words();
-hipError_t launch_sketch_filter(const SketchArgs& a, const BloomTables& bt, int n_cus, const FilterBuffers& b, hipStream_t stream,
-    KernelTimer timer = {});
+// filter -> candidates -> verify -> per-read clustering of the reads that fit read_cluster_kernel (coverage, PRG read
+// counts and the kept-cluster counters are updated); a.n_hits receives the number of hits of the whole batch,
+// rc.n_complex the number of reads left over.  fw is filled for the two follow-up calls.
+hipError_t launch_sketch_filter(const SketchArgs& a, const BloomTables& bt, int n_cus, const FilterBuffers& b, const ReadClusterArgs& rc,
+    FilterWork& fw, hipStream_t stream, KernelTimer timer = {});
+// leftover reads: a.n_hits receives the number of their hits, b.max_len their longest read ...
+hipError_t launch_filter_recount(const SketchArgs& a, const FilterWork& fw, hipStream_t stream);
+// ... and their hits are written to a.hit_key / a.hit_val ordered by (read, position)
+hipError_t launch_filter_expand(const SketchArgs& a, const FilterWork& fw, hipStream_t stream);
 // hits ordered by (read, pos) -> ordered by (read, prg, strand, pos), in place; meant for short reads.  scratch: u32
 // words (>= n) for the list of reads that need reordering; count: zeroed device scalar
 hipError_t launch_read_sort(uint64_t* key, uint32_t* val, uint32_t n, uint32_t* scratch, uint64_t scratch_words, unsigned long long* count,

@@ -27,7 +27,7 @@ template <typename T> static void dfree(T*& p)
 }
 
 // counter slots
-enum { C_HITS = 0, C_MINIMIZERS = 1, C_CLUSTERS_KEPT = 2, C_HITS_KEPT = 3, C_OVERFLOW = 4, C_MAXLEN = 5, C_UNSORTED = 6, C_N = 8 };
+enum { C_HITS = 0, C_MINIMIZERS = 1, C_CLUSTERS_KEPT = 2, C_HITS_KEPT = 3, C_OVERFLOW = 4, C_MAXLEN = 5, C_UNSORTED = 6, C_COMPLEX = 7, C_CHUNK = 8, C_N = 16 };
 // reads up to this length get their hits reordered per read (read_sort_kernel); longer ones take the radix sort
 constexpr uint64_t READ_SORT_MAX_LEN = 512;
 
@@ -113,7 +113,7 @@ Mapper::~Mapper()
     dfree(d_head_); dfree(d_scan_); dfree(d_cstart_); dfree(d_order_); dfree(d_clusters_);
     if (d_temp_) (void)hipFree(d_temp_);
     dfree(d_bases_); dfree(d_offsets_); dfree(d_tile_first_); dfree(d_bloom_); dfree(d_bloom0_); dfree(d_filter_small_);
-    dfree(d_raw_pos_); dfree(d_cand_info_); dfree(d_cand_pos1_);
+    dfree(d_raw_pos_); dfree(d_cand_info_); dfree(d_cand_pos1_); dfree(d_cand_rec_);
     if (h_counters_) (void)hipHostFree(h_counters_);
     if (h_bases_) (void)hipHostFree(h_bases_);
     if (h_offsets_) (void)hipHostFree(h_offsets_);
@@ -178,96 +178,19 @@ void Mapper::ensure_raw_workspace(uint64_t cap)
 {
     if (cap <= raw_capacity_) return;
     if (cap >= (1ull << 31)) throw Error(DRPRG_EOVERFLOW, "more than 2^31 candidate k-mers in one batch; map smaller batches");
-    dfree(d_raw_pos_); dfree(d_cand_info_); dfree(d_cand_pos1_);
+    dfree(d_raw_pos_); dfree(d_cand_info_); dfree(d_cand_pos1_); dfree(d_cand_rec_);
     raw_capacity_ = cap;
-    dmalloc(d_raw_pos_, cap); dmalloc(d_cand_info_, cap); dmalloc(d_cand_pos1_, cap);
+    dmalloc(d_raw_pos_, cap); dmalloc(d_cand_info_, cap); dmalloc(d_cand_pos1_, cap); dmalloc(d_cand_rec_, cap);
 }
 
-void Mapper::run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads, uint64_t n_bases,
-    uint32_t* covg, uint32_t* prg_reads, hipStream_t stream)
+// hits in d_key_a_/d_val_a_ -> clusters -> coverage (the generic pipeline).  ordered: the hits are ordered by
+// (read, position) already and no read is longer than READ_SORT_MAX_LEN, so a per-read reorder replaces the radix sort.
+void Mapper::cluster_hits(const uint64_t* d_offsets, uint32_t n_hits, bool ordered, uint32_t* covg, uint32_t* prg_reads, hipStream_t stream)
 {
-    if (n_bases == 0) return; // only empty reads: no k-mers, no hits
-    ensure_workspace(std::max<uint64_t>(1u << 20, n_bases / 64));
-    if (use_filter_) ensure_raw_workspace(std::max<uint64_t>(1u << 20, n_bases / 64));
-    const uint32_t n_tiles = use_filter_ ? 0u : dev::sketch_n_tiles(n_bases, halo_);
-    if (n_tiles > tile_cap_) { // direct kernel only: first read of every tile
-        dfree(d_tile_first_);
-        tile_cap_ = n_tiles + n_tiles / 4 + 16;
-        dmalloc(d_tile_first_, (size_t)tile_cap_);
-    }
-    for (int attempt = 0;; ++attempt) {
-        if (!use_filter_) // the filtered sequence stores the hit count, the direct kernel adds to it
-            HIPCHK(hipMemsetAsync(&d_counters_[C_HITS], 0, sizeof(unsigned long long), stream));
-        // overflow flags, longest read (stored later by the filtered sequence), list length of the per-read reorder
-        HIPCHK(hipMemsetAsync(&d_counters_[C_OVERFLOW], 0, 3 * sizeof(unsigned long long), stream));
-        dev::SketchArgs a {};
-        a.bases = d_bases;
-        a.offsets = d_offsets;
-        a.n_bases = n_bases;
-        a.n_reads = n_reads;
-        a.w = params_.w;
-        a.k = params_.k;
-        a.halo = halo_;
-        a.slot_key = d_slot_key_;
-        a.slot_rec = d_slot_rec_;
-        a.table_bits = table_bits_;
-        a.rec_knode = d_rec_knode_;
-        a.rec_prg = d_rec_prg_;
-        a.tile_first_read = d_tile_first_;
-        a.hit_key = d_key_a_;
-        a.hit_val = d_val_a_;
-        a.hit_capacity = hit_capacity_;
-        a.n_hits = &d_counters_[C_HITS];
-        a.n_minimizers = &d_counters_[C_MINIMIZERS];
-        a.overflow = reinterpret_cast<uint32_t*>(&d_counters_[C_OVERFLOW]);
-        dev::KernelTimer timer;
-        if (timing_) { // events bracket the dominant kernel only (sketch_filter_kernel / sketch_probe_kernel)
-            timer.begin = ev0_;
-            timer.end = ev1_;
-        }
-        if (use_filter_) {
-            dev::FilterBuffers fb { d_raw_pos_, d_cand_info_, d_cand_pos1_, raw_capacity_, d_filter_small_, &d_counters_[C_MAXLEN] };
-            dev::BloomTables bt { d_bloom_, bloom_wbits_, d_bloom0_, bloom0_wbits_ };
-            HIPCHK(dev::launch_sketch_filter(a, bt, n_cus_, fb, stream, timer));
-        } else HIPCHK(dev::launch_sketch_probe(a, wide_hash_, stream, timer));
-        HIPCHK(hipMemcpyAsync(h_counters_, d_counters_, C_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-        HIPCHK(hipStreamSynchronize(stream));
-        if (timing_ && n_bases > 0) {
-            float ms = 0;
-            HIPCHK(hipEventElapsedTime(&ms, ev0_, ev1_));
-            sketch_ms_ += ms;
-            sketch_launches_ += 1;
-        }
-        uint32_t ovf = (uint32_t)h_counters_[C_OVERFLOW];
-        if (ovf & 8u) throw Error(DRPRG_EIO, "sketch_filter_kernel: dynamic LDS does not start at address 0");
-        if (ovf & 2u) throw Error(DRPRG_EOVERFLOW, "a read is longer than 2^" + std::to_string(dev::HIT_POS_BITS) + " bases");
-        if (ovf & 4u) { // a wave's candidate slice of the filtered kernel was too small: grow the candidate workspace
-            if (attempt > 8) throw Error(DRPRG_EOVERFLOW, "candidate buffer overflow after regrow");
-            unsigned long long restored = last_minimizers_;
-            HIPCHK(hipMemcpyAsync(&d_counters_[C_MINIMIZERS], &restored, sizeof(restored), hipMemcpyHostToDevice, stream));
-            HIPCHK(hipStreamSynchronize(stream));
-            ensure_raw_workspace(raw_capacity_ * 4);
-            continue;
-        }
-        if (h_counters_[C_HITS] > hit_capacity_) {
-            if (attempt > 6) throw Error(DRPRG_EOVERFLOW, "hit buffer overflow after regrow");
-            // undo the minimizer count of the aborted pass, grow, and re-run the sketch
-            unsigned long long restored = last_minimizers_;
-            HIPCHK(hipMemcpyAsync(&d_counters_[C_MINIMIZERS], &restored, sizeof(restored), hipMemcpyHostToDevice, stream));
-            HIPCHK(hipStreamSynchronize(stream));
-            ensure_workspace(h_counters_[C_HITS] + h_counters_[C_HITS] / 8 + 1024);
-            continue;
-        }
-        last_minimizers_ = h_counters_[C_MINIMIZERS];
-        break;
-    }
-    const uint32_t n_hits = (uint32_t)h_counters_[C_HITS];
-    tot_hits_ += n_hits;
     if (n_hits == 0) return;
-    // the filtered sequence leaves the hits ordered by (read, pos): short reads only need a per-read reorder
     const uint64_t* s_key = d_key_b_;
     const uint32_t* s_val = d_val_b_;
-    if (use_filter_ && h_counters_[C_MAXLEN] <= READ_SORT_MAX_LEN) {
+    if (ordered) {
         HIPCHK(dev::launch_read_sort(d_key_a_, d_val_a_, n_hits, d_order_, hit_capacity_, &d_counters_[C_UNSORTED], stream));
         s_key = d_key_a_;
         s_val = d_val_a_;
@@ -292,6 +215,141 @@ void Mapper::run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32
     c.n_clusters_kept = &d_counters_[C_CLUSTERS_KEPT];
     c.n_hits_kept = &d_counters_[C_HITS_KEPT];
     HIPCHK(dev::launch_cluster_pipeline(c, n_hits, n_prgs_, stream));
+}
+
+dev::SketchArgs Mapper::sketch_args(const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads, uint64_t n_bases) const
+{
+    dev::SketchArgs a {};
+    a.bases = d_bases;
+    a.offsets = d_offsets;
+    a.n_bases = n_bases;
+    a.n_reads = n_reads;
+    a.w = params_.w;
+    a.k = params_.k;
+    a.halo = halo_;
+    a.slot_key = d_slot_key_;
+    a.slot_rec = d_slot_rec_;
+    a.table_bits = table_bits_;
+    a.rec_knode = d_rec_knode_;
+    a.rec_prg = d_rec_prg_;
+    a.tile_first_read = d_tile_first_;
+    a.hit_key = d_key_a_;
+    a.hit_val = d_val_a_;
+    a.hit_capacity = hit_capacity_;
+    a.n_hits = &d_counters_[C_HITS];
+    a.n_minimizers = &d_counters_[C_MINIMIZERS];
+    a.overflow = reinterpret_cast<uint32_t*>(&d_counters_[C_OVERFLOW]);
+    return a;
+}
+
+void Mapper::read_counters(hipStream_t stream)
+{
+    HIPCHK(hipMemcpyAsync(h_counters_, d_counters_, C_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+}
+
+void Mapper::note_kernel_time()
+{
+    if (!timing_) return;
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, ev0_, ev1_));
+    sketch_ms_ += ms;
+    sketch_launches_ += 1;
+}
+
+void Mapper::run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads, uint64_t n_bases,
+    uint32_t* covg, uint32_t* prg_reads, hipStream_t stream)
+{
+    if (n_bases == 0) return; // only empty reads: no k-mers, no hits
+    dev::KernelTimer timer;
+    if (timing_) { // events bracket the dominant kernel only (sketch_filter_kernel / sketch_probe_kernel)
+        timer.begin = ev0_;
+        timer.end = ev1_;
+    }
+    if (use_filter_) {
+        // ---- filtered sequence: the hits of short reads never leave the chip (read_cluster_kernel); one read-back at the end ----
+        ensure_raw_workspace(std::max<uint64_t>(1u << 20, n_bases / 64));
+        dev::FilterWork fw {};
+        for (int attempt = 0;; ++attempt) {
+            // overflow flags, longest leftover read, list length of the per-read reorder, leftover reads, chunk counter
+            HIPCHK(hipMemsetAsync(&d_counters_[C_OVERFLOW], 0, 5 * sizeof(unsigned long long), stream));
+            const dev::SketchArgs a = sketch_args(d_bases, d_offsets, n_reads, n_bases);
+            dev::FilterBuffers fb { d_raw_pos_, d_cand_info_, d_cand_pos1_, d_cand_rec_, raw_capacity_, d_filter_small_, &d_counters_[C_MAXLEN] };
+            dev::BloomTables bt { d_bloom_, bloom_wbits_, d_bloom0_, bloom0_wbits_ };
+            dev::ReadClusterArgs rc {};
+            rc.prg_min_path_len = d_min_path_len_;
+            rc.fraction = params_.cluster_fraction();
+            rc.min_cluster_size = params_.min_cluster_size;
+            rc.max_diff = params_.max_diff;
+            rc.n_prgs = n_prgs_;
+            rc.covg = covg;
+            rc.prg_reads = prg_reads;
+            rc.n_clusters_kept = &d_counters_[C_CLUSTERS_KEPT];
+            rc.n_hits_kept = &d_counters_[C_HITS_KEPT];
+            rc.n_complex = &d_counters_[C_COMPLEX];
+            rc.chunk_counter = reinterpret_cast<uint32_t*>(&d_counters_[C_CHUNK]);
+            HIPCHK(dev::launch_sketch_filter(a, bt, n_cus_, fb, rc, fw, stream, timer));
+            read_counters(stream);
+            note_kernel_time();
+            const uint32_t ovf = (uint32_t)h_counters_[C_OVERFLOW];
+            if (ovf & 8u) throw Error(DRPRG_EIO, "sketch_filter_kernel: dynamic LDS does not start at address 0");
+            if (ovf & 2u) throw Error(DRPRG_EOVERFLOW, "a read is longer than 2^" + std::to_string(dev::HIT_POS_BITS) + " bases");
+            if (ovf & 4u) { // a wave's candidate slice was too small (read_cluster_kernel did nothing): grow and re-run
+                if (attempt > 8) throw Error(DRPRG_EOVERFLOW, "candidate buffer overflow after regrow");
+                unsigned long long restored = last_minimizers_;
+                HIPCHK(hipMemcpyAsync(&d_counters_[C_MINIMIZERS], &restored, sizeof(restored), hipMemcpyHostToDevice, stream));
+                HIPCHK(hipStreamSynchronize(stream));
+                ensure_raw_workspace(raw_capacity_ * 4);
+                continue;
+            }
+            break;
+        }
+        last_minimizers_ = h_counters_[C_MINIMIZERS];
+        tot_hits_ += h_counters_[C_HITS];
+        if (h_counters_[C_COMPLEX] == 0) return;
+        // ---- reads that did not fit read_cluster_kernel (long reads, many clusters): the generic pipeline on their hits ----
+        dev::SketchArgs a = sketch_args(d_bases, d_offsets, n_reads, n_bases);
+        HIPCHK(dev::launch_filter_recount(a, fw, stream));
+        read_counters(stream);
+        const uint64_t n_left = h_counters_[C_HITS];
+        if (n_left == 0) return;
+        ensure_workspace(std::max<uint64_t>(1u << 20, n_left + n_left / 8));
+        a = sketch_args(d_bases, d_offsets, n_reads, n_bases); // the hit buffers may have moved
+        HIPCHK(dev::launch_filter_expand(a, fw, stream));
+        cluster_hits(d_offsets, (uint32_t)n_left, h_counters_[C_MAXLEN] <= READ_SORT_MAX_LEN, covg, prg_reads, stream);
+        return;
+    }
+    // ---- direct sequence: every k-mer hashed, hits in tile order, global radix sort ----
+    ensure_workspace(std::max<uint64_t>(1u << 20, n_bases / 64));
+    const uint32_t n_tiles = dev::sketch_n_tiles(n_bases, halo_);
+    if (n_tiles > tile_cap_) { // first read of every tile
+        dfree(d_tile_first_);
+        tile_cap_ = n_tiles + n_tiles / 4 + 16;
+        dmalloc(d_tile_first_, (size_t)tile_cap_);
+    }
+    for (int attempt = 0;; ++attempt) {
+        HIPCHK(hipMemsetAsync(&d_counters_[C_HITS], 0, sizeof(unsigned long long), stream));
+        HIPCHK(hipMemsetAsync(&d_counters_[C_OVERFLOW], 0, sizeof(unsigned long long), stream));
+        const dev::SketchArgs a = sketch_args(d_bases, d_offsets, n_reads, n_bases);
+        HIPCHK(dev::launch_sketch_probe(a, wide_hash_, stream, timer));
+        read_counters(stream);
+        note_kernel_time();
+        if ((uint32_t)h_counters_[C_OVERFLOW] & 2u)
+            throw Error(DRPRG_EOVERFLOW, "a read is longer than 2^" + std::to_string(dev::HIT_POS_BITS) + " bases");
+        if (h_counters_[C_HITS] > hit_capacity_) {
+            if (attempt > 6) throw Error(DRPRG_EOVERFLOW, "hit buffer overflow after regrow");
+            // undo the minimizer count of the aborted pass, grow, and re-run the sketch
+            unsigned long long restored = last_minimizers_;
+            HIPCHK(hipMemcpyAsync(&d_counters_[C_MINIMIZERS], &restored, sizeof(restored), hipMemcpyHostToDevice, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            ensure_workspace(h_counters_[C_HITS] + h_counters_[C_HITS] / 8 + 1024);
+            continue;
+        }
+        break;
+    }
+    last_minimizers_ = h_counters_[C_MINIMIZERS];
+    tot_hits_ += h_counters_[C_HITS];
+    cluster_hits(d_offsets, (uint32_t)h_counters_[C_HITS], false, covg, prg_reads, stream);
 }
 
 void Mapper::map_device(const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n_reads, uint64_t n_bases,

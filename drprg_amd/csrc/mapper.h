@@ -60,6 +60,10 @@ private:
     void ensure_raw_workspace(uint64_t raw_capacity);
     void run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads, uint64_t n_bases,
         uint32_t* d_covg, uint32_t* d_prg_reads, hipStream_t stream);
+    void cluster_hits(const uint64_t* d_offsets, uint32_t n_hits, bool ordered, uint32_t* d_covg, uint32_t* d_prg_reads, hipStream_t stream);
+    dev::SketchArgs sketch_args(const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads, uint64_t n_bases) const;
+    void read_counters(hipStream_t stream);
+    void note_kernel_time();
 
     int device_ = 0;
     MapParams params_;
@@ -97,6 +101,7 @@ private:
     uint64_t raw_capacity_ = 0;
     uint64_t *d_raw_pos_ = nullptr, *d_cand_info_ = nullptr;
     uint32_t* d_cand_pos1_ = nullptr;
+    uint4* d_cand_rec_ = nullptr;
     void* d_temp_ = nullptr;
     uint32_t* d_tile_first_ = nullptr;
     uint32_t tile_cap_ = 0;
