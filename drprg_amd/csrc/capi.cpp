@@ -255,7 +255,7 @@ int drprg_hip_counters(drprg_hip_ctx* ctx, uint64_t out[8])
     if (ctx->mapper) {
         MapCounters c = ctx->mapper->counters();
         out[0] = c.reads; out[1] = c.bases; out[2] = c.minimizers; out[3] = c.hits;
-        out[4] = c.clusters_kept; out[5] = c.hits_kept; out[6] = c.kernel;
+        out[4] = c.clusters_kept; out[5] = c.hits_kept; out[6] = c.kernel; out[7] = c.leftover_reads;
     }
     API_END(ctx)
 }

@@ -154,7 +154,7 @@ void Mapper::reset_coverage()
     HIPCHK(hipMemsetAsync(d_prg_reads_, 0, (size_t)n_prgs_ * sizeof(uint32_t), stream_));
     HIPCHK(hipMemsetAsync(d_counters_, 0, C_N * sizeof(unsigned long long), stream_));
     HIPCHK(hipStreamSynchronize(stream_));
-    tot_reads_ = tot_bases_ = tot_hits_ = 0;
+    tot_reads_ = tot_bases_ = tot_hits_ = tot_leftover_ = 0;
     last_minimizers_ = 0;
 }
 
@@ -306,6 +306,7 @@ void Mapper::run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32
         }
         last_minimizers_ = h_counters_[C_MINIMIZERS];
         tot_hits_ += h_counters_[C_HITS];
+        tot_leftover_ += h_counters_[C_COMPLEX];
         if (h_counters_[C_COMPLEX] == 0) return;
         // ---- reads that did not fit read_cluster_kernel (long reads, many clusters): the generic pipeline on their hits ----
         dev::SketchArgs a = sketch_args(d_bases, d_offsets, n_reads, n_bases);
@@ -421,6 +422,7 @@ MapCounters Mapper::counters()
     m.clusters_kept = c[C_CLUSTERS_KEPT];
     m.hits_kept = c[C_HITS_KEPT];
     m.kernel = use_filter_ ? 2 : 1;
+    m.leftover_reads = tot_leftover_;
     return m;
 }
 

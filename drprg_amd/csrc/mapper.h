@@ -12,6 +12,7 @@ namespace drprg {
 struct MapCounters {
     uint64_t reads = 0, bases = 0, minimizers = 0, hits = 0, clusters_kept = 0, hits_kept = 0;
     uint64_t kernel = 0; // sketch kernel in use: 1 direct (sketch_probe_kernel), 2 Bloom-prefiltered (sketch_filter_kernel)
+    uint64_t leftover_reads = 0; // filtered sequence: reads that read_cluster_kernel left to the generic pipeline
 };
 
 class Mapper {
@@ -89,7 +90,7 @@ private:
     uint32_t* d_prg_reads_ = nullptr;
     unsigned long long* d_counters_ = nullptr; // 8 x u64: hits(batch), minimizers, clusters_kept, hits_kept, overflow, ...
     unsigned long long* h_counters_ = nullptr; // pinned mirror
-    uint64_t tot_reads_ = 0, tot_bases_ = 0, tot_hits_ = 0;
+    uint64_t tot_reads_ = 0, tot_bases_ = 0, tot_hits_ = 0, tot_leftover_ = 0;
     unsigned long long last_minimizers_ = 0; // device minimizer counter after the last completed batch
     // workspace
     uint64_t hit_capacity_ = 0;

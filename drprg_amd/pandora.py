@@ -107,7 +107,7 @@ class Context:
     def counters(self):
         out = (C.c_uint64 * 8)()
         _check(lib.drprg_hip_counters(self._h, out), self._h)
-        names = ("reads", "bases", "minimizers", "hits", "clusters_kept", "hits_kept", "kernel")
+        names = ("reads", "bases", "minimizers", "hits", "clusters_kept", "hits_kept", "kernel", "leftover_reads")
         return dict(zip(names, (int(x) for x in out)))
 
     # ---- genotyping ----------------------------------------------------------------------------

@@ -50,6 +50,8 @@ def test_short_reads_bit_exact(tmp_path, oracle, w, k, kernel):
     bases, offs = synth.sample_short_reads(gen, 20000, seed=5)
     cnt = _compare(ctx, oracle, bases, offs, w, k, True, kernel)
     assert cnt["clusters_kept"] > 0
+    if k >= 13:  # (a 9-mer index matches everywhere: dozens of one-hit clusters per read)
+        assert ctx.counters()["leftover_reads"] == 0  # ordinary short reads never need the generic pipeline
 
 
 @pytest.mark.parametrize("kernel", [1, 2])
@@ -110,6 +112,94 @@ def test_dense_panel_reads(tmp_path, oracle):
         ctx = _ctx(tmp_path, panel, 11, 15, True, kernel=kernel)
         cnt = _compare(ctx, oracle, bases, offs, 11, 15, True, kernel)
         assert cnt["clusters_kept"] > 5000
+
+
+_RC = bytes.maketrans(b"ACGT", b"TGCA")
+
+
+def _reads_from(rng, seqs, n, length, sub_rate=0.002):
+    """n reads of `length` bases drawn from the given sequences (random strand, a few substitutions)"""
+    reads = []
+    for i in range(n):
+        hap = seqs[i % len(seqs)]
+        ln = min(length, len(hap))
+        s = int(rng.integers(0, len(hap) - ln + 1))
+        r = hap[s:s + ln]
+        if rng.random() < 0.5:
+            r = r.translate(_RC)[::-1]
+        a = np.frombuffer(r, np.uint8).copy()
+        err = np.nonzero(rng.random(ln) < sub_rate)[0]
+        a[err] = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size=err.size)]
+        reads.append(a)
+    offs = np.zeros(len(reads) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(r) for r in reads])
+    return np.concatenate(reads), offs
+
+
+@pytest.mark.parametrize("illumina", [True, False])
+def test_reads_with_hits_in_several_groups(tmp_path, oracle, illumina):
+    """duplicated loci, a reverse-complemented copy and an inverted repeat: every read has hits in several
+    (prg, strand) groups, so read_cluster_kernel takes its wave path and the overlap sweep decides (equal clusters on two
+    PRGs, same PRG on both strands); both kernels against the oracle"""
+    from drprg_amd import synth
+    rng = np.random.default_rng(5)
+    a = synth.make_locus(rng, 800, site_every=50)
+    b = synth.make_locus(rng, 600, site_every=50)
+    ref_a = synth.sample_haplotype(None, a, first_allele=True)
+    x = synth.random_seq(rng, 300)
+    inverted = x + synth.random_seq(rng, 40) + x.encode().translate(_RC)[::-1].decode() + synth.random_seq(rng, 60)
+    panel = synth.Panel(["a", "a_copy", "a_rc", "b", "inv"],
+                        [a, a, [ref_a.encode().translate(_RC)[::-1].decode()], b, [inverted]])
+    seqs = [synth.sample_haplotype(rng, t).encode() for t in (a, a, b) for _ in range(3)] + [inverted.encode()]
+    bases, offs = _reads_from(rng, seqs, 4000, 150)
+    lb, lo = _reads_from(rng, seqs, 300, 700)  # several clusters per read with the Illumina gap limit
+    bases = np.concatenate([bases, lb])
+    offs = np.concatenate([offs, lo[1:] + offs[-1]])
+    for kernel in (1, 2):
+        ctx = _ctx(tmp_path, panel, 11, 15, illumina, kernel=kernel)
+        cnt = _compare(ctx, oracle, bases, offs, 11, 15, illumina, kernel)
+        assert cnt["clusters_kept"] > 1000
+
+
+@pytest.mark.parametrize("copies", [70, 160])
+def test_reads_that_do_not_fit_the_per_read_kernel(tmp_path, oracle, copies):
+    """a k-mer shared by 70 PRGs gives a read 70 clusters (more than the 64 lanes of the wave path), 160 copies more hits
+    than a chunk stages: such reads are left to the generic pipeline, next to ordinary reads in the same batch"""
+    from drprg_amd import synth
+    rng = np.random.default_rng(9)
+    rep = synth.make_locus(rng, 400, site_every=70)
+    single = synth.make_locus(rng, 900, site_every=50)
+    panel = synth.Panel([f"rep{i}" for i in range(copies)] + ["single"], [rep] * copies + [single])
+    seqs = [synth.sample_haplotype(rng, rep).encode(), synth.sample_haplotype(rng, single).encode(),
+            synth.random_seq(rng, 5000).encode()]
+    bases, offs = _reads_from(rng, seqs, 1500, 150)
+    ctx = _ctx(tmp_path, panel, 11, 15, True, kernel=2)
+    cnt = _compare(ctx, oracle, bases, offs, 11, 15, True, 2)
+    assert cnt["clusters_kept"] > 500
+    assert 400 < ctx.counters()["leftover_reads"] < 1100  # the reads of the repeated locus, not the others
+
+
+def test_reads_longer_than_the_staged_range(tmp_path, oracle):
+    """long reads that lie entirely inside a long locus have thousands of minimizer hits, more than read_cluster_kernel
+    stages for one read: they take the generic pipeline while the short reads of the same batch do not"""
+    from drprg_amd import synth
+    rng = np.random.default_rng(12)
+    long_locus = synth.make_locus(rng, 16000, site_every=80)
+    short_locus = synth.make_locus(rng, 800, site_every=50)
+    panel = synth.Panel(["long", "short"], [long_locus, short_locus])
+    seqs_long = [synth.sample_haplotype(rng, long_locus).encode() for _ in range(3)]
+    seqs_short = [synth.sample_haplotype(rng, short_locus).encode() for _ in range(3)]
+    b1, o1 = _reads_from(rng, seqs_long, 60, 9000, sub_rate=0.01)
+    b2, o2 = _reads_from(rng, seqs_short + seqs_long, 1500, 150)
+    b3, o3 = _reads_from(rng, seqs_long, 40, 3000, sub_rate=0.03)
+    bases = np.concatenate([b1, b2, b3])
+    offs = np.concatenate([o1, o2[1:] + o1[-1], o3[1:] + o1[-1] + o2[-1]])
+    for kernel in (1, 2):
+        ctx = _ctx(tmp_path, panel, 11, 15, False, kernel=kernel)
+        cnt = _compare(ctx, oracle, bases, offs, 11, 15, False, kernel)
+        assert cnt["clusters_kept"] > 500
+        if kernel == 2:
+            assert 20 <= ctx.counters()["leftover_reads"] <= 100  # most 9 kb reads (a few fit: 2048 candidates are staged)
 
 
 def test_batches_accumulate(tmp_path, oracle):
