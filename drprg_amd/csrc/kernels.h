@@ -30,6 +30,11 @@ DRPRG_HD inline uint32_t hit_read(uint64_t k) { return (uint32_t)(k >> (HIT_PRG_
 DRPRG_HD inline uint32_t hit_prg(uint64_t k) { return (uint32_t)(k >> (1 + HIT_POS_BITS)) & (MAX_PRGS - 1); }
 DRPRG_HD inline uint32_t hit_rev(uint64_t k) { return (uint32_t)(k >> HIT_POS_BITS) & 1u; }
 
+// Bloom tier in front of the hash table (direct kernel, large indexes): word and two bits from one multiplicative hash
+DRPRG_HD inline uint32_t pbloom_mix(uint64_t key) { return ((uint32_t)key ^ (uint32_t)(key >> 32)) * 0x9E3779B1u; }
+DRPRG_HD inline uint32_t pbloom_word(uint32_t m, uint32_t wbits) { return m >> (32 - wbits); }
+DRPRG_HD inline uint32_t pbloom_bits(uint32_t m) { return (1u << (m & 31)) | (1u << ((m >> 5) & 31)); }
+
 struct SketchArgs {
     const uint8_t* bases;    // 16-byte aligned
     const uint64_t* offsets; // n_reads + 1
@@ -49,6 +54,8 @@ struct SketchArgs {
     uint64_t hit_capacity;
     unsigned long long* n_hits;
     unsigned long long* n_minimizers;
+    const uint32_t* pbloom; // direct kernel: Bloom tier in front of a table that does not fit L2 (nullptr: none)
+    uint32_t pbloom_wbits;
     uint32_t* overflow; // bit 0: hit buffer too small, bit 1: read longer than 2^HIT_POS_BITS, bit 2: candidate slice
                         // too small, bit 3: dynamic LDS does not start at address 0 (sketch_filter_kernel)
 };

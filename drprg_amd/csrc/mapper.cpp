@@ -80,6 +80,18 @@ Mapper::Mapper(const FlatIndex& idx, const MapParams& p, int device) : device_(d
     HIPCHK(hipMemcpy(d_rec_prg_, rp.data(), nrec * sizeof(uint16_t), hipMemcpyHostToDevice));
     dmalloc(d_min_path_len_, (size_t)n_prgs_);
     HIPCHK(hipMemcpy(d_min_path_len_, idx.min_path_len.data(), n_prgs_ * sizeof(uint32_t), hipMemcpyHostToDevice));
+    // Bloom tier of the direct kernel: only when keys + slot records outgrow an XCD's 4 MB L2 (<= ~4 keys per 32-bit word)
+    if (nslot * (size_t)(wide_hash_ ? 16 : 12) > ((size_t)2 << 20)) {
+        pbloom_wbits_ = 10;
+        while (((size_t)4 << pbloom_wbits_) < idx.keys.size()) ++pbloom_wbits_;
+        std::vector<uint32_t> pb((size_t)1 << pbloom_wbits_, 0);
+        for (uint64_t key : idx.keys) {
+            const uint32_t m = dev::pbloom_mix(key);
+            pb[dev::pbloom_word(m, pbloom_wbits_)] |= dev::pbloom_bits(m);
+        }
+        dmalloc(d_pbloom_, pb.size());
+        HIPCHK(hipMemcpy(d_pbloom_, pb.data(), pb.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     bloom_wbits_ = idx.bloom_wbits;
     if (bloom_wbits_) {
         dmalloc(d_bloom_, idx.bloom.size());
@@ -112,7 +124,7 @@ Mapper::~Mapper()
     dfree(d_key_a_); dfree(d_key_b_); dfree(d_val_a_); dfree(d_val_b_);
     dfree(d_head_); dfree(d_scan_); dfree(d_cstart_); dfree(d_order_); dfree(d_clusters_);
     if (d_temp_) (void)hipFree(d_temp_);
-    dfree(d_bases_); dfree(d_offsets_); dfree(d_tile_first_); dfree(d_bloom_); dfree(d_bloom0_); dfree(d_filter_small_);
+    dfree(d_bases_); dfree(d_offsets_); dfree(d_tile_first_); dfree(d_bloom_); dfree(d_bloom0_); dfree(d_pbloom_); dfree(d_filter_small_);
     dfree(d_raw_pos_); dfree(d_cand_info_); dfree(d_cand_pos1_); dfree(d_cand_rec_);
     if (h_counters_) (void)hipHostFree(h_counters_);
     if (h_bases_) (void)hipHostFree(h_bases_);
@@ -233,6 +245,8 @@ dev::SketchArgs Mapper::sketch_args(const uint8_t* d_bases, const uint64_t* d_of
     a.rec_knode = d_rec_knode_;
     a.rec_prg = d_rec_prg_;
     a.tile_first_read = d_tile_first_;
+    a.pbloom = d_pbloom_;
+    a.pbloom_wbits = pbloom_wbits_;
     a.hit_key = d_key_a_;
     a.hit_val = d_val_a_;
     a.hit_capacity = hit_capacity_;

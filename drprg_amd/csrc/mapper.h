@@ -81,6 +81,8 @@ private:
     uint32_t* d_bloom_ = nullptr;
     uint32_t* d_filter_small_ = nullptr; // slice / workgroup counters of the filtered launch sequence
     uint32_t bloom_wbits_ = 0;
+    uint32_t* d_pbloom_ = nullptr; // Bloom tier of the direct kernel (large indexes)
+    uint32_t pbloom_wbits_ = 0;
     uint32_t* d_bloom0_ = nullptr; // level 0 of the filter (k = 15, small indexes)
     uint32_t bloom0_wbits_ = 0;
     int n_cus_ = 256;

@@ -241,6 +241,13 @@ __global__ __launch_bounds__(SK_THREADS) void sketch_probe_kernel(SketchArgs a)
     for (uint32_t i = tid; i < nmin; i += SK_THREADS) {
         const int j = s_mins[i];
         const HT h = s_hash[hpad(j)] - 1;
+        if (a.pbloom) { // three of four minimizers are no index keys: they stop at one L2-resident word
+            const uint32_t m = pbloom_mix((uint64_t)h), need = pbloom_bits(m);
+            if ((a.pbloom[pbloom_word(m, a.pbloom_wbits)] & need) != need) {
+                s_hash[hpad(j)] = NOT_FOUND;
+                continue;
+            }
+        }
         uint32_t s = table_slot_dev((uint64_t)h, a.table_bits);
         bool found = false;
         while (true) {
