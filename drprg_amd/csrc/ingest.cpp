@@ -318,7 +318,7 @@ IngestStats ingest_fastx(const std::string& path, int threads, const IngestHooks
             while (!eof && !sh.failed) {
                 auto buf = std::make_shared<std::vector<char>>();
                 buf->resize(carry.size() + SLICE_BYTES);
-                std::memcpy(buf->data(), carry.data(), carry.size());
+                if (!carry.empty()) std::memcpy(buf->data(), carry.data(), carry.size());
                 size_t have = carry.size();
                 carry.clear();
                 while (have < buf->size()) {
