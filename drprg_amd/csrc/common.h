@@ -59,6 +59,8 @@ inline int nt4(unsigned char c)
 constexpr uint32_t BLOOM_C0 = 0xC2B2AFu; // level 0, also 24 x 24 bit
 constexpr uint32_t BLOOM_C1 = 0x9E3779u;
 constexpr uint32_t BLOOM_C2 = 0x85EBCA6Bu;
+constexpr uint32_t BLOOM_CR = 0xC2B2AE35u; // second stage of the level-0 form
+constexpr uint32_t BLOOMR_WBITS = 14;      // 64 KB
 
 // canonical hash of a k-mer given as a string of exactly k ACGT characters.
 // strand = true when the forward k-mer hashes <= its reverse complement.

@@ -125,6 +125,7 @@ void PrgIndex::flatten()
         if (level0) {
             f.bloom0_wbits = L0_WBITS;
             f.bloom0.assign(size_t(1) << L0_WBITS, 0);
+            f.bloomr.assign(size_t(1) << BLOOMR_WBITS, 0);
         }
         const uint32_t wmask0 = (1u << L0_WBITS) - 1;
         auto add = [&](uint32_t code) {
@@ -133,6 +134,10 @@ void PrgIndex::flatten()
             f.bloom[(h >> 18) & wmask] |= (1u << (31 - (h & 31))) | (1u << (31 - ((h >> 8) & 31))) | (1u << (31 - ((x >> 16) & 31)));
             const uint32_t h2 = code * BLOOM_C2; // level 2: an independent word, tested only for level-1 survivors
             f.bloom[h2 >> (32 - wbits)] |= (1u << (h2 & 31)) | (1u << ((h2 >> 5) & 31)) | (1u << ((h2 >> 10) & 31));
+            if (level0) { // second stage: one word, four bits (fill < 15 %: one in a few thousand false positives)
+                const uint32_t hr = code * BLOOM_CR;
+                f.bloomr[hr >> (32 - BLOOMR_WBITS)] |= (1u << (hr & 31)) | (1u << ((hr >> 5) & 31)) | (1u << ((hr >> 10) & 31)) | (1u << ((hr >> 15) & 31));
+            }
             if (level0)
                 for (int o = 0; o < 4; ++o) {
                     const uint32_t y = (code >> (2 * o)) & 0xFFFFFFu;

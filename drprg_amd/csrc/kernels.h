@@ -100,6 +100,7 @@ struct BloomTables {
     uint32_t bloom_wbits;
     const uint32_t* bloom0;
     uint32_t bloom0_wbits;
+    const uint32_t* bloomr; // second stage of the level-0 form (2^BLOOMR_WBITS words)
 };
 // Scratch of the filtered launch sequence.  raw_pos: raw_capacity candidate positions (one slice per filter wave);
 // cand_info / cand_pos1: raw_capacity entries each; small: filter_small_words() u32; max_len: device scalar that
@@ -107,6 +108,7 @@ struct BloomTables {
 // was too small.  The hits are written ordered by (read, position); a.n_hits receives their number.
 struct FilterBuffers {
     uint64_t* raw_pos;
+    uint4* raw_grp; // raw_capacity entries: level-0 survivors (groups of four positions) on their way to refine_kernel
     uint64_t* cand_info;
     uint32_t* cand_pos1;
     uint4* cand_rec; // raw_capacity entries
@@ -120,12 +122,17 @@ struct FilterWork {
     uint32_t bloom_wbits;
     const uint32_t* bloom0;  // level 0 (nullptr / 0: absent)
     uint32_t bloom0_wbits;
+    const uint32_t* bloomr;  // second stage of the level-0 form
     uint32_t n_tiles;        // wave tiles of FT_WPOS positions
     uint32_t tiles_per_wave; // wave g owns tiles [g * tiles_per_wave, (g+1) * tiles_per_wave)
-    uint32_t n_slices;       // filter waves
+    uint32_t tiles_per_slice; // ... and starts a new slice every tiles_per_slice tiles
+    uint32_t n_slices;       // slices of the candidate buffers (a fixed number per filter wave)
     uint32_t raw_slice;      // capacity of one slice
     uint64_t* raw_pos;       // [n_slices][raw_slice]: global base position of a candidate k-mer, ascending per slice
     uint32_t* slice_count;   // [n_slices] (may exceed raw_slice: overflow)
+    uint4* raw_grp;          // level-0 form only, [n_slices][raw_slice]: {position of a surviving group of four k-mers (lo, hi),
+                             // its 16 bases, the 2 after them}, ascending per slice; refine_kernel turns them into raw_pos
+    uint32_t* grp_count;     // [n_slices] (may exceed raw_slice: overflow)
     uint32_t* cand_prefix;   // [n_slices + 1]: exclusive scan of the clamped counts
     uint64_t* cand_info;     // [candidates]: slot << 32 | strand << 31 | read
     uint32_t* cand_pos1;     // [candidates]: read position + 1 of a minimizer, 0 = not a minimizer

@@ -101,6 +101,8 @@ Mapper::Mapper(const FlatIndex& idx, const MapParams& p, int device) : device_(d
     if (bloom0_wbits_) {
         dmalloc(d_bloom0_, idx.bloom0.size());
         HIPCHK(hipMemcpy(d_bloom0_, idx.bloom0.data(), idx.bloom0.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        dmalloc(d_bloomr_, idx.bloomr.size());
+        HIPCHK(hipMemcpy(d_bloomr_, idx.bloomr.data(), idx.bloomr.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
     HIPCHK(hipDeviceGetAttribute(&n_cus_, hipDeviceAttributeMultiprocessorCount, device_));
     set_params(p); // again: the kernel choice depends on the filter being available
@@ -124,8 +126,8 @@ Mapper::~Mapper()
     dfree(d_key_a_); dfree(d_key_b_); dfree(d_val_a_); dfree(d_val_b_);
     dfree(d_head_); dfree(d_scan_); dfree(d_cstart_); dfree(d_order_); dfree(d_clusters_);
     if (d_temp_) (void)hipFree(d_temp_);
-    dfree(d_bases_); dfree(d_offsets_); dfree(d_tile_first_); dfree(d_bloom_); dfree(d_bloom0_); dfree(d_pbloom_); dfree(d_filter_small_);
-    dfree(d_raw_pos_); dfree(d_cand_info_); dfree(d_cand_pos1_); dfree(d_cand_rec_);
+    dfree(d_bases_); dfree(d_offsets_); dfree(d_tile_first_); dfree(d_bloom_); dfree(d_bloom0_); dfree(d_bloomr_); dfree(d_pbloom_); dfree(d_filter_small_);
+    dfree(d_raw_pos_); dfree(d_raw_grp_); dfree(d_cand_info_); dfree(d_cand_pos1_); dfree(d_cand_rec_);
     if (h_counters_) (void)hipHostFree(h_counters_);
     if (h_bases_) (void)hipHostFree(h_bases_);
     if (h_offsets_) (void)hipHostFree(h_offsets_);
@@ -190,8 +192,9 @@ void Mapper::ensure_raw_workspace(uint64_t cap)
 {
     if (cap <= raw_capacity_) return;
     if (cap >= (1ull << 31)) throw Error(DRPRG_EOVERFLOW, "more than 2^31 candidate k-mers in one batch; map smaller batches");
-    dfree(d_raw_pos_); dfree(d_cand_info_); dfree(d_cand_pos1_); dfree(d_cand_rec_);
+    dfree(d_raw_pos_); dfree(d_raw_grp_); dfree(d_cand_info_); dfree(d_cand_pos1_); dfree(d_cand_rec_);
     raw_capacity_ = cap;
+    if (bloom0_wbits_) dmalloc(d_raw_grp_, cap);
     dmalloc(d_raw_pos_, cap); dmalloc(d_cand_info_, cap); dmalloc(d_cand_pos1_, cap); dmalloc(d_cand_rec_, cap);
 }
 
@@ -288,8 +291,8 @@ void Mapper::run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32
             // overflow flags, longest leftover read, list length of the per-read reorder, leftover reads, chunk counter
             HIPCHK(hipMemsetAsync(&d_counters_[C_OVERFLOW], 0, 5 * sizeof(unsigned long long), stream));
             const dev::SketchArgs a = sketch_args(d_bases, d_offsets, n_reads, n_bases);
-            dev::FilterBuffers fb { d_raw_pos_, d_cand_info_, d_cand_pos1_, d_cand_rec_, raw_capacity_, d_filter_small_, &d_counters_[C_MAXLEN] };
-            dev::BloomTables bt { d_bloom_, bloom_wbits_, d_bloom0_, bloom0_wbits_ };
+            dev::FilterBuffers fb { d_raw_pos_, d_raw_grp_, d_cand_info_, d_cand_pos1_, d_cand_rec_, raw_capacity_, d_filter_small_, &d_counters_[C_MAXLEN] };
+            dev::BloomTables bt { d_bloom_, bloom_wbits_, d_bloom0_, bloom0_wbits_, d_bloomr_ };
             dev::ReadClusterArgs rc {};
             rc.prg_min_path_len = d_min_path_len_;
             rc.fraction = params_.cluster_fraction();

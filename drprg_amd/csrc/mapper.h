@@ -85,6 +85,7 @@ private:
     uint32_t pbloom_wbits_ = 0;
     uint32_t* d_bloom0_ = nullptr; // level 0 of the filter (k = 15, small indexes)
     uint32_t bloom0_wbits_ = 0;
+    uint32_t* d_bloomr_ = nullptr; // second stage of the level-0 form
     int n_cus_ = 256;
     bool use_filter_ = false;
     // accumulators
@@ -105,6 +106,7 @@ private:
     uint64_t *d_raw_pos_ = nullptr, *d_cand_info_ = nullptr;
     uint32_t* d_cand_pos1_ = nullptr;
     uint4* d_cand_rec_ = nullptr;
+    uint4* d_raw_grp_ = nullptr;
     void* d_temp_ = nullptr;
     uint32_t* d_tile_first_ = nullptr;
     uint32_t tile_cap_ = 0;

@@ -43,7 +43,8 @@ constexpr int FT_BLOOM_WORDS = 1 << 14; // levels 1+2 of the filter, at most (64
 constexpr int FT_L0_WORDS = 1 << 15;    // level 0 (128 KB; levels 1+2 then get 32 KB: all 160 KB of a CU)
 constexpr int EX_THREADS = 256;
 constexpr int SCAN_THREADS = 1024;
-constexpr int MAX_SLICES = SCAN_THREADS * 8; // one slice per filter wave
+constexpr int FT_SUB = 2;                    // slices per filter wave
+constexpr int MAX_SLICES = SCAN_THREADS * 8;
 constexpr int MAX_EX_WG = SCAN_THREADS * 4;  // workgroups of verify_count_kernel / expand_kernel
 
 // 16 ASCII bases -> 32 bits, 2 per base, first base in the lowest bits.  The 2-bit letter is bits 2:1 of the ASCII code
@@ -101,18 +102,17 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
 
     if (LEVEL0)
         for (uint32_t i = tid; i < (1u << fw.bloom0_wbits); i += FT_THREADS) s_dyn[i] = fw.bloom0[i];
-    for (uint32_t i = tid; i < n_words; i += FT_THREADS) s_dyn[L12_BASE / 4 + i] = fw.bloom[i];
+    if (!LEVEL0) // (the level-0 form leaves levels 1+2 to refine_kernel)
+        for (uint32_t i = tid; i < n_words; i += FT_THREADS) s_dyn[L12_BASE / 4 + i] = fw.bloom[i];
     if (tid == 0 && (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)s_dyn != 0u) atomicOr(a.overflow, 8u);
 
-    const uint32_t gw = blockIdx.x * FT_WAVES + (uint32_t)(tid >> 6); // this wave's slice
+    // every wave owns a contiguous range of tiles and FT_SUB consecutive slices of the candidate buffers: it moves on to its
+    // next slice every tiles_per_slice tiles (more, shorter slices: more parallelism for refine_kernel / cand_gather_kernel)
+    const uint32_t gw = blockIdx.x * FT_WAVES + (uint32_t)(tid >> 6);
     uint32_t tile = gw * fw.tiles_per_wave;
-    uint32_t tile_end = tile + fw.tiles_per_wave < fw.n_tiles ? tile + fw.tiles_per_wave : fw.n_tiles;
-    uint32_t step = 1;
-    if (fw.debug & 2u) { // timing experiment only (breaks the candidate order): tiles interleaved across waves
-        tile = gw;
-        tile_end = fw.n_tiles;
-        step = fw.n_slices;
-    }
+    const uint32_t tile_end = tile + fw.tiles_per_wave < fw.n_tiles ? tile + fw.tiles_per_wave : fw.n_tiles;
+    constexpr uint32_t step = 1;
+    uint32_t slice = gw * FT_SUB, next_slice_at = tile + fw.tiles_per_slice;
 
     auto load16 = [&](int64_t g) -> uint4 { // 16 bases at global position g (a multiple of 16)
         if (g + 16 <= n_bases) return *reinterpret_cast<const uint4*>(a.bases + g);
@@ -141,47 +141,70 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
         p.a = *reinterpret_cast<const uint4*>(g);
         p.b = *reinterpret_cast<const uint4*>(g + 16);
     };
-    uint64_t* out = fw.raw_pos + (size_t)gw * fw.raw_slice;
-    uint32_t wcur = 0; // candidates of this wave so far (wave-uniform)
+    uint64_t* out = fw.raw_pos + (size_t)slice * fw.raw_slice;
+    uint4* grp_out = LEVEL0 ? fw.raw_grp + (size_t)slice * fw.raw_slice : nullptr;
+    (void)grp_out;
+    uint32_t wcur = 0; // candidates in the current slice so far (wave-uniform)
+    auto close_slice = [&]() {
+        if (lane == 0) {
+            (LEVEL0 ? fw.grp_count : fw.slice_count)[slice] = wcur;
+            if (wcur > fw.raw_slice) atomicOr(a.overflow, 4u);
+        }
+    };
 
     // one tile: my 32 positions start in words wa, wb; wc (the first word of lane+1) completes the last k-mers
     auto process = [&](uint32_t t, const Pair& p) {
+        if (t == next_slice_at) { // wave-uniform
+            close_slice();
+            ++slice;
+            next_slice_at += fw.tiles_per_slice;
+            out += fw.raw_slice;
+            if (LEVEL0) grp_out += fw.raw_slice;
+            wcur = 0;
+        }
         const uint32_t wa = pack16le(p.a), wb = pack16le(p.b);
         const uint32_t wc = __builtin_amdgcn_update_dpp(0u, wa, 0x130 /* wave_shl:1: lane i <- lane i+1 */, 0xF, 0xF, false);
-        uint32_t cand = 0;
-        if (!(fw.debug & 1u)) {
-            uint32_t c1 = 0; // level-1 survivors, position j in bit j
-            if (LEVEL0) {
-                // ---- level 0: one 12-mer per four positions (the one at 4g+3 lies inside every 15-mer starting at
-                // 4g..4g+3); group g ends up in bit g of grp ----
-                uint32_t grp = 0, xs[FT_G / 4], hs[FT_G / 4], ws[FT_G / 4];
+        if constexpr (LEVEL0) {
+            // ---- level 0: one 12-mer per four positions (the one at 4g+3 lies inside every 15-mer starting at 4g..4g+3); group g
+            // ends up in bit g of grp.  The ~2 % of the groups that pass leave the kernel as they are, with their bases: levels 1+2
+            // run in refine_kernel, one lane per group (here they would run for the whole wave as often as its busiest lane
+            // needs: a third of this kernel's instructions) ----
+            uint32_t grp = 0, xs[FT_G / 4], hs[FT_G / 4], ws[FT_G / 4];
 #pragma unroll
-                for (int g = 0; g < FT_G / 4; ++g) { // all eight LDS reads in flight before the first test
-                    const int j = 4 * g + 3;
-                    const uint32_t lo = j < 16 ? wa : wb, hi = j < 16 ? wb : wc;
-                    xs[g] = __builtin_amdgcn_alignbit(hi, lo, 2 * (j & 15));
-                    hs[g] = __umul24(xs[g], BLOOM_C0);
-                    ws[g] = lds_at((hs[g] >> 15) & amask0);
-                }
+            for (int g = 0; g < FT_G / 4; ++g) { // all eight LDS reads in flight before the first test
+                const int j = 4 * g + 3;
+                const uint32_t lo = j < 16 ? wa : wb, hi = j < 16 ? wb : wc;
+                xs[g] = __builtin_amdgcn_alignbit(hi, lo, 2 * (j & 15));
+                hs[g] = __umul24(xs[g], BLOOM_C0);
+                ws[g] = lds_at((hs[g] >> 15) & amask0);
+            }
 #pragma unroll
-                for (int g = FT_G / 4 - 1; g >= 0; --g) grp = __builtin_amdgcn_alignbit(grp, bloom_test(ws[g], hs[g], xs[g]), 31);
-                if (lane == 63) grp = 0;
-                // ---- level 1 on the four positions of every surviving group (~5 % of the groups) ----
+            for (int g = FT_G / 4 - 1; g >= 0; --g) grp = __builtin_amdgcn_alignbit(grp, bloom_test(ws[g], hs[g], xs[g]), 31);
+            if (lane == 63 || (fw.debug & 1u)) grp = 0;
+            // ---- append in (lane, group) = position order: exclusive prefix of the per-lane counts (0..8) from four ballots ----
+            const uint32_t cnt = (uint32_t)__popc(grp);
+            const uint64_t b0 = __ballot(cnt & 1u), b1 = __ballot(cnt & 2u), b2 = __ballot(cnt & 4u), b3 = __ballot(cnt & 8u);
+            if (b0 | b1 | b2 | b3) {
+                auto below = [&](uint64_t m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); };
+                uint32_t at = wcur + below(b0) + 2u * below(b1) + 4u * below(b2) + 8u * below(b3);
+                const uint64_t base = (uint64_t)t * FT_WPOS + (uint64_t)lane * FT_G;
                 while (grp) {
                     const int g = __ffs(grp) - 1;
                     grp &= grp - 1;
                     const uint32_t lo = g < 4 ? wa : wb, hi = g < 4 ? wb : wc;
-                    const uint32_t u0 = __funnelshift_r(lo, hi, (8 * g) & 31); // the 16 bases from position 4g
-                    uint32_t nib = 0;
-#pragma unroll
-                    for (int q = 3; q >= 0; --q) {
-                        const uint32_t x = u0 >> (2 * q);
-                        const uint32_t h = __umul24(x, BLOOM_C1);
-                        nib = __builtin_amdgcn_alignbit(nib, bloom_test(lds_at(L12_BASE + ((h >> 16) & amask)), h, x), 31);
-                    }
-                    c1 |= nib << (4 * g);
+                    const uint32_t sh = (8u * (uint32_t)g) & 31u;
+                    const uint64_t pos = base + 4u * (uint32_t)g;
+                    if (at < fw.raw_slice) grp_out[at] = make_uint4((uint32_t)pos, (uint32_t)(pos >> 32), __funnelshift_r(lo, hi, sh), hi >> sh);
+                    ++at;
                 }
-            } else {
+                wcur += (uint32_t)(__popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2) + 8 * __popcll(b3));
+            }
+            return;
+        }
+        uint32_t cand = 0;
+        if (!(fw.debug & 1u)) {
+            uint32_t c1 = 0; // level-1 survivors, position j in bit j
+            {
                 // ---- level 1 over my 32 positions ----
 #pragma unroll
                 for (int j = FT_G - 1; j >= 0; --j) {
@@ -225,7 +248,7 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
     };
 
     // register ring, unrolled so that no tile is copied between registers: the tile being processed plus two in
-    // flight (2 KB each per wave; Little's law asks for ~48 KB outstanding per CU, 32 waves give 128 KB)
+    // flight (2 KB each per wave, 16 waves: 64 KB outstanding per CU; a fourth register set made the kernel slower)
     Pair r0 {}, r1 {}, r2 {};
     const bool pipelined = tile < full_end; // wave-uniform
     if (pipelined) {
@@ -253,9 +276,64 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
         p.b = load16(g + 16);
         process(tile, p);
     }
-    if (lane == 0) {
-        fw.slice_count[gw] = wcur;
-        if (wcur > fw.raw_slice) atomicOr(a.overflow, 4u);
+    close_slice();
+    for (++slice; slice < (gw + 1) * FT_SUB; ++slice) // slices this wave never reached (the last waves of a short batch)
+        if (lane == 0) (LEVEL0 ? fw.grp_count : fw.slice_count)[slice] = 0;
+}
+
+// Second stage of the filter for the groups that passed level 0 (level-0 form of sketch_filter_kernel): one lane per
+// group tests its four k-mer codes against a 64 KB LDS-resident filter (four bits per code, < 15 % full); every wave
+// works through whole slices and compacts the surviving positions, in order, into the slice of raw_pos that
+// cand_scan_kernel / cand_gather_kernel expect.
+constexpr int RF_THREADS = 1024;
+__global__ __launch_bounds__(RF_THREADS) void refine_kernel(SketchArgs a, FilterWork fw)
+{
+    extern __shared__ uint32_t s_bloom[]; // the second-stage filter: 2^BLOOMR_WBITS words
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t kmask = (1u << (2 * a.k)) - 1; // k = 15
+    for (uint32_t i = tid; i < (1u << BLOOMR_WBITS); i += RF_THREADS) s_bloom[i] = fw.bloomr[i];
+    __syncthreads(); // the only barrier: from here on every wave works through its own slices
+    auto below = [&](uint64_t m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); };
+    const uint32_t n_waves = gridDim.x * (RF_THREADS / 64);
+    for (uint32_t s = blockIdx.x * (RF_THREADS / 64) + (uint32_t)(tid >> 6); s < fw.n_slices; s += n_waves) {
+        const uint32_t n_raw = fw.grp_count[s], n = n_raw < fw.raw_slice ? n_raw : fw.raw_slice;
+        const uint4* __restrict__ in = fw.raw_grp + (size_t)s * fw.raw_slice;
+        uint64_t* __restrict__ out = fw.raw_pos + (size_t)s * fw.raw_slice;
+        uint32_t written = 0; // wave-uniform
+        uint4 nxt = (uint32_t)lane < n ? in[lane] : make_uint4(0, 0, 0, 0);
+        for (uint32_t c0 = 0; c0 < n; c0 += 64) {
+            const uint4 r = nxt;
+            const uint32_t i = c0 + (uint32_t)lane;
+            if (i + 64 < n) nxt = in[i + 64]; // in flight while this chunk is tested
+            uint32_t cand = 0;
+            if (i < n) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { // four bits of one word, keyed on the whole code of the k-mer at position q
+                    const uint32_t f = (q ? __funnelshift_r(r.z, r.w, 2 * q) : r.z) & kmask;
+                    const uint32_t h = f * BLOOM_CR;
+                    const uint32_t word = s_bloom[h >> (32 - BLOOMR_WBITS)];
+                    cand |= ((word >> (h & 31)) & (word >> ((h >> 5) & 31)) & (word >> ((h >> 10) & 31)) & (word >> ((h >> 15) & 31)) & 1u) << q;
+                }
+            }
+            // ordered append: exclusive prefix of the per-lane counts (0..4) from three ballots
+            const uint32_t cnt = (uint32_t)__popc(cand);
+            const uint64_t b0 = __ballot(cnt & 1u), b1 = __ballot(cnt & 2u), b2 = __ballot(cnt & 4u);
+            if (b0 | b1 | b2) {
+                uint32_t at = written + below(b0) + 2u * below(b1) + 4u * below(b2);
+                const uint64_t pos = ((uint64_t)r.y << 32) | r.x;
+                while (cand) {
+                    const int q = __ffs(cand) - 1;
+                    cand &= cand - 1;
+                    if (at < fw.raw_slice) out[at] = pos + (uint64_t)q;
+                    ++at;
+                }
+                written += (uint32_t)(__popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2));
+            }
+        }
+        if (lane == 0) {
+            fw.slice_count[s] = written;
+            if (n_raw > fw.raw_slice || written > fw.raw_slice) atomicOr(a.overflow, 4u);
+        }
     }
 }
 
@@ -1068,11 +1146,11 @@ uint32_t filter_grid(bool level0, int n_cus, uint32_t n_tiles)
     uint32_t grid = (uint32_t)n_cus * (level0 ? 1 : 2);
     const uint32_t need = (n_tiles + FT_WAVES - 1) / FT_WAVES;
     if (grid > need) grid = need;
-    if (grid > (uint32_t)(MAX_SLICES / FT_WAVES)) grid = MAX_SLICES / FT_WAVES;
+    if (grid > (uint32_t)(MAX_SLICES / (FT_WAVES * FT_SUB))) grid = MAX_SLICES / (FT_WAVES * FT_SUB);
     return grid ? grid : 1;
 }
 
-size_t filter_small_words() { return (size_t)MAX_SLICES * 2 + 1 + 4 * (size_t)MAX_EX_WG; }
+size_t filter_small_words() { return (size_t)MAX_SLICES * 3 + 1 + 4 * (size_t)MAX_EX_WG; }
 
 hipError_t launch_sketch_filter(const SketchArgs& a, const BloomTables& bt, int n_cus, const FilterBuffers& b, const ReadClusterArgs& rc,
     FilterWork& fw, hipStream_t stream, KernelTimer timer)
@@ -1081,17 +1159,20 @@ hipError_t launch_sketch_filter(const SketchArgs& a, const BloomTables& bt, int 
     if (a.n_bases == 0) return hipSuccess;
     if ((1u << bt.bloom_wbits) > (uint32_t)FT_BLOOM_WORDS) return hipErrorInvalidValue;
     if (bt.bloom0 && (1u << bt.bloom0_wbits) != (uint32_t)FT_L0_WORDS) return hipErrorInvalidValue;
-    if (const char* dbg = std::getenv("DRPRG_FT_DEBUG")) fw.debug = (uint32_t)std::atoi(dbg); // 1 no filter test, 2 strided tiles, 4 no level 0, 8 no read_cluster_kernel
+    if (bt.bloom0 && (!b.raw_grp || !bt.bloomr)) return hipErrorInvalidValue;
+    if (const char* dbg = std::getenv("DRPRG_FT_DEBUG")) fw.debug = (uint32_t)std::atoi(dbg); // 1 no filter test, 4 no level 0, 8 no read_cluster_kernel
     const bool level0 = bt.bloom0 != nullptr && a.k == 15 && ((size_t)4 << bt.bloom_wbits) + (size_t)FT_L0_WORDS * 4 <= 160 * 1024
         && !(fw.debug & 4u);
     fw.bloom = bt.bloom;
     fw.bloom_wbits = bt.bloom_wbits;
+    fw.bloomr = bt.bloomr;
     fw.bloom0 = level0 ? bt.bloom0 : nullptr;
     fw.bloom0_wbits = level0 ? bt.bloom0_wbits : 0;
     fw.n_tiles = filter_n_tiles(a.n_bases);
     const uint32_t grid = filter_grid(level0, n_cus, fw.n_tiles);
-    fw.n_slices = grid * FT_WAVES;
-    fw.tiles_per_wave = (fw.n_tiles + fw.n_slices - 1) / fw.n_slices;
+    fw.n_slices = grid * FT_WAVES * FT_SUB;
+    fw.tiles_per_wave = (fw.n_tiles + grid * FT_WAVES - 1) / (grid * FT_WAVES);
+    fw.tiles_per_slice = (fw.tiles_per_wave + FT_SUB - 1) / FT_SUB;
     fw.raw_slice = (uint32_t)std::min<uint64_t>(b.raw_capacity / fw.n_slices, 0x7FFFFFFFull / fw.n_slices);
     fw.raw_pos = b.raw_pos;
     fw.cand_info = b.cand_info;
@@ -1099,7 +1180,9 @@ hipError_t launch_sketch_filter(const SketchArgs& a, const BloomTables& bt, int 
     fw.cand_rec = b.cand_rec;
     fw.slice_count = b.small;
     fw.cand_prefix = b.small + MAX_SLICES;
-    fw.wg_hits = b.small + 2 * MAX_SLICES + 1;
+    fw.grp_count = b.small + 2 * MAX_SLICES + 1;
+    fw.raw_grp = b.raw_grp;
+    fw.wg_hits = b.small + 3 * MAX_SLICES + 1;
     fw.wg_nmin = fw.wg_hits + MAX_EX_WG;
     fw.wg_maxlen = fw.wg_nmin + MAX_EX_WG;
     fw.wg_base = fw.wg_maxlen + MAX_EX_WG;
@@ -1112,7 +1195,7 @@ hipError_t launch_sketch_filter(const SketchArgs& a, const BloomTables& bt, int 
         const Kernel kernel = which == 2 ? &sketch_filter_kernel<false, true>
             : which == 1                 ? &sketch_filter_kernel<true, false>
                                          : &sketch_filter_kernel<false, false>;
-        const size_t dyn = (level0 ? (size_t)FT_L0_WORDS * 4 : 0) + ((size_t)4 << bt.bloom_wbits);
+        const size_t dyn = level0 ? (size_t)FT_L0_WORDS * 4 : ((size_t)4 << bt.bloom_wbits);
         static size_t configured[3] = { 0, 0, 0 };
         if (dyn > configured[which]) {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
@@ -1122,6 +1205,16 @@ hipError_t launch_sketch_filter(const SketchArgs& a, const BloomTables& bt, int 
     }
     HIP_TRY(hipGetLastError());
     if (timer.end) HIP_TRY(hipEventRecord(timer.end, stream));
+    if (level0) {
+        static size_t refine_configured = 0;
+        const size_t dyn = (size_t)4 << BLOOMR_WBITS;
+        if (dyn > refine_configured) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&refine_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+            refine_configured = dyn;
+        }
+        hipLaunchKernelGGL(refine_kernel, dim3(std::min<uint32_t>((fw.n_slices + RF_THREADS / 64 - 1) / (RF_THREADS / 64), (uint32_t)n_cus * 2)), dim3(RF_THREADS), dyn, stream, a, fw);
+        HIP_TRY(hipGetLastError());
+    }
     hipLaunchKernelGGL(cand_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, fw);
     hipLaunchKernelGGL(cand_gather_kernel, dim3(fw.n_slices), dim3(64), 0, stream, fw);
     hipLaunchKernelGGL(verify_count_kernel, dim3(fw.ex_grid), dim3(EX_THREADS), 0, stream, a, fw, rc);
