@@ -281,6 +281,13 @@ int drprg_hip_genotype_info(const drprg_hip_ctx* ctx, uint32_t out[4])
     return DRPRG_OK;
 }
 
+int drprg_hip_filter_selfcheck(const drprg_hip_ctx* ctx, uint64_t out[8])
+{
+    if (!ctx || !out) return DRPRG_EINVAL;
+    ctx->index.filter_selfcheck(out);
+    return DRPRG_OK;
+}
+
 int drprg_hip_index_sizes(const drprg_hip_ctx* ctx, uint64_t sizes[5])
 {
     if (!ctx || !sizes) return DRPRG_EINVAL;

@@ -162,6 +162,60 @@ void PrgIndex::flatten()
     }
 }
 
+void PrgIndex::filter_selfcheck(uint64_t out[8]) const
+{
+    for (int i = 0; i < 8; ++i) out[i] = 0;
+    const FlatIndex& f = flat;
+    if (!f.bloom_wbits) return;
+    const uint32_t wmask = (1u << f.bloom_wbits) - 1, kmask = (1u << (2 * k)) - 1, wmask0 = f.bloom0_wbits ? (1u << f.bloom0_wbits) - 1 : 0;
+    // the tests exactly as sketch_filter.hip states them (bloom_test: bits 31 - shift of the word)
+    auto three = [](uint32_t word, uint32_t h, uint32_t x) {
+        return ((word << (h & 31)) & (word << ((h >> 8) & 31)) & (word << ((x >> 16) & 31))) >> 31;
+    };
+    auto check = [&](uint32_t code) {
+        ++out[0];
+        if (f.bloom0_wbits) { // the kernel probes the 12-mer at offset 3 of a group of four positions: a 15-mer at position
+            bool any_miss = false; // 4g+o inside the group holds that 12-mer at its own offset 3-o
+            for (int o = 0; o < 4; ++o) {
+                const uint32_t y = (code >> (2 * o)) & 0xFFFFFFu;
+                const uint32_t g = (uint32_t)((uint64_t)y * BLOOM_C0);
+                any_miss |= !three(f.bloom0[(g >> 17) & wmask0], g, y);
+            }
+            out[1] += any_miss;
+            const uint32_t hr = code * BLOOM_CR, word = f.bloomr[hr >> (32 - BLOOMR_WBITS)];
+            out[3] += !((word >> (hr & 31)) & (word >> ((hr >> 5) & 31)) & (word >> ((hr >> 10) & 31)) & (word >> ((hr >> 15) & 31)) & 1u);
+        }
+        const uint32_t x = code & kmask & 0xFFFFFFu;
+        const uint32_t h = (uint32_t)((uint64_t)x * BLOOM_C1);
+        const uint32_t h2 = code * BLOOM_C2, w2 = f.bloom[h2 >> (32 - f.bloom_wbits)];
+        const bool l1 = three(f.bloom[(h >> 18) & wmask], h, x);
+        const bool l2 = (w2 >> (h2 & 31)) & (w2 >> ((h2 >> 5) & 31)) & (w2 >> ((h2 >> 10) & 31)) & 1u;
+        out[2] += !(l1 && l2);
+    };
+    for (size_t p = 0; p < prgs.size(); ++p) {
+        const auto& nodes = kgs[p].nodes;
+        for (size_t i = 1; i + 1 < nodes.size(); ++i) {
+            const std::string s = kpath_sequence(prgs[p], nodes[i].path);
+            uint32_t fw = 0, rc = 0;
+            for (int j = 0; j < k; ++j) {
+                const uint32_t c = ((uint32_t)(unsigned char)s[(size_t)j] >> 1) & 3u;
+                fw |= c << (2 * j);
+                rc |= (c ^ 2u) << (2 * (k - 1 - j));
+            }
+            check(fw);
+            check(rc);
+        }
+    }
+    auto fill = [](const std::vector<uint32_t>& v) -> uint64_t {
+        uint64_t bits = 0;
+        for (uint32_t w : v) bits += (uint64_t)__builtin_popcount(w);
+        return v.empty() ? 0 : bits * 1000 / (32 * (uint64_t)v.size());
+    };
+    out[4] = fill(f.bloom0);
+    out[5] = fill(f.bloom);
+    out[6] = fill(f.bloomr);
+}
+
 void PrgIndex::save(const std::string& prg_file) const
 {
     std::string kdir = dir_of(prg_file) + "/kmer_prgs";

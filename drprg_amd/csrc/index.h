@@ -47,6 +47,10 @@ struct PrgIndex {
     std::vector<LocalGraph> prgs;
     std::vector<KmerGraph> kgs;
     FlatIndex flat;
+    // Host restatement of the kernels' filter tests on every index k-mer (both orientations).  out[0] = codes tested,
+    // out[1..4] = codes that level 0 / levels 1+2 / the second stage of the level-0 form / nothing at all would let
+    // through... i.e. out[1..3] count FALSE NEGATIVES (must be 0); out[4..6] = bits set per thousand in bloom0 / bloom / bloomr.
+    void filter_selfcheck(uint64_t out[8]) const;
 
     // `pandora index`: sketch every PRG of prg_file, write <prg_file>.k<k>.w<w>.idx and
     // <dir>/kmer_prgs/<name>.k<k>.w<w>.gfa

@@ -119,6 +119,13 @@ class Context:
         return dict(exp_depth_covg=int(gi[0]), min_kmer_covg=int(gi[1]), loci_present=int(gi[2]), records=int(gi[3]))
 
     # ---- introspection -------------------------------------------------------------------------
+    def filter_selfcheck(self):
+        out = (C.c_uint64 * 8)()
+        _check(lib.drprg_hip_filter_selfcheck(self._h, out), self._h)
+        names = ("codes", "level0_false_negatives", "level12_false_negatives", "stage2_false_negatives", "level0_fill_permille",
+                 "level12_fill_permille", "stage2_fill_permille")
+        return dict(zip(names, (int(x) for x in out)))
+
     def export_index(self):
         """Flat index (sorted keys + CSR records) in the layout oracle/oracle.c consumes."""
         keys = np.zeros(self.n_keys, dtype=np.uint64)

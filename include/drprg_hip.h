@@ -93,6 +93,10 @@ int drprg_hip_genotype(drprg_hip_ctx* ctx, const char* vcf_refs, const char* out
 /* exp_depth_covg / min_kmer_covg / #present / #records of the last drprg_hip_genotype */
 int drprg_hip_genotype_info(const drprg_hip_ctx* ctx, uint32_t out[4]);
 
+/* Host-side check of the Bloom filters of the prefiltered kernel (no device needed): out[0] = index k-mer codes tested
+ * (both orientations), out[1..3] = codes that level 0 / levels 1+2 / the second stage would wrongly reject (false
+ * negatives: must be 0), out[4..6] = bits set per thousand in those three arrays.  All zero: the index has no filter. */
+int drprg_hip_filter_selfcheck(const drprg_hip_ctx* ctx, uint64_t out[8]);
 /* Index introspection for harnesses: sizes[0..4] = keys, records, prgs, k-mer nodes, table slots. */
 int drprg_hip_index_sizes(const drprg_hip_ctx* ctx, uint64_t sizes[5]);
 int drprg_hip_index_export(const drprg_hip_ctx* ctx, uint64_t* keys, uint32_t* rec_off, uint32_t* rec_prg,

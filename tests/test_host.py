@@ -278,3 +278,30 @@ def test_synthetic_mtb_like_panel_is_deterministic():
     a, b = synth.mtb_like_panel(), synth.mtb_like_panel()
     assert a.prgs == b.prgs and len(a.prgs) == 18
     assert [len(r) for r in a.refs] == [L for _, L in synth.MTB_LOCI]
+
+
+@pytest.mark.parametrize("w,k,panel_name", [(11, 15, "mtb"), (14, 15, "small"), (16, 13, "small"), (5, 9, "small"), (1, 15, "small")])
+def test_bloom_filters_have_no_false_negatives(tmp_path, w, k, panel_name):
+    """The prefiltered kernel may only skip a k-mer its filters reject: every index k-mer (both orientations) must pass
+    level 0, levels 1+2 and the second stage of the level-0 form.  Host restatement of the kernels' bit tests
+    (PrgIndex::filter_selfcheck), no device needed; the fill bounds keep the filters selective."""
+    from drprg_amd import Context, synth
+    panel = synth.mtb_like_panel() if panel_name == "mtb" else synth.small_panel(seed=w + k)
+    prg = str(tmp_path / "dr.prg")
+    panel.write(prg)
+    chk = Context(prg, w, k, device=-1, from_files=False).filter_selfcheck()
+    assert chk["codes"] > 0
+    assert chk["level0_false_negatives"] == 0 and chk["level12_false_negatives"] == 0 and chk["stage2_false_negatives"] == 0
+    assert 0 < chk["level12_fill_permille"] < 450
+    if k == 15:  # level 0 + second stage exist
+        assert 0 < chk["level0_fill_permille"] < 300 and 0 < chk["stage2_fill_permille"] < 250
+    else:
+        assert chk["level0_fill_permille"] == 0 and chk["stage2_fill_permille"] == 0
+
+
+def test_no_filter_for_wide_kmers(tmp_path):
+    from drprg_amd import Context, synth
+    panel = synth.small_panel(seed=1)
+    prg = str(tmp_path / "dr.prg")
+    panel.write(prg)
+    assert Context(prg, 19, 21, device=-1, from_files=False).filter_selfcheck()["codes"] == 0
