@@ -1,9 +1,11 @@
+#include <cstdio>
 // capi.cpp -- the C ABI declared in include/drprg_hip.h.
 #include "../../include/drprg_hip.h"
 #include "fastx.h"
 #include "genotype.h"
 #include "ingest.h"
 #include "mapper.h"
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <memory>
@@ -83,8 +85,20 @@ static drprg_hip_ctx* open_impl(const char* prg_file, int w, int k, int device, 
     if (!ctx) return nullptr;
     try {
         ctx->prg_file = prg_file;
-        if (from_files) ctx->index.load(prg_file, w, k);
-        else ctx->index.build(prg_file, w, k, threads > 0 ? threads : 1);
+        if (from_files) {
+            // The k-mer graphs and the .idx beside the PRG are this build's own files.  An index directory made by the real
+            // pandora holds files of the same names in pandora's private format: they are not parsed, the graphs are rebuilt
+            // from the PRG string (tens of milliseconds for an mtb-sized panel), unless DRPRG_HIP_STRICT_INDEX is set.
+            try {
+                ctx->index.load(prg_file, w, k);
+            } catch (const Error& e) {
+                const char* strict = std::getenv("DRPRG_HIP_STRICT_INDEX");
+                if ((e.code != DRPRG_EFORMAT && e.code != DRPRG_ENOENT) || (strict && *strict && *strict != '0')) throw;
+                std::fprintf(stderr, "drprg-hip: warning: %s; rebuilding the k-mer graphs from %s\n", e.what(), prg_file);
+                ctx->index = PrgIndex();
+                ctx->index.build(prg_file, w, k, threads > 0 ? threads : 1);
+            }
+        } else ctx->index.build(prg_file, w, k, threads > 0 ? threads : 1);
         ctx->params.w = w;
         ctx->params.k = k;
         apply_defaults(ctx->params, nullptr);

@@ -305,3 +305,32 @@ def test_no_filter_for_wide_kmers(tmp_path):
     prg = str(tmp_path / "dr.prg")
     panel.write(prg)
     assert Context(prg, 19, 21, device=-1, from_files=False).filter_selfcheck()["codes"] == 0
+
+
+def test_foreign_index_files_are_rebuilt_from_the_prg(tmp_path, capfd):
+    """An index directory made by the real pandora has <prg>.kK.wW.idx and kmer_prgs/ in pandora's own format; drprg only
+    checks that they exist (/root/reference/src/predict.rs:400-418).  drprg_hip_open then rebuilds the graphs from the
+    PRG (same index as a fresh build) unless DRPRG_HIP_STRICT_INDEX is set."""
+    from drprg_amd import Context, DependencyError, Pandora, synth
+    panel = synth.small_panel(seed=21)
+    prg = str(tmp_path / "dr.prg")
+    panel.write(prg)
+    built = Context(prg, 11, 15, device=-1, from_files=False).export_index()
+    # files of the right names, foreign content
+    (tmp_path / "kmer_prgs").mkdir()
+    (tmp_path / "dr.prg.k15.w11.idx").write_text("1234\n0 1 2 3\n")
+    for n in panel.names:
+        (tmp_path / "kmer_prgs" / f"{n}.k15.w11.gfa").write_text("H\tVN:Z:1.0\tbn:Z:--linear --singlearr\n")
+    loaded = Context(prg, 11, 15, device=-1, from_files=True).export_index()
+    assert "rebuilding the k-mer graphs" in capfd.readouterr().err
+    for key in built:
+        assert np.array_equal(built[key], loaded[key]), key
+    os.environ["DRPRG_HIP_STRICT_INDEX"] = "1"
+    try:
+        with pytest.raises(DependencyError):
+            Context(prg, 11, 15, device=-1, from_files=True)
+    finally:
+        del os.environ["DRPRG_HIP_STRICT_INDEX"]
+    # a missing PRG is still an error
+    with pytest.raises(DependencyError):
+        Context(str(tmp_path / "nope.prg"), 11, 15, device=-1, from_files=True)
