@@ -81,6 +81,14 @@ def load():
         raise ImportError(
             f"{LIB_PATH} is missing: build the HIP extension first (`make` at the repo root or "
             "`python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    # One HIP runtime per process: the PyTorch wheel bundles its own libamdhip64.so.  If this library pulls in
+    # /opt/rocm's copy first and torch is imported afterwards, the process holds two runtimes and the second one sees no
+    # device.  Importing torch first makes our DT_NEEDED resolve to the copy that is already loaded.  (Plumbing only:
+    # nothing here uses torch; without torch installed the system runtime is the only one anyway.)
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
