@@ -47,3 +47,15 @@ clean:
 	rm -rf build $(LIB) $(BIN) $(ORACLE)
 
 .PHONY: all clean
+
+# host code under AddressSanitizer + UBSan (CPU build only: GPU sanitizers are not available on the pool):
+#   make asan && LD_PRELOAD=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so) \
+#     ASAN_OPTIONS=detect_leaks=0 DRPRG_HIP_LIB=build/asan/libdrprg_hip.so python -m pytest tests -m "not gpu" -s
+ASAN_FLAGS := -O1 -g -std=c++17 -fPIC -Iinclude -fsanitize=address,undefined -fno-gpu-sanitize -fno-omit-frame-pointer
+asan:
+	@mkdir -p build/asan
+	for f in $(HOST_SRCS:.cpp=); do $(HIPCC) $(ASAN_FLAGS) -x hip --offload-arch=$(ARCH) -c $(SRC)/$$f.cpp -o build/asan/$$f.o || exit 1; done
+	for f in $(HIP_SRCS:.hip=); do $(HIPCC) $(ASAN_FLAGS) --offload-arch=$(ARCH) -c $(SRC)/$$f.hip -o build/asan/$$f.o || exit 1; done
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -fsanitize=address,undefined -fno-gpu-sanitize -o build/asan/libdrprg_hip.so build/asan/*.o -lz
+
+.PHONY: asan

@@ -10,8 +10,8 @@ the u32 coverage vector per step.
 
 Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (sketch_probe_kernel) against
 HBM bandwidth using the algorithmic bytes of SURVEY.md section 8d, with its duration measured live
-with HIP events on the launch stream; `cpu_baseline` times the CPU oracle (oracle/oracle.c, a
-single-threaded port) on a bounded sample of the same workload on the host's cores.
+with HIP events on the launch stream; `cpu_baseline` times the CPU oracle (oracle/oracle.c, a scalar
+port) on a bounded sample of the same workload, on one thread and on the host's cores (up to 64 threads).
 """
 import argparse
 import json
@@ -299,28 +299,48 @@ def main():
                 "avg_launch_ms": avg_ms, "launches_timed": k_launches,
             },
         }
-        # CPU baseline: the oracle (single-threaded port of the same path) on a bounded sample, rank 0, N=1 semantics
-        if args.cpu_sample != 0:
+        # CPU baseline: the oracle (a scalar port of the same path, oracle/oracle.c) on a bounded sample of rank 0's shard,
+        # once on one thread and once with the reads split over the host's cores (threads calling the same C function on
+        # disjoint read ranges; integer coverage sums commute).  The multi-thread sample is as large as ~10 s allow -- with
+        # enough cores the whole batch -- and the HIP path must give the identical vector on it.
+        if args.cpu_sample != 0 and world == 1:  # (rank 0 at N=1 only)
+            from concurrent.futures import ThreadPoolExecutor
             from util import Oracle, cluster_fraction, map_params
             orc = Oracle()
-            ns = args.cpu_sample if args.cpu_sample > 0 else max(1, int(2_000_000 * 150 / max(n_bases / n_reads, 1)))
-            ns = min(ns, n_reads)
+            idx = ctx.export_index()
+            md, er = map_params(K, illumina)
+            frac = cluster_fraction(er, K)
+            mean_len = max(n_bases / n_reads, 1.0)
+            ns1 = args.cpu_sample if args.cpu_sample > 0 else max(1, int(2_000_000 * 150 / mean_len))
+            ns1 = min(ns1, n_reads)
+            threads = max(1, min(os.cpu_count() or 1, 64))
+            ns = min(n_reads, ns1 * threads if args.cpu_sample < 0 else ns1, max(ns1, int(3e9 / mean_len)))
             nb = int(offsets[ns].item())
             hb = bases[:nb].cpu().numpy()
             ho = offsets[:ns + 1].cpu().numpy().astype(np.uint64)
-            idx = ctx.export_index()
-            md, er = map_params(K, illumina)
+
+            def cpu_map(lo, hi):
+                return orc.map_reads(hb[int(ho[lo]):int(ho[hi])], ho[lo:hi + 1] - ho[lo], idx, W, K, md, frac, 10)[0]
+
             t1 = time.perf_counter()
-            ocov, _, _ = orc.map_reads(hb, ho, idx, W, K, md, cluster_fraction(er, K), 10)
+            cpu_map(0, ns1)
+            cpu1_s = time.perf_counter() - t1
+            cuts = [ns * i // threads for i in range(threads + 1)]
+            t1 = time.perf_counter()
+            with ThreadPoolExecutor(threads) as pool:
+                parts = list(pool.map(lambda i: cpu_map(cuts[i], cuts[i + 1]), range(threads)))
             cpu_s = time.perf_counter() - t1
+            ocov = np.sum(np.stack(parts).astype(np.uint64), axis=0).astype(np.uint32)
             # the same sample through the HIP path must give the identical vector
             c2 = torch.zeros_like(covg)
             p2 = torch.zeros_like(prg_reads)
             torch.cuda.synchronize()
             map_range(ctx, bases, offsets, 0, ns, c2, p2, stream, torch)
             parity = bool(np.array_equal(c2.cpu().numpy().view(np.uint32), ocov))
-            out["cpu_baseline"] = {"value": ns / cpu_s, "unit": "reads/s", "cores": 1, "kind": "port",
-                                   "sample": f"first {ns} reads ({nb} bases) of rank 0's shard, oracle/oracle.c single thread, {cpu_s:.1f}s",
+            out["cpu_baseline"] = {"value": ns / cpu_s, "unit": "reads/s", "cores": threads, "kind": "port",
+                                   "sample": f"first {ns} reads ({nb} bases) of rank 0's shard, oracle/oracle.c on {threads} threads "
+                                             f"(disjoint read ranges), {cpu_s:.1f}s",
+                                   "single_thread_value": ns1 / cpu1_s, "single_thread_sample": f"first {ns1} reads, {cpu1_s:.1f}s",
                                    "host_cores_available": os.cpu_count(), "parity_vs_hip_on_sample": parity}
         print(json.dumps(out), flush=True)
     ctx.close()

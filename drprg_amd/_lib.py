@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdrprg_hip.so")
+LIB_PATH = os.environ.get("DRPRG_HIP_LIB") or os.path.join(_HERE, "lib", "libdrprg_hip.so")  # (override: sanitizer builds)
 PANDORA_EXE = os.path.join(_HERE, "bin", "pandora")
 
 
