@@ -259,10 +259,24 @@ dev::SketchArgs Mapper::sketch_args(const uint8_t* d_bases, const uint64_t* d_of
     return a;
 }
 
-void Mapper::read_counters(hipStream_t stream)
+// Counter block -> pinned host mirror, then wait.  rezero: the per-batch scratch counters (overflow flags .. chunk counter)
+// are cleared right behind the copy, while the host is still waiting, so that the next batch starts with its first kernel
+// instead of a memset (scratch_zero_ records that they are clean).  The wait polls the stream: an interrupt-driven
+// hipStreamSynchronize wakes up tens of microseconds late, which is visible at 0.6 ms per batch.
+void Mapper::read_counters(hipStream_t stream, bool rezero)
 {
     HIPCHK(hipMemcpyAsync(h_counters_, d_counters_, C_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-    HIPCHK(hipStreamSynchronize(stream));
+    if (rezero) HIPCHK(hipMemsetAsync(&d_counters_[C_OVERFLOW], 0, (C_CHUNK - C_OVERFLOW + 1) * sizeof(unsigned long long), stream));
+    scratch_zero_ = rezero;
+    for (int spins = 0;; ++spins) {
+        const hipError_t e = hipStreamQuery(stream);
+        if (e == hipSuccess) break;
+        if (e != hipErrorNotReady) HIPCHK(e);
+        if (spins > (1 << 22)) { // something is badly late (a multi-second batch): stop burning the core
+            HIPCHK(hipStreamSynchronize(stream));
+            break;
+        }
+    }
 }
 
 void Mapper::note_kernel_time()
@@ -288,8 +302,11 @@ void Mapper::run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32
         ensure_raw_workspace(std::max<uint64_t>(1u << 20, n_bases / 64));
         dev::FilterWork fw {};
         for (int attempt = 0;; ++attempt) {
-            // overflow flags, longest leftover read, list length of the per-read reorder, leftover reads, chunk counter
-            HIPCHK(hipMemsetAsync(&d_counters_[C_OVERFLOW], 0, 5 * sizeof(unsigned long long), stream));
+            // scratch counters: overflow flags, longest leftover read, list length of the per-read reorder, leftover reads,
+            // chunk counter (normally cleared already, behind the previous batch's read-back)
+            if (!scratch_zero_)
+                HIPCHK(hipMemsetAsync(&d_counters_[C_OVERFLOW], 0, (C_CHUNK - C_OVERFLOW + 1) * sizeof(unsigned long long), stream));
+            scratch_zero_ = false;
             const dev::SketchArgs a = sketch_args(d_bases, d_offsets, n_reads, n_bases);
             dev::FilterBuffers fb { d_raw_pos_, d_raw_grp_, d_cand_info_, d_cand_pos1_, d_cand_rec_, raw_capacity_, d_filter_small_, &d_counters_[C_MAXLEN] };
             dev::BloomTables bt { d_bloom_, bloom_wbits_, d_bloom0_, bloom0_wbits_, d_bloomr_ };
@@ -306,7 +323,7 @@ void Mapper::run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32
             rc.n_complex = &d_counters_[C_COMPLEX];
             rc.chunk_counter = reinterpret_cast<uint32_t*>(&d_counters_[C_CHUNK]);
             HIPCHK(dev::launch_sketch_filter(a, bt, n_cus_, fb, rc, fw, stream, timer));
-            read_counters(stream);
+            read_counters(stream, true);
             note_kernel_time();
             const uint32_t ovf = (uint32_t)h_counters_[C_OVERFLOW];
             if (ovf & 8u) throw Error(DRPRG_EIO, "sketch_filter_kernel: dynamic LDS does not start at address 0");
@@ -327,8 +344,9 @@ void Mapper::run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32
         if (h_counters_[C_COMPLEX] == 0) return;
         // ---- reads that did not fit read_cluster_kernel (long reads, many clusters): the generic pipeline on their hits ----
         dev::SketchArgs a = sketch_args(d_bases, d_offsets, n_reads, n_bases);
+        scratch_zero_ = false; // the generic pipeline uses the scratch counters again
         HIPCHK(dev::launch_filter_recount(a, fw, stream));
-        read_counters(stream);
+        read_counters(stream, false);
         const uint64_t n_left = h_counters_[C_HITS];
         if (n_left == 0) return;
         ensure_workspace(std::max<uint64_t>(1u << 20, n_left + n_left / 8));
@@ -349,8 +367,9 @@ void Mapper::run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32
         HIPCHK(hipMemsetAsync(&d_counters_[C_HITS], 0, sizeof(unsigned long long), stream));
         HIPCHK(hipMemsetAsync(&d_counters_[C_OVERFLOW], 0, sizeof(unsigned long long), stream));
         const dev::SketchArgs a = sketch_args(d_bases, d_offsets, n_reads, n_bases);
+        scratch_zero_ = false;
         HIPCHK(dev::launch_sketch_probe(a, wide_hash_, stream, timer));
-        read_counters(stream);
+        read_counters(stream, false);
         note_kernel_time();
         if ((uint32_t)h_counters_[C_OVERFLOW] & 2u)
             throw Error(DRPRG_EOVERFLOW, "a read is longer than 2^" + std::to_string(dev::HIT_POS_BITS) + " bases");

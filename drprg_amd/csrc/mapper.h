@@ -63,7 +63,7 @@ private:
         uint32_t* d_covg, uint32_t* d_prg_reads, hipStream_t stream);
     void cluster_hits(const uint64_t* d_offsets, uint32_t n_hits, bool ordered, uint32_t* d_covg, uint32_t* d_prg_reads, hipStream_t stream);
     dev::SketchArgs sketch_args(const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads, uint64_t n_bases) const;
-    void read_counters(hipStream_t stream);
+    void read_counters(hipStream_t stream, bool rezero);
     void note_kernel_time();
 
     int device_ = 0;
@@ -95,6 +95,7 @@ private:
     unsigned long long* h_counters_ = nullptr; // pinned mirror
     uint64_t tot_reads_ = 0, tot_bases_ = 0, tot_hits_ = 0, tot_leftover_ = 0;
     unsigned long long last_minimizers_ = 0; // device minimizer counter after the last completed batch
+    bool scratch_zero_ = false;              // the per-batch scratch counters are known to be zero on the device
     // workspace
     uint64_t hit_capacity_ = 0;
     uint64_t *d_key_a_ = nullptr, *d_key_b_ = nullptr;

@@ -9,6 +9,12 @@ from util import cluster_fraction, map_params
 
 pytestmark = pytest.mark.gpu
 
+import os
+
+# DRPRG_FT_DEBUG=8 sends every read through the generic pipeline (a second way to run this whole file): the counts of
+# reads the per-read kernel left over mean nothing then
+FORCED_GENERIC = bool(int(os.environ.get("DRPRG_FT_DEBUG", "0") or 0) & 8)
+
 
 def _ctx(tmp_path, panel, w, k, illumina, genome_size=20000, kernel=0):
     from drprg_amd import Context
@@ -50,7 +56,7 @@ def test_short_reads_bit_exact(tmp_path, oracle, w, k, kernel):
     bases, offs = synth.sample_short_reads(gen, 20000, seed=5)
     cnt = _compare(ctx, oracle, bases, offs, w, k, True, kernel)
     assert cnt["clusters_kept"] > 0
-    if k >= 13:  # (a 9-mer index matches everywhere: dozens of one-hit clusters per read)
+    if k >= 13 and not FORCED_GENERIC:  # (a 9-mer index matches everywhere: dozens of one-hit clusters per read)
         assert ctx.counters()["leftover_reads"] == 0  # ordinary short reads never need the generic pipeline
 
 
@@ -176,7 +182,8 @@ def test_reads_that_do_not_fit_the_per_read_kernel(tmp_path, oracle, copies):
     ctx = _ctx(tmp_path, panel, 11, 15, True, kernel=2)
     cnt = _compare(ctx, oracle, bases, offs, 11, 15, True, 2)
     assert cnt["clusters_kept"] > 500
-    assert 400 < ctx.counters()["leftover_reads"] < 1100  # the reads of the repeated locus, not the others
+    if not FORCED_GENERIC:
+        assert 400 < ctx.counters()["leftover_reads"] < 1100  # the reads of the repeated locus, not the others
 
 
 def test_reads_longer_than_the_staged_range(tmp_path, oracle):
@@ -198,7 +205,7 @@ def test_reads_longer_than_the_staged_range(tmp_path, oracle):
         ctx = _ctx(tmp_path, panel, 11, 15, False, kernel=kernel)
         cnt = _compare(ctx, oracle, bases, offs, 11, 15, False, kernel)
         assert cnt["clusters_kept"] > 500
-        if kernel == 2:
+        if kernel == 2 and not FORCED_GENERIC:
             assert 20 <= ctx.counters()["leftover_reads"] <= 100  # most 9 kb reads (a few fit: 2048 candidates are staged)
 
 
