@@ -1,0 +1,448 @@
+// candidates.hip -- the candidate stage of the filtered launch sequence (see the overview at the top of
+// sketch_filter.hip): slices of candidate positions -> one dense list ordered by (read, position) -> exact lookup and
+// window-minimizer test per candidate (verify_count_kernel) -> batch totals; and, for the reads that
+// read_cluster_kernel leaves over, the hit list for the generic cluster pipeline (recount / expand / per-read reorder).
+#include "filter_common.h"
+#include <cstdint>
+
+namespace drprg {
+namespace dev {
+
+// ---------------------------------------------------------------------------------------------
+// scans
+// ---------------------------------------------------------------------------------------------
+// one workgroup: cand_prefix = exclusive scan of min(slice_count, raw_slice)
+__global__ __launch_bounds__(SCAN_THREADS) void cand_scan_kernel(FilterWork fw)
+{
+    __shared__ uint32_t s_w[SCAN_THREADS / 64 + 1];
+    constexpr int PER = MAX_SLICES / SCAN_THREADS;
+    const int tid = threadIdx.x;
+    uint32_t v[PER], run = 0;
+    for (int i = 0; i < PER; ++i) {
+        const uint32_t s = (uint32_t)tid * PER + i;
+        const uint32_t n = s < fw.n_slices ? fw.slice_count[s] : 0u;
+        v[i] = run;
+        run += n < fw.raw_slice ? n : fw.raw_slice;
+    }
+    uint32_t total;
+    const uint32_t before = block_exclusive_scan<SCAN_THREADS / 64>(run, s_w, &total);
+    for (int i = 0; i < PER; ++i) {
+        const uint32_t s = (uint32_t)tid * PER + i;
+        if (s < fw.n_slices) fw.cand_prefix[s] = before + v[i];
+    }
+    if (tid == 0) fw.cand_prefix[fw.n_slices] = total;
+}
+
+// ---------------------------------------------------------------------------------------------
+// verification
+// ---------------------------------------------------------------------------------------------
+// 16 ASCII bases -> packed codes (A0 C1 G2 T3, first base highest) + 16-bit "not ACGT" mask (bit i = base i)
+__device__ inline void pack16n(const uint4& in, uint32_t& packed, uint32_t& nmask)
+{
+    const uint32_t e0 = encode4(in.x), e1 = encode4(in.y), e2 = encode4(in.z), e3 = encode4(in.w);
+    packed = ((((e0 & 0x03030303u) * 0x40100401u) >> 24) << 24) | ((((e1 & 0x03030303u) * 0x40100401u) >> 24) << 16)
+        | ((((e2 & 0x03030303u) * 0x40100401u) >> 24) << 8) | (((e3 & 0x03030303u) * 0x40100401u) >> 24);
+    nmask = 0;
+    if ((e0 | e1 | e2 | e3) & 0x04040404u) { // rare; (flags * 0x01020408) >> 24 gathers the flag of byte i into bit i
+        auto m4 = [](uint32_t e) { return ((((e >> 2) & 0x01010101u) * 0x01020408u) >> 24) & 0xFu; };
+        nmask = m4(e0) | (m4(e1) << 4) | (m4(e2) << 8) | (m4(e3) << 12);
+    }
+}
+
+// reverse complement of a k-mer code (2 bits per base, k <= 16)
+__device__ inline uint32_t revcomp_code(uint32_t f, int k)
+{
+    uint32_t x = __brev(f);                                    // bit reversal also swaps the two bits of every base
+    x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);   // swap them back
+    return (~x) >> (32 - 2 * k);                               // complement, right-align
+}
+
+// 16 bases at global position g (a multiple of 16); bytes past the end of the buffer read as 'N'
+__device__ inline uint4 load16_guarded(const uint8_t* __restrict__ bases, int64_t n_bases, int64_t g)
+{
+    if (g + 16 <= n_bases) return *reinterpret_cast<const uint4*>(bases + g);
+    uint32_t t4[4];
+    for (int q = 0; q < 4; ++q) {
+        uint32_t wd = 0;
+        for (int b = 0; b < 4; ++b) {
+            const int64_t gg = g + q * 4 + b;
+            wd |= (uint32_t)(gg < n_bases ? bases[gg] : (uint8_t)'N') << (8 * b);
+        }
+        t4[q] = wd;
+    }
+    return make_uint4(t4[0], t4[1], t4[2], t4[3]);
+}
+
+// slices -> one dense, ordered candidate list (cand_info[t] holds the position until verify_count_kernel replaces it)
+__global__ __launch_bounds__(64) void cand_gather_kernel(FilterWork fw)
+{
+    const uint32_t s = blockIdx.x;
+    const uint32_t n = fw.cand_prefix[s + 1] - fw.cand_prefix[s];
+    const uint64_t* __restrict__ src = fw.raw_pos + (size_t)s * fw.raw_slice;
+    uint64_t* __restrict__ dst = fw.cand_info + fw.cand_prefix[s];
+    for (uint32_t i = threadIdx.x; i < n; i += 64) dst[i] = src[i];
+}
+
+// One lane per candidate, start to finish: the 64 bases around it are packed into registers once (2 bits per base,
+// first base highest), the candidate's canonical hash goes to the exact table lookup (Bloom false positives end there),
+// then the 2w-1 neighbouring k-mers are hashed one after the other out of a 96-bit shift register -- a third of the
+// instructions of giving every neighbour its own lane, each of which had to load and pack its own bases.  It is a read
+// minimizer iff the run of neighbours with hash >= its own (inside the read, no N) reaches w-1 across both sides.
+__global__ __launch_bounds__(EX_THREADS) void verify_count_kernel(SketchArgs a, FilterWork fw, ReadClusterArgs rc)
+{
+    using Tr = HashTraits<uint32_t>;
+    __shared__ uint32_t s_red[3][EX_THREADS / 64];
+    const int tid = threadIdx.x;
+    uint32_t t_begin, t_end;
+    candidate_range(fw, blockIdx.x, gridDim.x, t_begin, t_end);
+    const uint32_t* __restrict__ slot_key = reinterpret_cast<const uint32_t*>(a.slot_key);
+    const uint32_t tmask = (1u << a.table_bits) - 1;
+    const int k = a.k, w = a.w;
+    const int sh_k = 32 - 2 * k;
+    const uint32_t kmask = (1u << (2 * k)) - 1;
+    const int64_t n_bases = (int64_t)a.n_bases;
+    const double reads_per_base = (double)a.n_reads / (double)(a.n_bases ? a.n_bases : 1);
+    uint32_t my_hits = 0, my_nmin = 0, my_maxlen = 0;
+    for (uint32_t t = t_begin + tid; t < t_end; t += EX_THREADS) {
+        const int64_t gp = (int64_t)fw.cand_info[t]; // position now, (slot, strand, read) when this lane is done
+        uint32_t pos1 = 0, slot = 0, read = READ_NONE, strand = 0;
+        uint4 crec = make_uint4(0, 0, 0, 0);
+        if (gp + k <= n_bases) {
+            // the read of every candidate, index k-mer or not: read_cluster_kernel finds the first candidate of a read by
+            // comparing neighbours (interpolated first guess: exact for fixed-length reads, a short gallop otherwise)
+            read = find_read_near(a.offsets, a.n_reads, (uint32_t)((double)gp * reads_per_base), (uint64_t)gp);
+            // ---- the 64 bases [a0, a0+64) hold the candidate and all its neighbours (w <= 16, k <= 15) ----
+            const int64_t a0 = (gp > 15 ? gp - 15 : 0) & ~(int64_t)15;
+            uint32_t r0w, r1w, r2w, r3w, n0, n1, n2, n3;
+            pack16n(load16_guarded(a.bases, n_bases, a0), r0w, n0);
+            pack16n(load16_guarded(a.bases, n_bases, a0 + 16), r1w, n1);
+            pack16n(load16_guarded(a.bases, n_bases, a0 + 32), r2w, n2);
+            pack16n(load16_guarded(a.bases, n_bases, a0 + 48), r3w, n3);
+            uint64_t bad = (uint64_t)(n0 | (n1 << 16)) | ((uint64_t)(n2 | (n3 << 16)) << 32); // bit i: base a0+i is not ACGT
+            if (bad) { // -> bit i: the k-mer starting at a0+i holds such a base
+                uint64_t m = bad;
+                for (int i = 1; i < k; ++i) m |= bad >> i;
+                bad = m;
+            }
+            // ---- the candidate's own canonical hash, exact lookup ----
+            const int oc = (int)(gp - a0); // 0..30
+            uint32_t g = 0;
+            if (!((bad >> oc) & 1u)) {
+                const uint32_t h0 = (oc & 16) ? r1w : r0w, h1 = (oc & 16) ? r2w : r1w;
+                const uint32_t f = __funnelshift_l(h1, h0, 2 * (oc & 15)) >> sh_k;
+                const uint32_t hf = Tr::mix(f, kmask), hr = Tr::mix(revcomp_code(f, k), kmask);
+                strand = hf <= hr ? 1u : 0u;
+                g = (hf < hr ? hf : hr) + 1;
+            }
+            bool found = false;
+            if (g) {
+                const uint32_t h = g - 1;
+                uint32_t sl = table_slot_dev((uint64_t)h, a.table_bits);
+                while (true) {
+                    const uint32_t key = slot_key[sl];
+                    if (key == h) { found = true; break; }
+                    if (key == Tr::EMPTY) break;
+                    sl = (sl + 1) & tmask;
+                }
+                slot = sl;
+            }
+            if (found) {
+                const int64_t r0 = (int64_t)a.offsets[read], r1 = (int64_t)a.offsets[read + 1];
+                if (gp + k <= r1) { // the k-mer lies inside one read
+                    // ---- scan q = q_first .. q_first + 2w-2; steps outside [gp-(w-1), gp+(w-1)] or the read are invalid ----
+                    const int64_t q_lo = gp - (w - 1);
+                    const int64_t q_first = q_lo > a0 ? q_lo : a0; // a0 <= max(q_lo, 0)
+                    const int of = (int)(q_first - a0);            // 0..30
+                    const int64_t v_lo = r0 > q_first ? r0 : q_first;
+                    const int64_t v_hi = (r1 - k) < (gp + w - 1) ? (r1 - k) : (gp + w - 1);
+                    const int i_lo = (int)(v_lo - q_first), i_hi = (int)(v_hi - q_first), ic = (int)(gp - q_first);
+                    // align the shift register on q_first: 48 bases in three words cover 2w-1 + k-1 <= 45
+                    if (of & 16) { r0w = r1w; r1w = r2w; r2w = r3w; r3w = 0; }
+                    const int s2 = 2 * (of & 15);
+                    r0w = __funnelshift_l(r1w, r0w, s2);
+                    r1w = __funnelshift_l(r2w, r1w, s2);
+                    r2w = __funnelshift_l(r3w, r2w, s2);
+                    // steps that can count at all: inside the read and the window, no N in the k-mer (bit i = step i)
+                    const uint32_t valid = ((2u << i_hi) - 1u) & ~((1u << i_lo) - 1u) & ~(uint32_t)(bad >> of);
+                    uint32_t streak = 0, right = 0, alive = 1;
+                    for (int i = 0; i < 2 * w - 1; ++i) {
+                        const uint32_t f = r0w >> sh_k;
+                        r0w = __funnelshift_l(r1w, r0w, 2);
+                        r1w = __funnelshift_l(r2w, r1w, 2);
+                        r2w <<= 2;
+                        const uint32_t hf = Tr::mix(f, kmask), hr = Tr::mix(revcomp_code(f, k), kmask);
+                        const uint32_t x = (hf < hr ? hf : hr) + 1;
+                        const bool ok = ((valid >> i) & 1u) && x >= g;
+                        if (i < ic) streak = ok ? streak + 1 : 0;
+                        else if (i > ic) {
+                            alive = ok ? alive : 0u;
+                            right += alive;
+                        }
+                    }
+                    if ((int)(streak + right) >= w - 1) {
+                        const uint64_t pos = (uint64_t)(gp - r0);
+                        if (pos >= (1ull << HIT_POS_BITS)) atomicOr(a.overflow, 2u);
+                        else {
+                            pos1 = (uint32_t)pos + 1;
+                            const uint2 rec = a.slot_rec[slot];
+                            my_hits += rec.y;
+                            my_nmin += 1;
+                            const uint32_t len = (uint32_t)((r1 - r0) > 0xFFFFFFFFll ? 0xFFFFFFFFll : (r1 - r0));
+                            my_maxlen = len > my_maxlen ? len : my_maxlen;
+                            // for read_cluster_kernel: the first hit of this minimizer and the size threshold of a cluster
+                            // of this read on that hit's PRG (cluster_eval_kernel)
+                            const uint32_t kn = a.rec_knode[rec.x], prg = a.rec_prg[rec.x];
+                            const uint32_t rev = ((kn & 1u) == strand) ? 0u : 1u;
+                            const uint64_t expected = (uint64_t)(r1 - r0) * 2 / (uint64_t)(w + 1);
+                            uint64_t m = rc.prg_min_path_len[prg];
+                            if (expected < m) m = expected;
+                            const uint32_t length_based = (uint32_t)((double)m * rc.fraction);
+                            uint32_t thr = length_based > rc.min_cluster_size ? length_based : rc.min_cluster_size;
+                            if (thr > 0xFFFFu) thr = 0xFFFFu; // read_cluster_kernel stages at most RC_HCAP hits: no difference
+                            crec = make_uint4(rec.x, rec.y, (strand << 31) | (((prg << 1) | rev) << 16) | thr, (kn >> 1) * 2u + rev);
+                        }
+                    }
+                }
+            }
+        }
+        fw.cand_pos1[t] = pos1;
+        fw.cand_info[t] = ((uint64_t)slot << 32) | ((uint64_t)strand << 31) | (uint64_t)read;
+        fw.cand_rec[t] = crec;
+    }
+    // ---- per-workgroup totals (the only barrier of the kernel) ----
+    const uint32_t wh = wave_inclusive_scan(my_hits), wn = wave_inclusive_scan(my_nmin), wm = wave_max(my_maxlen);
+    if ((tid & 63) == 63) {
+        s_red[0][tid >> 6] = wh;
+        s_red[1][tid >> 6] = wn;
+        s_red[2][tid >> 6] = wm;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t h = 0, n = 0, mx = 0;
+        for (int i = 0; i < EX_THREADS / 64; ++i) {
+            h += s_red[0][i];
+            n += s_red[1][i];
+            mx = s_red[2][i] > mx ? s_red[2][i] : mx;
+        }
+        fw.wg_hits[blockIdx.x] = h;
+        fw.wg_nmin[blockIdx.x] = n;
+        fw.wg_maxlen[blockIdx.x] = mx;
+    }
+}
+
+// one workgroup: wg_base = exclusive scan of wg_hits; batch totals
+__global__ __launch_bounds__(SCAN_THREADS) void hit_scan_kernel(SketchArgs a, FilterWork fw, int recount)
+{
+    __shared__ uint32_t s_w[SCAN_THREADS / 64 + 1];
+    __shared__ uint32_t s_n[SCAN_THREADS / 64], s_m[SCAN_THREADS / 64];
+    constexpr int PER = MAX_EX_WG / SCAN_THREADS;
+    const int tid = threadIdx.x;
+    uint32_t v[PER], run = 0, nmin = 0, mx = 0;
+    for (int i = 0; i < PER; ++i) {
+        const uint32_t g = (uint32_t)tid * PER + i;
+        v[i] = run;
+        if (g < fw.ex_grid) {
+            run += fw.wg_hits[g];
+            nmin += fw.wg_nmin[g];
+            const uint32_t m = fw.wg_maxlen[g];
+            mx = m > mx ? m : mx;
+        }
+    }
+    uint32_t total;
+    const uint32_t before = block_exclusive_scan<SCAN_THREADS / 64>(run, s_w, &total);
+    for (int i = 0; i < PER; ++i) {
+        const uint32_t g = (uint32_t)tid * PER + i;
+        if (g < fw.ex_grid) fw.wg_base[g] = before + v[i];
+    }
+    const uint32_t wn = wave_inclusive_scan(nmin), wm = wave_max(mx);
+    if ((tid & 63) == 63) {
+        s_n[tid >> 6] = wn;
+        s_m[tid >> 6] = wm;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t n = 0, m = 0;
+        for (int i = 0; i < SCAN_THREADS / 64; ++i) {
+            n += s_n[i];
+            m = s_m[i] > m ? s_m[i] : m;
+        }
+        *a.n_hits = (unsigned long long)total;
+        if (n && !recount) atomicAdd(a.n_minimizers, (unsigned long long)n);
+        *fw.max_len = (unsigned long long)m;
+    }
+}
+
+// one (key,val) per index record of every minimizer, at the scanned offset: hits come out ordered by (read, pos)
+__global__ __launch_bounds__(EX_THREADS) void expand_kernel(SketchArgs a, FilterWork fw)
+{
+    __shared__ uint32_t s_w[EX_THREADS / 64 + 1];
+    const int tid = threadIdx.x;
+    uint32_t t_begin, t_end;
+    candidate_range(fw, blockIdx.x, gridDim.x, t_begin, t_end);
+    uint64_t base = fw.wg_base[blockIdx.x];
+    for (uint32_t t0 = t_begin; t0 < t_end; t0 += EX_THREADS) {
+        const uint32_t t = t0 + tid;
+        const uint32_t pos1 = t < t_end ? fw.cand_pos1[t] : 0u;
+        uint64_t info = 0;
+        uint2 rec = make_uint2(0, 0);
+        if (pos1) {
+            info = fw.cand_info[t];
+            rec = a.slot_rec[(uint32_t)(info >> 32)];
+        }
+        uint32_t total;
+        const uint32_t off = block_exclusive_scan<EX_THREADS / 64>(rec.y, s_w, &total);
+        const uint64_t at = base + off;
+        if (pos1 && at + rec.y <= a.hit_capacity) {
+            const uint32_t read = (uint32_t)info & 0x7FFFFFFFu, strand = ((uint32_t)info >> 31) & 1u;
+            for (uint32_t q = 0; q < rec.y; ++q) {
+                const uint32_t kn = a.rec_knode[rec.x + q];
+                const uint32_t prg = a.rec_prg[rec.x + q];
+                const uint32_t rev = ((kn & 1u) == strand) ? 0u : 1u;
+                a.hit_key[at + q] = pack_hit_key(read, prg, rev, pos1 - 1);
+                a.hit_val[at + q] = kn >> 1;
+            }
+        }
+        base += total;
+    }
+}
+
+// Hits ordered by (read, pos) -> ordered by (read, prg, strand, pos).  A short read's hits nearly always lie in one
+// (prg, strand) group, i.e. they are in order already: read_inversion_kernel lists the few reads that are not (one
+// thread per adjacent pair, the first inversion of a read reports it) and read_fix_kernel reorders just those, in
+// place and stable.  Long reads take the global radix sort instead (Mapper::run_batch).
+__global__ void read_inversion_kernel(const uint64_t* __restrict__ key, uint32_t n, uint2* __restrict__ list, uint32_t cap,
+    unsigned long long* __restrict__ count)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i + 1 >= n) return;
+    const uint64_t a = key[i], b = key[i + 1];
+    const uint32_t read = hit_read(a);
+    if (hit_read(b) != read || a <= b) return;
+    // rare from here on: [s, e) = the hits of this read; an earlier inversion in it means another thread reports it
+    uint32_t s = i;
+    while (s > 0 && hit_read(key[s - 1]) == read) {
+        if (key[s - 1] > key[s]) return;
+        --s;
+    }
+    uint32_t e = i + 2;
+    while (e < n && hit_read(key[e]) == read) ++e;
+    const unsigned long long at = atomicAdd(count, 1ull);
+    if (at < cap) list[at] = make_uint2(s, e - s); // cap >= n / 2 >= the number of reads with two hits
+}
+
+constexpr int RS_THREADS = 256, RS_MAX = 1024;
+__global__ __launch_bounds__(RS_THREADS) void read_fix_kernel(uint64_t* __restrict__ key, uint32_t* __restrict__ val,
+    const uint2* __restrict__ list, const unsigned long long* __restrict__ count)
+{
+    __shared__ uint64_t s_key[RS_MAX];
+    __shared__ uint32_t s_val[RS_MAX];
+    const uint32_t n_list = (uint32_t)*count;
+    for (uint32_t r = blockIdx.x; r < n_list; r += gridDim.x) {
+        const uint32_t start = list[r].x, len = list[r].y;
+        if (len > RS_MAX) { // not expected for short reads; correct but serial
+            if (threadIdx.x == 0)
+                for (uint32_t j = start + 1; j < start + len; ++j) {
+                    const uint64_t kj = key[j];
+                    const uint32_t vj = val[j];
+                    uint32_t p = j;
+                    while (p > start && key[p - 1] > kj) {
+                        key[p] = key[p - 1];
+                        val[p] = val[p - 1];
+                        --p;
+                    }
+                    key[p] = kj;
+                    val[p] = vj;
+                }
+            continue;
+        }
+        for (uint32_t t = threadIdx.x; t < len; t += RS_THREADS) {
+            s_key[t] = key[start + t];
+            s_val[t] = val[start + t];
+        }
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t < len; t += RS_THREADS) {
+            const uint64_t kt = s_key[t];
+            uint32_t before = 0;
+            for (uint32_t j = 0; j < t; ++j) before += s_key[j] <= kt ? 1u : 0u; // earlier hits precede on ties
+            for (uint32_t j = t + 1; j < len; ++j) before += s_key[j] < kt ? 1u : 0u;
+            key[start + before] = kt;
+            val[start + before] = s_val[t];
+        }
+        __syncthreads();
+    }
+}
+
+// what read_cluster_kernel left behind: hits and longest read per workgroup range (the layout verify_count_kernel wrote)
+__global__ __launch_bounds__(EX_THREADS) void recount_kernel(SketchArgs a, FilterWork fw)
+{
+    __shared__ uint32_t s_red[2][EX_THREADS / 64];
+    const int tid = threadIdx.x;
+    uint32_t t_begin, t_end;
+    candidate_range(fw, blockIdx.x, gridDim.x, t_begin, t_end);
+    uint32_t my_hits = 0, my_maxlen = 0;
+    for (uint32_t t = t_begin + tid; t < t_end; t += EX_THREADS) {
+        if (!fw.cand_pos1[t]) continue;
+        const uint64_t info = fw.cand_info[t];
+        my_hits += a.slot_rec[(uint32_t)(info >> 32)].y;
+        const uint32_t read = (uint32_t)info & 0x7FFFFFFFu;
+        const uint64_t len64 = a.offsets[read + 1] - a.offsets[read];
+        const uint32_t len = len64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)len64;
+        my_maxlen = len > my_maxlen ? len : my_maxlen;
+    }
+    const uint32_t wh = wave_inclusive_scan(my_hits), wm = wave_max(my_maxlen);
+    if ((tid & 63) == 63) {
+        s_red[0][tid >> 6] = wh;
+        s_red[1][tid >> 6] = wm;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t h = 0, mx = 0;
+        for (int i = 0; i < EX_THREADS / 64; ++i) {
+            h += s_red[0][i];
+            mx = s_red[1][i] > mx ? s_red[1][i] : mx;
+        }
+        fw.wg_hits[blockIdx.x] = h;
+        fw.wg_nmin[blockIdx.x] = 0;
+        fw.wg_maxlen[blockIdx.x] = mx;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+hipError_t launch_candidate_stage(const SketchArgs& a, const FilterWork& fw, const ReadClusterArgs& rc, hipStream_t stream)
+{
+    hipLaunchKernelGGL(cand_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, fw);
+    hipLaunchKernelGGL(cand_gather_kernel, dim3(fw.n_slices), dim3(64), 0, stream, fw);
+    hipLaunchKernelGGL(verify_count_kernel, dim3(fw.ex_grid), dim3(EX_THREADS), 0, stream, a, fw, rc);
+    hipLaunchKernelGGL(hit_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, a, fw, 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_filter_recount(const SketchArgs& a, const FilterWork& fw, hipStream_t stream)
+{
+    hipLaunchKernelGGL(recount_kernel, dim3(fw.ex_grid), dim3(EX_THREADS), 0, stream, a, fw);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(hit_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, a, fw, 1);
+    return hipGetLastError();
+}
+
+hipError_t launch_filter_expand(const SketchArgs& a, const FilterWork& fw, hipStream_t stream)
+{
+    hipLaunchKernelGGL(expand_kernel, dim3(fw.ex_grid), dim3(EX_THREADS), 0, stream, a, fw);
+    return hipGetLastError();
+}
+
+hipError_t launch_read_sort(uint64_t* key, uint32_t* val, uint32_t n, uint32_t* scratch, uint64_t scratch_words, unsigned long long* count,
+    hipStream_t stream)
+{
+    if (n < 2) return hipSuccess;
+    uint2* list = reinterpret_cast<uint2*>(scratch);
+    hipLaunchKernelGGL(read_inversion_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, key, n, list, (uint32_t)(scratch_words / 2), count);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(read_fix_kernel, dim3(128), dim3(RS_THREADS), 0, stream, key, val, list, count);
+    return hipGetLastError();
+}
+
+} // namespace dev
+} // namespace drprg

@@ -1,0 +1,39 @@
+// filter_common.h -- constants and helpers shared by the kernels of the filtered launch sequence
+// (sketch_filter.hip -> candidates.hip -> read_cluster.hip).
+#pragma once
+#include "common.h"
+#include "device_common.h"
+
+namespace drprg {
+namespace dev {
+
+constexpr int FT_THREADS = 1024;
+constexpr int FT_WAVES = FT_THREADS / 64;
+constexpr int FT_G = 32;                // positions per lane
+constexpr int FT_WPOS = 63 * FT_G;      // positions per wave tile: lane 63's word is only lane 62's right neighbour
+constexpr int FT_BLOOM_WORDS = 1 << 14; // levels 1+2 of the filter, at most (64 KB of LDS)
+constexpr int FT_L0_WORDS = 1 << 15;    // level 0 (128 KB; levels 1+2 then get 32 KB: all 160 KB of a CU)
+constexpr int EX_THREADS = 256;
+constexpr int SCAN_THREADS = 1024;
+constexpr int FT_SUB = 2;                    // slices per filter wave
+constexpr int MAX_SLICES = SCAN_THREADS * 8;
+constexpr int MAX_EX_WG = SCAN_THREADS * 4;  // workgroups of verify_count_kernel / expand_kernel
+
+// the contiguous range of the ordered candidate list that workgroup `wg` of `n_wg` owns
+__device__ inline void candidate_range(const FilterWork& fw, uint32_t wg, uint32_t n_wg, uint32_t& t_begin, uint32_t& t_end)
+{
+    const uint32_t total = fw.cand_prefix[fw.n_slices];
+    const uint32_t per_wg = (total + n_wg - 1) / n_wg;
+    const uint64_t b = (uint64_t)wg * per_wg;
+    t_begin = b < total ? (uint32_t)b : total;
+    t_end = b + per_wg < total ? (uint32_t)(b + per_wg) : total;
+}
+
+// stages of the filtered sequence that live in the other translation units (all asynchronous on `stream`)
+// candidates.hip: slices -> dense ordered candidate list -> verified candidates + per-candidate records + batch totals
+hipError_t launch_candidate_stage(const SketchArgs& a, const FilterWork& fw, const ReadClusterArgs& rc, hipStream_t stream);
+// read_cluster.hip: per-read clustering straight from the candidate list (skip: mark the batch as left over instead)
+hipError_t launch_read_cluster(const SketchArgs& a, const FilterWork& fw, const ReadClusterArgs& rc, int n_cus, bool skip, hipStream_t stream);
+
+} // namespace dev
+} // namespace drprg

@@ -1,0 +1,408 @@
+// read_cluster.hip -- the last stage of the filtered launch sequence (see the overview at the top of
+// sketch_filter.hip): clusters, size / overlap filters and coverage straight from the ordered candidate list.
+#include "filter_common.h"
+#include <cstdint>
+
+namespace drprg {
+namespace dev {
+
+// ---------------------------------------------------------------------------------------------
+// per-read clustering straight from the candidate list
+// ---------------------------------------------------------------------------------------------
+// The candidates leave verify_count_kernel ordered by (read, position), so all minimizers of a read sit next to each
+// other, and a short read has a few dozen hits, nearly always in ONE cluster.  read_cluster_kernel therefore never
+// materialises the hit list.  A workgroup stages RC_SLOTS consecutive candidates and their index records (the hits) in
+// LDS.  A position gap > max_diff between two consecutive minimizers of a read starts a new segment; as long as all
+// hits of the read lie in one (prg, strand) group, the segments ARE the clusters and the overlap sweep of
+// cluster_filter_kernel cannot drop any of them (same group, disjoint position ranges).  So every minimizer adds its
+// hits to its segment's counter, the first slot of a segment applies the size threshold of cluster_eval_kernel, and
+// every minimizer of a kept segment then adds its own hits to the coverage vector -- all of it data parallel.  Only
+// the reads whose hits fall into several groups are walked serially by the thread of their first candidate (clusters
+// per group split at gaps, size threshold, the overlap sweep; pandora define_clusters / filter_clusters).  This replaces expand + reorder
+// + flag + scan + start + eval + filter + count + accumulate (13 launches) for such reads.  A read that does not fit
+// (its candidates run past the staged range, more than RC_MAXC clusters, too many hits in the chunk, a position >=
+// 2^16) is left alone: its candidates keep cand_pos1 != 0, n_complex counts it, and the host sends what is left
+// through the generic pipeline (long reads always go that way).  Handled reads get cand_pos1 = 0.  (A workgroup may
+// read cand_pos1 of a neighbouring chunk's read while that chunk zeroes it: either value only moves where the foreign
+// hits land in LDS, nothing else.)
+constexpr int RC_THREADS = 1024;
+constexpr int RC_WAVES = RC_THREADS / 64;
+constexpr int RC_PER = 2;
+constexpr int RC_SLOTS = RC_THREADS * RC_PER; // staged candidates
+constexpr int RC_AHEAD = 512;                 // look-ahead: a read belongs to the chunk that owns its first candidate
+constexpr int RC_OWN = RC_SLOTS - RC_AHEAD;
+constexpr int RC_HCAP = 3072;                 // staged hits
+constexpr int RC_POOL = 64;                   // reads per chunk that may take the wave path
+constexpr uint32_t RC_IRREGULAR = 2u, RC_COMPLEX = 1u;
+
+// later (read start << 16 | segment start) pair: the read start decides, then the segment start.  A gap inside a read
+// that began in an earlier thread's slots carries read start 0 here: it must take the earlier pair's read start.
+__device__ __forceinline__ uint32_t pack_max(uint32_t earlier, uint32_t later)
+{
+    const uint32_t lead = (later >> 16) > (earlier >> 16) ? (later >> 16) : (earlier >> 16);
+    const uint32_t seg = (later & 0xFFFFu) > (earlier & 0xFFFFu) ? (later & 0xFFFFu) : (earlier & 0xFFFFu);
+    return (lead << 16) | seg;
+}
+// LDS traffic only: global loads, stores and atomics stay in flight across the barrier
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs a, FilterWork fw, ReadClusterArgs rc)
+{
+    extern __shared__ uint32_t s_hist[]; // clusters kept per PRG
+    __shared__ uint32_t s_read[RC_SLOTS + 1], s_hstart[RC_SLOTS + 1];
+    __shared__ uint16_t s_pos1[RC_SLOTS]; // read position + 1 of a minimizer (0xFFFF: too far for this kernel), 0 = not a minimizer
+    __shared__ uint32_t s_gt[RC_SLOTS];   // at a segment's first slot: group << 16 | size threshold; later the decision for the segment
+    __shared__ uint16_t s_lead[RC_SLOTS]; // 1 + slot of the first candidate of this slot's read (0: the read started in an earlier chunk)
+    __shared__ uint16_t s_seg[RC_SLOTS];  // 1 + first slot of this slot's segment
+    __shared__ uint16_t s_end[RC_SLOTS];  // at a segment's first slot: the first slot of the next segment
+    __shared__ uint8_t s_cplx[RC_SLOTS], s_irrf[RC_SLOTS]; // at a read's first slot: does not fit / hits in several groups
+    __shared__ uint16_t s_grp[RC_HCAP];   // per hit: prg << 1 | rev
+    __shared__ uint16_t s_hpos[RC_HCAP];  // per hit: read position
+    __shared__ uint32_t s_cov[RC_HCAP];   // per hit: index into the coverage vector, 2 * k-mer node + rev
+    __shared__ uint32_t s_w[2][RC_WAVES];
+    __shared__ uint32_t s_irr[RC_POOL];
+    __shared__ uint32_t s_prev_read, s_n_irr, s_chunk;
+    __shared__ unsigned long long s_tot[3];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (*reinterpret_cast<volatile uint32_t*>(a.overflow) & 4u) return; // a candidate slice overflowed: the host re-runs the batch
+    const uint32_t total = fw.cand_prefix[fw.n_slices];
+    for (uint32_t i = tid; i < rc.n_prgs; i += RC_THREADS) s_hist[i] = 0;
+    if (tid < 3) s_tot[tid] = 0;
+    unsigned long long my_kept_hits = 0;
+    uint32_t my_kept = 0, my_complex = 0;
+
+    // chunks are handed out by a global counter (two or three chunks per workgroup: a static split leaves a third of
+    // the workgroups idle for the last round); the next chunk number is fetched while the current one is processed
+    if (tid == 0) s_chunk = atomicAdd(rc.chunk_counter, 1u);
+    for (;;) {
+        lds_barrier(); // LDS of the previous chunk is free, s_chunk is there
+        const uint64_t base64 = (uint64_t)s_chunk * RC_OWN;
+        if (base64 >= total) break;
+        const uint32_t base = (uint32_t)base64;
+        const uint32_t n_loaded = total - base < (uint32_t)RC_SLOTS ? total - base : (uint32_t)RC_SLOTS;
+        const uint32_t n_own = total - base < (uint32_t)RC_OWN ? total - base : (uint32_t)RC_OWN;
+        lds_barrier(); // everybody has read s_chunk
+        if (tid == 0) s_chunk = atomicAdd(rc.chunk_counter, 1u);
+        // ---- A: stage the candidates: three coalesced loads per slot, nothing depends on them but LDS work ----
+        uint4 crec[RC_PER];
+#pragma unroll
+        for (int q = 0; q < RC_PER; ++q) {
+            const uint32_t i = (uint32_t)tid + (uint32_t)q * RC_THREADS;
+            uint32_t read = READ_NONE, pos1 = 0;
+            crec[q] = make_uint4(0, 0, 0, 0);
+            if (i < n_loaded) {
+                read = (uint32_t)fw.cand_info[base + i] & 0x7FFFFFFFu;
+                pos1 = fw.cand_pos1[base + i];
+                crec[q] = fw.cand_rec[base + i];
+                if (!pos1) crec[q].y = 0; // handled by another chunk in the meantime (look-ahead slots only)
+            }
+            s_read[i] = read;
+            s_pos1[i] = (uint16_t)(pos1 < 0xFFFFu ? pos1 : 0xFFFFu);
+            s_hstart[i] = crec[q].y;
+            s_cplx[i] = 0;
+            s_irrf[i] = 0;
+        }
+        if (tid == 0) {
+            s_prev_read = base ? ((uint32_t)fw.cand_info[base - 1] & 0x7FFFFFFFu) : 0xFFFFFFFFu;
+            // the candidate after the staged range: a read that runs on into it does not fit
+            s_read[RC_SLOTS] = (n_loaded == (uint32_t)RC_SLOTS && base + n_loaded < total) ? ((uint32_t)fw.cand_info[base + n_loaded] & 0x7FFFFFFFu)
+                                                                                           : 0xFFFFFFFFu;
+            s_n_irr = 0;
+        }
+        lds_barrier();
+        // ---- B: exclusive sum scan of the hit counts and ONE inclusive max scan of (read start << 16 | segment start), in slot
+        // order: both starts only grow along the slots and a read start is a segment start, so the packed maximum is the pair ----
+        {
+            uint32_t v[RC_PER], m[RC_PER], run = 0, mx = 0;
+#pragma unroll
+            for (int q = 0; q < RC_PER; ++q) {
+                const uint32_t i = (uint32_t)tid * RC_PER + q;
+                v[q] = run;
+                run += s_hstart[i];
+                const uint32_t r = s_read[i], p1 = s_pos1[i];
+                const uint32_t r_prev = i ? s_read[i - 1] : s_prev_read;
+                if (r != r_prev) {
+                    if (r != READ_NONE) mx = ((i + 1) << 16) | (i + 1);
+                } else if (p1 && i) { // a gap to the previous minimizer of the read?
+                    uint32_t pp = s_pos1[i - 1];
+                    if (!pp) { // rare: candidates that are no minimizers lie between
+                        int j = (int)i - 2;
+                        while (j >= 0 && s_read[j] == r && !s_pos1[j]) --j;
+                        pp = (j >= 0 && s_read[j] == r) ? s_pos1[j] : p1;
+                    }
+                    if ((int)(p1 - pp) > rc.max_diff) mx = (mx & 0xFFFF0000u) | (i + 1);
+                }
+                m[q] = mx;
+            }
+            uint32_t incl = run, imx = mx;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t n = __shfl_up(incl, off), x = __shfl_up(imx, off);
+                if (lane >= off) {
+                    incl += n;
+                    imx = pack_max(x, imx);
+                }
+            }
+            if (lane == 63) {
+                s_w[0][wave] = incl;
+                s_w[1][wave] = imx;
+            }
+            const uint32_t excl_mx_in_wave = __shfl_up(imx, 1);
+            lds_barrier();
+            uint32_t before = incl - run, mx_before = lane ? excl_mx_in_wave : 0u, sum = 0;
+#pragma unroll
+            for (int i = 0; i < RC_WAVES; ++i) {
+                const uint32_t x = s_w[0][i], y = s_w[1][i];
+                if (i < wave) {
+                    before += x;
+                    mx_before = pack_max(mx_before, y);
+                }
+                sum += x;
+            }
+#pragma unroll
+            for (int q = 0; q < RC_PER; ++q) {
+                const uint32_t i = (uint32_t)tid * RC_PER + q;
+                const uint32_t pm = pack_max(mx_before, m[q]);
+                s_hstart[i] = before + v[q];
+                s_lead[i] = (uint16_t)(pm >> 16);
+                s_seg[i] = (uint16_t)pm;
+            }
+            if (tid == 0) s_hstart[RC_SLOTS] = sum;
+        }
+        lds_barrier();
+        // ---- C: the hits (one per index record of every minimizer); every segment start closes the segment before it ----
+#pragma unroll
+        for (int q = 0; q < RC_PER; ++q) {
+            const uint32_t i = (uint32_t)tid + (uint32_t)q * RC_THREADS;
+            const uint32_t seg = s_seg[i];
+            if (seg == i + 1 && i > 0 && s_seg[i - 1]) s_end[s_seg[i - 1] - 1] = (uint16_t)i;
+            if (i == RC_SLOTS - 1 && seg) s_end[seg - 1] = (uint16_t)RC_SLOTS;
+            const uint32_t cnt = crec[q].y;
+            if (!cnt) continue;
+            const uint32_t h0 = s_hstart[i], lead = s_lead[i];
+            const uint32_t pos = (uint32_t)s_pos1[i] - 1, strand = crec[q].z >> 31;
+            if (h0 + cnt > (uint32_t)RC_HCAP || pos >= 0xFFFEu) {
+                if (lead && lead <= n_own) s_cplx[lead - 1] = 1;
+                continue;
+            }
+            s_grp[h0] = (uint16_t)((crec[q].z >> 16) & 0x7FFFu);
+            s_hpos[h0] = (uint16_t)pos;
+            s_cov[h0] = crec[q].w;
+            for (uint32_t r = 1; r < cnt; ++r) { // rare: a k-mer that several k-mer nodes share
+                const uint32_t kn = a.rec_knode[crec[q].x + r], prg = a.rec_prg[crec[q].x + r];
+                const uint32_t rev = ((kn & 1u) == strand) ? 0u : 1u;
+                s_grp[h0 + r] = (uint16_t)((prg << 1) | rev);
+                s_hpos[h0 + r] = (uint16_t)pos;
+                s_cov[h0 + r] = (kn >> 1) * 2u + rev;
+            }
+        }
+        lds_barrier();
+        // ---- D: a minimizer whose group differs from the previous one of its read makes the read irregular; the first
+        // minimizer of a segment names the segment's group and threshold ----
+#pragma unroll
+        for (int q = 0; q < RC_PER; ++q) {
+            const uint32_t i = (uint32_t)tid + (uint32_t)q * RC_THREADS;
+            const uint32_t lead = s_lead[i], cnt = crec[q].y;
+            if (!cnt || lead == 0 || lead > n_own) continue;
+            const uint32_t first = lead - 1, seg = (uint32_t)s_seg[i] - 1, h0 = s_hstart[i];
+            if (h0 + cnt > (uint32_t)RC_HCAP) continue; // complex already
+            const uint32_t g = (crec[q].z >> 16) & 0x7FFFu;
+            bool irregular = false;
+            for (uint32_t r = 1; r < cnt; ++r) irregular |= s_grp[h0 + r] != g;
+            int j = (int)i - 1; // the previous minimizer of the read
+            while (j >= (int)first && !s_pos1[j]) --j;
+            if (j >= (int)first && s_grp[s_hstart[j]] != g) irregular = true; // (s_hstart[j] <= h0 < RC_HCAP)
+            if (j < (int)seg) s_gt[seg] = crec[q].z & 0x7FFFFFFFu;
+            if (irregular) s_irrf[first] = 1;
+        }
+        if (tid == 0 && s_read[RC_SLOTS] == s_read[RC_SLOTS - 1]) { // the last staged read runs on past the staged range
+            const uint32_t lead = s_lead[RC_SLOTS - 1];
+            if (lead && lead <= n_own) s_cplx[lead - 1] = 1;
+        }
+        lds_barrier();
+        // ---- E: the first slot of every segment decides for the segment; reads with several groups queue for the wave path ----
+        uint32_t dec[RC_PER];
+#pragma unroll
+        for (int q = 0; q < RC_PER; ++q) {
+            const uint32_t i = (uint32_t)tid + (uint32_t)q * RC_THREADS;
+            const uint32_t lead = s_lead[i];
+            dec[q] = 0xFFFFFFFFu; // not the first slot of a segment
+            if (i >= n_loaded || s_seg[i] != i + 1 || lead == 0 || lead > n_own) continue;
+            uint32_t flags = (s_cplx[lead - 1] ? RC_COMPLEX : 0u) | (s_irrf[lead - 1] ? RC_IRREGULAR : 0u);
+            if (lead == i + 1) { // first slot of the read
+                if (flags & RC_COMPLEX) ++my_complex;
+                else if (flags & RC_IRREGULAR) {
+                    uint32_t e = i; // the first slot after the read: follow its segments
+                    for (uint32_t sg = i; sg < (uint32_t)RC_SLOTS && s_lead[sg] == lead; sg = s_end[sg]) e = s_end[sg];
+                    const uint32_t at = atomicAdd(&s_n_irr, 1u);
+                    if (at < (uint32_t)RC_POOL) s_irr[at] = i | (e << 16);
+                    else ++my_complex;
+                }
+            }
+            const uint32_t n_hits = s_hstart[s_end[i]] - s_hstart[i];
+            dec[q] = 0; // 0 leave alone, 1 handled, 2 handled and every hit counts
+            if (!flags && n_hits) {
+                const uint32_t g_thr = s_gt[i];
+                dec[q] = 1;
+                if (n_hits > (g_thr & 0xFFFFu)) {
+                    dec[q] = 2;
+                    atomicAdd(&s_hist[g_thr >> 17], 1u);
+                    ++my_kept;
+                    my_kept_hits += n_hits;
+                }
+            }
+        }
+        lds_barrier(); // all thresholds are read
+#pragma unroll
+        for (int q = 0; q < RC_PER; ++q)
+            if (dec[q] != 0xFFFFFFFFu) s_gt[(uint32_t)tid + (uint32_t)q * RC_THREADS] = dec[q];
+        lds_barrier();
+        // ---- F: the minimizers of the kept segments ----
+        {
+#pragma unroll
+            for (int q = 0; q < RC_PER; ++q) {
+                const uint32_t i = (uint32_t)tid + (uint32_t)q * RC_THREADS;
+                const uint32_t lead = s_lead[i], cnt = crec[q].y;
+                if (!cnt || lead == 0 || lead > n_own) continue;
+                const uint32_t decision = s_gt[(uint32_t)s_seg[i] - 1];
+                if (!decision) continue;
+                fw.cand_pos1[base + i] = 0; // handled
+                if (decision == 2) {
+                    atomicAdd(&rc.covg[crec[q].w], 1u);
+                    const uint32_t h0 = s_hstart[i];
+                    for (uint32_t r = 1; r < cnt; ++r) atomicAdd(&rc.covg[s_cov[h0 + r]], 1u);
+                }
+            }
+        }
+        // ---- G: reads with hits in several groups, one wave per read: lane j holds cluster j, the hits are broadcast one by one
+        // (clusters per group split at gaps, size threshold, the overlap sweep of cluster_filter_kernel) ----
+        const uint32_t n_irr = s_n_irr < (uint32_t)RC_POOL ? s_n_irr : (uint32_t)RC_POOL;
+        for (uint32_t r = wave; r < n_irr; r += RC_WAVES) {
+            const uint32_t i = s_irr[r] & 0xFFFFu, e = s_irr[r] >> 16;
+            const uint32_t read = s_read[i], hb = s_hstart[i], he = s_hstart[e];
+            uint32_t cl_g = 0, cl_n = 0, cl_first = 0, cl_last = 0;
+            int nc = 0;
+            bool complex = false;
+            for (uint32_t b = hb; b < he && !complex; b += 64) {
+                const uint32_t h = b + lane;
+                const uint32_t hg = h < he ? s_grp[h] : 0u, hp = h < he ? s_hpos[h] : 0u;
+                const int nb = he - b < 64u ? (int)(he - b) : 64;
+                for (int t = 0; t < nb; ++t) {
+                    const uint32_t g = __builtin_amdgcn_readlane(hg, t), pos = __builtin_amdgcn_readlane(hp, t);
+                    const uint64_t mm = __ballot(lane < nc && cl_g == g);
+                    if (mm) {
+                        const int f = 63 - __clzll((long long)mm);
+                        const uint32_t last_f = __shfl(cl_last, f);
+                        if ((int)(pos - last_f) <= rc.max_diff) {
+                            if (lane == f) {
+                                ++cl_n;
+                                cl_last = pos;
+                            }
+                            continue;
+                        }
+                    }
+                    if (nc == 64) { complex = true; break; }
+                    if (lane == nc) {
+                        cl_g = g;
+                        cl_n = 1;
+                        cl_first = cl_last = pos;
+                    }
+                    ++nc;
+                }
+            }
+            if (complex) {
+                if (lane == 0) ++my_complex;
+                continue;
+            }
+            const uint64_t len = a.offsets[read + 1] - a.offsets[read];
+            const uint64_t expected = len * 2 / (uint64_t)(a.w + 1);
+            bool kept = false;
+            if (lane < nc) {
+                uint64_t m = rc.prg_min_path_len[cl_g >> 1];
+                if (expected < m) m = expected;
+                const uint32_t length_based = (uint32_t)((double)m * rc.fraction);
+                const uint32_t thr = length_based > rc.min_cluster_size ? length_based : rc.min_cluster_size;
+                kept = cl_n > thr;
+            }
+            uint64_t alive = __ballot(kept);
+            if (alive & (alive - 1)) {
+                // rank in cluster order: first position, larger first, prg, forward first
+                uint32_t rank = 0;
+                for (uint64_t mm = alive; mm; mm &= mm - 1) {
+                    const int o = __ffsll((long long)mm) - 1;
+                    const uint32_t of = __shfl(cl_first, o), on = __shfl(cl_n, o), og = __shfl(cl_g, o);
+                    rank += (of < cl_first || (of == cl_first && (on > cl_n || (on == cl_n && og < cl_g)))) ? 1u : 0u;
+                }
+                const int nk = __popcll(alive);
+                int prev = -1;
+                uint32_t pg = 0, pn = 0, p_last = 0;
+                for (int o = 0; o < nk; ++o) {
+                    const int cur = __ffsll((long long)__ballot(kept && rank == (uint32_t)o)) - 1;
+                    const uint32_t cg = __shfl(cl_g, cur), cn = __shfl(cl_n, cur), c_last = __shfl(cl_last, cur);
+                    if (prev >= 0) {
+                        const bool same_prg_other_strand = (pg >> 1) == (cg >> 1) && (pg & 1u) != (cg & 1u);
+                        if (same_prg_other_strand || c_last <= p_last) {
+                            if (pn >= cn) {
+                                alive &= ~(1ull << cur);
+                                continue;
+                            }
+                            alive &= ~(1ull << prev);
+                        }
+                    }
+                    prev = cur;
+                    pg = cg;
+                    pn = cn;
+                    p_last = c_last;
+                }
+            }
+            if ((alive >> lane) & 1ull) {
+                atomicAdd(&s_hist[cl_g >> 1], 1u);
+                ++my_kept;
+                my_kept_hits += cl_n;
+            }
+            for (uint32_t b = hb; b < he; b += 64) { // every hit finds its cluster among the survivors
+                const uint32_t h = b + lane;
+                const uint32_t hg = h < he ? s_grp[h] : 0xFFFFFFFFu, hp = h < he ? s_hpos[h] : 0u;
+                for (uint64_t mm = alive; mm; mm &= mm - 1) {
+                    const int o = __ffsll((long long)mm) - 1;
+                    const uint32_t og = __shfl(cl_g, o), of = __shfl(cl_first, o), ol = __shfl(cl_last, o);
+                    if (hg == og && hp >= of && hp <= ol) atomicAdd(&rc.covg[s_cov[h]], 1u);
+                }
+            }
+            for (uint32_t c = i + lane; c < e; c += 64)
+                if (s_pos1[c]) fw.cand_pos1[base + c] = 0; // handled
+        }
+    }
+    // ---- workgroup totals ----
+    if (my_kept) atomicAdd(&s_tot[0], (unsigned long long)my_kept);
+    if (my_kept_hits) atomicAdd(&s_tot[1], my_kept_hits);
+    if (my_complex) atomicAdd(&s_tot[2], (unsigned long long)my_complex);
+    __syncthreads();
+    for (uint32_t i = tid; i < rc.n_prgs; i += RC_THREADS)
+        if (s_hist[i]) atomicAdd(&rc.prg_reads[i], s_hist[i]);
+    if (tid == 0) {
+        if (s_tot[0]) atomicAdd(rc.n_clusters_kept, s_tot[0]);
+        if (s_tot[1]) atomicAdd(rc.n_hits_kept, s_tot[1]);
+        if (s_tot[2]) atomicAdd(rc.n_complex, s_tot[2]);
+    }
+}
+
+// DRPRG_FT_DEBUG=8: no read_cluster_kernel; the generic pipeline runs iff there is a hit
+__global__ void flag_complex_kernel(const unsigned long long* n_hits, unsigned long long* n_complex)
+{
+    if (*n_hits) *n_complex = 1;
+}
+
+hipError_t launch_read_cluster(const SketchArgs& a, const FilterWork& fw, const ReadClusterArgs& rc, int n_cus, bool skip, hipStream_t stream)
+{
+    if (skip) {
+        hipLaunchKernelGGL(flag_complex_kernel, dim3(1), dim3(1), 0, stream, a.n_hits, rc.n_complex);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(read_cluster_kernel, dim3((uint32_t)n_cus * 2), dim3(RC_THREADS), (size_t)rc.n_prgs * sizeof(uint32_t), stream, a, fw, rc);
+    return hipGetLastError();
+}
+
+} // namespace dev
+} // namespace drprg
