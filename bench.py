@@ -183,11 +183,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    # test hook for boxes with fewer GPUs than ranks: DRPRG_BENCH_BACKEND=gloo puts every rank on GPU 0 and reduces
+    # through gloo, which exercises the N > 1 control flow of this file (not a benchmark configuration)
+    backend = os.environ.get("DRPRG_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)  # nccl == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)  # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
 
     from drprg_amd import Context, synth
 
@@ -213,35 +221,62 @@ def main():
     n_bases = int(bases.numel())
     del hap_pad
     torch.cuda.empty_cache()
-    # the reduced vector: per-node coverage and per-PRG cluster counts in one buffer (one memset, one all-reduce)
-    acc = torch.zeros(2 * ctx.n_knodes + ctx.n_prgs, dtype=torch.int32, device=device)
-    covg, prg_reads = acc[: 2 * ctx.n_knodes], acc[2 * ctx.n_knodes:]
-    stream = torch.cuda.Stream(device)  # the hot path and the collective run on this stream
+    # the reduced vector: per-node coverage and per-PRG cluster counts in one buffer (one memset, one all-reduce).  With
+    # N > 1 two buffers alternate: the all-reduce of step i runs on RCCL's stream while step i+1 maps into the other
+    # buffer; a buffer is only zeroed again once its reduce has finished (every step's collective completes inside the
+    # timed region: drain() before the closing barrier).  DRPRG_BENCH_SYNC_REDUCE=1: one buffer, the stream waits for
+    # every reduce before the next step starts.
+    n_acc = 2 * ctx.n_knodes + ctx.n_prgs
+    overlap = world > 1 and os.environ.get("DRPRG_BENCH_SYNC_REDUCE", "0") in ("", "0")
+    accs = [torch.zeros(n_acc, dtype=torch.int32, device=device) for _ in range(2 if overlap else 1)]
+    pending = [None] * len(accs)
+    stream = torch.cuda.Stream(device)  # the hot path runs on this stream; the collective is ordered behind it
     torch.cuda.synchronize()
+    step_no = [0]
 
     def step():
+        b = step_no[0] % len(accs)
+        step_no[0] += 1
+        acc = accs[b]
         with torch.cuda.stream(stream):
+            if pending[b] is not None:
+                pending[b].wait()  # (the stream waits, not the host)
+                pending[b] = None
             acc.zero_()
-            ctx.map_device(bases.data_ptr(), offsets.data_ptr(), n_reads, n_bases, covg.data_ptr(), prg_reads.data_ptr(),
-                           stream.cuda_stream)
+            ctx.map_device(bases.data_ptr(), offsets.data_ptr(), n_reads, n_bases, acc.data_ptr(),
+                           acc.data_ptr() + 8 * ctx.n_knodes, stream.cuda_stream)
             if world > 1:
-                dist.all_reduce(acc)
+                if overlap:
+                    pending[b] = dist.all_reduce(acc, async_op=True)
+                else:
+                    dist.all_reduce(acc)
+        return acc
+
+    def drain():
+        with torch.cuda.stream(stream):
+            for b, w in enumerate(pending):
+                if w is not None:
+                    w.wait()
+                    pending[b] = None
 
     def barrier():
+        drain()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    acc = accs[0]
     for _ in range(args.warmup):
         step()
     ctx.kernel_timing(enable=True, reset=True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        acc = step()
     barrier()
     elapsed = time.perf_counter() - t0
+    covg, prg_reads = acc[: 2 * ctx.n_knodes], acc[2 * ctx.n_knodes:]  # the last step's (reduced) result
     k_ms, k_launches = ctx.kernel_timing(enable=False)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -250,6 +285,18 @@ def main():
 
     checksum = int(covg.to(torch.int64).sum().item())
     counters = ctx.counters()
+    # N > 1: the vector every rank holds must be the sum of the ranks' own vectors (one more, untimed, pass + reduce)
+    reduce_consistent = None
+    if world > 1:
+        own = torch.zeros_like(acc)
+        with torch.cuda.stream(stream):
+            ctx.map_device(bases.data_ptr(), offsets.data_ptr(), n_reads, n_bases, own.data_ptr(), own.data_ptr() + 8 * ctx.n_knodes,
+                           stream.cuda_stream)
+            dist.all_reduce(own)
+        torch.cuda.synchronize()
+        ok = torch.tensor([1 if torch.equal(own, acc) else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        reduce_consistent = bool(ok.item())
     shard_invariant = kernels_agree = None
     if world == 1 and not args.no_checks:
         shard_invariant, kernels_agree = full_size_checks(torch, ctx, opts, bases, offsets, n_reads, covg, prg_reads, stream)
@@ -286,7 +333,9 @@ def main():
                 "workload": f"{cfg_name}: {cfg_desc}",
                 "reads_per_gpu": n_reads, "bases_per_gpu": n_bases, "mean_read_len": n_bases / max(n_reads, 1), "w": W, "k": K,
                 "loci": ctx.n_prgs, "index_keys": ctx.n_keys, "kmer_nodes": ctx.n_knodes, "sharding": f"reads x{world}",
-                "collective": "all_reduce(u32 coverage) per step" if world > 1 else "none",
+                "collective": (("all_reduce(u32 coverage) per step, overlapped with the next step's mapping" if overlap
+                                else "all_reduce(u32 coverage) per step") if world > 1 else "none"),
+                "all_ranks_hold_the_sum_of_the_ranks_vectors": reduce_consistent,
                 "bases_per_s": n_bases * world * args.steps / elapsed,
                 "hits_per_batch": counters.get("hits", 0) // (args.warmup + args.steps),
                 "clusters_kept_per_batch": counters.get("clusters_kept", 0) // (args.warmup + args.steps),
