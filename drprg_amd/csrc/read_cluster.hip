@@ -400,7 +400,13 @@ hipError_t launch_read_cluster(const SketchArgs& a, const FilterWork& fw, const 
         hipLaunchKernelGGL(flag_complex_kernel, dim3(1), dim3(1), 0, stream, a.n_hits, rc.n_complex);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(read_cluster_kernel, dim3((uint32_t)n_cus * 2), dim3(RC_THREADS), (size_t)rc.n_prgs * sizeof(uint32_t), stream, a, fw, rc);
+    const size_t dyn = (size_t)rc.n_prgs * sizeof(uint32_t); // the per-PRG histogram, behind ~70 KB of static LDS
+    static size_t configured = 0;
+    if (dyn > configured) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&read_cluster_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+        configured = dyn;
+    }
+    hipLaunchKernelGGL(read_cluster_kernel, dim3((uint32_t)n_cus * 2), dim3(RC_THREADS), dyn, stream, a, fw, rc);
     return hipGetLastError();
 }
 

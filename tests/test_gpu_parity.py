@@ -16,19 +16,19 @@ import os
 FORCED_GENERIC = bool(int(os.environ.get("DRPRG_FT_DEBUG", "0") or 0) & 8)
 
 
-def _ctx(tmp_path, panel, w, k, illumina, genome_size=20000, kernel=0):
+def _ctx(tmp_path, panel, w, k, illumina, genome_size=20000, kernel=0, min_cluster_size=10):
     from drprg_amd import Context
     prg = str(tmp_path / "dr.prg")
     panel.write(prg, str(tmp_path / "genes.fa"))
     ctx = Context(prg, w, k, device=0, from_files=False)
-    ctx.set_opts(illumina=illumina, genome_size=genome_size, kernel=kernel)
+    ctx.set_opts(illumina=illumina, genome_size=genome_size, kernel=kernel, min_cluster_size=min_cluster_size)
     return ctx
 
 
-def _compare(ctx, oracle, bases, offsets, w, k, illumina, kernel):
+def _compare(ctx, oracle, bases, offsets, w, k, illumina, kernel, min_cluster_size=10):
     idx = ctx.export_index()
     md, er = map_params(k, illumina)
-    ocov, oprg, ocnt = oracle.map_reads(bases, offsets, idx, w, k, md, cluster_fraction(er, k), 10)
+    ocov, oprg, ocnt = oracle.map_reads(bases, offsets, idx, w, k, md, cluster_fraction(er, k), min_cluster_size)
     ctx.reset()
     ctx.map_host(bases, offsets)
     gcov, gprg = ctx.coverage()
@@ -207,6 +207,22 @@ def test_reads_longer_than_the_staged_range(tmp_path, oracle):
         assert cnt["clusters_kept"] > 500
         if kernel == 2 and not FORCED_GENERIC:
             assert 20 <= ctx.counters()["leftover_reads"] <= 100  # most 9 kb reads (a few fit: 2048 candidates are staged)
+
+
+def test_many_small_prgs(tmp_path, oracle):
+    """3000 loci of 56 bp (the most the LDS filter takes at ~8 k-mer nodes each): PRG ids up to 12 bits in the hit key, a
+    12 KB per-PRG histogram in read_cluster_kernel and cluster_count_kernel, every read spans three loci (three clusters
+    of a few hits each: min_cluster_size 2)"""
+    from drprg_amd import synth
+    rng = np.random.default_rng(17)
+    loci = [[synth.random_seq(rng, 56)] for _ in range(3000)]
+    panel = synth.Panel([f"p{i}" for i in range(3000)], loci)
+    genome = "".join(l[0] for l in loci).encode()
+    bases, offs = _reads_from(rng, [genome], 6000, 150, sub_rate=0.001)
+    for kernel in (1, 2):
+        ctx = _ctx(tmp_path, panel, 11, 15, True, kernel=kernel, min_cluster_size=2)
+        cnt = _compare(ctx, oracle, bases, offs, 11, 15, True, kernel, min_cluster_size=2)
+        assert cnt["clusters_kept"] > 1000
 
 
 def test_batches_accumulate(tmp_path, oracle):
