@@ -225,6 +225,35 @@ def test_many_small_prgs(tmp_path, oracle):
         assert cnt["clusters_kept"] > 1000
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("DRPRG_FUZZ_SEEDS", "12"))))
+def test_randomized_configurations(tmp_path, oracle, seed):
+    """seeded random (w, k, technology, min_cluster_size, panel shape, read-length mix): ragged short reads, reads across
+    duplicated loci, a few long ones -- whatever combination of the per-read kernel's paths that produces"""
+    from drprg_amd import synth
+    rng = np.random.default_rng(1000 + seed)
+    k = int(rng.choice([9, 11, 13, 15, 15, 15]))
+    w = int(rng.integers(1, 17))
+    illumina = bool(rng.integers(0, 2))
+    mcs = int(rng.choice([1, 2, 5, 10]))
+    n_loci = int(rng.integers(2, 7))
+    trees = [synth.make_locus(rng, int(rng.integers(300, 1500)), site_every=int(rng.integers(25, 90))) for _ in range(n_loci)]
+    if rng.random() < 0.5:
+        trees.append(trees[0])  # a duplicated locus: hits in two groups
+    panel = synth.Panel([f"l{i}" for i in range(len(trees))], trees)
+    seqs = [synth.sample_haplotype(rng, t).encode() for t in trees for _ in range(2)] + [synth.random_seq(rng, 4000).encode()]
+    parts = []
+    for length, n in ((int(rng.integers(16, 60)), 300), (150, 1500), (int(rng.integers(200, 700)), 400), (int(rng.integers(1500, 4000)), 40)):
+        parts.append(_reads_from(rng, seqs, n, length, sub_rate=float(rng.choice([0.0, 0.002, 0.02]))))
+    bases = np.concatenate([p[0] for p in parts])
+    offs = [np.zeros(1, np.uint64)]
+    for p in parts:
+        offs.append(p[1][1:] + offs[-1][-1])
+    offs = np.concatenate(offs)
+    for kernel in (1, 2):
+        ctx = _ctx(tmp_path, panel, w, k, illumina, kernel=kernel, min_cluster_size=mcs)
+        _compare(ctx, oracle, bases, offs, w, k, illumina, kernel, min_cluster_size=mcs)
+
+
 def test_batches_accumulate(tmp_path, oracle):
     """mapping in several batches == mapping in one (coverage is additive)"""
     from drprg_amd import synth
