@@ -102,12 +102,13 @@ __global__ __launch_bounds__(EX_THREADS) void verify_count_kernel(SketchArgs a, 
     const uint32_t kmask = (1u << (2 * k)) - 1;
     const int64_t n_bases = (int64_t)a.n_bases;
     const double reads_per_base = (double)a.n_reads / (double)(a.n_bases ? a.n_bases : 1);
+    const int64_t win_lo = (int64_t)a.offsets[fw.read_begin], win_hi = (int64_t)a.offsets[fw.read_end];
     uint32_t my_hits = 0, my_nmin = 0, my_maxlen = 0;
     for (uint32_t t = t_begin + tid; t < t_end; t += EX_THREADS) {
         const int64_t gp = (int64_t)fw.cand_info[t]; // position now, (slot, strand, read) when this lane is done
         uint32_t pos1 = 0, slot = 0, read = READ_NONE, strand = 0;
         uint4 crec = make_uint4(0, 0, 0, 0);
-        if (gp + k <= n_bases) {
+        if (gp >= win_lo && gp < win_hi && gp + k <= n_bases) { // (the boundary tiles of a read range reach past it)
             // the read of every candidate, index k-mer or not: read_cluster_kernel finds the first candidate of a read by
             // comparing neighbours (interpolated first guess: exact for fixed-length reads, a short gallop otherwise)
             read = find_read_near(a.offsets, a.n_reads, (uint32_t)((double)gp * reads_per_base), (uint64_t)gp);
@@ -267,7 +268,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void hit_scan_kernel(SketchArgs a, Fi
             m = s_m[i] > m ? s_m[i] : m;
         }
         *a.n_hits = (unsigned long long)total;
-        if (n && !recount) atomicAdd(a.n_minimizers, (unsigned long long)n);
+        // (a sequence whose candidate slices overflowed is run again by the host: it must not count twice)
+        if (n && !recount && !(*reinterpret_cast<volatile uint32_t*>(a.overflow) & 4u)) atomicAdd(a.n_minimizers, (unsigned long long)n);
         *fw.max_len = (unsigned long long)m;
     }
 }

@@ -123,9 +123,9 @@ struct FilterWork {
     const uint32_t* bloom0;  // level 0 (nullptr / 0: absent)
     uint32_t bloom0_wbits;
     const uint32_t* bloomr;  // second stage of the level-0 form
-    uint32_t n_tiles;        // wave tiles of FT_WPOS positions
-    uint32_t tiles_per_wave; // wave g owns tiles [g * tiles_per_wave, (g+1) * tiles_per_wave)
-    uint32_t tiles_per_slice; // ... and starts a new slice every tiles_per_slice tiles
+    uint32_t read_begin, read_end; // this launch sequence maps reads [read_begin, read_end) of the batch: the filter kernel
+                             // streams the wave tiles (FT_WPOS positions each) that cover their bases, candidates
+                             // outside [offsets[read_begin], offsets[read_end]) are dropped by verify_count_kernel
     uint32_t n_slices;       // slices of the candidate buffers (a fixed number per filter wave)
     uint32_t raw_slice;      // capacity of one slice
     uint64_t* raw_pos;       // [n_slices][raw_slice]: global base position of a candidate k-mer, ascending per slice
@@ -163,8 +163,10 @@ size_t filter_small_words();
 // filter -> candidates -> verify -> per-read clustering of the reads that fit read_cluster_kernel (coverage, PRG read
 // counts and the kept-cluster counters are updated); a.n_hits receives the number of hits of the whole batch,
 // rc.n_complex the number of reads left over.  fw is filled for the two follow-up calls.
-hipError_t launch_sketch_filter(const SketchArgs& a, const BloomTables& bt, int n_cus, const FilterBuffers& b, const ReadClusterArgs& rc,
-    FilterWork& fw, hipStream_t stream, KernelTimer timer = {});
+// Reads [read_begin, read_end) of the batch only (their bases are located on the device): the host can run several such
+// sequences, each with its own FilterBuffers and scratch counters, on different streams.
+hipError_t launch_sketch_filter(const SketchArgs& a, uint32_t read_begin, uint32_t read_end, const BloomTables& bt, int n_cus,
+    const FilterBuffers& b, const ReadClusterArgs& rc, FilterWork& fw, hipStream_t stream, KernelTimer timer = {});
 // leftover reads: a.n_hits receives the number of their hits, b.max_len their longest read ...
 hipError_t launch_filter_recount(const SketchArgs& a, const FilterWork& fw, hipStream_t stream);
 // ... and their hits are written to a.hit_key / a.hit_val ordered by (read, position)

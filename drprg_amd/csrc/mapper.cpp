@@ -322,7 +322,7 @@ void Mapper::run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32
             rc.n_hits_kept = &d_counters_[C_HITS_KEPT];
             rc.n_complex = &d_counters_[C_COMPLEX];
             rc.chunk_counter = reinterpret_cast<uint32_t*>(&d_counters_[C_CHUNK]);
-            HIPCHK(dev::launch_sketch_filter(a, bt, n_cus_, fb, rc, fw, stream, timer));
+            HIPCHK(dev::launch_sketch_filter(a, 0, n_reads, bt, n_cus_, fb, rc, fw, stream, timer));
             read_counters(stream, true);
             note_kernel_time();
             const uint32_t ovf = (uint32_t)h_counters_[C_OVERFLOW];

@@ -102,10 +102,15 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
     // every wave owns a contiguous range of tiles and FT_SUB consecutive slices of the candidate buffers: it moves on to its
     // next slice every tiles_per_slice tiles (more, shorter slices: more parallelism for refine_kernel / cand_gather_kernel)
     const uint32_t gw = blockIdx.x * FT_WAVES + (uint32_t)(tid >> 6);
-    uint32_t tile = gw * fw.tiles_per_wave;
-    const uint32_t tile_end = tile + fw.tiles_per_wave < fw.n_tiles ? tile + fw.tiles_per_wave : fw.n_tiles;
+    // the tiles that cover the bases of reads [read_begin, read_end), split evenly over the waves of the grid
+    const uint64_t win_lo = a.offsets[fw.read_begin], win_hi = a.offsets[fw.read_end];
+    const uint32_t t_lo = (uint32_t)(win_lo / FT_WPOS), t_hi = (uint32_t)((win_hi + FT_WPOS - 1) / FT_WPOS);
+    const uint32_t n_waves = gridDim.x * FT_WAVES;
+    const uint32_t tiles_per_wave = (t_hi - t_lo + n_waves - 1) / n_waves, tiles_per_slice = tiles_per_wave ? (tiles_per_wave + FT_SUB - 1) / FT_SUB : 1u;
+    uint32_t tile = t_lo + gw * tiles_per_wave;
+    const uint32_t tile_end = tile + tiles_per_wave < t_hi ? tile + tiles_per_wave : t_hi;
     constexpr uint32_t step = 1;
-    uint32_t slice = gw * FT_SUB, next_slice_at = tile + fw.tiles_per_slice;
+    uint32_t slice = gw * FT_SUB, next_slice_at = tile + tiles_per_slice;
 
     auto load16 = [&](int64_t g) -> uint4 { // 16 bases at global position g (a multiple of 16)
         if (g + 16 <= n_bases) return *reinterpret_cast<const uint4*>(a.bases + g);
@@ -150,7 +155,7 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
         if (t == next_slice_at) { // wave-uniform
             close_slice();
             ++slice;
-            next_slice_at += fw.tiles_per_slice;
+            next_slice_at += tiles_per_slice;
             out += fw.raw_slice;
             if (LEVEL0) grp_out += fw.raw_slice;
             wcur = 0;
@@ -348,10 +353,12 @@ uint32_t filter_grid(bool level0, int n_cus, uint32_t n_tiles)
 
 size_t filter_small_words() { return (size_t)MAX_SLICES * 3 + 1 + 4 * (size_t)MAX_EX_WG; }
 
-hipError_t launch_sketch_filter(const SketchArgs& a, const BloomTables& bt, int n_cus, const FilterBuffers& b, const ReadClusterArgs& rc,
-    FilterWork& fw, hipStream_t stream, KernelTimer timer)
+hipError_t launch_sketch_filter(const SketchArgs& a, uint32_t read_begin, uint32_t read_end, const BloomTables& bt, int n_cus,
+    const FilterBuffers& b, const ReadClusterArgs& rc, FilterWork& fw, hipStream_t stream, KernelTimer timer)
 {
     fw = FilterWork {};
+    fw.read_begin = read_begin;
+    fw.read_end = read_end;
     if (a.n_bases == 0) return hipSuccess;
     if ((1u << bt.bloom_wbits) > (uint32_t)FT_BLOOM_WORDS) return hipErrorInvalidValue;
     if (bt.bloom0 && (1u << bt.bloom0_wbits) != (uint32_t)FT_L0_WORDS) return hipErrorInvalidValue;
@@ -364,11 +371,8 @@ hipError_t launch_sketch_filter(const SketchArgs& a, const BloomTables& bt, int 
     fw.bloomr = bt.bloomr;
     fw.bloom0 = level0 ? bt.bloom0 : nullptr;
     fw.bloom0_wbits = level0 ? bt.bloom0_wbits : 0;
-    fw.n_tiles = filter_n_tiles(a.n_bases);
-    const uint32_t grid = filter_grid(level0, n_cus, fw.n_tiles);
+    const uint32_t grid = filter_grid(level0, n_cus, filter_n_tiles(a.n_bases));
     fw.n_slices = grid * FT_WAVES * FT_SUB;
-    fw.tiles_per_wave = (fw.n_tiles + grid * FT_WAVES - 1) / (grid * FT_WAVES);
-    fw.tiles_per_slice = (fw.tiles_per_wave + FT_SUB - 1) / FT_SUB;
     fw.raw_slice = (uint32_t)std::min<uint64_t>(b.raw_capacity / fw.n_slices, 0x7FFFFFFFull / fw.n_slices);
     fw.raw_pos = b.raw_pos;
     fw.cand_info = b.cand_info;
