@@ -28,7 +28,7 @@ $(OBJD)/%.o: $(SRC)/%.cpp $(wildcard $(SRC)/*.h) include/drprg_hip.h
 	@mkdir -p $(OBJD)
 	$(HIPCC) $(CXXFLAGS) -x hip --offload-arch=$(ARCH) -c $< -o $@
 
-$(OBJD)/%.o: $(SRC)/%.hip $(SRC)/kernels.h $(SRC)/device_common.h $(SRC)/filter_common.h
+$(OBJD)/%.o: $(SRC)/%.hip $(wildcard $(SRC)/*.h) include/drprg_hip.h
 	@mkdir -p $(OBJD)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 

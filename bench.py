@@ -307,7 +307,11 @@ def main():
         # algorithmic bytes per launch: sum(L + 8) over the reads + index table + 8 B per k-mer node
         table_bytes = ctx.n_slots * (4 + 8) + ctx.n_records * (4 + 2)
         alg_bytes = n_bases + 8 * n_reads + table_bytes + 8 * ctx.n_knodes
+        # a batch may be mapped as several read ranges (one launch of the dominant kernel each, on concurrent streams): the
+        # roofline prices one launch = its share of the batch's algorithmic bytes over its own duration (HIP events)
+        launches_per_step = max(k_launches, 1) / args.steps
         avg_ms = k_ms / max(k_launches, 1)
+        alg_bytes = alg_bytes / launches_per_step
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         kernel_name = {1: "sketch_probe_kernel", 2: "sketch_filter_kernel"}.get(counters.get("kernel"), "?")
         # HBM bytes per launch of that kernel from rocprofv3 PMC counters (separate --pmc passes, FETCH_SIZE doubled as
@@ -316,6 +320,8 @@ def main():
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if n_reads == default_reads and os.path.exists(tfile):
             traffic = json.load(open(tfile)).get(args.workload, {}).get(kernel_name, {}).get("hbm_bytes_per_launch")
+            if traffic is not None:
+                traffic = traffic / launches_per_step  # (measured per batch)
         out = {
             "metric": "reads/sec (+ achieved HBM GB/s) predicting on mtb index, 1/2/4/8 GPUs",
             "value": value,
@@ -345,7 +351,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
-                "avg_launch_ms": avg_ms, "launches_timed": k_launches,
+                "avg_launch_ms": avg_ms, "launches_timed": k_launches, "launches_per_step": launches_per_step,
             },
         }
         # CPU baseline: the oracle (a scalar port of the same path, oracle/oracle.c) on a bounded sample of rank 0's shard,

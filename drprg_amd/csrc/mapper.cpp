@@ -106,7 +106,8 @@ Mapper::Mapper(const FlatIndex& idx, const MapParams& p, int device) : device_(d
     }
     HIPCHK(hipDeviceGetAttribute(&n_cus_, hipDeviceAttributeMultiprocessorCount, device_));
     set_params(p); // again: the kernel choice depends on the filter being available
-    dmalloc(d_filter_small_, dev::filter_small_words());
+    if (const char* e = std::getenv("DRPRG_HIP_LANES")) max_lanes_ = std::min(4, std::max(1, std::atoi(e)));
+    if (const char* e = std::getenv("DRPRG_HIP_LANES_MIN_BASES")) lanes_min_bases_ = std::strtoull(e, nullptr, 10); // (tests: 0)
     dmalloc(d_covg_, 2 * (size_t)n_knodes_);
     dmalloc(d_prg_reads_, (size_t)n_prgs_);
     dmalloc(d_counters_, (size_t)C_N);
@@ -126,8 +127,9 @@ Mapper::~Mapper()
     dfree(d_key_a_); dfree(d_key_b_); dfree(d_val_a_); dfree(d_val_b_);
     dfree(d_head_); dfree(d_scan_); dfree(d_cstart_); dfree(d_order_); dfree(d_clusters_);
     if (d_temp_) (void)hipFree(d_temp_);
-    dfree(d_bases_); dfree(d_offsets_); dfree(d_tile_first_); dfree(d_bloom_); dfree(d_bloom0_); dfree(d_bloomr_); dfree(d_pbloom_); dfree(d_filter_small_);
-    dfree(d_raw_pos_); dfree(d_raw_grp_); dfree(d_cand_info_); dfree(d_cand_pos1_); dfree(d_cand_rec_);
+    dfree(d_bases_); dfree(d_offsets_); dfree(d_tile_first_); dfree(d_bloom_); dfree(d_bloom0_); dfree(d_bloomr_); dfree(d_pbloom_);
+    for (Lane& lane : lanes_) free_lane(lane);
+    if (ev_begin_) (void)hipEventDestroy(ev_begin_);
     if (h_counters_) (void)hipHostFree(h_counters_);
     if (h_bases_) (void)hipHostFree(h_bases_);
     if (h_offsets_) (void)hipHostFree(h_offsets_);
@@ -188,25 +190,109 @@ void Mapper::ensure_workspace(uint64_t cap)
     HIPCHK(hipMalloc(&d_temp_, temp_bytes_ ? temp_bytes_ : 1));
 }
 
-void Mapper::ensure_raw_workspace(uint64_t cap)
+void Mapper::free_lane(Lane& lane)
 {
-    if (cap <= raw_capacity_) return;
-    if (cap >= (1ull << 31)) throw Error(DRPRG_EOVERFLOW, "more than 2^31 candidate k-mers in one batch; map smaller batches");
-    dfree(d_raw_pos_); dfree(d_raw_grp_); dfree(d_cand_info_); dfree(d_cand_pos1_); dfree(d_cand_rec_);
-    raw_capacity_ = cap;
-    if (bloom0_wbits_) dmalloc(d_raw_grp_, cap);
-    dmalloc(d_raw_pos_, cap); dmalloc(d_cand_info_, cap); dmalloc(d_cand_pos1_, cap); dmalloc(d_cand_rec_, cap);
+    dfree(lane.raw_pos); dfree(lane.raw_grp); dfree(lane.cand_info); dfree(lane.cand_pos1); dfree(lane.cand_rec); dfree(lane.small);
+    dfree(lane.d_scratch);
+    if (lane.h_scratch) (void)hipHostFree(lane.h_scratch);
+    lane.h_scratch = nullptr;
+    if (lane.stream) (void)hipStreamDestroy(lane.stream);
+    for (hipEvent_t* e : { &lane.done, &lane.t0, &lane.t1 })
+        if (*e) (void)hipEventDestroy(*e);
+    lane = Lane();
+}
+
+void Mapper::grow_lane(Lane& lane, uint64_t cap)
+{
+    if (cap <= lane.raw_capacity) return;
+    if (cap >= (1ull << 31)) throw Error(DRPRG_EOVERFLOW, "more than 2^31 candidate k-mers in one read range; map smaller batches");
+    dfree(lane.raw_pos); dfree(lane.raw_grp); dfree(lane.cand_info); dfree(lane.cand_pos1); dfree(lane.cand_rec);
+    lane.raw_capacity = cap;
+    if (bloom0_wbits_) dmalloc(lane.raw_grp, cap);
+    dmalloc(lane.raw_pos, cap); dmalloc(lane.cand_info, cap); dmalloc(lane.cand_pos1, cap); dmalloc(lane.cand_rec, cap);
+}
+
+void Mapper::ensure_lanes(int n, uint64_t cap)
+{
+    if (!ev_begin_) HIPCHK(hipEventCreateWithFlags(&ev_begin_, hipEventDisableTiming));
+    while ((int)lanes_.size() < n) {
+        lanes_.emplace_back();
+        Lane& lane = lanes_.back();
+        if (lanes_.size() > 1) HIPCHK(hipStreamCreateWithFlags(&lane.stream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&lane.done, hipEventDisableTiming));
+        HIPCHK(hipEventCreate(&lane.t0));
+        HIPCHK(hipEventCreate(&lane.t1));
+        dmalloc(lane.small, dev::filter_small_words());
+        dmalloc(lane.d_scratch, (size_t)L_N);
+        HIPCHK(hipHostMalloc((void**)&lane.h_scratch, L_N * sizeof(unsigned long long), hipHostMallocDefault));
+        HIPCHK(hipMemset(lane.d_scratch, 0, L_N * sizeof(unsigned long long)));
+        lane.scratch_zero = true;
+    }
+    for (int j = 0; j < n; ++j) grow_lane(lanes_[j], cap);
+}
+
+// One filtered sequence for reads [lane.r0, lane.r1) of the batch, asynchronous on `stream`: kernels, then the lane's
+// counters to its pinned mirror, then the counters cleared again behind the copy (so that the next batch starts with its
+// first kernel instead of a memset).
+void Mapper::launch_lane(Lane& lane, hipStream_t stream, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads,
+    uint64_t n_bases, uint32_t* covg, uint32_t* prg_reads)
+{
+    if (!lane.scratch_zero) HIPCHK(hipMemsetAsync(lane.d_scratch, 0, L_N * sizeof(unsigned long long), stream));
+    lane.scratch_zero = false;
+    dev::SketchArgs a = sketch_args(d_bases, d_offsets, n_reads, n_bases);
+    a.n_hits = &lane.d_scratch[L_HITS];
+    a.overflow = reinterpret_cast<uint32_t*>(&lane.d_scratch[L_OVERFLOW]);
+    dev::FilterBuffers fb { lane.raw_pos, lane.raw_grp, lane.cand_info, lane.cand_pos1, lane.cand_rec, lane.raw_capacity, lane.small,
+        &lane.d_scratch[L_MAXLEN] };
+    dev::BloomTables bt { d_bloom_, bloom_wbits_, d_bloom0_, bloom0_wbits_, d_bloomr_ };
+    dev::ReadClusterArgs rc {};
+    rc.prg_min_path_len = d_min_path_len_;
+    rc.fraction = params_.cluster_fraction();
+    rc.min_cluster_size = params_.min_cluster_size;
+    rc.max_diff = params_.max_diff;
+    rc.n_prgs = n_prgs_;
+    rc.covg = covg;
+    rc.prg_reads = prg_reads;
+    rc.n_clusters_kept = &d_counters_[C_CLUSTERS_KEPT];
+    rc.n_hits_kept = &d_counters_[C_HITS_KEPT];
+    rc.n_complex = &lane.d_scratch[L_COMPLEX];
+    rc.chunk_counter = reinterpret_cast<uint32_t*>(&lane.d_scratch[L_CHUNK]);
+    dev::KernelTimer timer;
+    if (timing_) { // events bracket the dominant kernel only
+        timer.begin = lane.t0;
+        timer.end = lane.t1;
+    }
+    HIPCHK(dev::launch_sketch_filter(a, lane.r0, lane.r1, bt, n_cus_, fb, rc, lane.fw, stream, timer));
+    HIPCHK(hipMemcpyAsync(lane.h_scratch, lane.d_scratch, L_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipMemsetAsync(lane.d_scratch, 0, L_N * sizeof(unsigned long long), stream));
+    lane.scratch_zero = true;
+}
+
+// The wait polls the stream: an interrupt-driven hipStreamSynchronize wakes up tens of microseconds late, which is
+// visible at 0.6 ms per batch.
+void Mapper::wait_stream(hipStream_t stream)
+{
+    for (int spins = 0;; ++spins) {
+        const hipError_t e = hipStreamQuery(stream);
+        if (e == hipSuccess) return;
+        if (e != hipErrorNotReady) HIPCHK(e);
+        if (spins > (1 << 22)) { // something is badly late (a multi-second batch): stop burning the core
+            HIPCHK(hipStreamSynchronize(stream));
+            return;
+        }
+    }
 }
 
 // hits in d_key_a_/d_val_a_ -> clusters -> coverage (the generic pipeline).  ordered: the hits are ordered by
 // (read, position) already and no read is longer than READ_SORT_MAX_LEN, so a per-read reorder replaces the radix sort.
-void Mapper::cluster_hits(const uint64_t* d_offsets, uint32_t n_hits, bool ordered, uint32_t* covg, uint32_t* prg_reads, hipStream_t stream)
+void Mapper::cluster_hits(const uint64_t* d_offsets, uint32_t n_hits, bool ordered, unsigned long long* d_unsorted, uint32_t* covg,
+    uint32_t* prg_reads, hipStream_t stream)
 {
     if (n_hits == 0) return;
     const uint64_t* s_key = d_key_b_;
     const uint32_t* s_val = d_val_b_;
     if (ordered) {
-        HIPCHK(dev::launch_read_sort(d_key_a_, d_val_a_, n_hits, d_order_, hit_capacity_, &d_counters_[C_UNSORTED], stream));
+        HIPCHK(dev::launch_read_sort(d_key_a_, d_val_a_, n_hits, d_order_, hit_capacity_, d_unsorted, stream));
         s_key = d_key_a_;
         s_val = d_val_a_;
     } else HIPCHK(dev::sort_hits(d_temp_, temp_bytes_, d_key_a_, d_key_b_, d_val_a_, d_val_b_, n_hits, stream));
@@ -259,24 +345,10 @@ dev::SketchArgs Mapper::sketch_args(const uint8_t* d_bases, const uint64_t* d_of
     return a;
 }
 
-// Counter block -> pinned host mirror, then wait.  rezero: the per-batch scratch counters (overflow flags .. chunk counter)
-// are cleared right behind the copy, while the host is still waiting, so that the next batch starts with its first kernel
-// instead of a memset (scratch_zero_ records that they are clean).  The wait polls the stream: an interrupt-driven
-// hipStreamSynchronize wakes up tens of microseconds late, which is visible at 0.6 ms per batch.
-void Mapper::read_counters(hipStream_t stream, bool rezero)
+void Mapper::read_counters(hipStream_t stream)
 {
     HIPCHK(hipMemcpyAsync(h_counters_, d_counters_, C_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-    if (rezero) HIPCHK(hipMemsetAsync(&d_counters_[C_OVERFLOW], 0, (C_CHUNK - C_OVERFLOW + 1) * sizeof(unsigned long long), stream));
-    scratch_zero_ = rezero;
-    for (int spins = 0;; ++spins) {
-        const hipError_t e = hipStreamQuery(stream);
-        if (e == hipSuccess) break;
-        if (e != hipErrorNotReady) HIPCHK(e);
-        if (spins > (1 << 22)) { // something is badly late (a multi-second batch): stop burning the core
-            HIPCHK(hipStreamSynchronize(stream));
-            break;
-        }
-    }
+    wait_stream(stream);
 }
 
 void Mapper::note_kernel_time()
@@ -298,61 +370,70 @@ void Mapper::run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32
         timer.end = ev1_;
     }
     if (use_filter_) {
-        // ---- filtered sequence: the hits of short reads never leave the chip (read_cluster_kernel); one read-back at the end ----
-        ensure_raw_workspace(std::max<uint64_t>(1u << 20, n_bases / 64));
-        dev::FilterWork fw {};
-        for (int attempt = 0;; ++attempt) {
-            // scratch counters: overflow flags, longest leftover read, list length of the per-read reorder, leftover reads,
-            // chunk counter (normally cleared already, behind the previous batch's read-back)
-            if (!scratch_zero_)
-                HIPCHK(hipMemsetAsync(&d_counters_[C_OVERFLOW], 0, (C_CHUNK - C_OVERFLOW + 1) * sizeof(unsigned long long), stream));
-            scratch_zero_ = false;
-            const dev::SketchArgs a = sketch_args(d_bases, d_offsets, n_reads, n_bases);
-            dev::FilterBuffers fb { d_raw_pos_, d_raw_grp_, d_cand_info_, d_cand_pos1_, d_cand_rec_, raw_capacity_, d_filter_small_, &d_counters_[C_MAXLEN] };
-            dev::BloomTables bt { d_bloom_, bloom_wbits_, d_bloom0_, bloom0_wbits_, d_bloomr_ };
-            dev::ReadClusterArgs rc {};
-            rc.prg_min_path_len = d_min_path_len_;
-            rc.fraction = params_.cluster_fraction();
-            rc.min_cluster_size = params_.min_cluster_size;
-            rc.max_diff = params_.max_diff;
-            rc.n_prgs = n_prgs_;
-            rc.covg = covg;
-            rc.prg_reads = prg_reads;
-            rc.n_clusters_kept = &d_counters_[C_CLUSTERS_KEPT];
-            rc.n_hits_kept = &d_counters_[C_HITS_KEPT];
-            rc.n_complex = &d_counters_[C_COMPLEX];
-            rc.chunk_counter = reinterpret_cast<uint32_t*>(&d_counters_[C_CHUNK]);
-            HIPCHK(dev::launch_sketch_filter(a, 0, n_reads, bt, n_cus_, fb, rc, fw, stream, timer));
-            read_counters(stream, true);
-            note_kernel_time();
-            const uint32_t ovf = (uint32_t)h_counters_[C_OVERFLOW];
-            if (ovf & 8u) throw Error(DRPRG_EIO, "sketch_filter_kernel: dynamic LDS does not start at address 0");
-            if (ovf & 2u) throw Error(DRPRG_EOVERFLOW, "a read is longer than 2^" + std::to_string(dev::HIT_POS_BITS) + " bases");
-            if (ovf & 4u) { // a wave's candidate slice was too small (read_cluster_kernel did nothing): grow and re-run
-                if (attempt > 8) throw Error(DRPRG_EOVERFLOW, "candidate buffer overflow after regrow");
-                unsigned long long restored = last_minimizers_;
-                HIPCHK(hipMemcpyAsync(&d_counters_[C_MINIMIZERS], &restored, sizeof(restored), hipMemcpyHostToDevice, stream));
-                HIPCHK(hipStreamSynchronize(stream));
-                ensure_raw_workspace(raw_capacity_ * 4);
-                continue;
-            }
-            break;
+        // ---- filtered sequences: the hits of short reads never leave the chip (read_cluster_kernel).  The batch is cut into
+        // one read range per lane; the ranges run concurrently (lane 0 on the caller's stream), one host wait at the end ----
+        const int n_lanes = (n_bases >= lanes_min_bases_ && n_reads >= 64) ? max_lanes_ : 1;
+        const uint64_t lane_cap = std::max<uint64_t>(1u << 20, n_bases / 64 / (uint64_t)n_lanes * (n_lanes > 1 ? 3 : 2) / 2);
+        ensure_lanes(n_lanes, lane_cap);
+        if (n_lanes > 1) HIPCHK(hipEventRecord(ev_begin_, stream));
+        for (int j = n_lanes - 1; j >= 0; --j) { // (lane 0 last: its stream is the one the host then waits on)
+            Lane& lane = lanes_[j];
+            lane.r0 = (uint32_t)((uint64_t)n_reads * (uint64_t)j / (uint64_t)n_lanes);
+            lane.r1 = (uint32_t)((uint64_t)n_reads * (uint64_t)(j + 1) / (uint64_t)n_lanes);
+            hipStream_t ls = j == 0 ? stream : lane.stream;
+            if (j > 0) HIPCHK(hipStreamWaitEvent(ls, ev_begin_, 0));
+            launch_lane(lane, ls, d_bases, d_offsets, n_reads, n_bases, covg, prg_reads);
+            if (j > 0) HIPCHK(hipEventRecord(lane.done, ls));
         }
-        last_minimizers_ = h_counters_[C_MINIMIZERS];
-        tot_hits_ += h_counters_[C_HITS];
-        tot_leftover_ += h_counters_[C_COMPLEX];
-        if (h_counters_[C_COMPLEX] == 0) return;
-        // ---- reads that did not fit read_cluster_kernel (long reads, many clusters): the generic pipeline on their hits ----
-        dev::SketchArgs a = sketch_args(d_bases, d_offsets, n_reads, n_bases);
-        scratch_zero_ = false; // the generic pipeline uses the scratch counters again
-        HIPCHK(dev::launch_filter_recount(a, fw, stream));
-        read_counters(stream, false);
-        const uint64_t n_left = h_counters_[C_HITS];
-        if (n_left == 0) return;
-        ensure_workspace(std::max<uint64_t>(1u << 20, n_left + n_left / 8));
-        a = sketch_args(d_bases, d_offsets, n_reads, n_bases); // the hit buffers may have moved
-        HIPCHK(dev::launch_filter_expand(a, fw, stream));
-        cluster_hits(d_offsets, (uint32_t)n_left, h_counters_[C_MAXLEN] <= READ_SORT_MAX_LEN, covg, prg_reads, stream);
+        for (int j = 1; j < n_lanes; ++j) HIPCHK(hipStreamWaitEvent(stream, lanes_[j].done, 0));
+        wait_stream(stream);
+        if (timing_) {
+            for (int j = 0; j < n_lanes; ++j) {
+                float ms = 0;
+                HIPCHK(hipEventElapsedTime(&ms, lanes_[j].t0, lanes_[j].t1));
+                sketch_ms_ += ms;
+                sketch_launches_ += 1;
+            }
+        }
+        for (int j = 0; j < n_lanes; ++j) {
+            Lane& lane = lanes_[j];
+            for (int attempt = 0;; ++attempt) {
+                const uint32_t ovf = (uint32_t)lane.h_scratch[L_OVERFLOW];
+                if (ovf & 8u) throw Error(DRPRG_EIO, "sketch_filter_kernel: dynamic LDS does not start at address 0");
+                if (ovf & 2u) throw Error(DRPRG_EOVERFLOW, "a read is longer than 2^" + std::to_string(dev::HIT_POS_BITS) + " bases");
+                if (!(ovf & 4u)) break;
+                // a candidate slice of this range was too small: its sequence counted nothing and touched no coverage
+                // (hit_scan_kernel / read_cluster_kernel check the flag); grow the lane and run the range again, alone
+                if (attempt > 8) throw Error(DRPRG_EOVERFLOW, "candidate buffer overflow after regrow");
+                grow_lane(lane, lane.raw_capacity * 4);
+                launch_lane(lane, stream, d_bases, d_offsets, n_reads, n_bases, covg, prg_reads);
+                wait_stream(stream);
+            }
+            tot_hits_ += lane.h_scratch[L_HITS];
+            tot_leftover_ += lane.h_scratch[L_COMPLEX];
+        }
+        // ---- reads that did not fit read_cluster_kernel (long reads, many clusters): the generic pipeline on their hits,
+        // one range after the other ----
+        for (int j = 0; j < n_lanes; ++j) {
+            Lane& lane = lanes_[j];
+            if (lane.h_scratch[L_COMPLEX] == 0) continue;
+            dev::SketchArgs a = sketch_args(d_bases, d_offsets, n_reads, n_bases);
+            a.n_hits = &lane.d_scratch[L_HITS];
+            a.overflow = reinterpret_cast<uint32_t*>(&lane.d_scratch[L_OVERFLOW]);
+            lane.scratch_zero = false; // the leftover pass uses the lane's counters again
+            HIPCHK(dev::launch_filter_recount(a, lane.fw, stream));
+            HIPCHK(hipMemcpyAsync(lane.h_scratch, lane.d_scratch, L_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+            wait_stream(stream);
+            const uint64_t n_left = lane.h_scratch[L_HITS];
+            if (n_left == 0) continue;
+            ensure_workspace(std::max<uint64_t>(1u << 20, n_left + n_left / 8));
+            a.hit_key = d_key_a_; // the hit buffers may have moved
+            a.hit_val = d_val_a_;
+            a.hit_capacity = hit_capacity_;
+            HIPCHK(dev::launch_filter_expand(a, lane.fw, stream));
+            cluster_hits(d_offsets, (uint32_t)n_left, lane.h_scratch[L_MAXLEN] <= READ_SORT_MAX_LEN, &lane.d_scratch[L_UNSORTED], covg, prg_reads,
+                stream);
+        }
         return;
     }
     // ---- direct sequence: every k-mer hashed, hits in tile order, global radix sort ----
@@ -367,9 +448,8 @@ void Mapper::run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32
         HIPCHK(hipMemsetAsync(&d_counters_[C_HITS], 0, sizeof(unsigned long long), stream));
         HIPCHK(hipMemsetAsync(&d_counters_[C_OVERFLOW], 0, sizeof(unsigned long long), stream));
         const dev::SketchArgs a = sketch_args(d_bases, d_offsets, n_reads, n_bases);
-        scratch_zero_ = false;
         HIPCHK(dev::launch_sketch_probe(a, wide_hash_, stream, timer));
-        read_counters(stream, false);
+        read_counters(stream);
         note_kernel_time();
         if ((uint32_t)h_counters_[C_OVERFLOW] & 2u)
             throw Error(DRPRG_EOVERFLOW, "a read is longer than 2^" + std::to_string(dev::HIT_POS_BITS) + " bases");
@@ -386,7 +466,7 @@ void Mapper::run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32
     }
     last_minimizers_ = h_counters_[C_MINIMIZERS];
     tot_hits_ += h_counters_[C_HITS];
-    cluster_hits(d_offsets, (uint32_t)h_counters_[C_HITS], false, covg, prg_reads, stream);
+    cluster_hits(d_offsets, (uint32_t)h_counters_[C_HITS], false, nullptr, covg, prg_reads, stream);
 }
 
 void Mapper::map_device(const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n_reads, uint64_t n_bases,

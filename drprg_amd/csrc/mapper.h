@@ -6,6 +6,7 @@
 #pragma once
 #include "index.h"
 #include "kernels.h"
+#include <vector>
 
 namespace drprg {
 
@@ -58,12 +59,35 @@ public:
 
 private:
     void ensure_workspace(uint64_t hit_capacity);
-    void ensure_raw_workspace(uint64_t raw_capacity);
+    // One filtered launch sequence (sketch_filter -> refine -> candidates -> read_cluster) and everything private to it.
+    // A batch is cut into as many read ranges as there are lanes (default: one); lane 0 runs on the caller's stream, the
+    // others on their own, so that the candidate / cluster kernels of one range can overlap the filter kernel of the next.
+    struct Lane {
+        hipStream_t stream = nullptr; // lanes >= 1 (lane 0 uses the stream of the call)
+        hipEvent_t done = nullptr, t0 = nullptr, t1 = nullptr;
+        uint64_t raw_capacity = 0;
+        uint64_t *raw_pos = nullptr, *cand_info = nullptr;
+        uint4 *raw_grp = nullptr, *cand_rec = nullptr;
+        uint32_t *cand_pos1 = nullptr, *small = nullptr;
+        unsigned long long* d_scratch = nullptr; // L_N x u64 per-sequence counters (below)
+        unsigned long long* h_scratch = nullptr; // pinned mirror
+        bool scratch_zero = false;               // d_scratch is known to be zero on the device
+        dev::FilterWork fw {};
+        uint32_t r0 = 0, r1 = 0;                 // read range of the current batch
+    };
+    enum { L_HITS = 0, L_OVERFLOW = 1, L_MAXLEN = 2, L_UNSORTED = 3, L_COMPLEX = 4, L_CHUNK = 5, L_N = 8 };
+    void ensure_lanes(int n, uint64_t raw_capacity);
+    void grow_lane(Lane& lane, uint64_t raw_capacity);
+    void free_lane(Lane& lane);
+    void launch_lane(Lane& lane, hipStream_t stream, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads,
+        uint64_t n_bases, uint32_t* covg, uint32_t* prg_reads);
+    void wait_stream(hipStream_t stream);
     void run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads, uint64_t n_bases,
         uint32_t* d_covg, uint32_t* d_prg_reads, hipStream_t stream);
-    void cluster_hits(const uint64_t* d_offsets, uint32_t n_hits, bool ordered, uint32_t* d_covg, uint32_t* d_prg_reads, hipStream_t stream);
+    void cluster_hits(const uint64_t* d_offsets, uint32_t n_hits, bool ordered, unsigned long long* d_unsorted, uint32_t* d_covg,
+        uint32_t* d_prg_reads, hipStream_t stream);
     dev::SketchArgs sketch_args(const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads, uint64_t n_bases) const;
-    void read_counters(hipStream_t stream, bool rezero);
+    void read_counters(hipStream_t stream);
     void note_kernel_time();
 
     int device_ = 0;
@@ -79,7 +103,6 @@ private:
     uint16_t* d_rec_prg_ = nullptr;
     uint32_t* d_min_path_len_ = nullptr;
     uint32_t* d_bloom_ = nullptr;
-    uint32_t* d_filter_small_ = nullptr; // slice / workgroup counters of the filtered launch sequence
     uint32_t bloom_wbits_ = 0;
     uint32_t* d_pbloom_ = nullptr; // Bloom tier of the direct kernel (large indexes)
     uint32_t pbloom_wbits_ = 0;
@@ -94,8 +117,7 @@ private:
     unsigned long long* d_counters_ = nullptr; // 8 x u64: hits(batch), minimizers, clusters_kept, hits_kept, overflow, ...
     unsigned long long* h_counters_ = nullptr; // pinned mirror
     uint64_t tot_reads_ = 0, tot_bases_ = 0, tot_hits_ = 0, tot_leftover_ = 0;
-    unsigned long long last_minimizers_ = 0; // device minimizer counter after the last completed batch
-    bool scratch_zero_ = false;              // the per-batch scratch counters are known to be zero on the device
+    unsigned long long last_minimizers_ = 0; // device minimizer counter after the last completed batch (direct sequence)
     // workspace
     uint64_t hit_capacity_ = 0;
     uint64_t *d_key_a_ = nullptr, *d_key_b_ = nullptr;
@@ -103,11 +125,13 @@ private:
     uint32_t *d_head_ = nullptr, *d_scan_ = nullptr, *d_cstart_ = nullptr, *d_order_ = nullptr;
     dev::ClusterRec* d_clusters_ = nullptr;
     // candidate workspace of the filtered sequence
-    uint64_t raw_capacity_ = 0;
-    uint64_t *d_raw_pos_ = nullptr, *d_cand_info_ = nullptr;
-    uint32_t* d_cand_pos1_ = nullptr;
-    uint4* d_cand_rec_ = nullptr;
-    uint4* d_raw_grp_ = nullptr;
+    std::vector<Lane> lanes_;
+    int max_lanes_ = 1;             // DRPRG_HIP_LANES (1..4).  Measured on configs[1] (10 M x 150 bp): 0.66 ms with one lane, 0.73 / 0.83 ms
+                                    // with two / four: a resident sketch_filter_kernel workgroup holds 128 KB of a CU's LDS, so refine
+                                    // and read_cluster of the other range wait for it, and what does overlap (verify) competes for the
+                                    // same VALU issue slots -- every kernel stretches by about what the overlap saves
+    uint64_t lanes_min_bases_ = 64ull << 20; // smaller batches always take one lane
+    hipEvent_t ev_begin_ = nullptr; // recorded on the caller's stream: the other lanes start behind it
     void* d_temp_ = nullptr;
     uint32_t* d_tile_first_ = nullptr;
     uint32_t tile_cap_ = 0;
