@@ -51,10 +51,12 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
     extern __shared__ uint32_t s_hist[]; // clusters kept per PRG
     __shared__ uint32_t s_read[RC_SLOTS + 1], s_hstart[RC_SLOTS + 1];
     __shared__ uint16_t s_pos1[RC_SLOTS]; // read position + 1 of a minimizer (0xFFFF: too far for this kernel), 0 = not a minimizer
-    __shared__ uint32_t s_gt[RC_SLOTS];   // at a segment's first slot: group << 16 | size threshold; later the decision for the segment
+    __shared__ uint32_t s_gt[RC_SLOTS];   // at a segment's first slot: group << 16 | size threshold
     __shared__ uint16_t s_lead[RC_SLOTS]; // 1 + slot of the first candidate of this slot's read (0: the read started in an earlier chunk)
     __shared__ uint16_t s_seg[RC_SLOTS];  // 1 + first slot of this slot's segment
     __shared__ uint16_t s_end[RC_SLOTS];  // at a segment's first slot: the first slot of the next segment
+    __shared__ uint16_t s_g0[RC_SLOTS];   // group (prg << 1 | rev) of the slot's first hit
+    __shared__ uint8_t s_dec[RC_SLOTS];   // at a segment's first slot: 0 leave alone, 1 handled, 2 handled and every hit counts
     __shared__ uint8_t s_cplx[RC_SLOTS], s_irrf[RC_SLOTS]; // at a read's first slot: does not fit / hits in several groups
     __shared__ uint16_t s_grp[RC_HCAP];   // per hit: prg << 1 | rev
     __shared__ uint16_t s_hpos[RC_HCAP];  // per hit: read position
@@ -100,6 +102,7 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
             s_read[i] = read;
             s_pos1[i] = (uint16_t)(pos1 < 0xFFFFu ? pos1 : 0xFFFFu);
             s_hstart[i] = crec[q].y;
+            s_g0[i] = (uint16_t)((crec[q].z >> 16) & 0x7FFFu);
             s_cplx[i] = 0;
             s_irrf[i] = 0;
         }
@@ -171,48 +174,41 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
             if (tid == 0) s_hstart[RC_SLOTS] = sum;
         }
         lds_barrier();
-        // ---- C: the hits (one per index record of every minimizer); every segment start closes the segment before it ----
+        // ---- C: the hits (one per index record of every minimizer); every segment start closes the segment before it; a
+        // minimizer whose group differs from the previous one of its read makes the read irregular; the first minimizer of a
+        // segment names the segment's group and threshold ----
 #pragma unroll
         for (int q = 0; q < RC_PER; ++q) {
             const uint32_t i = (uint32_t)tid + (uint32_t)q * RC_THREADS;
-            const uint32_t seg = s_seg[i];
-            if (seg == i + 1 && i > 0 && s_seg[i - 1]) s_end[s_seg[i - 1] - 1] = (uint16_t)i;
-            if (i == RC_SLOTS - 1 && seg) s_end[seg - 1] = (uint16_t)RC_SLOTS;
+            const uint32_t seg1 = s_seg[i];
+            if (seg1 == i + 1 && i > 0 && s_seg[i - 1]) s_end[s_seg[i - 1] - 1] = (uint16_t)i;
+            if (i == RC_SLOTS - 1 && seg1) s_end[seg1 - 1] = (uint16_t)RC_SLOTS;
             const uint32_t cnt = crec[q].y;
             if (!cnt) continue;
             const uint32_t h0 = s_hstart[i], lead = s_lead[i];
-            const uint32_t pos = (uint32_t)s_pos1[i] - 1, strand = crec[q].z >> 31;
+            const bool mine = lead != 0 && lead <= n_own; // the read starts in the owned range
+            const uint32_t pos = (uint32_t)s_pos1[i] - 1, strand = crec[q].z >> 31, g = (crec[q].z >> 16) & 0x7FFFu;
             if (h0 + cnt > (uint32_t)RC_HCAP || pos >= 0xFFFEu) {
-                if (lead && lead <= n_own) s_cplx[lead - 1] = 1;
+                if (mine) s_cplx[lead - 1] = 1;
                 continue;
             }
-            s_grp[h0] = (uint16_t)((crec[q].z >> 16) & 0x7FFFu);
+            bool irregular = false;
+            s_grp[h0] = (uint16_t)g;
             s_hpos[h0] = (uint16_t)pos;
             s_cov[h0] = crec[q].w;
             for (uint32_t r = 1; r < cnt; ++r) { // rare: a k-mer that several k-mer nodes share
                 const uint32_t kn = a.rec_knode[crec[q].x + r], prg = a.rec_prg[crec[q].x + r];
                 const uint32_t rev = ((kn & 1u) == strand) ? 0u : 1u;
+                irregular |= ((prg << 1) | rev) != g;
                 s_grp[h0 + r] = (uint16_t)((prg << 1) | rev);
                 s_hpos[h0 + r] = (uint16_t)pos;
                 s_cov[h0 + r] = (kn >> 1) * 2u + rev;
             }
-        }
-        lds_barrier();
-        // ---- D: a minimizer whose group differs from the previous one of its read makes the read irregular; the first
-        // minimizer of a segment names the segment's group and threshold ----
-#pragma unroll
-        for (int q = 0; q < RC_PER; ++q) {
-            const uint32_t i = (uint32_t)tid + (uint32_t)q * RC_THREADS;
-            const uint32_t lead = s_lead[i], cnt = crec[q].y;
-            if (!cnt || lead == 0 || lead > n_own) continue;
-            const uint32_t first = lead - 1, seg = (uint32_t)s_seg[i] - 1, h0 = s_hstart[i];
-            if (h0 + cnt > (uint32_t)RC_HCAP) continue; // complex already
-            const uint32_t g = (crec[q].z >> 16) & 0x7FFFu;
-            bool irregular = false;
-            for (uint32_t r = 1; r < cnt; ++r) irregular |= s_grp[h0 + r] != g;
+            if (!mine) continue;
+            const uint32_t first = lead - 1, seg = seg1 - 1;
             int j = (int)i - 1; // the previous minimizer of the read
             while (j >= (int)first && !s_pos1[j]) --j;
-            if (j >= (int)first && s_grp[s_hstart[j]] != g) irregular = true; // (s_hstart[j] <= h0 < RC_HCAP)
+            if (j >= (int)first && s_g0[j] != g) irregular = true;
             if (j < (int)seg) s_gt[seg] = crec[q].z & 0x7FFFFFFFu;
             if (irregular) s_irrf[first] = 1;
         }
@@ -222,12 +218,10 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
         }
         lds_barrier();
         // ---- E: the first slot of every segment decides for the segment; reads with several groups queue for the wave path ----
-        uint32_t dec[RC_PER];
 #pragma unroll
         for (int q = 0; q < RC_PER; ++q) {
             const uint32_t i = (uint32_t)tid + (uint32_t)q * RC_THREADS;
             const uint32_t lead = s_lead[i];
-            dec[q] = 0xFFFFFFFFu; // not the first slot of a segment
             if (i >= n_loaded || s_seg[i] != i + 1 || lead == 0 || lead > n_own) continue;
             uint32_t flags = (s_cplx[lead - 1] ? RC_COMPLEX : 0u) | (s_irrf[lead - 1] ? RC_IRREGULAR : 0u);
             if (lead == i + 1) { // first slot of the read
@@ -241,22 +235,19 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
                 }
             }
             const uint32_t n_hits = s_hstart[s_end[i]] - s_hstart[i];
-            dec[q] = 0; // 0 leave alone, 1 handled, 2 handled and every hit counts
+            uint32_t dec = 0; // 0 leave alone, 1 handled, 2 handled and every hit counts
             if (!flags && n_hits) {
                 const uint32_t g_thr = s_gt[i];
-                dec[q] = 1;
+                dec = 1;
                 if (n_hits > (g_thr & 0xFFFFu)) {
-                    dec[q] = 2;
+                    dec = 2;
                     atomicAdd(&s_hist[g_thr >> 17], 1u);
                     ++my_kept;
                     my_kept_hits += n_hits;
                 }
             }
+            s_dec[i] = (uint8_t)dec;
         }
-        lds_barrier(); // all thresholds are read
-#pragma unroll
-        for (int q = 0; q < RC_PER; ++q)
-            if (dec[q] != 0xFFFFFFFFu) s_gt[(uint32_t)tid + (uint32_t)q * RC_THREADS] = dec[q];
         lds_barrier();
         // ---- F: the minimizers of the kept segments ----
         {
@@ -265,7 +256,7 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
                 const uint32_t i = (uint32_t)tid + (uint32_t)q * RC_THREADS;
                 const uint32_t lead = s_lead[i], cnt = crec[q].y;
                 if (!cnt || lead == 0 || lead > n_own) continue;
-                const uint32_t decision = s_gt[(uint32_t)s_seg[i] - 1];
+                const uint32_t decision = s_dec[(uint32_t)s_seg[i] - 1];
                 if (!decision) continue;
                 fw.cand_pos1[base + i] = 0; // handled
                 if (decision == 2) {
