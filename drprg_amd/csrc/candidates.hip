@@ -413,6 +413,38 @@ __global__ __launch_bounds__(EX_THREADS) void recount_kernel(SketchArgs a, Filte
 }
 
 // ---------------------------------------------------------------------------------------------
+// candidate form of the direct sequence: tile slices -> dense list
+// ---------------------------------------------------------------------------------------------
+constexpr int TG_THREADS = 256, TG_TILES = 32; // tiles per workgroup
+__global__ __launch_bounds__(TG_THREADS) void tile_gather_kernel(SketchArgs a, FilterWork fw, const uint32_t* __restrict__ tile_prefix,
+    uint32_t n_tiles, uint64_t dense_capacity)
+{
+    __shared__ uint32_t s_w[TG_THREADS / 64 + 1];
+    const int tid = threadIdx.x;
+    // (a slice or the dense list too small: the host grows the workspace and runs the batch again; count nothing)
+    const bool overflow = (*reinterpret_cast<volatile uint32_t*>(a.overflow) & 4u) != 0 || (uint64_t)tile_prefix[n_tiles] > dense_capacity;
+    if (overflow) {
+        if (blockIdx.x == 0 && tid == 0) atomicOr(a.overflow, 4u);
+        return;
+    }
+    const uint32_t t0 = blockIdx.x * TG_TILES, t1 = t0 + TG_TILES < n_tiles ? t0 + TG_TILES : n_tiles;
+    uint32_t my_hits = 0;
+    for (uint32_t t = t0 + (uint32_t)tid; t < t1; t += TG_THREADS) my_hits += a.tile_hits[t];
+    for (uint32_t t = t0; t < t1; ++t) {
+        const uint32_t n = a.tile_count[t], dst = tile_prefix[t];
+        const size_t src = (size_t)t * a.tile_cap;
+        for (uint32_t i = tid; i < n; i += TG_THREADS) {
+            fw.cand_info[dst + i] = a.tile_info[src + i];
+            fw.cand_pos1[dst + i] = a.tile_pos1[src + i];
+            fw.cand_rec[dst + i] = a.tile_rec[src + i];
+        }
+    }
+    uint32_t hits;
+    (void)block_exclusive_scan<TG_THREADS / 64>(my_hits, s_w, &hits);
+    if (tid == 0 && hits) atomicAdd(a.n_hits, (unsigned long long)hits);
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 hipError_t launch_candidate_stage(const SketchArgs& a, const FilterWork& fw, const ReadClusterArgs& rc, hipStream_t stream)
@@ -422,6 +454,21 @@ hipError_t launch_candidate_stage(const SketchArgs& a, const FilterWork& fw, con
     hipLaunchKernelGGL(verify_count_kernel, dim3(fw.ex_grid), dim3(EX_THREADS), 0, stream, a, fw, rc);
     hipLaunchKernelGGL(hit_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, a, fw, 0);
     return hipGetLastError();
+}
+
+hipError_t launch_direct_candidates(const SketchArgs& a, bool wide_hash, uint32_t* tile_prefix, void* temp, size_t temp_bytes,
+    uint64_t dense_capacity, const ReadClusterArgs& rc, int n_cus, FilterWork& fw, hipStream_t stream, KernelTimer timer)
+{
+    if (a.n_bases == 0 || !a.tile_cap) return hipErrorInvalidValue;
+    const uint32_t n_tiles = sketch_n_tiles(a.n_bases, a.halo);
+    HIP_TRY(launch_sketch_probe(a, wide_hash, stream, timer));
+    // tile_count[n_tiles] is a zero the caller keeps there: the exclusive scan of n_tiles + 1 counts ends with the total
+    HIP_TRY(exclusive_scan_u32(temp, temp_bytes, a.tile_count, tile_prefix, n_tiles + 1, stream));
+    fw.cand_total = tile_prefix + n_tiles;
+    hipLaunchKernelGGL(tile_gather_kernel, dim3((n_tiles + TG_TILES - 1) / TG_TILES), dim3(TG_THREADS), 0, stream, a, fw, tile_prefix, n_tiles,
+        dense_capacity);
+    HIP_TRY(hipGetLastError());
+    return launch_read_cluster(a, fw, rc, n_cus, false, stream);
 }
 
 hipError_t launch_filter_recount(const SketchArgs& a, const FilterWork& fw, hipStream_t stream)

@@ -166,6 +166,11 @@ size_t scan_temp_bytes(uint32_t n)
     return bytes;
 }
 
+hipError_t exclusive_scan_u32(void* temp, size_t temp_bytes, const uint32_t* in, uint32_t* out, uint32_t n, hipStream_t stream)
+{
+    return rocprim::exclusive_scan(temp, temp_bytes, in, out, 0u, n, rocprim::plus<uint32_t>(), stream);
+}
+
 hipError_t sort_hits(void* temp, size_t temp_bytes, const uint64_t* key_in, uint64_t* key_out, const uint32_t* val_in,
     uint32_t* val_out, uint32_t n, hipStream_t stream)
 {

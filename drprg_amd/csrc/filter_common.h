@@ -22,7 +22,7 @@ constexpr int MAX_EX_WG = SCAN_THREADS * 4;  // workgroups of verify_count_kerne
 // the contiguous range of the ordered candidate list that workgroup `wg` of `n_wg` owns
 __device__ inline void candidate_range(const FilterWork& fw, uint32_t wg, uint32_t n_wg, uint32_t& t_begin, uint32_t& t_end)
 {
-    const uint32_t total = fw.cand_prefix[fw.n_slices];
+    const uint32_t total = *fw.cand_total;
     const uint32_t per_wg = (total + n_wg - 1) / n_wg;
     const uint64_t b = (uint64_t)wg * per_wg;
     t_begin = b < total ? (uint32_t)b : total;

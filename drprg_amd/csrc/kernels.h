@@ -58,6 +58,17 @@ struct SketchArgs {
     uint32_t pbloom_wbits;
     uint32_t* overflow; // bit 0: hit buffer too small, bit 1: read longer than 2^HIT_POS_BITS, bit 2: candidate slice
                         // too small, bit 3: dynamic LDS does not start at address 0 (sketch_filter_kernel)
+    // candidate form of the direct kernel (tile_cap != 0): instead of hits, every tile leaves the records
+    // read_cluster_kernel wants (same layout as FilterWork::cand_info / cand_pos1 / cand_rec), in position order, in its own
+    // slice of tile_cap entries; tile_count[t] = minimizers found, tile_hits[t] = their hits
+    uint32_t tile_cap;
+    uint64_t* tile_info;
+    uint32_t* tile_pos1;
+    uint4* tile_rec;
+    uint32_t *tile_count, *tile_hits;
+    const uint32_t* prg_min_path_len; // for the size threshold stored in the records
+    double fraction;
+    uint32_t min_cluster_size;
 };
 
 struct ClusterRec {
@@ -134,6 +145,7 @@ struct FilterWork {
                              // its 16 bases, the 2 after them}, ascending per slice; refine_kernel turns them into raw_pos
     uint32_t* grp_count;     // [n_slices] (may exceed raw_slice: overflow)
     uint32_t* cand_prefix;   // [n_slices + 1]: exclusive scan of the clamped counts
+    const uint32_t* cand_total; // the number of candidates (filtered sequence: &cand_prefix[n_slices])
     uint64_t* cand_info;     // [candidates]: slot << 32 | strand << 31 | read
     uint32_t* cand_pos1;     // [candidates]: read position + 1 of a minimizer, 0 = not a minimizer
     uint4* cand_rec;         // [candidates]: what read_cluster_kernel needs of a minimizer: first index record, number of
@@ -160,6 +172,8 @@ struct ReadClusterArgs {
     uint32_t* chunk_counter;       // zeroed device scalar: work distribution of read_cluster_kernel
 };
 size_t filter_small_words();
+// the fields of fw that the consumers of a dense candidate list use (candidates.hip, read_cluster.hip)
+void init_candidate_work(FilterWork& fw, const FilterBuffers& b, int n_cus);
 // filter -> candidates -> verify -> per-read clustering of the reads that fit read_cluster_kernel (coverage, PRG read
 // counts and the kept-cluster counters are updated); a.n_hits receives the number of hits of the whole batch,
 // rc.n_complex the number of reads left over.  fw is filled for the two follow-up calls.
@@ -171,6 +185,13 @@ hipError_t launch_sketch_filter(const SketchArgs& a, uint32_t read_begin, uint32
 hipError_t launch_filter_recount(const SketchArgs& a, const FilterWork& fw, hipStream_t stream);
 // ... and their hits are written to a.hit_key / a.hit_val ordered by (read, position)
 hipError_t launch_filter_expand(const SketchArgs& a, const FilterWork& fw, hipStream_t stream);
+// Candidate form of the direct sequence: launch_sketch_probe with a.tile_cap != 0, then the tile slices -> one dense
+// ordered candidate list (fw.cand_info / cand_pos1 / cand_rec, *fw.cand_total) -> read_cluster_kernel.  tile_prefix:
+// n_tiles + 1 words; temp: scan_temp_bytes(n_tiles + 1) bytes.  a.n_hits receives the hits of the batch; overflow bit 2:
+// a tile slice or the dense list (dense_capacity entries) was too small (nothing was counted then).
+hipError_t launch_direct_candidates(const SketchArgs& a, bool wide_hash, uint32_t* tile_prefix, void* temp, size_t temp_bytes,
+    uint64_t dense_capacity, const ReadClusterArgs& rc, int n_cus, FilterWork& fw, hipStream_t stream, KernelTimer timer = {});
+hipError_t exclusive_scan_u32(void* temp, size_t temp_bytes, const uint32_t* in, uint32_t* out, uint32_t n, hipStream_t stream);
 // hits ordered by (read, pos) -> ordered by (read, prg, strand, pos), in place; meant for short reads.  scratch: u32
 // words (>= n) for the list of reads that need reordering; count: zeroed device scalar
 hipError_t launch_read_sort(uint64_t* key, uint32_t* val, uint32_t n, uint32_t* scratch, uint64_t scratch_words, unsigned long long* count,

@@ -127,6 +127,8 @@ Mapper::~Mapper()
     dfree(d_key_a_); dfree(d_key_b_); dfree(d_val_a_); dfree(d_val_b_);
     dfree(d_head_); dfree(d_scan_); dfree(d_cstart_); dfree(d_order_); dfree(d_clusters_);
     if (d_temp_) (void)hipFree(d_temp_);
+    dfree(d_tile_info_); dfree(d_tile_pos1_); dfree(d_tile_count_); dfree(d_tile_hits_); dfree(d_tile_prefix_); dfree(d_tile_rec_);
+    if (d_tile_temp_) (void)hipFree(d_tile_temp_);
     dfree(d_bases_); dfree(d_offsets_); dfree(d_tile_first_); dfree(d_bloom_); dfree(d_bloom0_); dfree(d_bloomr_); dfree(d_pbloom_);
     for (Lane& lane : lanes_) free_lane(lane);
     if (ev_begin_) (void)hipEventDestroy(ev_begin_);
@@ -158,9 +160,11 @@ void Mapper::set_params(const MapParams& p)
     wide_hash_ = p.k > 15;
     halo_ = std::max(16, ((p.w - 1 + 15) / 16) * 16);
     const bool filter_ok = bloom_wbits_ != 0 && p.k <= 15 && p.w <= 16;
+    if (p.kernel_mode < 0 || p.kernel_mode > 3) throw Error(DRPRG_EINVAL, "kernel must be 0 (auto), 1, 2 or 3");
     if (p.kernel_mode == 2 && !filter_ok)
         throw Error(DRPRG_EINVAL, "the Bloom-prefiltered kernel needs k <= 15, w <= 16 and an index small enough for an LDS filter");
     use_filter_ = p.kernel_mode == 2 || (p.kernel_mode == 0 && filter_ok);
+    use_direct_cands_ = p.kernel_mode == 3 || (p.kernel_mode == 0 && !filter_ok);
 }
 
 void Mapper::reset_coverage()
@@ -360,6 +364,122 @@ void Mapper::note_kernel_time()
     sketch_launches_ += 1;
 }
 
+// The reads read_cluster_kernel left over in this lane's candidate list: their hits -> the generic cluster pipeline.
+void Mapper::leftovers(Lane& lane, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads, uint64_t n_bases, uint32_t* covg,
+    uint32_t* prg_reads, hipStream_t stream)
+{
+    if (lane.h_scratch[L_COMPLEX] == 0) return;
+    dev::SketchArgs a = sketch_args(d_bases, d_offsets, n_reads, n_bases);
+    a.n_hits = &lane.d_scratch[L_HITS];
+    a.overflow = reinterpret_cast<uint32_t*>(&lane.d_scratch[L_OVERFLOW]);
+    lane.scratch_zero = false; // the leftover pass uses the lane's counters again
+    HIPCHK(dev::launch_filter_recount(a, lane.fw, stream));
+    HIPCHK(hipMemcpyAsync(lane.h_scratch, lane.d_scratch, L_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    wait_stream(stream);
+    const uint64_t n_left = lane.h_scratch[L_HITS];
+    if (n_left == 0) return;
+    ensure_workspace(std::max<uint64_t>(1u << 20, n_left + n_left / 8));
+    a.hit_key = d_key_a_; // the hit buffers may have moved
+    a.hit_val = d_val_a_;
+    a.hit_capacity = hit_capacity_;
+    HIPCHK(dev::launch_filter_expand(a, lane.fw, stream));
+    cluster_hits(d_offsets, (uint32_t)n_left, lane.h_scratch[L_MAXLEN] <= READ_SORT_MAX_LEN, &lane.d_scratch[L_UNSORTED], covg, prg_reads, stream);
+}
+
+void Mapper::ensure_tile_workspace(uint32_t n_tiles, uint32_t tile_cap)
+{
+    if (n_tiles <= tile_ws_tiles_ && tile_cap <= tile_ws_cap_) return;
+    dfree(d_tile_info_); dfree(d_tile_pos1_); dfree(d_tile_count_); dfree(d_tile_hits_); dfree(d_tile_prefix_); dfree(d_tile_rec_);
+    if (d_tile_temp_) (void)hipFree(d_tile_temp_);
+    d_tile_temp_ = nullptr;
+    tile_ws_tiles_ = std::max(tile_ws_tiles_, n_tiles + n_tiles / 8 + 16);
+    tile_ws_cap_ = std::max(tile_ws_cap_, tile_cap);
+    const size_t n = (size_t)tile_ws_tiles_ * tile_ws_cap_;
+    dmalloc(d_tile_info_, n); dmalloc(d_tile_pos1_, n); dmalloc(d_tile_rec_, n);
+    dmalloc(d_tile_count_, (size_t)tile_ws_tiles_ + 1); dmalloc(d_tile_hits_, (size_t)tile_ws_tiles_ + 1); dmalloc(d_tile_prefix_, (size_t)tile_ws_tiles_ + 1);
+    tile_temp_bytes_ = dev::scan_temp_bytes(tile_ws_tiles_ + 1);
+    HIPCHK(hipMalloc(&d_tile_temp_, tile_temp_bytes_ ? tile_temp_bytes_ : 1));
+}
+
+// Direct sequence, candidate form: every k-mer hashed (any k, any w, any index size); each tile leaves its index minimizers
+// as candidate records in position order, a scan + gather makes the dense ordered list and read_cluster_kernel takes it from
+// there -- no hit list, no radix sort, no cluster kernels for the reads that fit it.
+void Mapper::run_batch_direct_candidates(const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads, uint64_t n_bases,
+    uint32_t* covg, uint32_t* prg_reads, hipStream_t stream)
+{
+    const uint32_t n_tiles = dev::sketch_n_tiles(n_bases, halo_);
+    if (n_tiles > tile_cap_) { // first read of every tile
+        dfree(d_tile_first_);
+        tile_cap_ = n_tiles + n_tiles / 4 + 16;
+        dmalloc(d_tile_first_, (size_t)tile_cap_);
+    }
+    ensure_lanes(1, std::max<uint64_t>(1u << 20, n_bases / 16));
+    Lane& lane = lanes_[0];
+    for (int attempt = 0;; ++attempt) {
+        ensure_tile_workspace(n_tiles, tile_slice_cap_);
+        if (!lane.scratch_zero) HIPCHK(hipMemsetAsync(lane.d_scratch, 0, L_N * sizeof(unsigned long long), stream));
+        lane.scratch_zero = false;
+        HIPCHK(hipMemsetAsync(d_tile_count_ + n_tiles, 0, sizeof(uint32_t), stream)); // the scan's closing zero
+        dev::SketchArgs a = sketch_args(d_bases, d_offsets, n_reads, n_bases);
+        a.n_hits = &lane.d_scratch[L_HITS];
+        a.overflow = reinterpret_cast<uint32_t*>(&lane.d_scratch[L_OVERFLOW]);
+        a.tile_cap = tile_ws_cap_;
+        a.tile_info = d_tile_info_;
+        a.tile_pos1 = d_tile_pos1_;
+        a.tile_rec = d_tile_rec_;
+        a.tile_count = d_tile_count_;
+        a.tile_hits = d_tile_hits_;
+        a.prg_min_path_len = d_min_path_len_;
+        a.fraction = params_.cluster_fraction();
+        a.min_cluster_size = params_.min_cluster_size;
+        dev::FilterBuffers fb { lane.raw_pos, lane.raw_grp, lane.cand_info, lane.cand_pos1, lane.cand_rec, lane.raw_capacity, lane.small,
+            &lane.d_scratch[L_MAXLEN] };
+        dev::ReadClusterArgs rc {};
+        rc.prg_min_path_len = d_min_path_len_;
+        rc.fraction = params_.cluster_fraction();
+        rc.min_cluster_size = params_.min_cluster_size;
+        rc.max_diff = params_.max_diff;
+        rc.n_prgs = n_prgs_;
+        rc.covg = covg;
+        rc.prg_reads = prg_reads;
+        rc.n_clusters_kept = &d_counters_[C_CLUSTERS_KEPT];
+        rc.n_hits_kept = &d_counters_[C_HITS_KEPT];
+        rc.n_complex = &lane.d_scratch[L_COMPLEX];
+        rc.chunk_counter = reinterpret_cast<uint32_t*>(&lane.d_scratch[L_CHUNK]);
+        lane.fw = dev::FilterWork {};
+        lane.fw.read_begin = 0;
+        lane.fw.read_end = n_reads;
+        dev::init_candidate_work(lane.fw, fb, n_cus_);
+        dev::KernelTimer timer;
+        if (timing_) {
+            timer.begin = ev0_;
+            timer.end = ev1_;
+        }
+        HIPCHK(dev::launch_direct_candidates(a, wide_hash_, d_tile_prefix_, d_tile_temp_, tile_temp_bytes_, lane.raw_capacity, rc, n_cus_, lane.fw,
+            stream, timer));
+        HIPCHK(hipMemcpyAsync(lane.h_scratch, lane.d_scratch, L_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipMemcpyAsync(&h_counters_[C_MINIMIZERS], &d_counters_[C_MINIMIZERS], sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipMemsetAsync(lane.d_scratch, 0, L_N * sizeof(unsigned long long), stream));
+        lane.scratch_zero = true;
+        wait_stream(stream);
+        note_kernel_time();
+        const uint32_t ovf = (uint32_t)lane.h_scratch[L_OVERFLOW];
+        if (ovf & 2u) throw Error(DRPRG_EOVERFLOW, "a read is longer than 2^" + std::to_string(dev::HIT_POS_BITS) + " bases");
+        if (!(ovf & 4u)) break;
+        // a tile slice or the dense list was too small: nothing was counted except the minimizers; grow both and run again
+        if (attempt > 6) throw Error(DRPRG_EOVERFLOW, "candidate buffer overflow after regrow");
+        unsigned long long restored = last_minimizers_;
+        HIPCHK(hipMemcpyAsync(&d_counters_[C_MINIMIZERS], &restored, sizeof(restored), hipMemcpyHostToDevice, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        tile_slice_cap_ = std::min<uint32_t>(tile_slice_cap_ * 2, 4096);
+        grow_lane(lane, lane.raw_capacity * 2);
+    }
+    last_minimizers_ = h_counters_[C_MINIMIZERS];
+    tot_hits_ += lane.h_scratch[L_HITS];
+    tot_leftover_ += lane.h_scratch[L_COMPLEX];
+    leftovers(lane, d_bases, d_offsets, n_reads, n_bases, covg, prg_reads, stream);
+}
+
 void Mapper::run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads, uint64_t n_bases,
     uint32_t* covg, uint32_t* prg_reads, hipStream_t stream)
 {
@@ -414,29 +534,14 @@ void Mapper::run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32
         }
         // ---- reads that did not fit read_cluster_kernel (long reads, many clusters): the generic pipeline on their hits,
         // one range after the other ----
-        for (int j = 0; j < n_lanes; ++j) {
-            Lane& lane = lanes_[j];
-            if (lane.h_scratch[L_COMPLEX] == 0) continue;
-            dev::SketchArgs a = sketch_args(d_bases, d_offsets, n_reads, n_bases);
-            a.n_hits = &lane.d_scratch[L_HITS];
-            a.overflow = reinterpret_cast<uint32_t*>(&lane.d_scratch[L_OVERFLOW]);
-            lane.scratch_zero = false; // the leftover pass uses the lane's counters again
-            HIPCHK(dev::launch_filter_recount(a, lane.fw, stream));
-            HIPCHK(hipMemcpyAsync(lane.h_scratch, lane.d_scratch, L_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-            wait_stream(stream);
-            const uint64_t n_left = lane.h_scratch[L_HITS];
-            if (n_left == 0) continue;
-            ensure_workspace(std::max<uint64_t>(1u << 20, n_left + n_left / 8));
-            a.hit_key = d_key_a_; // the hit buffers may have moved
-            a.hit_val = d_val_a_;
-            a.hit_capacity = hit_capacity_;
-            HIPCHK(dev::launch_filter_expand(a, lane.fw, stream));
-            cluster_hits(d_offsets, (uint32_t)n_left, lane.h_scratch[L_MAXLEN] <= READ_SORT_MAX_LEN, &lane.d_scratch[L_UNSORTED], covg, prg_reads,
-                stream);
-        }
+        for (int j = 0; j < n_lanes; ++j) leftovers(lanes_[j], d_bases, d_offsets, n_reads, n_bases, covg, prg_reads, stream);
         return;
     }
-    // ---- direct sequence: every k-mer hashed, hits in tile order, global radix sort ----
+    if (use_direct_cands_) {
+        run_batch_direct_candidates(d_bases, d_offsets, n_reads, n_bases, covg, prg_reads, stream);
+        return;
+    }
+    // ---- direct sequence, generic form: every k-mer hashed, hits in tile order, global radix sort ----
     ensure_workspace(std::max<uint64_t>(1u << 20, n_bases / 64));
     const uint32_t n_tiles = dev::sketch_n_tiles(n_bases, halo_);
     if (n_tiles > tile_cap_) { // first read of every tile
@@ -537,7 +642,7 @@ MapCounters Mapper::counters()
     m.hits = tot_hits_;
     m.clusters_kept = c[C_CLUSTERS_KEPT];
     m.hits_kept = c[C_HITS_KEPT];
-    m.kernel = use_filter_ ? 2 : 1;
+    m.kernel = use_filter_ ? 2 : (use_direct_cands_ ? 3 : 1);
     m.leftover_reads = tot_leftover_;
     return m;
 }

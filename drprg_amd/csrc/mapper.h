@@ -82,6 +82,11 @@ private:
     void launch_lane(Lane& lane, hipStream_t stream, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads,
         uint64_t n_bases, uint32_t* covg, uint32_t* prg_reads);
     void wait_stream(hipStream_t stream);
+    void leftovers(Lane& lane, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads, uint64_t n_bases, uint32_t* covg,
+        uint32_t* prg_reads, hipStream_t stream);
+    void run_batch_direct_candidates(const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads, uint64_t n_bases,
+        uint32_t* covg, uint32_t* prg_reads, hipStream_t stream);
+    void ensure_tile_workspace(uint32_t n_tiles, uint32_t tile_cap);
     void run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads, uint64_t n_bases,
         uint32_t* d_covg, uint32_t* d_prg_reads, hipStream_t stream);
     void cluster_hits(const uint64_t* d_offsets, uint32_t n_hits, bool ordered, unsigned long long* d_unsorted, uint32_t* d_covg,
@@ -111,6 +116,7 @@ private:
     uint32_t* d_bloomr_ = nullptr; // second stage of the level-0 form
     int n_cus_ = 256;
     bool use_filter_ = false;
+    bool use_direct_cands_ = false; // direct sketch kernel in its candidate form (read_cluster_kernel instead of sort + cluster kernels)
     // accumulators
     uint32_t* d_covg_ = nullptr;
     uint32_t* d_prg_reads_ = nullptr;
@@ -134,6 +140,13 @@ private:
     hipEvent_t ev_begin_ = nullptr; // recorded on the caller's stream: the other lanes start behind it
     void* d_temp_ = nullptr;
     uint32_t* d_tile_first_ = nullptr;
+    // candidate form of the direct sequence: one slice of tile_cap_ records per tile
+    uint32_t tile_slice_cap_ = 256, tile_ws_tiles_ = 0, tile_ws_cap_ = 0;
+    uint64_t* d_tile_info_ = nullptr;
+    uint32_t *d_tile_pos1_ = nullptr, *d_tile_count_ = nullptr, *d_tile_hits_ = nullptr, *d_tile_prefix_ = nullptr;
+    uint4* d_tile_rec_ = nullptr;
+    void* d_tile_temp_ = nullptr;
+    size_t tile_temp_bytes_ = 0;
     uint32_t tile_cap_ = 0;
     size_t temp_bytes_ = 0;
     // host staging

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (*reinterpret_cast<volatile uint32_t*>(a.overflow) & 4u) return; // a candidate slice overflowed: the host re-runs the batch
-    const uint32_t total = fw.cand_prefix[fw.n_slices];
+    const uint32_t total = *fw.cand_total;
     for (uint32_t i = tid; i < rc.n_prgs; i += RC_THREADS) s_hist[i] = 0;
     if (tid < 3) s_tot[tid] = 0;
     unsigned long long my_kept_hits = 0;

@@ -354,6 +354,19 @@ uint32_t filter_grid(bool level0, int n_cus, uint32_t n_tiles)
 
 size_t filter_small_words() { return (size_t)MAX_SLICES * 3 + 1 + 4 * (size_t)MAX_EX_WG; }
 
+void init_candidate_work(FilterWork& fw, const FilterBuffers& b, int n_cus)
+{
+    fw.cand_info = b.cand_info;
+    fw.cand_pos1 = b.cand_pos1;
+    fw.cand_rec = b.cand_rec;
+    fw.wg_hits = b.small + 3 * MAX_SLICES + 1;
+    fw.wg_nmin = fw.wg_hits + MAX_EX_WG;
+    fw.wg_maxlen = fw.wg_nmin + MAX_EX_WG;
+    fw.wg_base = fw.wg_maxlen + MAX_EX_WG;
+    fw.ex_grid = std::min<uint32_t>((uint32_t)n_cus * 8, MAX_EX_WG);
+    fw.max_len = b.max_len;
+}
+
 hipError_t launch_sketch_filter(const SketchArgs& a, uint32_t read_begin, uint32_t read_end, const BloomTables& bt, int n_cus,
     const FilterBuffers& b, const ReadClusterArgs& rc, FilterWork& fw, hipStream_t stream, KernelTimer timer)
 {
@@ -379,16 +392,12 @@ hipError_t launch_sketch_filter(const SketchArgs& a, uint32_t read_begin, uint32
     fw.cand_info = b.cand_info;
     fw.cand_pos1 = b.cand_pos1;
     fw.cand_rec = b.cand_rec;
+    init_candidate_work(fw, b, n_cus);
     fw.slice_count = b.small;
     fw.cand_prefix = b.small + MAX_SLICES;
+    fw.cand_total = fw.cand_prefix + grid * FT_WAVES * FT_SUB;
     fw.grp_count = b.small + 2 * MAX_SLICES + 1;
     fw.raw_grp = b.raw_grp;
-    fw.wg_hits = b.small + 3 * MAX_SLICES + 1;
-    fw.wg_nmin = fw.wg_hits + MAX_EX_WG;
-    fw.wg_maxlen = fw.wg_nmin + MAX_EX_WG;
-    fw.wg_base = fw.wg_maxlen + MAX_EX_WG;
-    fw.ex_grid = std::min<uint32_t>((uint32_t)n_cus * 8, MAX_EX_WG);
-    fw.max_len = b.max_len;
     if (timer.begin) HIP_TRY(hipEventRecord(timer.begin, stream));
     {
         using Kernel = void (*)(SketchArgs, FilterWork);

@@ -155,8 +155,8 @@ __global__ __launch_bounds__(SK_THREADS) void sketch_probe_kernel(SketchArgs a)
 
     // ---- phase 2a: which of my positions are window minimizers? ----
     // position j is a minimizer iff some window of w consecutive valid k-mers containing j has no value below g[j].
+    uint32_t minbits = 0;
     if (base0 >= halo && base0 < SK_NPOS - halo) {
-        uint32_t minbits = 0;
         const int pbase = base0 - (w - 1); // tile position of element 0 of my neighbourhood
         if constexpr (WC > 0) {
             // branch-free: sliding minimum over windows (an invalid k-mer is 0, so an invalid window has minimum 0 and
@@ -218,14 +218,16 @@ __global__ __launch_bounds__(SK_THREADS) void sketch_probe_kernel(SketchArgs a)
                 }
             }
         }
-        if (minbits) {
-            uint32_t at = atomicAdd(&s_nmin, (uint32_t)__popc(minbits));
-            while (minbits) {
-                int j = __ffs(minbits) - 1;
-                minbits &= minbits - 1;
-                s_mins[at++] = (uint16_t)(base0 + j);
-            }
+    }
+    { // the minimizers of the tile, compacted in position order (threads own consecutive positions)
+        uint32_t n_all;
+        uint32_t at = block_exclusive_scan<SK_THREADS / 64>((uint32_t)__popc(minbits), s_scan, &n_all);
+        while (minbits) {
+            int j = __ffs(minbits) - 1;
+            minbits &= minbits - 1;
+            s_mins[at++] = (uint16_t)(base0 + j);
         }
+        if (tid == 0) s_nmin = n_all;
     }
     __syncthreads();
 
@@ -237,6 +239,70 @@ __global__ __launch_bounds__(SK_THREADS) void sketch_probe_kernel(SketchArgs a)
     const uint32_t tmask = (1u << a.table_bits) - 1;
     const HT* __restrict__ slot_key = reinterpret_cast<const HT*>(a.slot_key);
     constexpr HT NOT_FOUND = (HT)~(HT)0;
+    if (a.tile_cap) {
+        // ---- candidate form: one record per index minimizer, in position order, into this tile's slice ----
+        const size_t slice = (size_t)blockIdx.x * a.tile_cap;
+        uint32_t written = 0, my_hits = 0;
+        for (uint32_t i0 = 0; i0 < nmin; i0 += SK_THREADS) { // (wave-uniform trip count: the scans hold barriers)
+            const uint32_t i = i0 + (uint32_t)tid;
+            bool found = false;
+            uint32_t s = 0;
+            int j = 0;
+            if (i < nmin) {
+                j = s_mins[i];
+                const HT h = s_hash[hpad(j)] - 1;
+                bool maybe = true;
+                if (a.pbloom) {
+                    const uint32_t m = pbloom_mix((uint64_t)h), need = pbloom_bits(m);
+                    maybe = (a.pbloom[pbloom_word(m, a.pbloom_wbits)] & need) == need;
+                }
+                if (maybe) {
+                    s = table_slot_dev((uint64_t)h, a.table_bits);
+                    while (true) {
+                        const HT key = slot_key[s];
+                        if (key == h) { found = true; break; }
+                        if (key == Tr::EMPTY) break;
+                        s = (s + 1) & tmask;
+                    }
+                }
+            }
+            uint32_t n_found;
+            const uint32_t at = written + block_exclusive_scan<SK_THREADS / 64>(found ? 1u : 0u, s_scan, &n_found);
+            if (found) {
+                const uint2 rec = a.slot_rec[s];
+                const uint64_t gp = (uint64_t)(origin + j);
+                const uint32_t read = find_read_from(a.offsets, a.n_reads, first_read ? first_read - 1 : 0, gp);
+                const uint64_t r0 = a.offsets[read], r1 = a.offsets[read + 1], pos = gp - r0;
+                const uint32_t strand = (s_strand[j / SK_G] >> (j % SK_G)) & 1u;
+                my_hits += rec.y;
+                if (pos >= (1ull << HIT_POS_BITS)) atomicOr(a.overflow, 2u);
+                else if (at < a.tile_cap) {
+                    const uint32_t kn = a.rec_knode[rec.x], prg = a.rec_prg[rec.x];
+                    const uint32_t rev = ((kn & 1u) == strand) ? 0u : 1u;
+                    // size threshold of a cluster of this read on that PRG (cluster_eval_kernel)
+                    const uint64_t expected = (r1 - r0) * 2 / (uint64_t)(w + 1);
+                    uint64_t m = a.prg_min_path_len[prg];
+                    if (expected < m) m = expected;
+                    const uint32_t length_based = (uint32_t)((double)m * a.fraction);
+                    uint32_t thr = length_based > a.min_cluster_size ? length_based : a.min_cluster_size;
+                    if (thr > 0xFFFFu) thr = 0xFFFFu;
+                    a.tile_info[slice + at] = ((uint64_t)s << 32) | ((uint64_t)strand << 31) | (uint64_t)read;
+                    a.tile_pos1[slice + at] = (uint32_t)pos + 1;
+                    a.tile_rec[slice + at] = make_uint4(rec.x, rec.y, (strand << 31) | (((prg << 1) | rev) << 16) | thr, (kn >> 1) * 2u + rev);
+                }
+            }
+            written += n_found;
+        }
+        uint32_t tile_hits;
+        (void)block_exclusive_scan<SK_THREADS / 64>(my_hits, s_scan, &tile_hits);
+        if (tid == 0) {
+            a.tile_count[blockIdx.x] = written < a.tile_cap ? written : a.tile_cap;
+            a.tile_hits[blockIdx.x] = tile_hits;
+            if (written > a.tile_cap) atomicOr(a.overflow, 4u);
+            if (nmin) atomicAdd(a.n_minimizers, (unsigned long long)nmin);
+        }
+        return;
+    }
     uint32_t mine = 0;
     for (uint32_t i = tid; i < nmin; i += SK_THREADS) {
         const int j = s_mins[i];

@@ -67,7 +67,8 @@ class Context:
     # ---- options -------------------------------------------------------------------------------
     def set_opts(self, illumina=False, min_cluster_size=10, genome_size=MTB_GENOME_SIZE, max_diff=0, error_rate=0.0,
                  genotyping_error_rate=0.0, kernel=0):
-        """kernel: 0 auto, 1 direct sketch kernel, 2 Bloom-prefiltered kernel"""
+        """kernel: 0 auto, 1 direct sketch kernel + generic cluster pipeline, 2 Bloom-prefiltered kernel, 3 direct sketch
+        kernel in its candidate form (read_cluster_kernel)"""
         o = MapOpts(max_diff, error_rate, min_cluster_size, 1 if illumina else 0, genome_size, genotyping_error_rate, kernel)
         _check(lib.drprg_hip_set_opts(self._h, C.byref(o)), self._h)
 

@@ -82,7 +82,7 @@ int drprg_hip_set_coverage(drprg_hip_ctx* ctx, const uint32_t* covg, uint64_t n_
 int drprg_hip_device_coverage(drprg_hip_ctx* ctx, void** d_covg, void** d_prg_reads);
 int drprg_hip_reset(drprg_hip_ctx* ctx);
 /* out[0..7] = reads, bases, minimizers examined (direct kernel: every read minimizer; filtered kernel: those that are
- * index keys), hits, clusters kept, hits kept, sketch kernel in use (1 direct, 2 Bloom-prefiltered), reads of the
+ * index keys), hits, clusters kept, hits kept, sketch kernel in use (1 direct + generic cluster pipeline, 2 Bloom-prefiltered, 3 direct in its candidate form), reads of the
  * filtered sequence that went through the generic cluster pipeline instead of the per-read kernel */
 int drprg_hip_counters(drprg_hip_ctx* ctx, uint64_t out[8]);
 

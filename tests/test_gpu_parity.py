@@ -33,7 +33,7 @@ def _compare(ctx, oracle, bases, offsets, w, k, illumina, kernel, min_cluster_si
     ctx.map_host(bases, offsets)
     gcov, gprg = ctx.coverage()
     gcnt = ctx.counters()
-    if kernel == 1:  # the filtered kernel only counts the minimizers that are index keys
+    if kernel != 2:  # the filtered kernel only counts the minimizers that are index keys
         assert gcnt["minimizers"] == ocnt["minimizers"]
     assert gcnt["hits"] == ocnt["hits"]
     assert gcnt["clusters_kept"] == ocnt["clusters_kept"]
@@ -43,8 +43,8 @@ def _compare(ctx, oracle, bases, offsets, w, k, illumina, kernel, min_cluster_si
     return ocnt
 
 
-CASES = [(11, 15, 1), (11, 15, 2), (14, 15, 1), (14, 15, 2), (5, 9, 1), (5, 9, 2), (16, 13, 2), (19, 21, 1), (1, 15, 1),
-         (1, 15, 2), (11, 31, 1)]
+CASES = [(11, 15, 1), (11, 15, 2), (11, 15, 3), (14, 15, 1), (14, 15, 2), (14, 15, 3), (5, 9, 1), (5, 9, 2), (5, 9, 3), (16, 13, 2),
+         (16, 13, 3), (19, 21, 1), (19, 21, 3), (1, 15, 1), (1, 15, 2), (1, 15, 3), (11, 31, 1), (11, 31, 3)]
 
 
 @pytest.mark.parametrize("w,k,kernel", CASES)
@@ -60,7 +60,7 @@ def test_short_reads_bit_exact(tmp_path, oracle, w, k, kernel):
         assert ctx.counters()["leftover_reads"] == 0  # ordinary short reads never need the generic pipeline
 
 
-@pytest.mark.parametrize("kernel", [1, 2])
+@pytest.mark.parametrize("kernel", [1, 2, 3])
 def test_long_reads_bit_exact(tmp_path, oracle, kernel):
     from drprg_amd import synth
     panel = synth.small_panel(seed=11, n_loci=6, length=1500)
@@ -71,7 +71,7 @@ def test_long_reads_bit_exact(tmp_path, oracle, kernel):
     assert cnt["clusters_kept"] > 0
 
 
-@pytest.mark.parametrize("kernel", [1, 2])
+@pytest.mark.parametrize("kernel", [1, 2, 3])
 def test_ragged_and_degenerate_inputs(tmp_path, oracle, kernel):
     """empty reads, reads shorter than k, N runs, lower case, read boundaries at tile edges"""
     from drprg_amd import synth
@@ -114,7 +114,7 @@ def test_dense_panel_reads(tmp_path, oracle):
         reads.append(hap[s:s + 150])
     offs = np.arange(len(reads) + 1, dtype=np.uint64) * np.uint64(150)
     bases = np.concatenate(reads)
-    for kernel in (1, 2):
+    for kernel in (1, 2, 3):
         ctx = _ctx(tmp_path, panel, 11, 15, True, kernel=kernel)
         cnt = _compare(ctx, oracle, bases, offs, 11, 15, True, kernel)
         assert cnt["clusters_kept"] > 5000
@@ -161,7 +161,7 @@ def test_reads_with_hits_in_several_groups(tmp_path, oracle, illumina):
     lb, lo = _reads_from(rng, seqs, 300, 700)  # several clusters per read with the Illumina gap limit
     bases = np.concatenate([bases, lb])
     offs = np.concatenate([offs, lo[1:] + offs[-1]])
-    for kernel in (1, 2):
+    for kernel in (1, 2, 3):
         ctx = _ctx(tmp_path, panel, 11, 15, illumina, kernel=kernel)
         cnt = _compare(ctx, oracle, bases, offs, 11, 15, illumina, kernel)
         assert cnt["clusters_kept"] > 1000
@@ -201,7 +201,7 @@ def test_reads_longer_than_the_staged_range(tmp_path, oracle):
     b3, o3 = _reads_from(rng, seqs_long, 40, 3000, sub_rate=0.03)
     bases = np.concatenate([b1, b2, b3])
     offs = np.concatenate([o1, o2[1:] + o1[-1], o3[1:] + o1[-1] + o2[-1]])
-    for kernel in (1, 2):
+    for kernel in (1, 2, 3):
         ctx = _ctx(tmp_path, panel, 11, 15, False, kernel=kernel)
         cnt = _compare(ctx, oracle, bases, offs, 11, 15, False, kernel)
         assert cnt["clusters_kept"] > 500
@@ -219,7 +219,7 @@ def test_many_small_prgs(tmp_path, oracle):
     panel = synth.Panel([f"p{i}" for i in range(3000)], loci)
     genome = "".join(l[0] for l in loci).encode()
     bases, offs = _reads_from(rng, [genome], 6000, 150, sub_rate=0.001)
-    for kernel in (1, 2):
+    for kernel in (1, 2, 3):
         ctx = _ctx(tmp_path, panel, 11, 15, True, kernel=kernel, min_cluster_size=2)
         cnt = _compare(ctx, oracle, bases, offs, 11, 15, True, kernel, min_cluster_size=2)
         assert cnt["clusters_kept"] > 1000
@@ -249,7 +249,7 @@ def test_randomized_configurations(tmp_path, oracle, seed):
     for p in parts:
         offs.append(p[1][1:] + offs[-1][-1])
     offs = np.concatenate(offs)
-    for kernel in (1, 2):
+    for kernel in (1, 2, 3):
         ctx = _ctx(tmp_path, panel, w, k, illumina, kernel=kernel, min_cluster_size=mcs)
         _compare(ctx, oracle, bases, offs, w, k, illumina, kernel, min_cluster_size=mcs)
 
