@@ -415,12 +415,12 @@ __global__ __launch_bounds__(EX_THREADS) void recount_kernel(SketchArgs a, Filte
 // ---------------------------------------------------------------------------------------------
 // candidate form of the direct sequence: tile slices -> dense list
 // ---------------------------------------------------------------------------------------------
-constexpr int TG_THREADS = 256, TG_TILES = 32; // tiles per workgroup
+constexpr int TG_THREADS = 1024, TG_TILES = 64; // tiles per workgroup: every wave copies four tile slices
 __global__ __launch_bounds__(TG_THREADS) void tile_gather_kernel(SketchArgs a, FilterWork fw, const uint32_t* __restrict__ tile_prefix,
     uint32_t n_tiles, uint64_t dense_capacity)
 {
     __shared__ uint32_t s_w[TG_THREADS / 64 + 1];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // (a slice or the dense list too small: the host grows the workspace and runs the batch again; count nothing)
     const bool overflow = (*reinterpret_cast<volatile uint32_t*>(a.overflow) & 4u) != 0 || (uint64_t)tile_prefix[n_tiles] > dense_capacity;
     if (overflow) {
@@ -430,10 +430,10 @@ __global__ __launch_bounds__(TG_THREADS) void tile_gather_kernel(SketchArgs a, F
     const uint32_t t0 = blockIdx.x * TG_TILES, t1 = t0 + TG_TILES < n_tiles ? t0 + TG_TILES : n_tiles;
     uint32_t my_hits = 0;
     for (uint32_t t = t0 + (uint32_t)tid; t < t1; t += TG_THREADS) my_hits += a.tile_hits[t];
-    for (uint32_t t = t0; t < t1; ++t) {
+    for (uint32_t t = t0 + (uint32_t)wave; t < t1; t += TG_THREADS / 64) {
         const uint32_t n = a.tile_count[t], dst = tile_prefix[t];
         const size_t src = (size_t)t * a.tile_cap;
-        for (uint32_t i = tid; i < n; i += TG_THREADS) {
+        for (uint32_t i = lane; i < n; i += 64) {
             fw.cand_info[dst + i] = a.tile_info[src + i];
             fw.cand_pos1[dst + i] = a.tile_pos1[src + i];
             fw.cand_rec[dst + i] = a.tile_rec[src + i];
