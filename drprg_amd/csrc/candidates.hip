@@ -428,8 +428,11 @@ __global__ __launch_bounds__(TG_THREADS) void tile_gather_kernel(SketchArgs a, F
         return;
     }
     const uint32_t t0 = blockIdx.x * TG_TILES, t1 = t0 + TG_TILES < n_tiles ? t0 + TG_TILES : n_tiles;
-    uint32_t my_hits = 0;
-    for (uint32_t t = t0 + (uint32_t)tid; t < t1; t += TG_THREADS) my_hits += a.tile_hits[t];
+    uint32_t my_hits = 0, my_nmin = 0;
+    for (uint32_t t = t0 + (uint32_t)tid; t < t1; t += TG_THREADS) {
+        my_hits += a.tile_hits[t];
+        my_nmin += a.tile_nmin[t];
+    }
     for (uint32_t t = t0 + (uint32_t)wave; t < t1; t += TG_THREADS / 64) {
         const uint32_t n = a.tile_count[t], dst = tile_prefix[t];
         const size_t src = (size_t)t * a.tile_cap;
@@ -439,9 +442,13 @@ __global__ __launch_bounds__(TG_THREADS) void tile_gather_kernel(SketchArgs a, F
             fw.cand_rec[dst + i] = a.tile_rec[src + i];
         }
     }
-    uint32_t hits;
+    uint32_t hits, nmin;
     (void)block_exclusive_scan<TG_THREADS / 64>(my_hits, s_w, &hits);
-    if (tid == 0 && hits) atomicAdd(a.n_hits, (unsigned long long)hits);
+    (void)block_exclusive_scan<TG_THREADS / 64>(my_nmin, s_w, &nmin);
+    if (tid == 0) {
+        if (hits) atomicAdd(a.n_hits, (unsigned long long)hits);
+        if (nmin) atomicAdd(a.n_minimizers, (unsigned long long)nmin);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -60,12 +60,12 @@ struct SketchArgs {
                         // too small, bit 3: dynamic LDS does not start at address 0 (sketch_filter_kernel)
     // candidate form of the direct kernel (tile_cap != 0): instead of hits, every tile leaves the records
     // read_cluster_kernel wants (same layout as FilterWork::cand_info / cand_pos1 / cand_rec), in position order, in its own
-    // slice of tile_cap entries; tile_count[t] = minimizers found, tile_hits[t] = their hits
+    // slice of tile_cap entries; tile_count[t] = minimizers found, tile_hits[t] = their hits, tile_nmin[t] = all minimizers of the tile
     uint32_t tile_cap;
     uint64_t* tile_info;
     uint32_t* tile_pos1;
     uint4* tile_rec;
-    uint32_t *tile_count, *tile_hits;
+    uint32_t *tile_count, *tile_hits, *tile_nmin;
     const uint32_t* prg_min_path_len; // for the size threshold stored in the records
     double fraction;
     uint32_t min_cluster_size;

@@ -127,7 +127,7 @@ Mapper::~Mapper()
     dfree(d_key_a_); dfree(d_key_b_); dfree(d_val_a_); dfree(d_val_b_);
     dfree(d_head_); dfree(d_scan_); dfree(d_cstart_); dfree(d_order_); dfree(d_clusters_);
     if (d_temp_) (void)hipFree(d_temp_);
-    dfree(d_tile_info_); dfree(d_tile_pos1_); dfree(d_tile_count_); dfree(d_tile_hits_); dfree(d_tile_prefix_); dfree(d_tile_rec_);
+    dfree(d_tile_info_); dfree(d_tile_pos1_); dfree(d_tile_count_); dfree(d_tile_hits_); dfree(d_tile_nmin_); dfree(d_tile_prefix_); dfree(d_tile_rec_);
     if (d_tile_temp_) (void)hipFree(d_tile_temp_);
     dfree(d_bases_); dfree(d_offsets_); dfree(d_tile_first_); dfree(d_bloom_); dfree(d_bloom0_); dfree(d_bloomr_); dfree(d_pbloom_);
     for (Lane& lane : lanes_) free_lane(lane);
@@ -389,14 +389,14 @@ void Mapper::leftovers(Lane& lane, const uint8_t* d_bases, const uint64_t* d_off
 void Mapper::ensure_tile_workspace(uint32_t n_tiles, uint32_t tile_cap)
 {
     if (n_tiles <= tile_ws_tiles_ && tile_cap <= tile_ws_cap_) return;
-    dfree(d_tile_info_); dfree(d_tile_pos1_); dfree(d_tile_count_); dfree(d_tile_hits_); dfree(d_tile_prefix_); dfree(d_tile_rec_);
+    dfree(d_tile_info_); dfree(d_tile_pos1_); dfree(d_tile_count_); dfree(d_tile_hits_); dfree(d_tile_nmin_); dfree(d_tile_prefix_); dfree(d_tile_rec_);
     if (d_tile_temp_) (void)hipFree(d_tile_temp_);
     d_tile_temp_ = nullptr;
     tile_ws_tiles_ = std::max(tile_ws_tiles_, n_tiles + n_tiles / 8 + 16);
     tile_ws_cap_ = std::max(tile_ws_cap_, tile_cap);
     const size_t n = (size_t)tile_ws_tiles_ * tile_ws_cap_;
     dmalloc(d_tile_info_, n); dmalloc(d_tile_pos1_, n); dmalloc(d_tile_rec_, n);
-    dmalloc(d_tile_count_, (size_t)tile_ws_tiles_ + 1); dmalloc(d_tile_hits_, (size_t)tile_ws_tiles_ + 1); dmalloc(d_tile_prefix_, (size_t)tile_ws_tiles_ + 1);
+    dmalloc(d_tile_count_, (size_t)tile_ws_tiles_ + 1); dmalloc(d_tile_hits_, (size_t)tile_ws_tiles_ + 1); dmalloc(d_tile_nmin_, (size_t)tile_ws_tiles_ + 1); dmalloc(d_tile_prefix_, (size_t)tile_ws_tiles_ + 1);
     tile_temp_bytes_ = dev::scan_temp_bytes(tile_ws_tiles_ + 1);
     HIPCHK(hipMalloc(&d_tile_temp_, tile_temp_bytes_ ? tile_temp_bytes_ : 1));
 }
@@ -429,6 +429,7 @@ void Mapper::run_batch_direct_candidates(const uint8_t* d_bases, const uint64_t*
         a.tile_rec = d_tile_rec_;
         a.tile_count = d_tile_count_;
         a.tile_hits = d_tile_hits_;
+        a.tile_nmin = d_tile_nmin_;
         a.prg_min_path_len = d_min_path_len_;
         a.fraction = params_.cluster_fraction();
         a.min_cluster_size = params_.min_cluster_size;

@@ -143,7 +143,7 @@ private:
     // candidate form of the direct sequence: one slice of tile_cap_ records per tile
     uint32_t tile_slice_cap_ = 256, tile_ws_tiles_ = 0, tile_ws_cap_ = 0;
     uint64_t* d_tile_info_ = nullptr;
-    uint32_t *d_tile_pos1_ = nullptr, *d_tile_count_ = nullptr, *d_tile_hits_ = nullptr, *d_tile_prefix_ = nullptr;
+    uint32_t *d_tile_pos1_ = nullptr, *d_tile_count_ = nullptr, *d_tile_hits_ = nullptr, *d_tile_nmin_ = nullptr, *d_tile_prefix_ = nullptr;
     uint4* d_tile_rec_ = nullptr;
     void* d_tile_temp_ = nullptr;
     size_t tile_temp_bytes_ = 0;
