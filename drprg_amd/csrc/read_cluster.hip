@@ -9,22 +9,24 @@ namespace dev {
 // ---------------------------------------------------------------------------------------------
 // per-read clustering straight from the candidate list
 // ---------------------------------------------------------------------------------------------
-// The candidates leave verify_count_kernel ordered by (read, position), so all minimizers of a read sit next to each
-// other, and a short read has a few dozen hits, nearly always in ONE cluster.  read_cluster_kernel therefore never
-// materialises the hit list.  A workgroup stages RC_SLOTS consecutive candidates and their index records (the hits) in
-// LDS.  A position gap > max_diff between two consecutive minimizers of a read starts a new segment; as long as all
-// hits of the read lie in one (prg, strand) group, the segments ARE the clusters and the overlap sweep of
-// cluster_filter_kernel cannot drop any of them (same group, disjoint position ranges).  So every minimizer adds its
-// hits to its segment's counter, the first slot of a segment applies the size threshold of cluster_eval_kernel, and
-// every minimizer of a kept segment then adds its own hits to the coverage vector -- all of it data parallel.  Only
-// the reads whose hits fall into several groups are walked serially by the thread of their first candidate (clusters
-// per group split at gaps, size threshold, the overlap sweep; pandora define_clusters / filter_clusters).  This replaces expand + reorder
-// + flag + scan + start + eval + filter + count + accumulate (13 launches) for such reads.  A read that does not fit
-// (its candidates run past the staged range, more than RC_MAXC clusters, too many hits in the chunk, a position >=
-// 2^16) is left alone: its candidates keep cand_pos1 != 0, n_complex counts it, and the host sends what is left
-// through the generic pipeline (long reads always go that way).  Handled reads get cand_pos1 = 0.  (A workgroup may
-// read cand_pos1 of a neighbouring chunk's read while that chunk zeroes it: either value only moves where the foreign
-// hits land in LDS, nothing else.)
+// The candidates arrive ordered by (read, position) -- from verify_count_kernel, or from the direct sketch kernel in its
+// candidate form -- so all minimizers of a read sit next to each other, and a short read has a few dozen hits, nearly
+// always in ONE cluster.  read_cluster_kernel therefore never materialises the hit list.  A workgroup stages RC_SLOTS
+// consecutive candidates and their index records (the hits) in LDS.  A position gap > max_diff between two consecutive
+// minimizers of a read starts a new segment; as long as all hits of the read lie in one (prg, strand) group, the
+// segments ARE the clusters and the overlap sweep of cluster_filter_kernel cannot drop any of them (same group,
+// disjoint position ranges).  So: a segment's hit count is a difference of two scan values, the first slot of a segment
+// compares it with the size threshold of cluster_eval_kernel (stored per candidate), and every minimizer of a kept
+// segment then adds its own hits to the coverage vector -- all of it data parallel.  Only the reads whose hits fall into
+// several groups are queued and handled one wave per read: lane j holds cluster j, the hits are broadcast one by one
+// (clusters per group split at gaps, size threshold, rank in clusterComp order, the overlap sweep; pandora
+// define_clusters / filter_clusters).  This replaces expand + reorder + flag + scan + start + eval + filter + count +
+// accumulate (13 launches) for such reads.  A read that does not fit (its candidates run past the staged range, more
+// than 64 clusters, more than RC_HCAP staged hits in the chunk, a position >= 2^16 - 2, more than RC_POOL multi-group
+// reads in a chunk) is left alone: its candidates keep cand_pos1 != 0, n_complex counts it, and the host sends what is
+// left through the generic pipeline.  Handled reads get cand_pos1 = 0.  (A workgroup may read cand_pos1 of a
+// neighbouring chunk's read while that chunk zeroes it: either value only moves where the foreign hits land in LDS,
+// nothing else.)  Chunks are handed out through a global counter.
 constexpr int RC_THREADS = 1024;
 constexpr int RC_WAVES = RC_THREADS / 64;
 constexpr int RC_PER = 2;
