@@ -413,7 +413,7 @@ void Mapper::run_batch_direct_candidates(const uint8_t* d_bases, const uint64_t*
         tile_cap_ = n_tiles + n_tiles / 4 + 16;
         dmalloc(d_tile_first_, (size_t)tile_cap_);
     }
-    ensure_lanes(1, std::max<uint64_t>(1u << 20, n_bases / 16));
+    ensure_lanes(1, std::min<uint64_t>(std::max<uint64_t>(1u << 20, n_bases / 16), (1ull << 31) - 1));
     Lane& lane = lanes_[0];
     for (int attempt = 0;; ++attempt) {
         ensure_tile_workspace(n_tiles, tile_slice_cap_);
@@ -473,7 +473,7 @@ void Mapper::run_batch_direct_candidates(const uint8_t* d_bases, const uint64_t*
         HIPCHK(hipMemcpyAsync(&d_counters_[C_MINIMIZERS], &restored, sizeof(restored), hipMemcpyHostToDevice, stream));
         HIPCHK(hipStreamSynchronize(stream));
         tile_slice_cap_ = std::min<uint32_t>(tile_slice_cap_ * 2, 4096);
-        grow_lane(lane, lane.raw_capacity * 2);
+        grow_lane(lane, std::min<uint64_t>(lane.raw_capacity * 2, (1ull << 31) - 1));
     }
     last_minimizers_ = h_counters_[C_MINIMIZERS];
     tot_hits_ += lane.h_scratch[L_HITS];
