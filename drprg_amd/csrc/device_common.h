@@ -90,6 +90,15 @@ __device__ inline uint32_t find_read_from(const uint64_t* __restrict__ offsets, 
     return lo;
 }
 
+// read holding gp: the interpolated guess first (exact for fixed-length reads: two independent loads), else the gallop from
+// `lo` (offsets[lo] <= gp; a read that starts shortly before the tile)
+__device__ inline uint32_t find_read_guess(const uint64_t* __restrict__ offsets, uint32_t n_reads, uint32_t guess, uint32_t lo, uint64_t gp)
+{
+    if (guess >= n_reads) guess = n_reads - 1;
+    if (offsets[guess] <= gp && gp < offsets[guess + 1]) return guess;
+    return find_read_from(offsets, n_reads, lo, gp);
+}
+
 // read holding global base position gp, searched outwards from `guess` (any read index): gallops down or up, then
 // bisects.  With near-uniform read lengths and guess = gp * n_reads / n_bases this costs two or three loads.
 __device__ inline uint32_t find_read_near(const uint64_t* __restrict__ offsets, uint32_t n_reads, uint32_t guess, uint64_t gp)

@@ -236,6 +236,7 @@ __global__ __launch_bounds__(SK_THREADS) void sketch_probe_kernel(SketchArgs a)
     // reservation (a per-minimizer atomic on the hit counter serialises on a single L2 address once millions of
     // minimizers hit, as they do with a large index).
     const uint32_t nmin = s_nmin;
+    const double reads_per_base = (double)a.n_reads / (double)(a.n_bases ? a.n_bases : 1);
     const uint32_t tmask = (1u << a.table_bits) - 1;
     const HT* __restrict__ slot_key = reinterpret_cast<const HT*>(a.slot_key);
     constexpr HT NOT_FOUND = (HT)~(HT)0;
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(SK_THREADS) void sketch_probe_kernel(SketchArgs a)
             if (found) {
                 const uint2 rec = a.slot_rec[s];
                 const uint64_t gp = (uint64_t)(origin + j);
-                const uint32_t read = find_read_from(a.offsets, a.n_reads, first_read ? first_read - 1 : 0, gp);
+                const uint32_t read = find_read_guess(a.offsets, a.n_reads, (uint32_t)((double)gp * reads_per_base), first_read ? first_read - 1 : 0, gp);
                 const uint64_t r0 = a.offsets[read], r1 = a.offsets[read + 1], pos = gp - r0;
                 const uint32_t strand = (s_strand[j / SK_G] >> (j % SK_G)) & 1u;
                 my_hits += rec.y;
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(SK_THREADS) void sketch_probe_kernel(SketchArgs a)
         const uint2 rec = a.slot_rec[s];
         // a hit: locate the read and emit one hit per index record
         const uint64_t gp = (uint64_t)(origin + j);
-        const uint32_t read = find_read_from(a.offsets, a.n_reads, first_read ? first_read - 1 : 0, gp);
+        const uint32_t read = find_read_guess(a.offsets, a.n_reads, (uint32_t)((double)gp * reads_per_base), first_read ? first_read - 1 : 0, gp);
         const uint64_t pos = gp - a.offsets[read];
         const uint32_t strand = (s_strand[j / SK_G] >> (j % SK_G)) & 1u;
         const unsigned long long mine_at = at;
