@@ -188,17 +188,18 @@ __global__ __launch_bounds__(EX_THREADS) void verify_count_kernel(SketchArgs a, 
                         if (pos >= (1ull << HIT_POS_BITS)) atomicOr(a.overflow, 2u);
                         else {
                             pos1 = (uint32_t)pos + 1;
-                            const uint2 rec = a.slot_rec[slot];
+                            const uint4 sf = a.slot_first[slot]; // record offset, count, first record's node, its prg and that prg's shortest path
+                            const uint2 rec = make_uint2(sf.x, sf.y);
                             my_hits += rec.y;
                             my_nmin += 1;
                             const uint32_t len = (uint32_t)((r1 - r0) > 0xFFFFFFFFll ? 0xFFFFFFFFll : (r1 - r0));
                             my_maxlen = len > my_maxlen ? len : my_maxlen;
                             // for read_cluster_kernel: the first hit of this minimizer and the size threshold of a cluster
                             // of this read on that hit's PRG (cluster_eval_kernel)
-                            const uint32_t kn = a.rec_knode[rec.x], prg = a.rec_prg[rec.x];
+                            const uint32_t kn = sf.z, prg = sf.w & 0xFFFu;
                             const uint32_t rev = ((kn & 1u) == strand) ? 0u : 1u;
                             const uint64_t expected = (uint64_t)(r1 - r0) * 2 / (uint64_t)(w + 1);
-                            uint64_t m = rc.prg_min_path_len[prg];
+                            uint64_t m = sf.w >> 12;
                             if (expected < m) m = expected;
                             const uint32_t length_based = (uint32_t)((double)m * rc.fraction);
                             uint32_t thr = length_based > rc.min_cluster_size ? length_based : rc.min_cluster_size;

@@ -44,6 +44,8 @@ struct SketchArgs {
     // index
     const void* slot_key; // u32[2^bits] (k <= 15) or u64[2^bits]
     const uint2* slot_rec; // {record offset, record count}; count 0 = empty slot
+    const uint4* slot_first; // {record offset, record count, rec_knode of the first record, its prg | min path length of that prg << 12}:
+                             // everything a candidate record needs of a slot in one load instead of three dependent ones
     uint32_t table_bits;
     const uint32_t* rec_knode; // (global k-mer node << 1) | strand
     const uint16_t* rec_prg;

@@ -66,6 +66,20 @@ Mapper::Mapper(const FlatIndex& idx, const MapParams& p, int device) : device_(d
     for (size_t i = 0; i < nslot; ++i) rec[i] = make_uint2(idx.slot_off[i], idx.slot_cnt[i]);
     dmalloc(d_slot_rec_, nslot);
     HIPCHK(hipMemcpy(d_slot_rec_, rec.data(), nslot * sizeof(uint2), hipMemcpyHostToDevice));
+    {
+        std::vector<uint4> first(nslot);
+        for (size_t i = 0; i < nslot; ++i) {
+            first[i] = make_uint4(idx.slot_off[i], idx.slot_cnt[i], 0u, 0u);
+            if (idx.slot_cnt[i]) {
+                const uint32_t r = idx.slot_off[i], prg = idx.rec_prg[r];
+                if (idx.min_path_len[prg] >= (1u << 20)) throw Error(DRPRG_EOVERFLOW, "a PRG's shortest k-mer path has 2^20 nodes or more");
+                first[i].z = (idx.rec_knode_global[r] << 1) | idx.rec_strand[r];
+                first[i].w = prg | (idx.min_path_len[prg] << 12);
+            }
+        }
+        dmalloc(d_slot_first_, nslot);
+        HIPCHK(hipMemcpy(d_slot_first_, first.data(), nslot * sizeof(uint4), hipMemcpyHostToDevice));
+    }
     const size_t nrec = idx.rec_prg.size();
     std::vector<uint32_t> rk(nrec);
     std::vector<uint16_t> rp(nrec);
@@ -121,7 +135,7 @@ Mapper::~Mapper()
 {
     (void)hipSetDevice(device_);
     if (stream_) (void)hipStreamSynchronize(stream_);
-    dfree(d_slot_rec_); dfree(d_rec_knode_); dfree(d_rec_prg_); dfree(d_min_path_len_);
+    dfree(d_slot_rec_); dfree(d_slot_first_); dfree(d_rec_knode_); dfree(d_rec_prg_); dfree(d_min_path_len_);
     if (d_slot_key_) (void)hipFree(d_slot_key_);
     dfree(d_covg_); dfree(d_prg_reads_); dfree(d_counters_);
     dfree(d_key_a_); dfree(d_key_b_); dfree(d_val_a_); dfree(d_val_b_);
@@ -334,6 +348,7 @@ dev::SketchArgs Mapper::sketch_args(const uint8_t* d_bases, const uint64_t* d_of
     a.halo = halo_;
     a.slot_key = d_slot_key_;
     a.slot_rec = d_slot_rec_;
+    a.slot_first = d_slot_first_;
     a.table_bits = table_bits_;
     a.rec_knode = d_rec_knode_;
     a.rec_prg = d_rec_prg_;

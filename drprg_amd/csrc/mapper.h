@@ -104,6 +104,7 @@ private:
     // index tables
     void* d_slot_key_ = nullptr;
     uint2* d_slot_rec_ = nullptr;
+    uint4* d_slot_first_ = nullptr;
     uint32_t* d_rec_knode_ = nullptr;
     uint16_t* d_rec_prg_ = nullptr;
     uint32_t* d_min_path_len_ = nullptr;

@@ -270,7 +270,8 @@ __global__ __launch_bounds__(SK_THREADS) void sketch_probe_kernel(SketchArgs a)
             uint32_t n_found;
             const uint32_t at = written + block_exclusive_scan<SK_THREADS / 64>(found ? 1u : 0u, s_scan, &n_found);
             if (found) {
-                const uint2 rec = a.slot_rec[s];
+                const uint4 sf = a.slot_first[s]; // record offset, count, first record's node, its prg and that prg's shortest path
+                const uint2 rec = make_uint2(sf.x, sf.y);
                 const uint64_t gp = (uint64_t)(origin + j);
                 const uint32_t read = find_read_guess(a.offsets, a.n_reads, (uint32_t)((double)gp * reads_per_base), first_read ? first_read - 1 : 0, gp);
                 const uint64_t r0 = a.offsets[read], r1 = a.offsets[read + 1], pos = gp - r0;
@@ -278,11 +279,11 @@ __global__ __launch_bounds__(SK_THREADS) void sketch_probe_kernel(SketchArgs a)
                 my_hits += rec.y;
                 if (pos >= (1ull << HIT_POS_BITS)) atomicOr(a.overflow, 2u);
                 else if (at < a.tile_cap) {
-                    const uint32_t kn = a.rec_knode[rec.x], prg = a.rec_prg[rec.x];
+                    const uint32_t kn = sf.z, prg = sf.w & 0xFFFu;
                     const uint32_t rev = ((kn & 1u) == strand) ? 0u : 1u;
                     // size threshold of a cluster of this read on that PRG (cluster_eval_kernel)
                     const uint64_t expected = (r1 - r0) * 2 / (uint64_t)(w + 1);
-                    uint64_t m = a.prg_min_path_len[prg];
+                    uint64_t m = sf.w >> 12;
                     if (expected < m) m = expected;
                     const uint32_t length_based = (uint32_t)((double)m * a.fraction);
                     uint32_t thr = length_based > a.min_cluster_size ? length_based : a.min_cluster_size;
