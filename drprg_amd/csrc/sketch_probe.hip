@@ -247,11 +247,19 @@ __global__ __launch_bounds__(SK_THREADS) void sketch_probe_kernel(SketchArgs a)
         for (uint32_t i0 = 0; i0 < nmin; i0 += SK_THREADS) { // (wave-uniform trip count: the scans hold barriers)
             const uint32_t i = i0 + (uint32_t)tid;
             bool found = false;
-            uint32_t s = 0;
+            uint32_t s = 0, guess = 0;
             int j = 0;
+            uint64_t gp = 0, o0 = 0, o1 = 0;
+            uint4 sf = make_uint4(0, 0, 0, 0);
             if (i < nmin) {
                 j = s_mins[i];
                 const HT h = s_hash[hpad(j)] - 1;
+                // the read lookup does not depend on the probe: its two loads go out first and overlap the probe's chain
+                gp = (uint64_t)(origin + j);
+                guess = (uint32_t)((double)gp * reads_per_base);
+                if (guess >= a.n_reads) guess = a.n_reads - 1;
+                o0 = a.offsets[guess];
+                o1 = a.offsets[guess + 1];
                 bool maybe = true;
                 if (a.pbloom) {
                     const uint32_t m = pbloom_mix((uint64_t)h), need = pbloom_bits(m);
@@ -266,15 +274,19 @@ __global__ __launch_bounds__(SK_THREADS) void sketch_probe_kernel(SketchArgs a)
                         s = (s + 1) & tmask;
                     }
                 }
+                if (found) sf = a.slot_first[s]; // (in flight across the scan's barriers)
             }
             uint32_t n_found;
             const uint32_t at = written + block_exclusive_scan<SK_THREADS / 64>(found ? 1u : 0u, s_scan, &n_found);
             if (found) {
-                const uint4 sf = a.slot_first[s]; // record offset, count, first record's node, its prg and that prg's shortest path
-                const uint2 rec = make_uint2(sf.x, sf.y);
-                const uint64_t gp = (uint64_t)(origin + j);
-                const uint32_t read = find_read_guess(a.offsets, a.n_reads, (uint32_t)((double)gp * reads_per_base), first_read ? first_read - 1 : 0, gp);
-                const uint64_t r0 = a.offsets[read], r1 = a.offsets[read + 1], pos = gp - r0;
+                const uint2 rec = make_uint2(sf.x, sf.y); // record offset, count; sf.z the first record's node, sf.w its prg | shortest path << 12
+                uint32_t read = guess;
+                if (!(o0 <= gp && gp < o1)) { // interpolation missed (reads of different lengths): gallop from the tile's first read
+                    read = find_read_from(a.offsets, a.n_reads, first_read ? first_read - 1 : 0, gp);
+                    o0 = a.offsets[read];
+                    o1 = a.offsets[read + 1];
+                }
+                const uint64_t r0 = o0, r1 = o1, pos = gp - r0;
                 const uint32_t strand = (s_strand[j / SK_G] >> (j % SK_G)) & 1u;
                 my_hits += rec.y;
                 if (pos >= (1ull << HIT_POS_BITS)) atomicOr(a.overflow, 2u);
