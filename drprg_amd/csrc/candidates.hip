@@ -105,6 +105,7 @@ __global__ __launch_bounds__(EX_THREADS) void verify_count_kernel(SketchArgs a, 
     const uint32_t kmask = (1u << (2 * k)) - 1;
     const int64_t n_bases = (int64_t)a.n_bases;
     const double reads_per_base = (double)a.n_reads / (double)(a.n_bases ? a.n_bases : 1);
+    const uint32_t w1_magic = w1_reciprocal(w);
     const int64_t win_lo = (int64_t)a.offsets[fw.read_begin], win_hi = (int64_t)a.offsets[fw.read_end];
     uint32_t my_hits = 0, my_nmin = 0, my_maxlen = 0;
     for (uint32_t t = t_begin + tid; t < t_end; t += EX_THREADS) {
@@ -169,12 +170,14 @@ __global__ __launch_bounds__(EX_THREADS) void verify_count_kernel(SketchArgs a, 
                     // steps that can count at all: inside the read and the window, no N in the k-mer (bit i = step i)
                     const uint32_t valid = ((2u << i_hi) - 1u) & ~((1u << i_lo) - 1u) & ~(uint32_t)(bad >> of);
                     uint32_t streak = 0, right = 0, alive = 1;
+                    uint32_t rcw = revcomp_code(r0w >> sh_k, k) << 2; // the reverse complement rolls along: one base in, one out
                     for (int i = 0; i < 2 * w - 1; ++i) {
                         const uint32_t f = r0w >> sh_k;
+                        rcw = (rcw >> 2) | ((~f & 3u) << (2 * k - 2));
                         r0w = __funnelshift_l(r1w, r0w, 2);
                         r1w = __funnelshift_l(r2w, r1w, 2);
                         r2w <<= 2;
-                        const uint32_t hf = Tr::mix(f, kmask), hr = Tr::mix(revcomp_code(f, k), kmask);
+                        const uint32_t hf = Tr::mix(f, kmask), hr = Tr::mix(rcw, kmask);
                         const uint32_t x = (hf < hr ? hf : hr) + 1;
                         const bool ok = ((valid >> i) & 1u) && x >= g;
                         if (i < ic) streak = ok ? streak + 1 : 0;
@@ -198,7 +201,7 @@ __global__ __launch_bounds__(EX_THREADS) void verify_count_kernel(SketchArgs a, 
                             // of this read on that hit's PRG (cluster_eval_kernel)
                             const uint32_t kn = sf.z, prg = sf.w & 0xFFFu;
                             const uint32_t rev = ((kn & 1u) == strand) ? 0u : 1u;
-                            const uint64_t expected = (uint64_t)(r1 - r0) * 2 / (uint64_t)(w + 1);
+                            const uint64_t expected = expected_minimizers((uint64_t)(r1 - r0), w, w1_magic);
                             uint64_t m = sf.w >> 12;
                             if (expected < m) m = expected;
                             const uint32_t length_based = (uint32_t)((double)m * rc.fraction);

@@ -130,6 +130,15 @@ __device__ inline uint32_t find_read_near(const uint64_t* __restrict__ offsets, 
     return lo;
 }
 
+// 2 * len / (w + 1) of pandora's cluster threshold without a 64-bit division per call: for w < 200 and len < 2^23 (the longest
+// read the hit key takes) floor(x / d) == (x * M) >> 32 with M = floor(2^32 / d) + 1, because x * (d * M - 2^32) < 2^32
+__device__ inline uint32_t w1_reciprocal(int w) { return (uint32_t)(0x100000000ull / (uint32_t)(w + 1)) + 1u; }
+__device__ inline uint64_t expected_minimizers(uint64_t len, int w, uint32_t magic)
+{
+    if (w < 200 && len < (1ull << 23)) return (uint64_t)__umulhi((uint32_t)len * 2u, magic);
+    return len * 2 / (uint64_t)(w + 1);
+}
+
 // ---------------------------------------------------------------------------------------------
 // wave / workgroup scans
 // ---------------------------------------------------------------------------------------------

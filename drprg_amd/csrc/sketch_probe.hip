@@ -237,6 +237,7 @@ __global__ __launch_bounds__(SK_THREADS) void sketch_probe_kernel(SketchArgs a)
     // minimizers hit, as they do with a large index).
     const uint32_t nmin = s_nmin;
     const double reads_per_base = (double)a.n_reads / (double)(a.n_bases ? a.n_bases : 1);
+    const uint32_t w1_magic = w1_reciprocal(w);
     const uint32_t tmask = (1u << a.table_bits) - 1;
     const HT* __restrict__ slot_key = reinterpret_cast<const HT*>(a.slot_key);
     constexpr HT NOT_FOUND = (HT)~(HT)0;
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(SK_THREADS) void sketch_probe_kernel(SketchArgs a)
                     const uint32_t kn = sf.z, prg = sf.w & 0xFFFu;
                     const uint32_t rev = ((kn & 1u) == strand) ? 0u : 1u;
                     // size threshold of a cluster of this read on that PRG (cluster_eval_kernel)
-                    const uint64_t expected = (r1 - r0) * 2 / (uint64_t)(w + 1);
+                    const uint64_t expected = expected_minimizers(r1 - r0, w, w1_magic);
                     uint64_t m = sf.w >> 12;
                     if (expected < m) m = expected;
                     const uint32_t length_based = (uint32_t)((double)m * a.fraction);
