@@ -34,7 +34,8 @@ typedef struct drprg_hip_map_opts {
     int32_t illumina;          /* -I */
     uint64_t genome_size;      /* -g (drprg passes 4411532) */
     double genotyping_error_rate; /* <=0: 0.01 */
-    int32_t kernel;            /* 0 auto; 1 direct sketch kernel; 2 Bloom-prefiltered kernel (k<=15, w<=16, small index) */
+    int32_t kernel;            /* 0 auto (2 when it applies, else 3); 1 direct sketch kernel + generic cluster pipeline (radix sort);
+                                * 2 Bloom-prefiltered kernel (k<=15, w<=16, small index); 3 direct sketch kernel, candidate form */
 } drprg_hip_map_opts;
 
 /* Replaces Pandora::index_with (`pandora index -t T -w W -k K <prg>`, /root/reference/src/lib.rs:479-510):
@@ -82,8 +83,9 @@ int drprg_hip_set_coverage(drprg_hip_ctx* ctx, const uint32_t* covg, uint64_t n_
 int drprg_hip_device_coverage(drprg_hip_ctx* ctx, void** d_covg, void** d_prg_reads);
 int drprg_hip_reset(drprg_hip_ctx* ctx);
 /* out[0..7] = reads, bases, minimizers examined (direct kernel: every read minimizer; filtered kernel: those that are
- * index keys), hits, clusters kept, hits kept, sketch kernel in use (1 direct + generic cluster pipeline, 2 Bloom-prefiltered, 3 direct in its candidate form), reads of the
- * filtered sequence that went through the generic cluster pipeline instead of the per-read kernel */
+ * index keys), hits, clusters kept, hits kept, sequence in use (1 direct + generic cluster pipeline, 2 Bloom-prefiltered,
+ * 3 direct in its candidate form), reads of sequences 2 / 3 that went through the generic cluster pipeline instead of the
+ * per-read kernel */
 int drprg_hip_counters(drprg_hip_ctx* ctx, uint64_t out[8]);
 
 /* Coverage -> VCF: the tail of `pandora map --genotype --local --vcf-refs <genes.fa>`; writes the file
@@ -133,7 +135,8 @@ int drprg_hip_annotate(const char* index_dir, const char* pandora_vcf, const cha
 int drprg_hip_report_json(const char* index_dir, const char* annotated_vcf, const char* out_json, const char* sample,
     int padding, const char* index_version, char* err, size_t err_len);
 
-/* HIP-event timing of the sketch+probe kernel on the launch stream (bench.py roofline).
+/* HIP-event timing of the dominant kernel (sketch_filter_kernel / sketch_probe_kernel) on its launch stream (bench.py roofline);
+ * launches = launches of that kernel (a batch cut into several read ranges counts one per range).
  * enable != 0 starts/keeps timing; ms_total / launches may be NULL; reset != 0 clears the sums. */
 int drprg_hip_kernel_timing(drprg_hip_ctx* ctx, int enable, int reset, double* ms_total, uint64_t* launches);
 
