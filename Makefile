@@ -40,8 +40,8 @@ $(BIN): $(SRC)/pandora_main.cpp $(LIB)
 	@mkdir -p $(dir $@)
 	$(HIPCC) $(CXXFLAGS) -o $@ $< -Ldrprg_amd/lib -ldrprg_hip -Wl,-rpath,'$$ORIGIN/../lib'
 
-$(ORACLE): oracle/oracle.c
-	$(CC) -O2 -fPIC -shared -Wall -o $@ $< -lm
+$(ORACLE): oracle/oracle.c oracle/oracle_index.c
+	$(CC) -O2 -fPIC -shared -Wall -o $@ oracle/oracle.c oracle/oracle_index.c -lm
 
 clean:
 	rm -rf build $(LIB) $(BIN) $(ORACLE)

@@ -20,30 +20,35 @@ struct Ext {
     uint32_t node, off;
 };
 
-void extensions_rec(const LocalGraph& g, uint32_t node, std::vector<PathPiece>& prefix, std::vector<Ext>& out)
+// `at_end` is set when some route from `node` reaches the end of the graph without reading another base (the node itself
+// is the last one, or only empty nodes follow on that route)
+void extensions_rec(const LocalGraph& g, uint32_t node, std::vector<PathPiece>& prefix, std::vector<Ext>& out, bool& at_end)
 {
+    if (g.nodes[node].out.empty()) at_end = true;
     for (uint32_t o : g.nodes[node].out) {
         if (g.nodes[o].len() > 0) {
             out.push_back(Ext { prefix, o, 0 });
         } else {
             prefix.push_back(PathPiece { o, 0, 0 });
-            extensions_rec(g, o, prefix, out);
+            extensions_rec(g, o, prefix, out, at_end);
             prefix.pop_back();
         }
     }
 }
 
-// all ways to read one more base after the last base of `p`
-void extensions(const LocalGraph& g, const KPath& p, std::vector<Ext>& out)
+// all ways to read one more base after the last base of `p`; returns true if a walk may also end here
+bool extensions(const LocalGraph& g, const KPath& p, std::vector<Ext>& out)
 {
     out.clear();
     const PathPiece& last = p.back();
     if (last.off_end < g.nodes[last.node].len()) {
         out.push_back(Ext { {}, last.node, last.off_end });
-        return;
+        return false;
     }
     std::vector<PathPiece> prefix;
-    extensions_rec(g, last.node, prefix, out);
+    bool at_end = false;
+    extensions_rec(g, last.node, prefix, out, at_end);
+    return at_end;
 }
 
 void append_base(KPath& p, const Ext& e)
@@ -119,14 +124,12 @@ struct Builder {
     void slide(uint32_t from, const KPath& cur, std::vector<Cand>& cands)
     {
         std::vector<Ext> exts;
-        extensions(g, cur, exts);
-        if (exts.empty()) { // end of the graph
+        if (extensions(g, cur, exts)) { // a walk ends here (the last node, or through empty alleles up to the end of the PRG)
             if (from == 0) {
                 if (!cands.empty()) link_leftmost_min(0, cands);
             } else {
                 link(from, SINK);
             }
-            return;
         }
         for (const Ext& e : exts) {
             KPath np = cur;
@@ -161,7 +164,8 @@ struct Builder {
             if (g.nodes[0].len() > 0) exts.push_back(Ext { {}, 0, 0 });
             else {
                 std::vector<PathPiece> prefix;
-                extensions_rec(g, 0, prefix, exts);
+                bool at_end = false;
+                extensions_rec(g, 0, prefix, exts, at_end);
                 for (Ext& e : exts) e.empties.clear(); // a k-mer path never starts with empty pieces
             }
         } else {

@@ -48,6 +48,83 @@ class Oracle:
                                    C.POINTER(C.c_int), C.POINTER(C.c_double)]
         L.orc_exp_depth_covg.restype = C.c_uint32
         L.orc_exp_depth_covg.argtypes = [C.c_void_p, C.c_int64, C.c_uint32]
+        # oracle_index.c
+        L.orc_index_prg.restype = C.c_void_p
+        L.orc_index_prg.argtypes = [C.c_char_p, C.c_int, C.c_int]
+        L.orc_kg_free.restype = None
+        L.orc_kg_free.argtypes = [C.c_void_p]
+        for name in ("orc_kg_n_nodes", "orc_kg_min_path_len", "orc_kg_n_local_nodes"):
+            getattr(L, name).restype = C.c_uint32
+            getattr(L, name).argtypes = [C.c_void_p]
+        L.orc_kg_n_edges.restype = C.c_uint64
+        L.orc_kg_n_edges.argtypes = [C.c_void_p]
+        L.orc_kg_local_nodes.restype = None
+        L.orc_kg_local_nodes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_kg_kmers.restype = None
+        L.orc_kg_kmers.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_kg_edges.restype = None
+        L.orc_kg_edges.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_kg_path.restype = C.c_uint32
+        L.orc_kg_path.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
+        L.orc_kg_walk_check.restype = C.c_int
+        L.orc_kg_walk_check.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+
+    # ---- a-4: the oracle's own index (oracle/oracle_index.c); nothing here comes from the product ----------------
+    def sketch_prg(self, prg_string, w, k, paths=False, walk_check=False):
+        """k-mer graph of one PRG string: dict(n_nodes, min_path_len, hash, strand, edges[, paths][, walk])"""
+        L = self.lib
+        g = L.orc_index_prg(prg_string.encode() if isinstance(prg_string, str) else prg_string, w, k)
+        if not g:
+            raise ValueError("malformed PRG string")
+        try:
+            n = L.orc_kg_n_nodes(g)
+            h = np.zeros(n - 2, np.uint64)
+            st = np.zeros(n - 2, np.uint8)
+            L.orc_kg_kmers(g, _p(h), _p(st))
+            ne = L.orc_kg_n_edges(g)
+            ef = np.zeros(ne, np.uint32)
+            et = np.zeros(ne, np.uint32)
+            L.orc_kg_edges(g, _p(ef), _p(et))
+            nl = L.orc_kg_n_local_nodes(g)
+            ls = np.zeros(nl, np.uint32)
+            le = np.zeros(nl, np.uint32)
+            L.orc_kg_local_nodes(g, _p(ls), _p(le))
+            out = dict(n_nodes=int(n), min_path_len=int(L.orc_kg_min_path_len(g)), hash=h, strand=st,
+                       edges=np.stack([ef, et], axis=1), local_starts=ls, local_ends=le)
+            if paths:
+                iv = np.zeros(2 * 128, np.uint32)
+                out["paths"] = []
+                for i in range(1, n - 1):
+                    m = L.orc_kg_path(g, i, _p(iv), 128)
+                    out["paths"].append([(int(iv[2 * j]), int(iv[2 * j + 1])) for j in range(m)])
+            if walk_check:
+                res = np.zeros(4, np.uint64)
+                conf = np.zeros(max(n - 2, 1), np.uint8)
+                rc = L.orc_kg_walk_check(g, _p(res), _p(conf))
+                assert rc == 0
+                out["walk"] = dict(windows=int(res[0]), missing=int(res[1]), confirmed=int(res[2]), unconfirmed=int(res[3]),
+                                   mask=conf[:n - 2].astype(bool))
+            return out
+        finally:
+            L.orc_kg_free(g)
+
+    def build_index(self, prg_strings, w, k):
+        """The flat index oracle.c's orc_map_reads consumes, built by the oracle itself from PRG strings (same layout as
+        Context.export_index(): sorted distinct keys, CSR records ordered by (key, prg, k-mer node), global node numbers)."""
+        graphs = [self.sketch_prg(s, w, k) for s in prg_strings]
+        knode_base = np.zeros(len(graphs) + 1, np.uint32)
+        knode_base[1:] = np.cumsum([g["n_nodes"] for g in graphs])
+        key = np.concatenate([g["hash"] for g in graphs]) if graphs else np.zeros(0, np.uint64)
+        prg = np.concatenate([np.full(len(g["hash"]), i, np.uint32) for i, g in enumerate(graphs)])
+        knode = np.concatenate([np.arange(1, len(g["hash"]) + 1, dtype=np.uint32) for g in graphs])
+        strand = np.concatenate([g["strand"] for g in graphs])
+        order = np.lexsort((knode, prg, key))
+        key, prg, knode, strand = key[order], prg[order], knode[order], strand[order]
+        keys, first = np.unique(key, return_index=True)
+        rec_off = np.concatenate([first, [len(key)]]).astype(np.uint32)
+        return dict(keys=keys.astype(np.uint64), rec_off=rec_off, rec_prg=prg.astype(np.uint32),
+                    rec_knode=(knode_base[prg] + knode).astype(np.uint32), rec_strand=strand.astype(np.uint8),
+                    min_path_len=np.array([g["min_path_len"] for g in graphs], np.uint32), knode_base=knode_base)
 
     def sketch(self, seq, w, k):
         seq = np.frombuffer(seq if isinstance(seq, bytes) else seq.encode(), dtype=np.uint8)
