@@ -66,6 +66,7 @@ SIGNATURES = {
     "drprg_hip_genotype_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "drprg_hip_index_sizes": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "drprg_hip_filter_selfcheck": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "drprg_hip_device_tables": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "drprg_hip_index_export": (C.c_int, [C.c_void_p] + [C.c_void_p] * 7),
     "drprg_hip_prg_nodes": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32),
                                       C.POINTER(C.c_uint32)]),

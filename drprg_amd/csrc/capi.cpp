@@ -343,6 +343,13 @@ int drprg_hip_prg_nodes(const drprg_hip_ctx* ctx, uint32_t prg, uint32_t* starts
     return DRPRG_OK;
 }
 
+int drprg_hip_device_tables(drprg_hip_ctx* ctx, uint64_t out[4])
+{
+    API_BEGIN(ctx)
+    need_mapper(ctx).device_tables(out);
+    API_END(ctx)
+}
+
 int drprg_hip_kernel_timing(drprg_hip_ctx* ctx, int enable, int reset, double* ms_total, uint64_t* launches)
 {
     API_BEGIN(ctx)

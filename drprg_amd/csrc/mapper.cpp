@@ -154,10 +154,12 @@ Mapper::~Mapper()
     if (stream_) (void)hipStreamDestroy(stream_);
 }
 
+// Portable: the ingest's parser threads call this with whatever device is current on their thread; a portable
+// allocation is page-locked for every device, so the copy engine of the mapper's device takes it at DMA speed.
 void* Mapper::pinned_alloc(size_t bytes)
 {
     void* p = nullptr;
-    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) return nullptr;
     return p;
 }
 
@@ -168,15 +170,16 @@ void Mapper::pinned_free(void* p)
 
 void Mapper::set_params(const MapParams& p)
 {
+    // validate everything before any state changes: a refused call leaves the previous parameters in force
     if (p.k < 1 || p.k > 31) throw Error(DRPRG_EINVAL, "k must be in [1,31]");
     if (p.w < 1 || p.w > 1024) throw Error(DRPRG_EINVAL, "w must be in [1,1024]");
-    params_ = p;
-    wide_hash_ = p.k > 15;
-    halo_ = std::max(16, ((p.w - 1 + 15) / 16) * 16);
     const bool filter_ok = bloom_wbits_ != 0 && p.k <= 15 && p.w <= 16;
     if (p.kernel_mode < 0 || p.kernel_mode > 3) throw Error(DRPRG_EINVAL, "kernel must be 0 (auto), 1, 2 or 3");
     if (p.kernel_mode == 2 && !filter_ok)
         throw Error(DRPRG_EINVAL, "the Bloom-prefiltered kernel needs k <= 15, w <= 16 and an index small enough for an LDS filter");
+    params_ = p;
+    wide_hash_ = p.k > 15;
+    halo_ = std::max(16, ((p.w - 1 + 15) / 16) * 16);
     use_filter_ = p.kernel_mode == 2 || (p.kernel_mode == 0 && filter_ok);
     use_direct_cands_ = p.kernel_mode == 3 || (p.kernel_mode == 0 && !filter_ok);
 }
@@ -188,8 +191,7 @@ void Mapper::reset_coverage()
     HIPCHK(hipMemsetAsync(d_prg_reads_, 0, (size_t)n_prgs_ * sizeof(uint32_t), stream_));
     HIPCHK(hipMemsetAsync(d_counters_, 0, C_N * sizeof(unsigned long long), stream_));
     HIPCHK(hipStreamSynchronize(stream_));
-    tot_reads_ = tot_bases_ = tot_hits_ = tot_leftover_ = 0;
-    last_minimizers_ = 0;
+    tot_reads_ = tot_bases_ = tot_hits_ = tot_leftover_ = tot_minimizers_ = 0;
 }
 
 void Mapper::ensure_workspace(uint64_t cap)
@@ -259,6 +261,7 @@ void Mapper::launch_lane(Lane& lane, hipStream_t stream, const uint8_t* d_bases,
     lane.scratch_zero = false;
     dev::SketchArgs a = sketch_args(d_bases, d_offsets, n_reads, n_bases);
     a.n_hits = &lane.d_scratch[L_HITS];
+    a.n_minimizers = &lane.d_scratch[L_MINIMIZERS];
     a.overflow = reinterpret_cast<uint32_t*>(&lane.d_scratch[L_OVERFLOW]);
     dev::FilterBuffers fb { lane.raw_pos, lane.raw_grp, lane.cand_info, lane.cand_pos1, lane.cand_rec, lane.raw_capacity, lane.small,
         &lane.d_scratch[L_MAXLEN] };
@@ -386,6 +389,7 @@ void Mapper::leftovers(Lane& lane, const uint8_t* d_bases, const uint64_t* d_off
     if (lane.h_scratch[L_COMPLEX] == 0) return;
     dev::SketchArgs a = sketch_args(d_bases, d_offsets, n_reads, n_bases);
     a.n_hits = &lane.d_scratch[L_HITS];
+    a.n_minimizers = &lane.d_scratch[L_MINIMIZERS]; // (the recount pass does not count minimizers again)
     a.overflow = reinterpret_cast<uint32_t*>(&lane.d_scratch[L_OVERFLOW]);
     lane.scratch_zero = false; // the leftover pass uses the lane's counters again
     HIPCHK(dev::launch_filter_recount(a, lane.fw, stream));
@@ -437,6 +441,7 @@ void Mapper::run_batch_direct_candidates(const uint8_t* d_bases, const uint64_t*
         HIPCHK(hipMemsetAsync(d_tile_count_ + n_tiles, 0, sizeof(uint32_t), stream)); // the scan's closing zero
         dev::SketchArgs a = sketch_args(d_bases, d_offsets, n_reads, n_bases);
         a.n_hits = &lane.d_scratch[L_HITS];
+        a.n_minimizers = &lane.d_scratch[L_MINIMIZERS];
         a.overflow = reinterpret_cast<uint32_t*>(&lane.d_scratch[L_OVERFLOW]);
         a.tile_cap = tile_ws_cap_;
         a.tile_info = d_tile_info_;
@@ -474,7 +479,6 @@ void Mapper::run_batch_direct_candidates(const uint8_t* d_bases, const uint64_t*
         HIPCHK(dev::launch_direct_candidates(a, wide_hash_, d_tile_prefix_, d_tile_temp_, tile_temp_bytes_, lane.raw_capacity, rc, n_cus_, lane.fw,
             stream, timer));
         HIPCHK(hipMemcpyAsync(lane.h_scratch, lane.d_scratch, L_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-        HIPCHK(hipMemcpyAsync(&h_counters_[C_MINIMIZERS], &d_counters_[C_MINIMIZERS], sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipMemsetAsync(lane.d_scratch, 0, L_N * sizeof(unsigned long long), stream));
         lane.scratch_zero = true;
         wait_stream(stream);
@@ -482,15 +486,13 @@ void Mapper::run_batch_direct_candidates(const uint8_t* d_bases, const uint64_t*
         const uint32_t ovf = (uint32_t)lane.h_scratch[L_OVERFLOW];
         if (ovf & 2u) throw Error(DRPRG_EOVERFLOW, "a read is longer than 2^" + std::to_string(dev::HIT_POS_BITS) + " bases");
         if (!(ovf & 4u)) break;
-        // a tile slice or the dense list was too small: nothing was counted except the minimizers; grow both and run again
+        // a tile slice or the dense list was too small: nothing was counted except the minimizers, and those only in this
+        // attempt's scratch block; grow both and run again
         if (attempt > 6) throw Error(DRPRG_EOVERFLOW, "candidate buffer overflow after regrow");
-        unsigned long long restored = last_minimizers_;
-        HIPCHK(hipMemcpyAsync(&d_counters_[C_MINIMIZERS], &restored, sizeof(restored), hipMemcpyHostToDevice, stream));
-        HIPCHK(hipStreamSynchronize(stream));
         tile_slice_cap_ = std::min<uint32_t>(tile_slice_cap_ * 2, 4096);
         grow_lane(lane, std::min<uint64_t>(lane.raw_capacity * 2, (1ull << 31) - 1));
     }
-    last_minimizers_ = h_counters_[C_MINIMIZERS];
+    tot_minimizers_ += lane.h_scratch[L_MINIMIZERS];
     tot_hits_ += lane.h_scratch[L_HITS];
     tot_leftover_ += lane.h_scratch[L_COMPLEX];
     leftovers(lane, d_bases, d_offsets, n_reads, n_bases, covg, prg_reads, stream);
@@ -545,6 +547,7 @@ void Mapper::run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32
                 launch_lane(lane, stream, d_bases, d_offsets, n_reads, n_bases, covg, prg_reads);
                 wait_stream(stream);
             }
+            tot_minimizers_ += lane.h_scratch[L_MINIMIZERS];
             tot_hits_ += lane.h_scratch[L_HITS];
             tot_leftover_ += lane.h_scratch[L_COMPLEX];
         }
@@ -566,7 +569,7 @@ void Mapper::run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32
         dmalloc(d_tile_first_, (size_t)tile_cap_);
     }
     for (int attempt = 0;; ++attempt) {
-        HIPCHK(hipMemsetAsync(&d_counters_[C_HITS], 0, sizeof(unsigned long long), stream));
+        HIPCHK(hipMemsetAsync(&d_counters_[C_HITS], 0, 2 * sizeof(unsigned long long), stream)); // hits + minimizers of this attempt
         HIPCHK(hipMemsetAsync(&d_counters_[C_OVERFLOW], 0, sizeof(unsigned long long), stream));
         const dev::SketchArgs a = sketch_args(d_bases, d_offsets, n_reads, n_bases);
         HIPCHK(dev::launch_sketch_probe(a, wide_hash_, stream, timer));
@@ -576,16 +579,12 @@ void Mapper::run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32
             throw Error(DRPRG_EOVERFLOW, "a read is longer than 2^" + std::to_string(dev::HIT_POS_BITS) + " bases");
         if (h_counters_[C_HITS] > hit_capacity_) {
             if (attempt > 6) throw Error(DRPRG_EOVERFLOW, "hit buffer overflow after regrow");
-            // undo the minimizer count of the aborted pass, grow, and re-run the sketch
-            unsigned long long restored = last_minimizers_;
-            HIPCHK(hipMemcpyAsync(&d_counters_[C_MINIMIZERS], &restored, sizeof(restored), hipMemcpyHostToDevice, stream));
-            HIPCHK(hipStreamSynchronize(stream));
             ensure_workspace(h_counters_[C_HITS] + h_counters_[C_HITS] / 8 + 1024);
             continue;
         }
         break;
     }
-    last_minimizers_ = h_counters_[C_MINIMIZERS];
+    tot_minimizers_ += h_counters_[C_MINIMIZERS];
     tot_hits_ += h_counters_[C_HITS];
     cluster_hits(d_offsets, (uint32_t)h_counters_[C_HITS], false, nullptr, covg, prg_reads, stream);
 }
@@ -645,6 +644,14 @@ void Mapper::upload(const std::vector<uint32_t>& covg, const std::vector<uint32_
     HIPCHK(hipMemcpy(d_prg_reads_, prg_reads.data(), prg_reads.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 }
 
+void Mapper::device_tables(uint64_t out[4]) const
+{
+    out[0] = d_pbloom_ ? (uint64_t)1 << pbloom_wbits_ : 0;
+    out[1] = ((uint64_t)1 << table_bits_) * (wide_hash_ ? 16 : 12);
+    out[2] = bloom_wbits_ ? ((uint64_t)4 << bloom_wbits_) + (bloom0_wbits_ ? ((uint64_t)4 << bloom0_wbits_) + ((uint64_t)4 << BLOOMR_WBITS) : 0) : 0;
+    out[3] = use_filter_ ? 2 : (use_direct_cands_ ? 3 : 1);
+}
+
 MapCounters Mapper::counters()
 {
     HIPCHK(hipSetDevice(device_));
@@ -654,7 +661,7 @@ MapCounters Mapper::counters()
     MapCounters m;
     m.reads = tot_reads_;
     m.bases = tot_bases_;
-    m.minimizers = c[C_MINIMIZERS];
+    m.minimizers = tot_minimizers_;
     m.hits = tot_hits_;
     m.clusters_kept = c[C_CLUSTERS_KEPT];
     m.hits_kept = c[C_HITS_KEPT];

@@ -50,6 +50,9 @@ public:
     void download(std::vector<uint32_t>& covg, std::vector<uint32_t>& prg_reads);
     void upload(const std::vector<uint32_t>& covg, const std::vector<uint32_t>& prg_reads);
     MapCounters counters(); // synchronises
+    // out[0] = words of the L2-resident Bloom tier in front of the probe table (0: none), out[1] = bytes of the probe table
+    // (keys + slot records), out[2] = bytes of the LDS-resident filter arrays (0: none), out[3] = sequence in use (1/2/3)
+    void device_tables(uint64_t out[4]) const;
 
     // timing of the dominant kernel (HIP events on the launch stream), for bench.py
     void enable_kernel_timing(bool on) { timing_ = on; }
@@ -75,7 +78,7 @@ private:
         dev::FilterWork fw {};
         uint32_t r0 = 0, r1 = 0;                 // read range of the current batch
     };
-    enum { L_HITS = 0, L_OVERFLOW = 1, L_MAXLEN = 2, L_UNSORTED = 3, L_COMPLEX = 4, L_CHUNK = 5, L_N = 8 };
+    enum { L_HITS = 0, L_OVERFLOW = 1, L_MAXLEN = 2, L_UNSORTED = 3, L_COMPLEX = 4, L_CHUNK = 5, L_MINIMIZERS = 6, L_N = 8 };
     void ensure_lanes(int n, uint64_t raw_capacity);
     void grow_lane(Lane& lane, uint64_t raw_capacity);
     void free_lane(Lane& lane);
@@ -123,8 +126,9 @@ private:
     uint32_t* d_prg_reads_ = nullptr;
     unsigned long long* d_counters_ = nullptr; // 8 x u64: hits(batch), minimizers, clusters_kept, hits_kept, overflow, ...
     unsigned long long* h_counters_ = nullptr; // pinned mirror
-    uint64_t tot_reads_ = 0, tot_bases_ = 0, tot_hits_ = 0, tot_leftover_ = 0;
-    unsigned long long last_minimizers_ = 0; // device minimizer counter after the last completed batch (direct sequence)
+    // per-batch device counters are read back once per batch and summed here (an aborted attempt -- a buffer that has to
+    // grow -- is simply not added, whatever sequence ran before it)
+    uint64_t tot_reads_ = 0, tot_bases_ = 0, tot_hits_ = 0, tot_leftover_ = 0, tot_minimizers_ = 0;
     // workspace
     uint64_t hit_capacity_ = 0;
     uint64_t *d_key_a_ = nullptr, *d_key_b_ = nullptr;

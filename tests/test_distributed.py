@@ -35,7 +35,8 @@ WORKER = textwrap.dedent("""
     bases, offs = synth.sample_short_reads(gen, 5001, seed=9)       # odd count: uneven shards
     b, o = shard_batch(bases, offs, rank, world)
     md, er = map_params(k, True)
-    covg, prg_reads, _ = Oracle().map_reads(b, o, ctx.export_index(), w, k, md, cluster_fraction(er, k), 10)
+    orc = Oracle()
+    covg, prg_reads, _ = orc.map_reads(b, o, orc.build_index(panel.prgs, w, k), w, k, md, cluster_fraction(er, k), 10)
     tc = torch.from_numpy(covg.view(np.int32).copy())
     tp = torch.from_numpy(prg_reads.view(np.int32).copy())
     total = reduce_coverage(tc, tp, int(o[-1]))
@@ -63,9 +64,13 @@ def test_two_rank_reduce_equals_single_rank(tmp_path, oracle):
     from drprg_amd import Context, synth
     script = tmp_path / "worker.py"
     script.write_text(WORKER.format(root=ROOT))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", OMP_NUM_THREADS="1")
+    import socket
+    with socket.socket() as sock:  # a free port chosen at run time (concurrent jobs on one host must not collide)
+        sock.bind(("127.0.0.1", 0))
+        port = str(sock.getsockname()[1])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29533", str(script), str(tmp_path)],
+                        "--master-addr", "127.0.0.1", "--master-port", port, str(script), str(tmp_path)],
                        capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     # single-process reference on the whole batch
@@ -78,7 +83,7 @@ def test_two_rank_reduce_equals_single_rank(tmp_path, oracle):
     gen = synth.HaplotypeGenomes(panel, genome_size=20000, n_hap=4, seed=3)
     bases, offs = synth.sample_short_reads(gen, 5001, seed=9)
     md, er = map_params(k, True)
-    covg, prg_reads, _ = oracle.map_reads(bases, offs, ctx.export_index(), w, k, md, cluster_fraction(er, k), 10)
+    covg, prg_reads, _ = oracle.map_reads(bases, offs, oracle.build_index(panel.prgs, w, k), w, k, md, cluster_fraction(er, k), 10)
     assert np.array_equal(np.load(tmp_path / "multi_covg.npy"), covg)
     ctx.set_coverage(covg, prg_reads, int(offs[-1]))
     ctx.genotype(genes, str(tmp_path / "single.vcf"))

@@ -20,15 +20,54 @@ def _ctx(tmp_path, panel, w, k, illumina, genome_size=20000, kernel=0, min_clust
     from drprg_amd import Context
     prg = str(tmp_path / "dr.prg")
     panel.write(prg, str(tmp_path / "genes.fa"))
-    ctx = Context(prg, w, k, device=0, from_files=False)
+    ctx = Context(prg, w, k, device=0, from_files=False, threads=8)
     ctx.set_opts(illumina=illumina, genome_size=genome_size, kernel=kernel, min_cluster_size=min_cluster_size)
+    ctx.prg_strings = panel.prgs  # (what the oracle builds its own index from)
     return ctx
 
 
-def _compare(ctx, oracle, bases, offsets, w, k, illumina, kernel, min_cluster_size=10):
-    idx = ctx.export_index()
+_ORACLE_INDEX = {}
+
+
+def _oracle_index(oracle, prg_strings, w, k):
+    """the oracle's own index of these PRG strings (oracle/oracle_index.c): nothing but the reads is shared with the product"""
+    key = (hash(tuple(prg_strings)), w, k)
+    if key not in _ORACLE_INDEX:
+        if len(_ORACLE_INDEX) > 4:
+            _ORACLE_INDEX.clear()
+        _ORACLE_INDEX[key] = oracle.build_index(prg_strings, w, k)
+    return _ORACLE_INDEX[key]
+
+
+def _oracle_map(oracle, idx, bases, offsets, w, k, illumina, min_cluster_size=10, threads=1):
+    """oracle.map_reads, optionally over disjoint read ranges on several threads (the C call releases the GIL; integer
+    coverage sums commute)"""
     md, er = map_params(k, illumina)
-    ocov, oprg, ocnt = oracle.map_reads(bases, offsets, idx, w, k, md, cluster_fraction(er, k), min_cluster_size)
+    frac = cluster_fraction(er, k)
+    n = len(offsets) - 1
+    if threads <= 1 or n < 4 * threads:
+        return oracle.map_reads(bases, offsets, idx, w, k, md, frac, min_cluster_size)
+    from concurrent.futures import ThreadPoolExecutor
+    offsets = np.ascontiguousarray(offsets, np.uint64)
+    cuts = [n * i // threads for i in range(threads + 1)]
+
+    def part(i):
+        lo, hi = cuts[i], cuts[i + 1]
+        return oracle.map_reads(bases[int(offsets[lo]):int(offsets[hi])], offsets[lo:hi + 1] - offsets[lo], idx, w, k, md, frac,
+                                min_cluster_size)
+
+    with ThreadPoolExecutor(threads) as pool:
+        parts = list(pool.map(part, range(threads)))
+    cov = np.sum(np.stack([p[0] for p in parts]).astype(np.uint64), axis=0).astype(np.uint32)
+    prg = np.sum(np.stack([p[1] for p in parts]).astype(np.uint64), axis=0).astype(np.uint32)
+    cnt = {key: sum(p[2][key] for p in parts) for key in parts[0][2]}
+    return cov, prg, cnt
+
+
+def _compare(ctx, oracle, bases, offsets, w, k, illumina, kernel, min_cluster_size=10, threads=1):
+    idx = _oracle_index(oracle, ctx.prg_strings, w, k)
+    assert int(idx["knode_base"][-1]) == ctx.n_knodes and len(idx["keys"]) == ctx.n_keys
+    ocov, oprg, ocnt = _oracle_map(oracle, idx, bases, offsets, w, k, illumina, min_cluster_size, threads)
     ctx.reset()
     ctx.map_host(bases, offsets)
     gcov, gprg = ctx.coverage()
@@ -312,13 +351,137 @@ def test_cli_map_end_to_end(tmp_path, oracle):
     assert r.returncode == 0, r.stderr
     from drprg_amd import Pandora
     assert Pandora.list_prgs_with_novel_variants(str(tmp_path / "disc" / "denovo_paths.txt")) == []
-    # reference VCF: host genotyper on the oracle's coverage of the same reads
+    # reference VCF: host genotyper on the oracle's coverage of the same reads (oracle's own index of the same PRGs)
     ctx = Context(prg, w, k, device=-1, from_files=True)
     ctx.set_opts(illumina=True, genome_size=4411532)
     md, er = map_params(k, True)
-    covg, prg_reads, _ = oracle.map_reads(bases, offs, ctx.export_index(), w, k, md, cluster_fraction(er, k), 10)
+    covg, prg_reads, _ = oracle.map_reads(bases, offs, oracle.build_index(panel.prgs, w, k), w, k, md, cluster_fraction(er, k), 10)
     ctx.set_coverage(covg, prg_reads, int(offs[-1]))
     ref = str(tmp_path / "ref.vcf")
     ctx.genotype(genes, ref)
     strip = lambda p: [l for l in open(p) if not l.startswith("##fileDate")]
     assert strip(vcf) == strip(ref)
+
+
+# ---- the BASELINE.json configurations ----------------------------------------------------------------------------
+# configs[1] 10M x 150 bp vs the mtb index, configs[2] Nanopore reads vs the mtb index, configs[4] the 500-locus /
+# 50k-variant index.  Two mtb-like indexes: synth.mtb_like_panel() (random backbone, the bench's alternative workload) and
+# the SURVEY 8d index (backbone = the reference's genes.fa, sites = its panel.bcf records).  Oracle parity on read counts the
+# oracle maps in seconds on the host's cores; the full BASELINE sizes through size-independent properties.
+ORACLE_THREADS = max(1, min(os.cpu_count() or 1, 32))
+GOLDEN_INDEX_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "downstream")
+_PANELS = {}
+
+
+def _baseline_panel(name):
+    from drprg_amd import synth
+    if name not in _PANELS:
+        if name == "mtb_like":
+            _PANELS[name] = synth.mtb_like_panel()
+        elif name == "mtb_8d":
+            _PANELS[name] = synth.panel_from_index_dir(GOLDEN_INDEX_DIR)[0]
+        else:
+            _PANELS[name] = synth.big_panel()
+        _PANELS[name + "/genomes"] = synth.HaplotypeGenomes(_PANELS[name], n_hap=8)
+    return _PANELS[name], _PANELS[name + "/genomes"]
+
+
+def _baseline_reads(name, long_reads, n_reads):
+    """seeded reads of a BASELINE configuration (sampled once per session: the three kernel sequences map the same batch)"""
+    from drprg_amd import synth
+    key = f"{name}/reads/{int(long_reads)}"
+    if key not in _PANELS:
+        genomes = _baseline_panel(name)[1]
+        _PANELS[key] = synth.sample_long_reads(genomes, n_reads, seed=3) if long_reads else synth.sample_short_reads(genomes, n_reads, seed=2)
+    return _PANELS[key]
+
+
+def _expected_kernel(name, kernel):
+    """what `auto` resolves to: the LDS filter for the mtb-sized indexes, the candidate form for the 500-locus index"""
+    return kernel or (3 if name == "big" else 2)
+
+
+@pytest.mark.parametrize("kernel", [0, 1, 3])
+@pytest.mark.parametrize("name", ["mtb_like", "mtb_8d"])
+def test_config1_illumina_reads_vs_mtb_index(tmp_path, oracle, name, kernel):
+    """configs[1] at 1.2 M reads, 4.4 Mb background genome: auto (= the Bloom-prefiltered sequence), the direct kernel with
+    the generic cluster pipeline, and the direct kernel's candidate form, all against the oracle"""
+    from drprg_amd import synth
+    panel, genomes = _baseline_panel(name)
+    ctx = _ctx(tmp_path, panel, 11, 15, True, genome_size=synth.MTB_GENOME_SIZE, kernel=kernel)
+    bases, offs = _baseline_reads(name, False, 1_200_000)
+    cnt = _compare(ctx, oracle, bases, offs, 11, 15, True, kernel or 2, threads=ORACLE_THREADS)
+    assert ctx.counters()["kernel"] == _expected_kernel(name, kernel)
+    assert cnt["clusters_kept"] > 5000
+    if not FORCED_GENERIC:
+        assert ctx.counters()["leftover_reads"] == 0
+
+
+@pytest.mark.parametrize("kernel", [0, 1, 3])
+@pytest.mark.parametrize("name", ["mtb_like", "mtb_8d"])
+def test_config2_nanopore_reads_vs_mtb_index(tmp_path, oracle, name, kernel):
+    """configs[2] at 24 k reads (mean 4 kb, 5 % errors split 40/30/30 sub/ins/del), max_diff 250, error rate 0.11"""
+    from drprg_amd import synth
+    panel, genomes = _baseline_panel(name)
+    ctx = _ctx(tmp_path, panel, 11, 15, False, genome_size=synth.MTB_GENOME_SIZE, kernel=kernel)
+    bases, offs = _baseline_reads(name, True, 24_000)
+    cnt = _compare(ctx, oracle, bases, offs, 11, 15, False, kernel or 2, threads=ORACLE_THREADS)
+    assert ctx.counters()["kernel"] == _expected_kernel(name, kernel)
+    assert cnt["clusters_kept"] > 200
+
+
+@pytest.mark.parametrize("kernel", [0, 1])
+def test_config4_500_locus_index(tmp_path, oracle, kernel):
+    """configs[4]: 500 loci / 50 k sites / 573 k keys.  No LDS filter at this size: `auto` is the direct kernel in its
+    candidate form behind the L2-resident Bloom tier and a 12 MB probe table; kernel 1 the same kernel + generic pipeline."""
+    from drprg_amd import DependencyError, synth
+    panel, genomes = _baseline_panel("big")
+    ctx = _ctx(tmp_path, panel, 11, 15, True, genome_size=synth.MTB_GENOME_SIZE, kernel=kernel)
+    assert ctx.n_keys > 500_000 and ctx.n_prgs == 500
+    sc = ctx.filter_selfcheck()
+    assert sc["codes"] == 0  # no LDS-resident filter for this index ...
+    with pytest.raises(DependencyError):
+        ctx.set_opts(illumina=True, genome_size=synth.MTB_GENOME_SIZE, kernel=2)  # ... so the filtered sequence is refused
+    ctx.set_opts(illumina=True, genome_size=synth.MTB_GENOME_SIZE, kernel=kernel)
+    assert ctx.table_tier()["pbloom_words"] > 0 and ctx.table_tier()["table_bytes"] > 8 << 20
+    bases, offs = _baseline_reads("big", False, 600_000)
+    cnt = _compare(ctx, oracle, bases, offs, 11, 15, True, kernel or 3, threads=ORACLE_THREADS)
+    assert ctx.counters()["kernel"] == _expected_kernel("big", kernel)
+    assert cnt["clusters_kept"] > 50_000
+
+
+def _device_reads(torch, genomes, n_reads, seed, long_reads=False):
+    import bench
+    dev = torch.device("cuda", 0)
+    hap_pad = torch.from_numpy(genomes.padded()).to(dev)
+    hap_lens = torch.from_numpy(genomes.lens).to(dev)
+    if long_reads:
+        return bench.gpu_sample_long_reads(torch, hap_pad, hap_lens, n_reads, seed, dev)
+    return bench.gpu_sample_reads(torch, hap_pad, hap_lens, n_reads, 150, seed, dev)
+
+
+@pytest.mark.parametrize("name,illumina,n_reads", [("mtb_8d", True, 10_000_000), ("mtb_8d", False, 2_000_000), ("big", True, 10_000_000)],
+                         ids=["config1_10M_illumina", "config2_2M_nanopore", "config4_10M_500_loci"])
+def test_full_size_properties(tmp_path, name, illumina, n_reads):
+    """BASELINE.json's full sizes, where the oracle cannot follow in seconds: (1) sharding invariance -- coverage(whole batch)
+    == coverage(first half) + coverage(second half), bit for bit (what makes the multi-GPU reduce exact); (2) the sequence
+    `auto` picks and the direct kernel + generic cluster pipeline (radix sort, cluster kernels) give the identical vector;
+    (3) a second pass over the same batch doubles every counter (accumulation, no lost or duplicated atomics)."""
+    import torch
+    import bench
+    from drprg_amd import synth
+    panel, genomes = _baseline_panel(name)
+    ctx = _ctx(tmp_path, panel, 11, 15, illumina, genome_size=synth.MTB_GENOME_SIZE)
+    bases, offsets = _device_reads(torch, genomes, n_reads, 2, long_reads=not illumina)
+    dev = bases.device
+    stream = torch.cuda.Stream(dev)
+    covg = torch.zeros(2 * ctx.n_knodes, dtype=torch.int32, device=dev)
+    prg_reads = torch.zeros(ctx.n_prgs, dtype=torch.int32, device=dev)
+    bench.map_range(ctx, bases, offsets, 0, n_reads, covg, prg_reads, stream, torch)
+    assert int(covg.sum().item()) > 100_000
+    opts = dict(illumina=illumina, min_cluster_size=10, genome_size=synth.MTB_GENOME_SIZE)
+    shard_invariant, kernels_agree = bench.full_size_checks(torch, ctx, opts, bases, offsets, n_reads, covg, prg_reads, stream)
+    assert shard_invariant is True and kernels_agree is True
+    twice = covg.clone()
+    bench.map_range(ctx, bases, offsets, 0, n_reads, twice, prg_reads, stream, torch)
+    assert torch.equal(twice, 2 * covg)

@@ -175,7 +175,7 @@ def test_genotyper_vcf_surface_and_arithmetic(tmp_path, oracle):
     gen = synth.HaplotypeGenomes(panel, genome_size=20000, n_hap=4, seed=3)
     bases, offs = synth.sample_short_reads(gen, 4000, seed=1)
     md, er = map_params(k, True)
-    covg, prg_reads, _ = oracle.map_reads(bases, offs, ctx.export_index(), w, k, md, cluster_fraction(er, k), 10)
+    covg, prg_reads, _ = oracle.map_reads(bases, offs, oracle.build_index(panel.prgs, w, k), w, k, md, cluster_fraction(er, k), 10)
     ctx.set_coverage(covg, prg_reads, int(offs[-1]))
     out = str(tmp_path / "pandora_genotyped.vcf")
     info = ctx.genotype(genes, out)
@@ -237,7 +237,7 @@ def test_absent_locus_has_no_contig_line(tmp_path, oracle):
     reads = [hap[s:s + 150] for s in rng.integers(0, len(hap) - 150, size=300)]
     offs = np.arange(301, dtype=np.uint64) * np.uint64(150)
     md, er = map_params(k, True)
-    covg, prg_reads, _ = oracle.map_reads(np.concatenate(reads), offs, ctx.export_index(), w, k, md, cluster_fraction(er, k), 10)
+    covg, prg_reads, _ = oracle.map_reads(np.concatenate(reads), offs, oracle.build_index(panel.prgs, w, k), w, k, md, cluster_fraction(er, k), 10)
     assert prg_reads[2] > 0 and prg_reads[0] == 0
     ctx.set_coverage(covg, prg_reads, 300 * 150)
     out = str(tmp_path / "o.vcf")
