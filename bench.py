@@ -4,14 +4,20 @@
 A "step" is one pass of the hot path (sketch + probe + cluster + coverage accumulation, then the
 sum-reduce of the coverage vector across ranks) over one batch of synthetic reads that is already
 resident in HBM.  At N=1 the workload is BASELINE.json configs[1]: 10M synthetic 150 bp Illumina reads
-against the mtb-like PRG index (18 loci, k=15, w=11).  With N>1 every rank maps its own 10M-read shard
-(weak scaling, reads shard embarrassingly) and the only data-path collective is one RCCL all-reduce of
-the u32 coverage vector per step.
+against the mtb-like PRG index of SURVEY.md section 8d (backbone = the reference's test genes.fa, sites =
+its panel.bcf records + seeded random bubbles; 18 loci, k=15, w=11).  With N>1 every rank maps its own
+10M-read shard (weak scaling, reads shard embarrassingly) and the only data-path collective is one RCCL
+all-reduce of the u32 coverage vector per step.
 
-Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (sketch_probe_kernel) against
-HBM bandwidth using the algorithmic bytes of SURVEY.md section 8d, with its duration measured live
-with HIP events on the launch stream; `cpu_baseline` times the CPU oracle (oracle/oracle.c, a scalar
-port) on a bounded sample of the same workload, on one thread and on the host's cores (up to 64 threads).
+`--gpus N` with N > 1 and no launcher in the environment starts the N ranks itself (a child
+`python -m torch.distributed.run --nproc-per-node N bench.py ...`, spawned before this process touches
+the GPU) and relays rank 0's line and the exit code; it refuses to run with fewer than N devices.
+
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (sketch_filter_kernel for the
+mtb-sized indexes, sketch_probe_kernel for the 500-locus one) against HBM bandwidth using the
+algorithmic bytes of SURVEY.md section 8d, with its duration measured live with HIP events on the
+launch stream; `cpu_baseline` times the CPU oracle (oracle/oracle.c + oracle_index.c, a scalar port) on a
+bounded sample of the same workload, on one thread and on the host's cores (up to 64 threads).
 """
 import argparse
 import json
@@ -116,11 +122,42 @@ def gpu_sample_long_reads(torch, hap_pad, hap_lens, n_reads, seed, device, mean_
 
 
 WORKLOADS = {
-    # name: (BASELINE.json config, description, default reads per GPU, illumina)
-    "mtb": ("configs[1]", "10M synthetic 150 bp Illumina reads vs mtb-like PRG index", 10_000_000, True),
-    "nanopore": ("configs[2]", "2M synthetic Nanopore reads (mean 4 kb, 5% error) vs mtb-like PRG index", 2_000_000, False),
-    "big": ("configs[4]", "10M synthetic 150 bp reads vs 500-locus / 50k-variant synthetic PRG index", 10_000_000, True),
+    # name: (BASELINE.json config, description, default reads per GPU, illumina, panel)
+    "mtb": ("configs[1]", "10M synthetic 150 bp Illumina reads vs mtb-like PRG index (reference genes.fa backbone + panel.bcf sites, "
+            "SURVEY 8d)", 10_000_000, True, "mtb_8d"),
+    "mtb-random": ("configs[1]", "10M synthetic 150 bp Illumina reads vs mtb-like PRG index (random backbone with the 18 loci's lengths, "
+                   "1 site / 60 bp)", 10_000_000, True, "mtb_like"),
+    "nanopore": ("configs[2]", "2M synthetic Nanopore reads (mean 4 kb, 5% error) vs mtb-like PRG index (SURVEY 8d)", 2_000_000, False,
+                 "mtb_8d"),
+    "big": ("configs[4]", "10M synthetic 150 bp reads vs 500-locus / 50k-variant synthetic PRG index", 10_000_000, True, "big"),
 }
+
+
+def make_panel(synth, which):
+    return {"mtb_8d": synth.mtb_8d_panel, "mtb_like": synth.mtb_like_panel, "big": synth.big_panel}[which]()
+
+
+def spawn_ranks(n, argv):
+    """`--gpus N` without a launcher: start N ranks as a child torch.distributed.run (one process per GPU, RCCL) and return its
+    exit code.  Nothing in this process has initialised the GPU (torch.cuda.device_count() does not on this image)."""
+    import socket
+    import subprocess
+    if os.environ.get("DRPRG_BENCH_BACKEND", "nccl") == "nccl":
+        import torch
+        have = torch.cuda.device_count()
+        if have < n:
+            print(f"bench.py: --gpus {n} but only {have} device(s) are visible; refusing to run fewer ranks than asked for",
+                  file=sys.stderr)
+            return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def map_range(ctx, bases, offsets, lo, hi, covg, prg_reads, stream, torch):
@@ -165,7 +202,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="mtb", choices=sorted(WORKLOADS),
-                    help="mtb = configs[1] (the bench line); nanopore = configs[2]; big = configs[4]'s index")
+                    help="mtb = configs[1] (the bench line); mtb-random = the same reads against a random-backbone panel; "
+                         "nanopore = configs[2]; big = configs[4]'s index")
     ap.add_argument("--reads-per-gpu", type=int, default=0, help="0 = the workload's size")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--cpu-sample", type=int, default=-1, help="reads timed on the CPU oracle (0 = skip, -1 = ~10 s worth)")
@@ -174,14 +212,19 @@ def main():
                          "timed full-size one, so rocprofv3 per-kernel averages compare directly with avg_launch_ms)")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+
+    import torch
+    import torch.distributed as dist
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     # test hook for boxes with fewer GPUs than ranks: DRPRG_BENCH_BACKEND=gloo puts every rank on GPU 0 and reduces
@@ -201,8 +244,8 @@ def main():
     from drprg_amd import Context, synth
 
     W, K = 11, 15
-    cfg_name, cfg_desc, default_reads, illumina = WORKLOADS[args.workload]
-    panel = synth.big_panel() if args.workload == "big" else synth.mtb_like_panel()
+    cfg_name, cfg_desc, default_reads, illumina, which_panel = WORKLOADS[args.workload]
+    panel = make_panel(synth, which_panel)
     tmp = tempfile.mkdtemp(prefix=f"drprg_bench_r{rank}_")
     prg = os.path.join(tmp, "dr.prg")
     panel.write(prg, os.path.join(tmp, "genes.fa"))
@@ -363,7 +406,7 @@ def main():
             from concurrent.futures import ThreadPoolExecutor
             from util import Oracle, cluster_fraction, map_params
             orc = Oracle()
-            idx = ctx.export_index()
+            idx = orc.build_index(panel.prgs, W, K)  # the oracle's own index of the same PRG strings
             md, er = map_params(K, illumina)
             frac = cluster_fraction(er, K)
             mean_len = max(n_bases / n_reads, 1.0)

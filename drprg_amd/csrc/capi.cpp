@@ -1,3 +1,4 @@
+#include <fstream>
 #include <cstdio>
 // capi.cpp -- the C ABI declared in include/drprg_hip.h.
 #include "../../include/drprg_hip.h"
@@ -24,6 +25,7 @@ struct drprg_hip_ctx {
     uint64_t total_bases = 0;
     int threads = 4; // parser threads of drprg_hip_map_fastx
     uint32_t ginfo[4] = { 0, 0, 0, 0 };
+    std::vector<VcfRecord> last_records; // of the last drprg_hip_genotype (drprg_hip_genotype_alleles)
 };
 
 static thread_local std::string g_last_error;
@@ -285,7 +287,51 @@ int drprg_hip_genotype(drprg_hip_ctx* ctx, const char* vcf_refs, const char* out
     ctx->ginfo[1] = r.min_kmer_covg;
     ctx->ginfo[2] = (uint32_t)r.present.size();
     ctx->ginfo[3] = (uint32_t)r.records.size();
+    ctx->last_records = std::move(r.records);
     API_END(ctx)
+}
+
+int drprg_hip_genotype_alleles(drprg_hip_ctx* ctx, const char* out_tsv)
+{
+    API_BEGIN(ctx)
+    if (!out_tsv) throw Error(DRPRG_EINVAL, "null output path");
+    std::ofstream o(out_tsv);
+    if (!o) throw Error(DRPRG_EIO, std::string("cannot write ") + out_tsv);
+    o << "#chrom\tpos\tallele\tn_kmers\tglobal_kmer_nodes\n";
+    for (const VcfRecord& rec : ctx->last_records)
+        for (size_t a = 0; a < rec.allele_knodes.size(); ++a) {
+            o << rec.chrom << "\t" << rec.pos << "\t" << a << "\t" << rec.allele_knodes[a].size() << "\t";
+            for (size_t i = 0; i < rec.allele_knodes[a].size(); ++i) o << (i ? "," : "") << rec.allele_knodes[a][i];
+            o << "\n";
+        }
+    if (!o) throw Error(DRPRG_EIO, std::string("short write to ") + out_tsv);
+    API_END(ctx)
+}
+
+int drprg_hip_allele_stats(const uint32_t* fwd, const uint32_t* rev, uint32_t n, uint32_t min_kmer_covg, uint32_t out[6], double* gaps)
+{
+    if ((n && (!fwd || !rev)) || !out || !gaps) return DRPRG_EINVAL;
+    const AlleleStats s = allele_stats(std::vector<uint32_t>(fwd, fwd + n), std::vector<uint32_t>(rev, rev + n), min_kmer_covg);
+    out[0] = s.mean_fwd; out[1] = s.mean_rev; out[2] = s.med_fwd; out[3] = s.med_rev; out[4] = s.sum_fwd; out[5] = s.sum_rev;
+    *gaps = s.gaps;
+    return DRPRG_OK;
+}
+
+int drprg_hip_genotype_site(const uint32_t* mean_fwd, const uint32_t* mean_rev, const double* gaps, uint32_t n_alleles, double e,
+    double eps, double* likelihood, int32_t* gt, double* gt_conf)
+{
+    if (!n_alleles || !mean_fwd || !mean_rev || !gaps || !likelihood || !gt || !gt_conf) return DRPRG_EINVAL;
+    std::vector<AlleleStats> al(n_alleles);
+    for (uint32_t a = 0; a < n_alleles; ++a) {
+        al[a].mean_fwd = mean_fwd[a];
+        al[a].mean_rev = mean_rev[a];
+        al[a].gaps = gaps[a];
+    }
+    int g = 0;
+    genotype_site(al, e, eps, g, *gt_conf);
+    *gt = g;
+    for (uint32_t a = 0; a < n_alleles; ++a) likelihood[a] = al[a].likelihood;
+    return DRPRG_OK;
 }
 
 int drprg_hip_genotype_info(const drprg_hip_ctx* ctx, uint32_t out[4])

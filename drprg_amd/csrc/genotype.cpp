@@ -127,6 +127,7 @@ struct LocusGenotyper {
     const LocalGraph& g;
     const KmerGraph& kg;
     const uint32_t* covg; // this PRG's slice: [2*id], [2*id+1]
+    uint32_t knode_base;  // global number of this PRG's k-mer node 0
     const std::vector<uint32_t>& refp;
     const std::string& refseq;
     uint32_t min_kmer_covg;
@@ -144,7 +145,7 @@ struct LocusGenotyper {
     }
 
     // k-mer coverages of the allele whose nodes replace refp(idx_pre, idx_post)
-    AlleleStats allele_coverage(int idx_pre, int idx_post, const Route& allele_nodes)
+    AlleleStats allele_coverage(int idx_pre, int idx_post, const Route& allele_nodes, std::vector<uint32_t>& knodes)
     {
         const int k = kg.k;
         // local route window: >= k bases of reference flank on both sides
@@ -189,6 +190,7 @@ struct LocusGenotyper {
                 if (!on_route) continue;
                 fwd.push_back(covg[2 * (size_t)kn]);
                 rev.push_back(covg[2 * (size_t)kn + 1]);
+                knodes.push_back(knode_base + kn);
             }
         }
         return allele_stats(fwd, rev, min_kmer_covg);
@@ -232,8 +234,10 @@ struct LocusGenotyper {
         }
         VcfRecord rec;
         rec.chrom = g.name;
-        rec.alleles.push_back(allele_coverage(idx_pre, idx_post, ref_nodes));
-        for (auto& a : alts) rec.alleles.push_back(allele_coverage(idx_pre, idx_post, a.second));
+        rec.allele_knodes.resize(1 + alts.size());
+        rec.alleles.push_back(allele_coverage(idx_pre, idx_post, ref_nodes, rec.allele_knodes[0]));
+        for (size_t ai = 0; ai < alts.size(); ++ai)
+            rec.alleles.push_back(allele_coverage(idx_pre, idx_post, alts[ai].second, rec.allele_knodes[1 + ai]));
         genotype_site(rec.alleles, e, eps, rec.gt, rec.gt_conf);
         // VCF text: pad with the preceding reference base when an allele is empty
         bool any_empty = ref.empty();
@@ -322,7 +326,7 @@ GenotypeResult genotype(const PrgIndex& idx, const std::vector<uint32_t>& covg, 
         const uint32_t base = f.knode_base[pi], n = (uint32_t)idx.kgs[pi].nodes.size();
         std::vector<uint32_t> local(2 * (size_t)n);
         for (size_t i = 0; i < local.size(); ++i) local[i] = std::min<uint32_t>(covg[2 * (size_t)base + i], 65535u);
-        LocusGenotyper lg { g, idx.kgs[pi], local.data(), refp, refseq, res.min_kmer_covg, (double)res.exp_depth_covg,
+        LocusGenotyper lg { g, idx.kgs[pi], local.data(), base, refp, refseq, res.min_kmer_covg, (double)res.exp_depth_covg,
             p.genotyping_error_rate, {}, {}, res.records };
         lg.init();
         uint32_t refpos = 0;

@@ -22,6 +22,7 @@ struct VcfRecord {
     std::vector<std::string> alts;
     std::string vc, graphtype;
     std::vector<AlleleStats> alleles; // ref first
+    std::vector<std::vector<uint32_t>> allele_knodes; // per allele: the global k-mer nodes its statistics were taken over
     int gt = 0;
     double gt_conf = 0.0;
 };

@@ -119,6 +119,17 @@ class Context:
         lib.drprg_hip_genotype_info(self._h, gi)
         return dict(exp_depth_covg=int(gi[0]), min_kmer_covg=int(gi[1]), loci_present=int(gi[2]), records=int(gi[3]))
 
+    def genotype_alleles(self, out_tsv):
+        """per allele of the last genotype(): (chrom, pos, allele) -> global k-mer nodes its statistics were taken over"""
+        _check(lib.drprg_hip_genotype_alleles(self._h, os.fsencode(out_tsv)), self._h)
+        out = {}
+        for line in open(out_tsv):
+            if line.startswith("#"):
+                continue
+            chrom, pos, a, n, nodes = line.rstrip("\n").split("\t")
+            out[(chrom, int(pos), int(a))] = np.array([int(x) for x in nodes.split(",") if x], dtype=np.int64)
+        return out
+
     # ---- introspection -------------------------------------------------------------------------
     def filter_selfcheck(self):
         out = (C.c_uint64 * 8)()
@@ -159,6 +170,27 @@ class Context:
         ms, n = C.c_double(), C.c_uint64()
         _check(lib.drprg_hip_kernel_timing(self._h, 1 if enable else 0, 1 if reset else 0, C.byref(ms), C.byref(n)), self._h)
         return ms.value, int(n.value)
+
+
+def allele_stats(fwd, rev, min_kmer_covg):
+    """the product's per-allele statistics on raw k-mer coverages: ([MEAN_FWD, MEAN_REV, MED_FWD, MED_REV, SUM_FWD, SUM_REV], GAPS)"""
+    fwd = np.ascontiguousarray(fwd, dtype=np.uint32)
+    rev = np.ascontiguousarray(rev, dtype=np.uint32)
+    out = np.zeros(6, np.uint32)
+    gaps = C.c_double()
+    _check(lib.drprg_hip_allele_stats(_ptr(fwd), _ptr(rev), len(fwd), min_kmer_covg, _ptr(out), C.byref(gaps)))
+    return [int(x) for x in out], gaps.value
+
+
+def genotype_site(mean_fwd, mean_rev, gaps, e, eps=0.01):
+    """the product's likelihood / GT / GT_CONF of one site from its per-allele means and gaps"""
+    mf = np.ascontiguousarray(mean_fwd, dtype=np.uint32)
+    mr = np.ascontiguousarray(mean_rev, dtype=np.uint32)
+    g = np.ascontiguousarray(gaps, dtype=np.float64)
+    lik = np.zeros(len(mf), np.float64)
+    gt, conf = C.c_int32(), C.c_double()
+    _check(lib.drprg_hip_genotype_site(_ptr(mf), _ptr(mr), _ptr(g), len(mf), e, eps, _ptr(lik), C.byref(gt), C.byref(conf)))
+    return lik, gt.value, conf.value
 
 
 class Pandora:

@@ -280,11 +280,37 @@ def write_fastq(path, bases, offsets, gz=False):
 
 
 # ---- an mtb-like panel built from a real index directory (genes.fa + panel.bcf) -------------------------------
-def panel_from_index_dir(index_dir, max_alts=4, min_gap=2, lead=30):
+def _fill_segment(rng, seg, fill_every, margin=12, max_alts=4, nested_frac=0.1):
+    """random SNP bubbles about every `fill_every` bases inside a stretch of backbone that holds no panel site (SURVEY.md
+    section 8d: "else seeded random SNP bubbles at 1 per 60 bp, <= 4 alts, 10 % nested depth-2"); the first-allele path stays
+    the backbone.  Returns a segment list [str, Site, str, ...]."""
+    out, cur = [], 0
+    pos = margin + int(rng.integers(0, fill_every))
+    while pos + 1 + margin <= len(seg):
+        ref = seg[pos]
+        others = "ACGT".replace(ref, "")
+        n_alts = int(rng.integers(1, min(max_alts, 3) + 1))
+        alleles = [[ref]] + [[others[i]] for i in rng.permutation(3)[:n_alts]]
+        if rng.random() < nested_frac:
+            inner_ref = random_seq(rng, 1)
+            inner_alt = "ACGT".replace(inner_ref, "")[int(rng.integers(0, 3))]
+            alleles.append([random_seq(rng, int(rng.integers(0, 6))), Site([[inner_ref], [inner_alt]]), random_seq(rng, int(rng.integers(2, 9)))])
+        out.append(seg[cur:pos])
+        out.append(Site(alleles))
+        cur = pos + 1
+        pos = cur + int(rng.integers(max(8, fill_every // 2), fill_every * 3 // 2 + 1))
+    out.append(seg[cur:])
+    return out
+
+
+def panel_from_index_dir(index_dir, max_alts=4, min_gap=2, lead=30, fill_every=0, seed=20230308):
     """PRGs whose first-allele path is the genes.fa sequence and whose sites are the (non-overlapping) records of
-    panel.bcf.  Returns (Panel, sites) where sites[gene] = [(record id, pos, ref, alts)]."""
+    panel.bcf.  fill_every > 0 adds seeded random SNP bubbles at that spacing in the stretches the
+    panel leaves empty (the 8d "mtb-like" index: fill_every=60).  Returns (Panel, sites) where
+    sites[gene] = [(record id, pos, ref, alts)] lists the panel sites in order."""
     import os
     from .bcf_lite import read_bcf
+    rng = np.random.default_rng(seed)
     genes = []
     name, seq = None, []
     for line in open(os.path.join(index_dir, "genes.fa")):
@@ -316,10 +342,36 @@ def panel_from_index_dir(index_dir, max_alts=4, min_gap=2, lead=30):
             cur = r["pos"] + len(r["ref"])
             chosen.append((r["id"], r["pos"], r["ref"], alts))
         segs.append(gseq[cur:])
+        if fill_every:
+            filled = []
+            for i, seg in enumerate(segs):
+                if isinstance(seg, str) and len(seg) >= fill_every:
+                    # (keep `lead` bases clear at both ends of the gene, as for the panel sites)
+                    head = lead if i == 0 else 0
+                    tail = lead if i == len(segs) - 1 else 0
+                    body = seg[head:len(seg) - tail] if tail else seg[head:]
+                    parts = _fill_segment(rng, body, fill_every)
+                    parts[0] = seg[:head] + parts[0]
+                    parts[-1] = parts[-1] + (seg[len(seg) - tail:] if tail else "")
+                    filled.extend(parts)
+                else:
+                    filled.append(seg)
+            segs = filled
         names.append(gname)
         trees.append(segs)
         sites[gname] = chosen
     return Panel(names, trees), sites
+
+
+def mtb_8d_panel(index_dir=None):
+    """The "mtb-like" index of SURVEY.md section 8d: backbone = the reference's test genes.fa (18 genes, 30,355 bp with
+    padding 100), sites = the panel.bcf records that fit without overlapping + seeded random SNP bubbles at 1 per 60 bp
+    elsewhere, <= 4 alts, 10 % nested; k = 15, w = 11, seed 20230308.  The index files are the committed copies under
+    tests/golden/downstream/ (data fixtures of /root/reference/tests/cases/predict/)."""
+    import os
+    if index_dir is None:
+        index_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "downstream")
+    return panel_from_index_dir(index_dir, fill_every=60)[0]
 
 
 def haplotype_with(segs, choose):

@@ -95,6 +95,16 @@ int drprg_hip_genotype(drprg_hip_ctx* ctx, const char* vcf_refs, const char* out
 /* exp_depth_covg / min_kmer_covg / #present / #records of the last drprg_hip_genotype */
 int drprg_hip_genotype_info(const drprg_hip_ctx* ctx, uint32_t out[4]);
 
+/* a-9 on raw inputs, for parity harnesses (host only, no context): the same functions drprg_hip_genotype applies per allele
+ * and per site (pandora SampleInfo; pinned by the reference's fixture VCFs, tests/golden/likelihood_kat.tsv).
+ * out[0..5] = MEAN_FWD, MEAN_REV, MED_FWD, MED_REV, SUM_FWD, SUM_REV; *gaps = GAPS. */
+int drprg_hip_allele_stats(const uint32_t* fwd, const uint32_t* rev, uint32_t n, uint32_t min_kmer_covg, uint32_t out[6], double* gaps);
+int drprg_hip_genotype_site(const uint32_t* mean_fwd, const uint32_t* mean_rev, const double* gaps, uint32_t n_alleles, double e,
+    double eps, double* likelihood, int32_t* gt, double* gt_conf);
+/* Which k-mer nodes every allele of the last drprg_hip_genotype took its statistics over: one TSV line per allele
+ * (chrom, pos, allele, n, comma-separated global k-mer node numbers = indexes/2 into the coverage vector). */
+int drprg_hip_genotype_alleles(drprg_hip_ctx* ctx, const char* out_tsv);
+
 /* Host-side check of the Bloom filters of the prefiltered kernel (no device needed): out[0] = index k-mer codes tested
  * (both orientations), out[1..3] = codes that level 0 / levels 1+2 / the second stage would wrongly reject (false
  * negatives: must be 0), out[4..6] = bits set per thousand in those three arrays.  All zero: the index has no filter. */

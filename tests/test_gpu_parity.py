@@ -366,7 +366,7 @@ def test_cli_map_end_to_end(tmp_path, oracle):
 # ---- the BASELINE.json configurations ----------------------------------------------------------------------------
 # configs[1] 10M x 150 bp vs the mtb index, configs[2] Nanopore reads vs the mtb index, configs[4] the 500-locus /
 # 50k-variant index.  Two mtb-like indexes: synth.mtb_like_panel() (random backbone, the bench's alternative workload) and
-# the SURVEY 8d index (backbone = the reference's genes.fa, sites = its panel.bcf records).  Oracle parity on read counts the
+# the SURVEY 8d index (backbone = the reference's genes.fa, sites = its panel.bcf records + seeded bubbles; bench.py's headline).  Oracle parity on read counts the
 # oracle maps in seconds on the host's cores; the full BASELINE sizes through size-independent properties.
 ORACLE_THREADS = max(1, min(os.cpu_count() or 1, 32))
 GOLDEN_INDEX_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "downstream")
@@ -379,7 +379,7 @@ def _baseline_panel(name):
         if name == "mtb_like":
             _PANELS[name] = synth.mtb_like_panel()
         elif name == "mtb_8d":
-            _PANELS[name] = synth.panel_from_index_dir(GOLDEN_INDEX_DIR)[0]
+            _PANELS[name] = synth.mtb_8d_panel(GOLDEN_INDEX_DIR)
         else:
             _PANELS[name] = synth.big_panel()
         _PANELS[name + "/genomes"] = synth.HaplotypeGenomes(_PANELS[name], n_hap=8)

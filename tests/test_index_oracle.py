@@ -104,6 +104,7 @@ def _panels():
     yield "mtb_like", synth.mtb_like_panel(), (11, 15)
     panel, _ = synth.panel_from_index_dir(os.path.join(GOLDEN, "downstream"))
     yield "reference_genes_fa_with_panel_bcf_sites", panel, (11, 15)
+    yield "survey_8d_mtb_index", synth.mtb_8d_panel(), (11, 15)
     yield "big_first_40_loci", synth.Panel(*(lambda p: (p.names[:40], p.trees[:40]))(synth.big_panel())), (11, 15)
 
 
