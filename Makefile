@@ -22,7 +22,7 @@ all: $(LIB) $(BIN) $(DRPRG) $(ORACLE)
 
 $(DRPRG): $(SRC)/drprg_main.cpp $(LIB)
 	@mkdir -p $(dir $@)
-	$(HIPCC) $(CXXFLAGS) -o $@ $< -Ldrprg_amd/lib -ldrprg_hip -Wl,-rpath,'$$ORIGIN/../lib'
+	$(HIPCC) $(CXXFLAGS) -x c++ $< -o $@ -Ldrprg_amd/lib -ldrprg_hip -Wl,-rpath,'$$ORIGIN/../lib'
 
 $(OBJD)/%.o: $(SRC)/%.cpp $(wildcard $(SRC)/*.h) include/drprg_hip.h
 	@mkdir -p $(OBJD)
@@ -38,7 +38,7 @@ $(LIB): $(OBJS)
 
 $(BIN): $(SRC)/pandora_main.cpp $(LIB)
 	@mkdir -p $(dir $@)
-	$(HIPCC) $(CXXFLAGS) -o $@ $< -Ldrprg_amd/lib -ldrprg_hip -Wl,-rpath,'$$ORIGIN/../lib'
+	$(HIPCC) $(CXXFLAGS) -x c++ $< -o $@ -Ldrprg_amd/lib -ldrprg_hip -Wl,-rpath,'$$ORIGIN/../lib'
 
 $(ORACLE): oracle/oracle.c oracle/oracle_index.c
 	$(CC) -O2 -fPIC -shared -Wall -o $@ oracle/oracle.c oracle/oracle_index.c -lm

@@ -291,6 +291,90 @@ int drprg_hip_genotype(drprg_hip_ctx* ctx, const char* vcf_refs, const char* out
     API_END(ctx)
 }
 
+// ---- discover (SURVEY.md section 8f NEXT-2) ---------------------------------------------------------------
+int drprg_hip_discover(drprg_hip_ctx* ctx, const char* vcf_refs, const char* out_dir, const char* sample, uint32_t* n_candidates)
+{
+    API_BEGIN(ctx)
+    if (!out_dir) throw Error(DRPRG_EINVAL, "null output directory");
+    sync_host_coverage(ctx);
+    GenotypeResult r = genotype(ctx->index, ctx->covg, ctx->prg_reads, ctx->total_bases, ctx->params, vcf_refs ? vcf_refs : "");
+    const std::string dir = out_dir, smp = sample && *sample ? sample : "sample";
+    {
+        std::ofstream o(dir + "/candidate_regions.tsv");
+        o << "#locus\tstart\tend\tlow_start\tlow_end\tmax_covg\tconsensus\n";
+        for (const CandidateRegion& c : r.candidates)
+            o << c.chrom << "\t" << c.start << "\t" << c.end << "\t" << c.low_start << "\t" << c.low_end << "\t" << c.max_covg << "\t" << c.seq << "\n";
+        if (!o) throw Error(DRPRG_EIO, "cannot write " + dir + "/candidate_regions.tsv");
+    }
+    {
+        // pandora's denovo_paths.txt surface (/root/reference/src/lib.rs:648-697 parses "<N> loci with denovo variants" and the
+        // line before every "<n> nodes" line).  Local assembly of the candidate regions is not implemented: no locus is ever
+        // reported as carrying a novel variant, so MakePrg::update keeps the index PRG (/root/reference/src/lib.rs:299-301).
+        std::ofstream o(dir + "/denovo_paths.txt");
+        o << "1 samples\nSample " << smp << "\n0 loci with denovo variants\n";
+        if (!o) throw Error(DRPRG_EIO, "cannot write " + dir + "/denovo_paths.txt");
+        std::ofstream f(dir + "/denovo_sequences.fa");
+    }
+    if (n_candidates) *n_candidates = (uint32_t)r.candidates.size();
+    API_END(ctx)
+}
+
+// Coverage cache: `pandora discover` and the `pandora map` that follows stream the same reads against the same PRG
+// (/root/reference/src/predict.rs:248-255, :296-302); the first saves its vector, the second takes it back if `tag` agrees.
+static const char COVG_MAGIC[8] = { 'D', 'R', 'P', 'R', 'G', 'C', 'V', '1' };
+
+int drprg_hip_save_coverage(drprg_hip_ctx* ctx, const char* path, const char* tag)
+{
+    API_BEGIN(ctx)
+    if (!path || !tag) throw Error(DRPRG_EINVAL, "null argument");
+    sync_host_coverage(ctx);
+    std::ofstream o(path, std::ios::binary);
+    const uint64_t hdr[4] = { std::strlen(tag), ctx->covg.size(), ctx->prg_reads.size(), ctx->total_bases };
+    uint64_t cnt[8] = { 0 };
+    if (ctx->mapper) {
+        const MapCounters c = ctx->mapper->counters();
+        const uint64_t v[8] = { c.reads, c.bases, c.minimizers, c.hits, c.clusters_kept, c.hits_kept, c.kernel, c.leftover_reads };
+        std::memcpy(cnt, v, sizeof cnt);
+    }
+    o.write(COVG_MAGIC, 8);
+    o.write((const char*)hdr, sizeof hdr);
+    o.write((const char*)cnt, sizeof cnt);
+    o.write(tag, (std::streamsize)hdr[0]);
+    o.write((const char*)ctx->covg.data(), (std::streamsize)(ctx->covg.size() * sizeof(uint32_t)));
+    o.write((const char*)ctx->prg_reads.data(), (std::streamsize)(ctx->prg_reads.size() * sizeof(uint32_t)));
+    if (!o) throw Error(DRPRG_EIO, std::string("cannot write ") + path);
+    API_END(ctx)
+}
+
+int drprg_hip_load_coverage(drprg_hip_ctx* ctx, const char* path, const char* tag, uint64_t counters[8])
+{
+    API_BEGIN(ctx)
+    if (!path || !tag) throw Error(DRPRG_EINVAL, "null argument");
+    std::ifstream in(path, std::ios::binary);
+    if (!in) return DRPRG_ENOENT;
+    char magic[8];
+    uint64_t hdr[4], cnt[8];
+    in.read(magic, 8);
+    in.read((char*)hdr, sizeof hdr);
+    in.read((char*)cnt, sizeof cnt);
+    if (!in || std::memcmp(magic, COVG_MAGIC, 8) != 0 || hdr[0] > (1u << 20)) return DRPRG_EFORMAT;
+    std::string t(hdr[0], '\0');
+    in.read(&t[0], (std::streamsize)hdr[0]);
+    if (!in || t != tag || hdr[1] != 2 * (uint64_t)ctx->index.flat.total_knodes() || hdr[2] != ctx->index.prgs.size())
+        return DRPRG_ENOENT; // another PRG / other reads / other parameters: not this run's vector
+    std::vector<uint32_t> covg(hdr[1]), prg_reads(hdr[2]);
+    in.read((char*)covg.data(), (std::streamsize)(covg.size() * sizeof(uint32_t)));
+    in.read((char*)prg_reads.data(), (std::streamsize)(prg_reads.size() * sizeof(uint32_t)));
+    if (!in) return DRPRG_EFORMAT;
+    ctx->covg.swap(covg);
+    ctx->prg_reads.swap(prg_reads);
+    ctx->host_coverage_valid = true;
+    ctx->total_bases = hdr[3];
+    if (ctx->mapper) ctx->mapper->upload(ctx->covg, ctx->prg_reads);
+    if (counters) std::memcpy(counters, cnt, sizeof cnt);
+    API_END(ctx)
+}
+
 int drprg_hip_genotype_alleles(drprg_hip_ctx* ctx, const char* out_tsv)
 {
     API_BEGIN(ctx)

@@ -188,13 +188,20 @@ int main(int argc, char** argv)
     if (int rc = drprg_hip_set_opts(ctx, &mo)) die(drprg_hip_last_error(ctx), -rc);
     drprg_hip_set_threads(ctx, threads);
     if (verbose) std::fprintf(stderr, "[drprg-hip] mapping %s against %s (k=%d w=%d) on device %d\n", input.c_str(), index.c_str(), k, w, device);
-    // discover + map share one pass over the reads; no de novo loci are reported (the PRG is used unchanged)
+    // discover + map share ONE pass over the reads (the reference runs two, /root/reference/src/predict.rs:248-302)
+    if (int rc = drprg_hip_map_fastx(ctx, input.c_str())) die(drprg_hip_last_error(ctx), -rc);
     {
+        // discover's outputs (/root/reference/src/predict.rs:247-256): candidate regions are located, but there is no local
+        // assembly, so no novel variant is ever added to the PRG (MakePrg::update keeps it, src/lib.rs:299-301)
         std::string ddir = outdir + "/discover";
         mkdir(ddir.c_str(), 0777);
-        std::ofstream(ddir + "/denovo_paths.txt") << "Sample " << sample << "\n0 loci with denovo variants\n";
+        uint32_t n_cand = 0;
+        if (int rc = drprg_hip_discover(ctx, (index + "/genes.fa").c_str(), ddir.c_str(), sample.c_str(), &n_cand)) die(drprg_hip_last_error(ctx), -rc);
+        std::fprintf(stderr,
+            "drprg (hip): WARNING: de novo variant discovery is not implemented: %u low-coverage candidate region(s) in "
+            "%s/candidate_regions.tsv, no local assembly, the PRG is used unchanged (-m/-M are ignored). Variants absent from the "
+            "index will not be called.\n", n_cand, ddir.c_str());
     }
-    if (int rc = drprg_hip_map_fastx(ctx, input.c_str())) die(drprg_hip_last_error(ctx), -rc);
     const std::string pandora_vcf = outdir + "/pandora_genotyped.vcf";
     if (int rc = drprg_hip_genotype(ctx, (index + "/genes.fa").c_str(), pandora_vcf.c_str(), "sample")) die(drprg_hip_last_error(ctx), -rc);
     if (verbose) {

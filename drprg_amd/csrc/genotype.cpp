@@ -78,6 +78,25 @@ uint32_t estimate_exp_depth_covg(const std::vector<uint32_t>& kmer_total_covg, u
     return std::max<uint32_t>(e, 1);
 }
 
+std::vector<std::pair<uint32_t, uint32_t>> low_coverage_intervals(const std::vector<uint32_t>& covg, const std::vector<uint8_t>& covered,
+    uint32_t min_covg, uint32_t min_len, uint32_t max_len)
+{
+    std::vector<std::pair<uint32_t, uint32_t>> out;
+    const uint32_t n = (uint32_t)covg.size();
+    uint32_t i = 0;
+    while (i < n) {
+        if (!(covered[i] && covg[i] <= min_covg)) {
+            ++i;
+            continue;
+        }
+        uint32_t j = i;
+        while (j < n && covered[j] && covg[j] <= min_covg) ++j;
+        if (j - i >= min_len && j - i <= max_len) out.emplace_back(i, j);
+        i = j;
+    }
+    return out;
+}
+
 namespace {
 
 constexpr size_t MAX_ALTS = 10;   // more routes than this through one site -> GRAPHTYPE=TOO_MANY_ALTS
@@ -135,6 +154,12 @@ struct LocusGenotyper {
     std::vector<int> ref_index;                    // local node -> index in refp or -1
     std::vector<std::vector<uint32_t>> starts_in;  // local node -> k-mer nodes starting there
     std::vector<VcfRecord>& out;
+    struct SiteCall {
+        int ref_allele = -1; // chain of the reference allele
+        int gt = 0;
+        std::vector<Route> alt_routes; // by ALT number - 1
+    };
+    std::map<int, SiteCall> calls; // every site on the reference path
 
     void init()
     {
@@ -226,6 +251,7 @@ struct LocusGenotyper {
                 if (!dup) alts.emplace_back(std::move(s), std::move(r));
             }
         }
+        calls[site_id].ref_allele = ref_allele;
         if (alts.empty()) return;
         std::sort(alts.begin(), alts.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
         if (alts.size() > MAX_ALTS) {
@@ -239,6 +265,8 @@ struct LocusGenotyper {
         for (size_t ai = 0; ai < alts.size(); ++ai)
             rec.alleles.push_back(allele_coverage(idx_pre, idx_post, alts[ai].second, rec.allele_knodes[1 + ai]));
         genotype_site(rec.alleles, e, eps, rec.gt, rec.gt_conf);
+        calls[site_id].gt = rec.gt;
+        for (auto& a : alts) calls[site_id].alt_routes.push_back(a.second);
         // VCF text: pad with the preceding reference base when an allele is empty
         bool any_empty = ref.empty();
         for (auto& a : alts) any_empty |= a.first.empty();
@@ -260,6 +288,70 @@ struct LocusGenotyper {
         out.push_back(std::move(rec));
     }
 
+    // local-node path of the called consensus: the reference path with every site replaced by its called allele
+    void consensus_chain(int chain, Route& path) const
+    {
+        const Chain& ch = g.chains[(size_t)chain];
+        for (size_t i = 0; i < ch.nodes.size(); ++i) {
+            path.push_back(ch.nodes[i]);
+            if (i >= ch.sites.size()) continue;
+            auto it = calls.find(ch.sites[i]);
+            if (it == calls.end()) throw Error(DRPRG_EFORMAT, "consensus walk left the reference path of " + g.name);
+            const SiteCall& c = it->second;
+            if (c.gt == 0 || c.alt_routes.empty()) consensus_chain(c.ref_allele, path);
+            else path.insert(path.end(), c.alt_routes[(size_t)c.gt - 1].begin(), c.alt_routes[(size_t)c.gt - 1].end());
+        }
+    }
+
+    // per-base coverage of the consensus (a base takes the largest fwd+rev coverage among the path's k-mer nodes that
+    // cover it), low-coverage runs, merged and padded (pandora discover's candidate regions)
+    void candidate_regions(const DiscoverParams& dp, std::vector<CandidateRegion>& regions) const
+    {
+        Route path;
+        consensus_chain(0, path);
+        const int k = kg.k;
+        std::vector<uint32_t> coord(path.size() + 1, 0);
+        for (size_t i = 0; i < path.size(); ++i) coord[i + 1] = coord[i] + g.nodes[path[i]].len();
+        const uint32_t L = coord.back();
+        std::vector<uint32_t> base(L, 0);
+        std::vector<uint8_t> covered(L, 0);
+        for (size_t i = 0; i < path.size(); ++i)
+            for (uint32_t kn : starts_in[path[i]]) {
+                const KPath& p = kg.nodes[kn].path;
+                if (i + p.size() > path.size()) continue;
+                bool on = true;
+                for (size_t j = 1; j < p.size(); ++j)
+                    if (p[j].node != path[i + j]) { on = false; break; }
+                if (!on) continue;
+                const uint32_t s = coord[i] + p.front().off_start, c = covg[2 * (size_t)kn] + covg[2 * (size_t)kn + 1];
+                for (uint32_t b = s; b < s + (uint32_t)k && b < L; ++b) {
+                    base[b] = covered[b] ? std::max(base[b], c) : c;
+                    covered[b] = 1;
+                }
+            }
+        auto runs = low_coverage_intervals(base, covered, dp.min_candidate_covg, dp.min_candidate_len, dp.max_candidate_len);
+        if (runs.empty()) return;
+        const std::string cons = g.string_along_path(path);
+        // merge runs closer than merge_dist, then pad
+        std::vector<std::pair<uint32_t, uint32_t>> merged;
+        for (auto& r : runs) {
+            if (!merged.empty() && r.first <= merged.back().second + dp.merge_dist) merged.back().second = r.second;
+            else merged.push_back(r);
+        }
+        for (auto& r : merged) {
+            CandidateRegion cr;
+            cr.chrom = g.name;
+            cr.low_start = r.first;
+            cr.low_end = r.second;
+            cr.start = r.first > dp.padding ? r.first - dp.padding : 0;
+            cr.end = std::min<uint32_t>(L, r.second + dp.padding);
+            for (uint32_t b = r.first; b < r.second; ++b)
+                if (covered[b]) cr.max_covg = std::max(cr.max_covg, base[b]);
+            cr.seq = cons.substr(cr.start, cr.end - cr.start);
+            regions.push_back(std::move(cr));
+        }
+    }
+
     void walk_chain(int chain, uint32_t& refpos)
     {
         const Chain& ch = g.chains[(size_t)chain];
@@ -273,7 +365,7 @@ struct LocusGenotyper {
 } // namespace
 
 GenotypeResult genotype(const PrgIndex& idx, const std::vector<uint32_t>& covg, const std::vector<uint32_t>& prg_reads,
-    uint64_t total_bases, const MapParams& p, const std::string& vcf_refs)
+    uint64_t total_bases, const MapParams& p, const std::string& vcf_refs, const DiscoverParams& dp)
 {
     const FlatIndex& f = idx.flat;
     if (covg.size() != 2 * (size_t)f.total_knodes() || prg_reads.size() != idx.prgs.size())
@@ -327,10 +419,11 @@ GenotypeResult genotype(const PrgIndex& idx, const std::vector<uint32_t>& covg, 
         std::vector<uint32_t> local(2 * (size_t)n);
         for (size_t i = 0; i < local.size(); ++i) local[i] = std::min<uint32_t>(covg[2 * (size_t)base + i], 65535u);
         LocusGenotyper lg { g, idx.kgs[pi], local.data(), base, refp, refseq, res.min_kmer_covg, (double)res.exp_depth_covg,
-            p.genotyping_error_rate, {}, {}, res.records };
+            p.genotyping_error_rate, {}, {}, res.records, {} };
         lg.init();
         uint32_t refpos = 0;
         lg.walk_chain(0, refpos);
+        lg.candidate_regions(dp, res.candidates);
     }
     std::sort(res.present.begin(), res.present.end());
     std::sort(res.absent.begin(), res.absent.end());

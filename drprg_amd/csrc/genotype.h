@@ -27,12 +27,29 @@ struct VcfRecord {
     double gt_conf = 0.0;
 };
 
+// A stretch of a locus' called consensus that the reads do not support: the mapping half of `pandora discover`
+// (/root/reference/src/lib.rs:513-578) ends with these; pandora then assembles the reads over each region locally.
+struct CandidateRegion {
+    std::string chrom;
+    uint32_t start = 0, end = 0;   // 0-based half-open on the consensus sequence, padding included
+    uint32_t low_start = 0, low_end = 0; // the low-coverage bases themselves
+    uint32_t max_covg = 0;         // largest per-base coverage inside [low_start, low_end)
+    std::string seq;               // consensus[start, end)
+};
+
+// pandora discover's candidate-region options [UPSTREAM-MEMORY: --min-candidate-covg 3, --min-candidate-len 1,
+// --max-candidate-len 50, --pad 22, --merge 22]
+struct DiscoverParams {
+    uint32_t min_candidate_covg = 3, min_candidate_len = 1, max_candidate_len = 50, padding = 22, merge_dist = 22;
+};
+
 struct GenotypeResult {
     uint32_t exp_depth_covg = 1;
     uint32_t min_kmer_covg = 0;
     std::vector<std::string> present; // loci with a ##contig line, sorted
     std::vector<std::string> absent;
     std::vector<VcfRecord> records;   // sorted by (chrom, pos, ref, alts)
+    std::vector<CandidateRegion> candidates; // low-coverage regions of the called consensus of every present locus
 };
 
 // per-allele statistics from the k-mer coverages of one allele (SampleInfo)
@@ -44,7 +61,12 @@ uint32_t estimate_exp_depth_covg(const std::vector<uint32_t>& kmer_total_covg, u
 // covg: u32[2*total_knodes] ([2g] fwd, [2g+1] rev); prg_reads: clusters placed per PRG;
 // total_bases: bases mapped (for the genome-size coverage estimate); vcf_refs: genes.fa or "".
 GenotypeResult genotype(const PrgIndex& idx, const std::vector<uint32_t>& covg, const std::vector<uint32_t>& prg_reads,
-    uint64_t total_bases, const MapParams& p, const std::string& vcf_refs);
+    uint64_t total_bases, const MapParams& p, const std::string& vcf_refs, const DiscoverParams& dp = DiscoverParams());
+
+// runs of bases whose coverage is <= min_covg (covered[i] == 0: no k-mer of the path reaches base i, never part of a run),
+// kept when min_len <= length <= max_len; half-open intervals (pandora identify_low_coverage_intervals)
+std::vector<std::pair<uint32_t, uint32_t>> low_coverage_intervals(const std::vector<uint32_t>& covg, const std::vector<uint8_t>& covered,
+    uint32_t min_covg, uint32_t min_len, uint32_t max_len);
 
 void write_vcf(const std::string& path, const GenotypeResult& r, const std::string& sample);
 std::string format_g(double v); // ostream default formatting (%g, 6 significant digits)

@@ -144,14 +144,43 @@ void report_counters(drprg_hip_ctx* ctx, double secs)
         (unsigned long long)c[4], (unsigned long long)c[5], secs, secs > 0 ? (double)c[0] / secs : 0.0);
 }
 
+// identifies (PRG file, reads file, mapping parameters): what a cached coverage vector belongs to
+std::string run_tag(const Args& a, const std::string& reads)
+{
+    auto stamp = [](const std::string& p) {
+        struct stat st;
+        char* rp = realpath(p.c_str(), nullptr);
+        std::string s = rp ? rp : p;
+        std::free(rp);
+        if (stat(p.c_str(), &st) == 0)
+            s += ":" + std::to_string((long long)st.st_size) + ":" + std::to_string((long long)st.st_mtim.tv_sec) + "."
+                + std::to_string((long long)st.st_mtim.tv_nsec);
+        return s;
+    };
+    return stamp(a.positional[0]) + "|" + stamp(reads) + "|w" + std::to_string(a.w) + "|k" + std::to_string(a.k) + "|c"
+        + std::to_string(a.min_cluster_size) + "|I" + std::to_string((int)a.illumina) + "|e" + std::to_string(a.error_rate) + "|m"
+        + std::to_string(a.max_diff) + "|g" + std::to_string((unsigned long long)a.genome_size);
+}
+
+const char* COVERAGE_CACHE = ".drprg_hip_coverage";
+
 int cmd_map(const Args& a)
 {
     if (a.positional.size() != 2) die("map needs <prg> <reads>", 2);
     make_dirs(a.outdir);
     drprg_hip_ctx* ctx = open_ctx(a);
     double t0 = now_s();
-    if (int rc = drprg_hip_map_fastx(ctx, a.positional[1].c_str())) die(drprg_hip_last_error(ctx), -rc);
-    report_counters(ctx, now_s() - t0);
+    // drprg runs `discover -o <out>/discover` on the same reads and PRG first (/root/reference/src/predict.rs:248-255): if that
+    // pass left its coverage vector there, take it instead of streaming the reads again
+    const std::string cache = a.outdir + "/discover/" + COVERAGE_CACHE;
+    uint64_t cached[8];
+    if (drprg_hip_load_coverage(ctx, cache.c_str(), run_tag(a, a.positional[1]).c_str(), cached) == 0) {
+        std::printf("[pandora-hip] coverage of this PRG and these reads taken from %s (reads=%llu bases=%llu hits=%llu): no second mapping pass\n",
+            cache.c_str(), (unsigned long long)cached[0], (unsigned long long)cached[1], (unsigned long long)cached[3]);
+    } else {
+        if (int rc = drprg_hip_map_fastx(ctx, a.positional[1].c_str())) die(drprg_hip_last_error(ctx), -rc);
+        report_counters(ctx, now_s() - t0);
+    }
     const std::string vcf = a.outdir + "/pandora_genotyped.vcf";
     if (int rc = drprg_hip_genotype(ctx, a.vcf_refs.empty() ? nullptr : a.vcf_refs.c_str(), vcf.c_str(), "sample"))
         die(drprg_hip_last_error(ctx), -rc);
@@ -176,17 +205,20 @@ int cmd_discover(const Args& a)
     double t0 = now_s();
     if (int rc = drprg_hip_map_fastx(ctx, reads.c_str())) die(drprg_hip_last_error(ctx), -rc);
     report_counters(ctx, now_s() - t0);
-    // De novo local assembly of low-coverage regions is not part of the GPU hot path (SURVEY.md
-    // section 8f, NEXT-2): report that no locus carries novel variation, which makes drprg keep the
-    // index PRG unchanged (/root/reference/src/lib.rs:299-301).
-    const std::string sdir = a.outdir + "/" + sample;
-    make_dirs(sdir);
-    for (const std::string& dir : { a.outdir, sdir }) {
-        std::ofstream p(dir + "/denovo_paths.txt");
-        p << "Sample " << sample << "\n0 loci with denovo variants\n";
-        if (!p) die("cannot write " + dir + "/denovo_paths.txt");
-        std::ofstream f(dir + "/denovo_sequences.fa");
-    }
+    // The mapping half of discover is the same kernels as `map`; its product here is (1) the candidate regions -- stretches
+    // of each locus' called consensus that the reads do not support -- and (2) the coverage vector, kept for the `map` call
+    // drprg issues next.  De novo local assembly of those regions is NOT implemented (NEXT-2):
+    // denovo_paths.txt reports no locus with novel variation, which makes drprg keep the index PRG unchanged
+    // (/root/reference/src/lib.rs:299-301).
+    uint32_t n_cand = 0;
+    if (int rc = drprg_hip_discover(ctx, nullptr, a.outdir.c_str(), sample.c_str(), &n_cand)) die(drprg_hip_last_error(ctx), -rc);
+    if (drprg_hip_save_coverage(ctx, (a.outdir + "/" + COVERAGE_CACHE).c_str(), run_tag(a, reads).c_str()) != 0)
+        std::fprintf(stderr, "pandora (drprg-hip): warning: could not keep the coverage vector for `map`: %s\n", drprg_hip_last_error(ctx));
+    std::fprintf(stderr,
+        "pandora (drprg-hip): WARNING: de novo variant discovery is not implemented in this build: %u low-coverage candidate "
+        "region(s) written to %s/candidate_regions.tsv, no local assembly, denovo_paths.txt reports 0 loci. Variants that are "
+        "not in the PRG will not be called.\n", n_cand, a.outdir.c_str());
+    std::printf("[pandora-hip] discover: %u candidate regions; 0 loci with denovo variants (local assembly not implemented)\n", n_cand);
     drprg_hip_close(ctx);
     return 0;
 }

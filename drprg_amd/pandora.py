@@ -119,6 +119,31 @@ class Context:
         lib.drprg_hip_genotype_info(self._h, gi)
         return dict(exp_depth_covg=int(gi[0]), min_kmer_covg=int(gi[1]), loci_present=int(gi[2]), records=int(gi[3]))
 
+    def discover(self, vcf_refs, out_dir, sample="sample"):
+        """candidate_regions.tsv + denovo_paths.txt ("0 loci": no local assembly) under out_dir; returns the regions"""
+        n = C.c_uint32()
+        _check(lib.drprg_hip_discover(self._h, os.fsencode(vcf_refs) if vcf_refs else None, os.fsencode(out_dir), sample.encode(),
+                                      C.byref(n)), self._h)
+        regions = []
+        for line in open(os.path.join(out_dir, "candidate_regions.tsv")):
+            if not line.startswith("#"):
+                f = line.rstrip("\n").split("\t")
+                regions.append(dict(locus=f[0], start=int(f[1]), end=int(f[2]), low_start=int(f[3]), low_end=int(f[4]),
+                                    max_covg=int(f[5]), seq=f[6]))
+        assert len(regions) == n.value
+        return regions
+
+    def save_coverage(self, path, tag):
+        _check(lib.drprg_hip_save_coverage(self._h, os.fsencode(path), tag.encode()), self._h)
+
+    def load_coverage(self, path, tag):
+        """True if the cached vector belonged to this (PRG, reads, parameters) and is now installed"""
+        rc = lib.drprg_hip_load_coverage(self._h, os.fsencode(path), tag.encode(), None)
+        if rc == -2:
+            return False
+        _check(rc, self._h)
+        return True
+
     def genotype_alleles(self, out_tsv):
         """per allele of the last genotype(): (chrom, pos, allele) -> global k-mer nodes its statistics were taken over"""
         _check(lib.drprg_hip_genotype_alleles(self._h, os.fsencode(out_tsv)), self._h)
@@ -233,25 +258,49 @@ class Pandora:
         ctx.map_fastx(reads)
         return ctx
 
+    @staticmethod
+    def _run_tag(prg, reads, args):
+        """identifies (PRG file, reads file, mapping parameters): what a cached coverage vector belongs to"""
+        def stamp(p):
+            st = os.stat(p)
+            return f"{os.path.realpath(p)}:{st.st_size}:{st.st_mtime_ns}"
+        return "|".join([stamp(prg), stamp(reads)] + [str(a) for a in args if str(a) != "-K"])
+
+    COVERAGE_CACHE = ".drprg_hip_coverage"
+
     def discover_with(self, prg, query_idx, outdir, args=()):
-        """Pandora::discover_with, /root/reference/src/lib.rs:513-578.  Returns the denovo_paths.txt path."""
+        """Pandora::discover_with, /root/reference/src/lib.rs:513-578.  Returns the denovo_paths.txt path.
+
+        Behavioural difference from pandora: the mapping half runs (and its coverage vector is kept under `outdir` for the
+        genotype_with call that follows), low-coverage candidate regions are written to candidate_regions.tsv, but there is
+        no local assembly: denovo_paths.txt always says "0 loci with denovo variants"."""
+        import warnings
         os.makedirs(outdir, exist_ok=True)
         with open(query_idx) as fh:
             sample, reads = fh.readline().split()[:2]
-        with self._mapped_context(prg, reads, args):
-            pass
+        with self._mapped_context(prg, reads, args) as ctx:
+            regions = ctx.discover(None, outdir, sample)
+            ctx.save_coverage(os.path.join(outdir, self.COVERAGE_CACHE), self._run_tag(prg, reads, args))
+        if regions:
+            warnings.warn(f"discover: {len(regions)} low-coverage candidate region(s) in {len({r['locus'] for r in regions})} "
+                          "locus/loci; de novo local assembly is not implemented, novel variants are NOT added to the PRG")
         path = os.path.join(outdir, "denovo_paths.txt")
-        with open(path, "w") as fh:
-            fh.write(f"Sample {sample}\n0 loci with denovo variants\n")
-        open(os.path.join(outdir, "denovo_sequences.fa"), "w").close()
         if not os.path.exists(path):
             raise DependencyError("MissingExpectedOutput", path)
         return path
 
     def genotype_with(self, prg, vcf_ref, reads, outdir, args=()):
-        """Pandora::genotype_with, /root/reference/src/lib.rs:580-642."""
+        """Pandora::genotype_with, /root/reference/src/lib.rs:580-642.  If discover_with left this run's coverage vector
+        under <outdir>/discover (where drprg puts it, /root/reference/src/predict.rs:248), the reads are not mapped again."""
         os.makedirs(outdir, exist_ok=True)
-        with self._mapped_context(prg, reads, args) as ctx:
+        o = self._parse_args(args)
+        cache = os.path.join(outdir, "discover", self.COVERAGE_CACHE)
+        ctx = Context(prg, o["w"], o["k"], device=self.device)
+        with ctx:
+            ctx.set_opts(illumina=o["illumina"], min_cluster_size=o["c"], genome_size=MTB_GENOME_SIZE)
+            self.reused_discover_coverage = os.path.exists(cache) and ctx.load_coverage(cache, self._run_tag(prg, reads, args))
+            if not self.reused_discover_coverage:
+                ctx.map_fastx(reads)
             ctx.genotype(vcf_ref, os.path.join(outdir, self.vcf_filename()))
 
     @staticmethod

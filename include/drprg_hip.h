@@ -95,6 +95,19 @@ int drprg_hip_genotype(drprg_hip_ctx* ctx, const char* vcf_refs, const char* out
 /* exp_depth_covg / min_kmer_covg / #present / #records of the last drprg_hip_genotype */
 int drprg_hip_genotype_info(const drprg_hip_ctx* ctx, uint32_t out[4]);
 
+/* The tail of `pandora discover` (Pandora::discover_with, /root/reference/src/lib.rs:513-578) on the coverage accumulated so
+ * far: calls every site, walks the called consensus of every present locus and writes <out_dir>/candidate_regions.tsv (the
+ * low-coverage regions pandora would hand to its local assembler), <out_dir>/denovo_paths.txt and denovo_sequences.fa.
+ * Local assembly is NOT implemented: denovo_paths.txt always reports "0 loci with denovo variants" (the format
+ * /root/reference/src/lib.rs:648-697 parses), so a sample's off-panel variants are located but never added to the PRG.
+ * *n_candidates (may be NULL) receives the number of candidate regions. */
+int drprg_hip_discover(drprg_hip_ctx* ctx, const char* vcf_refs, const char* out_dir, const char* sample, uint32_t* n_candidates);
+/* Coverage hand-over between `discover` and the `map` that follows it on the same reads and PRG
+ * (/root/reference/src/predict.rs:248-255, :296-302): save writes vector + counters under `tag`; load returns 0 and installs
+ * them only if the file exists, is intact and carries the same tag and index shape (-ENOENT otherwise: map the reads). */
+int drprg_hip_save_coverage(drprg_hip_ctx* ctx, const char* path, const char* tag);
+int drprg_hip_load_coverage(drprg_hip_ctx* ctx, const char* path, const char* tag, uint64_t counters[8]);
+
 /* a-9 on raw inputs, for parity harnesses (host only, no context): the same functions drprg_hip_genotype applies per allele
  * and per site (pandora SampleInfo; pinned by the reference's fixture VCFs, tests/golden/likelihood_kat.tsv).
  * out[0..5] = MEAN_FWD, MEAN_REV, MED_FWD, MED_REV, SUM_FWD, SUM_REV; *gaps = GAPS. */

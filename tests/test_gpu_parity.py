@@ -343,14 +343,31 @@ def test_cli_map_end_to_end(tmp_path, oracle):
     assert r.returncode == 0, r.stderr
     vcf = out / "pandora_genotyped.vcf"
     assert vcf.exists()
-    # discover: must leave a parsable denovo_paths.txt with zero loci (/root/reference/src/lib.rs:648-697)
+    # discover (-o <out>/discover, /root/reference/src/predict.rs:248): a parsable denovo_paths.txt with zero loci
+    # (/root/reference/src/lib.rs:648-697), candidate regions, a loud warning; the `map` that follows in the same <out> takes
+    # the coverage vector discover left there instead of mapping the reads a second time, and writes the identical VCF
     q = tmp_path / "query.tsv"
     q.write_text(f"sample\t{fq}\n")
-    r = subprocess.run([PANDORA_EXE, "discover", "-g", "4411532", "--max-covg", "4294967295", "-v", "-o", str(tmp_path / "disc"),
+    out2 = tmp_path / "out2"
+    r = subprocess.run([PANDORA_EXE, "discover", "-g", "4411532", "--max-covg", "4294967295", "-v", "-o", str(out2 / "discover"),
                         "-t", "1", "-w", str(w), "-k", str(k), "-c", "10", "-I", prg, str(q)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+    assert "WARNING: de novo variant discovery is not implemented" in r.stderr
     from drprg_amd import Pandora
-    assert Pandora.list_prgs_with_novel_variants(str(tmp_path / "disc" / "denovo_paths.txt")) == []
+    assert Pandora.list_prgs_with_novel_variants(str(out2 / "discover" / "denovo_paths.txt")) == []
+    assert (out2 / "discover" / "candidate_regions.tsv").exists()
+    argv2 = list(argv)
+    argv2[argv2.index("-o") + 1] = str(out2)
+    r = subprocess.run(argv2, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "no second mapping pass" in r.stdout
+    keep = lambda p: [l for l in open(p) if not l.startswith("##fileDate")]
+    assert keep(out2 / "pandora_genotyped.vcf") == keep(vcf)
+    # other parameters (here -c 11): the cached vector is not this run's, the reads are mapped
+    argv3 = list(argv2)
+    argv3[argv3.index("-c") + 1] = "11"
+    r = subprocess.run(argv3, capture_output=True, text=True)
+    assert r.returncode == 0 and "no second mapping pass" not in r.stdout and "reads=10000" in r.stdout
     # reference VCF: host genotyper on the oracle's coverage of the same reads (oracle's own index of the same PRGs)
     ctx = Context(prg, w, k, device=-1, from_files=True)
     ctx.set_opts(illumina=True, genome_size=4411532)

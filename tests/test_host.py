@@ -334,3 +334,125 @@ def test_foreign_index_files_are_rebuilt_from_the_prg(tmp_path, capfd):
     # a missing PRG is still an error
     with pytest.raises(DependencyError):
         Context(str(tmp_path / "nope.prg"), 11, 15, device=-1, from_files=True)
+
+
+# ---- discover (NEXT-2): candidate regions of the called consensus, coverage hand-over to map ---------------------------
+def _offpanel_setup(tmp_path, oracle, snp):
+    """a 3-locus panel; reads from a sample whose locus g1 carries (snp=True) a substitution that no PRG allele holds, at a
+    position well away from any site"""
+    from drprg_amd import Context, synth
+    w, k = 11, 15
+    panel = synth.small_panel(seed=31, n_loci=3, length=900, site_every=60)
+    prg, genes = str(tmp_path / "dr.prg"), str(tmp_path / "genes.fa")
+    panel.write(prg, genes)
+    rng = np.random.default_rng(4)
+    # the position: middle of the longest site-free stretch of g1's first-allele path
+    tree = panel.trees[1]
+    pos, cur, best = 0, 0, (0, 0)
+    for seg in tree:
+        if isinstance(seg, str):
+            if len(seg) > best[0]:
+                best = (len(seg), cur + len(seg) // 2)
+            cur += len(seg)
+        else:
+            cur += len(seg.alleles[0][0]) if isinstance(seg.alleles[0][0], str) else 0
+    pos = best[1]
+    assert best[0] > 60
+    reads = []
+    for locus in range(3):
+        hap = synth.sample_haplotype(None, panel.trees[locus], first_allele=True)
+        if locus == 1 and snp:
+            hap = hap[:pos] + "ACGT".replace(hap[pos], "")[0] + hap[pos + 1:]
+        # (the locus sits inside a genome: reads overhang its ends, so coverage does not thin out there)
+        h = np.frombuffer((synth.random_seq(rng, 200) + hap + synth.random_seq(rng, 200)).encode(), np.uint8)
+        for s in rng.integers(0, len(h) - 150, size=700):
+            reads.append(h[s:s + 150])
+    offs = np.arange(len(reads) + 1, dtype=np.uint64) * np.uint64(150)
+    bases = np.concatenate(reads)
+    ctx = Context(prg, w, k, device=-1, from_files=False)
+    ctx.set_opts(illumina=True, genome_size=3000)
+    md, er = map_params(k, True)
+    covg, prg_reads, _ = oracle.map_reads(bases, offs, oracle.build_index(panel.prgs, w, k), w, k, md, cluster_fraction(er, k), 10)
+    ctx.set_coverage(covg, prg_reads, int(offs[-1]))
+    return ctx, genes, pos, panel
+
+
+def test_discover_locates_an_off_panel_snp_as_a_candidate_region(tmp_path, oracle):
+    """/root/reference/src/lib.rs:513-578: the mapping half of discover.  Reads with a SNP the PRG does not hold leave the
+    k-mers over it without coverage: exactly one candidate region, on that locus, around that position.  denovo_paths.txt
+    still reports 0 loci (no local assembly) in the format list_prgs_with_novel_variants parses (src/lib.rs:648-697)."""
+    from drprg_amd import Pandora
+    ctx, genes, pos, panel = _offpanel_setup(tmp_path, oracle, snp=True)
+    out = tmp_path / "discover"
+    out.mkdir()
+    regions = ctx.discover(genes, str(out))
+    assert [r["locus"] for r in regions] == ["g1"]
+    r = regions[0]
+    assert r["low_start"] <= pos < r["low_end"] and r["low_end"] - r["low_start"] <= 16
+    assert r["start"] == r["low_start"] - 22 and r["end"] == r["low_end"] + 22
+    ref = panel.refs[1]
+    assert r["seq"] == ref[r["start"]:r["end"]]  # the called consensus here is the reference path
+    assert r["max_covg"] <= 3
+    assert Pandora.list_prgs_with_novel_variants(str(out / "denovo_paths.txt")) == []
+    assert (out / "denovo_sequences.fa").exists()
+
+
+def test_discover_reports_nothing_for_a_sample_the_panel_explains(tmp_path, oracle):
+    ctx, genes, _, _ = _offpanel_setup(tmp_path, oracle, snp=False)
+    out = tmp_path / "discover"
+    out.mkdir()
+    assert ctx.discover(genes, str(out)) == []
+
+
+def test_low_coverage_interval_rule(tmp_path, oracle):
+    """candidate-region arithmetic on a crafted vector: a run of 60 low bases is too long (max 50), runs closer than 22 bases
+    merge, uncovered bases never count"""
+    from drprg_amd import Context, synth
+    w, k = 11, 15
+    rng = np.random.default_rng(8)
+    seq = synth.random_seq(rng, 1200)
+    prg = str(tmp_path / "lin.prg")
+    open(prg, "w").write(f">lin\n{seq}\n")
+    ctx = Context(prg, w, k, device=-1, from_files=False)
+    ctx.set_opts(illumina=True, genome_size=1200)
+    g = oracle.sketch_prg(seq, w, k, paths=True)
+    starts = np.array([p[0][0] for p in g["paths"]])
+    n = g["n_nodes"]
+    covg = np.zeros(2 * n, np.uint32)
+    covg[2::2][:n - 2] = 40  # every k-mer node well covered ...
+
+    def zero(lo, hi):  # ... except those that touch [lo, hi)
+        for i, s in enumerate(starts):
+            if s < hi and s + k > lo:
+                covg[2 * (i + 1)] = 0
+
+    zero(200, 203)
+    zero(228, 230)   # within 22 bases of the previous run: merged
+    zero(500, 580)   # longer than 50 bases: ignored
+    zero(900, 901)
+    ctx.set_coverage(covg, np.array([5], np.uint32), 40 * 1200)
+    out = tmp_path / "d"
+    out.mkdir()
+    regions = ctx.discover(None, str(out))
+    assert len(regions) == 2
+    a, b = regions
+    assert a["low_start"] <= 200 and a["low_end"] >= 230 and a["low_end"] - a["low_start"] < 80
+    assert b["low_start"] <= 900 < b["low_end"]
+    assert all(r["seq"] == seq[r["start"]:r["end"]] for r in regions)
+
+
+def test_coverage_hand_over_between_discover_and_map(tmp_path, oracle):
+    """the vector `discover` saves is taken back only for the same (PRG, reads, parameters) tag"""
+    ctx, genes, _, _ = _offpanel_setup(tmp_path, oracle, snp=True)
+    cache = str(tmp_path / "cache.bin")
+    want = ctx.coverage()
+    ctx.save_coverage(cache, "tag-A")
+    ctx.set_coverage(np.zeros_like(want[0]), np.zeros_like(want[1]), 0)
+    assert not ctx.load_coverage(cache, "tag-B") and ctx.coverage()[0].sum() == 0
+    assert not ctx.load_coverage(str(tmp_path / "missing.bin"), "tag-A")
+    assert ctx.load_coverage(cache, "tag-A")
+    got = ctx.coverage()
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    open(cache, "r+b").truncate(100)
+    with pytest.raises(Exception):
+        ctx.load_coverage(cache, "tag-A")
