@@ -3,6 +3,8 @@
 // window-minimizer test per candidate (verify_count_kernel) -> batch totals; and, for the reads that
 // read_cluster_kernel leaves over, the hit list for the generic cluster pipeline (recount / expand / per-read reorder).
 #include "filter_common.h"
+#include <cstdlib>
+#include <string>
 #include <cstdint>
 
 namespace drprg {
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(EX_THREADS) void verify_count_kernel(SketchArgs a, 
             bool found = false;
             if (g) {
                 const uint32_t h = g - 1;
-                uint32_t sl = table_slot_dev((uint64_t)h, a.table_bits);
+                uint32_t sl = table_slot_dev(h, a.table_bits);
                 while (true) {
                     const uint32_t key = slot_key[sl];
                     if (key == h) { found = true; break; }
@@ -467,12 +469,33 @@ hipError_t launch_candidate_stage(const SketchArgs& a, const FilterWork& fw, con
     return hipGetLastError();
 }
 
+// DRPRG_DIRECT_FORM=lds keeps sketch_probe_kernel for every (k, w) (A/B runs, and a second way through the parity tests)
+static bool use_wave_form(int k, int w, bool wide_hash)
+{
+    static const bool forced_lds = [] {
+        const char* e = std::getenv("DRPRG_DIRECT_FORM");
+        return e && std::string(e) == "lds";
+    }();
+    return !wide_hash && !forced_lds && wave_kernel_applies(k, w);
+}
+
+uint32_t direct_candidate_tiles(uint64_t n_bases, int halo, int k, int w, bool wide_hash)
+{
+    return use_wave_form(k, w, wide_hash) ? wave_n_slices(n_bases) : sketch_n_tiles(n_bases, halo);
+}
+
+uint32_t direct_first_read_tiles(uint64_t n_bases, int halo, int k, int w, bool wide_hash)
+{
+    return use_wave_form(k, w, wide_hash) ? wave_n_tiles(n_bases) : sketch_n_tiles(n_bases, halo);
+}
+
 hipError_t launch_direct_candidates(const SketchArgs& a, bool wide_hash, uint32_t* tile_prefix, void* temp, size_t temp_bytes,
     uint64_t dense_capacity, const ReadClusterArgs& rc, int n_cus, FilterWork& fw, hipStream_t stream, KernelTimer timer)
 {
     if (a.n_bases == 0 || !a.tile_cap) return hipErrorInvalidValue;
-    const uint32_t n_tiles = sketch_n_tiles(a.n_bases, a.halo);
-    HIP_TRY(launch_sketch_probe(a, wide_hash, stream, timer));
+    const uint32_t n_tiles = direct_candidate_tiles(a.n_bases, a.halo, a.k, a.w, wide_hash);
+    if (use_wave_form(a.k, a.w, wide_hash)) HIP_TRY(launch_sketch_wave(a, stream, timer));
+    else HIP_TRY(launch_sketch_probe(a, wide_hash, stream, timer));
     // tile_count[n_tiles] is a zero the caller keeps there: the exclusive scan of n_tiles + 1 counts ends with the total
     HIP_TRY(exclusive_scan_u32(temp, temp_bytes, a.tile_count, tile_prefix, n_tiles + 1, stream));
     fw.cand_total = tile_prefix + n_tiles;

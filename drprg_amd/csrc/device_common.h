@@ -31,6 +31,49 @@ template <> struct HashTraits<uint32_t> {
         return key;
     }
 };
+// 16 bytes that are read exactly once (the base stream): non-temporal, so that the stream does not push the probe tables
+// out of the XCD's L2
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 load_once_16(const void* p)
+{
+    const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+// (a << SH) + b in one full-rate instruction.  Spelled as inline assembly because the compiler otherwise folds
+// key + (key << 3) + (key << 8) into v_mul_lo_u32, which issues at a quarter of the rate on gfx950.
+template <int SH> __device__ __forceinline__ uint32_t lshl_add(uint32_t a, uint32_t b)
+{
+    uint32_t d;
+    asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "n"(SH), "v"(b));
+    return d;
+}
+
+// bits [OFF + WIDTH - 1 : OFF] of x in one instruction (the compiler's own choice for __builtin_amdgcn_ubfe is shift + and)
+template <int OFF, int WIDTH> __device__ __forceinline__ uint32_t bfe(uint32_t x)
+{
+    uint32_t d;
+    asm("v_bfe_u32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "n"(OFF), "n"(WIDTH));
+    return d;
+}
+
+// hash64 restricted to 2K <= 30 bits for a compile-time K, without the intermediate masks: additions and left shifts only
+// carry upwards, so bits >= 2K never reach bits < 2K; the three right shifts read exactly bits [2K-1 : s] through v_bfe_u32.
+// Bits >= 2K of the argument are ignored; the result is exact in bits < 2K and ZERO above (the last step masks).
+// 12 full-rate VALU instructions + the closing mask.
+template <int K> __device__ __forceinline__ uint32_t mix_k(uint32_t key)
+{
+    static_assert(K >= 1 && K <= 15, "32-bit hash path");
+    constexpr uint32_t MASK = (1u << (2 * K)) - 1u;
+    uint32_t x = lshl_add<21>(key, ~key);
+    if constexpr (2 * K > 24) x ^= bfe<24, (2 * K > 24 ? 2 * K - 24 : 1)>(x);
+    x = lshl_add<8>(x, lshl_add<3>(x, x));
+    if constexpr (2 * K > 14) x ^= bfe<14, (2 * K > 14 ? 2 * K - 14 : 1)>(x);
+    x = lshl_add<4>(x, lshl_add<2>(x, x));
+    if constexpr (2 * K > 28) return (x & MASK) ^ bfe<28, (2 * K > 28 ? 2 * K - 28 : 1)>(x);
+    return x & MASK;
+}
+
 template <> struct HashTraits<uint64_t> {
     static constexpr uint64_t EMPTY = ~0ULL; // k <= 31: hashes stay below 2^62
     __device__ static inline uint64_t mix(uint64_t key, uint64_t mask)
@@ -46,6 +89,8 @@ template <> struct HashTraits<uint64_t> {
     }
 };
 
+// index.h table_slot on the device: 32-bit keys (k <= 15) take one 32-bit multiply, 64-bit keys the 64-bit one
+__device__ inline uint32_t table_slot_dev(uint32_t key, uint32_t bits) { return (key * 0x9E3779B1u) >> (32 - bits); }
 __device__ inline uint32_t table_slot_dev(uint64_t key, uint32_t bits)
 {
     return (uint32_t)((key * 0x9E3779B97F4A7C15ULL) >> (64 - bits));

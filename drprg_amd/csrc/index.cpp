@@ -98,7 +98,7 @@ void PrgIndex::flatten()
     f.slot_off.assign(nslot, 0);
     f.slot_cnt.assign(nslot, 0);
     for (size_t i = 0; i < f.keys.size(); ++i) {
-        uint32_t s = table_slot(f.keys[i], bits);
+        uint32_t s = table_slot(f.keys[i], bits, k <= 15);
         while (f.slot_cnt[s] != 0) s = (s + 1) & (uint32_t)(nslot - 1);
         f.slot_key[s] = f.keys[i];
         f.slot_off[s] = f.rec_off[i];

@@ -68,9 +68,12 @@ private:
     void flatten();
 };
 
-// slot index of `key` in a table of 2^bits slots (multiplicative hash; same function on the device)
-inline uint32_t table_slot(uint64_t key, uint32_t bits)
+// slot index of `key` in a table of 2^bits slots (multiplicative hash; same function on the device).  narrow: the keys are
+// 32-bit hashes (k <= 15) and the device does the whole thing in one 32-bit multiply -- the same product that picks the word
+// and the bits of the Bloom tier in front of a large table (kernels.h pbloom_mix)
+inline uint32_t table_slot(uint64_t key, uint32_t bits, bool narrow)
 {
+    if (narrow) return ((uint32_t)key * 0x9E3779B1u) >> (32 - bits);
     return (uint32_t)((key * 0x9E3779B97F4A7C15ULL) >> (64 - bits));
 }
 

@@ -69,6 +69,7 @@ struct SketchArgs {
     uint4* tile_rec;
     uint32_t *tile_count, *tile_hits, *tile_nmin;
     const uint32_t* prg_min_path_len; // for the size threshold stored in the records
+    const uint32_t* prg_thr;          // per PRG: floor(shortest k-mer path * fraction) (sketch_wave_kernel)
     double fraction;
     uint32_t min_cluster_size;
 };
@@ -104,6 +105,18 @@ struct KernelTimer {
 uint32_t sketch_tile_eval(int halo);
 uint32_t sketch_n_tiles(uint64_t n_bases, int halo);
 hipError_t launch_sketch_probe(const SketchArgs& a, bool wide_hash, hipStream_t stream, KernelTimer timer = {});
+// first read that starts at or after the first staged base (tile * t_eval - halo) of every tile
+hipError_t launch_tile_first_read(const uint64_t* offsets, uint32_t n_reads, int t_eval, int halo, uint32_t n_tiles, uint32_t* out,
+    hipStream_t stream);
+// register-resident form of the direct kernel's candidate form (sketch_wave.hip): k = 15, w in {11, 14}; one tile per wave
+bool wave_kernel_applies(int k, int w);
+uint32_t wave_tile_eval();
+uint32_t wave_n_tiles(uint64_t n_bases);
+uint32_t wave_n_slices(uint64_t n_bases); // one slice of tile_cap records per workgroup of four tiles
+hipError_t launch_sketch_wave(const SketchArgs& a, hipStream_t stream, KernelTimer timer = {});
+// tiles of the candidate form of the direct sequence for these parameters (whichever kernel serves them)
+uint32_t direct_candidate_tiles(uint64_t n_bases, int halo, int k, int w, bool wide_hash); // = slices
+uint32_t direct_first_read_tiles(uint64_t n_bases, int halo, int k, int w, bool wide_hash); // entries of tile_first_read
 // filtered form (k <= 15, w <= 16): bloom = 2^bloom_wbits words of index k-mer codes
 uint32_t filter_n_tiles(uint64_t n_bases);
 uint32_t filter_grid(bool level0, int n_cus, uint32_t n_tiles);

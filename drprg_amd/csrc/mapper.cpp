@@ -94,6 +94,8 @@ Mapper::Mapper(const FlatIndex& idx, const MapParams& p, int device) : device_(d
     HIPCHK(hipMemcpy(d_rec_prg_, rp.data(), nrec * sizeof(uint16_t), hipMemcpyHostToDevice));
     dmalloc(d_min_path_len_, (size_t)n_prgs_);
     HIPCHK(hipMemcpy(d_min_path_len_, idx.min_path_len.data(), n_prgs_ * sizeof(uint32_t), hipMemcpyHostToDevice));
+    h_min_path_len_ = idx.min_path_len;
+    dmalloc(d_prg_thr_, (size_t)n_prgs_);
     // Bloom tier of the direct kernel: only when keys + slot records outgrow an XCD's 4 MB L2 (<= ~4 keys per 32-bit word)
     if (nslot * (size_t)(wide_hash_ ? 16 : 12) > ((size_t)2 << 20)) {
         pbloom_wbits_ = 10;
@@ -135,7 +137,7 @@ Mapper::~Mapper()
 {
     (void)hipSetDevice(device_);
     if (stream_) (void)hipStreamSynchronize(stream_);
-    dfree(d_slot_rec_); dfree(d_slot_first_); dfree(d_rec_knode_); dfree(d_rec_prg_); dfree(d_min_path_len_);
+    dfree(d_slot_rec_); dfree(d_slot_first_); dfree(d_rec_knode_); dfree(d_rec_prg_); dfree(d_min_path_len_); dfree(d_prg_thr_);
     if (d_slot_key_) (void)hipFree(d_slot_key_);
     dfree(d_covg_); dfree(d_prg_reads_); dfree(d_counters_);
     dfree(d_key_a_); dfree(d_key_b_); dfree(d_val_a_); dfree(d_val_b_);
@@ -180,6 +182,13 @@ void Mapper::set_params(const MapParams& p)
     params_ = p;
     wide_hash_ = p.k > 15;
     halo_ = std::max(16, ((p.w - 1 + 15) / 16) * 16);
+    if (d_prg_thr_) { // the PRG's share of the cluster size threshold, in the oracle's own arithmetic
+        std::vector<uint32_t> thr(n_prgs_);
+        const double fraction = params_.cluster_fraction();
+        for (uint32_t i = 0; i < n_prgs_; ++i) thr[i] = (uint32_t)((double)h_min_path_len_[i] * fraction);
+        HIPCHK(hipSetDevice(device_));
+        HIPCHK(hipMemcpy(d_prg_thr_, thr.data(), n_prgs_ * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     use_filter_ = p.kernel_mode == 2 || (p.kernel_mode == 0 && filter_ok);
     use_direct_cands_ = p.kernel_mode == 3 || (p.kernel_mode == 0 && !filter_ok);
 }
@@ -411,7 +420,7 @@ void Mapper::ensure_tile_workspace(uint32_t n_tiles, uint32_t tile_cap)
     dfree(d_tile_info_); dfree(d_tile_pos1_); dfree(d_tile_count_); dfree(d_tile_hits_); dfree(d_tile_nmin_); dfree(d_tile_prefix_); dfree(d_tile_rec_);
     if (d_tile_temp_) (void)hipFree(d_tile_temp_);
     d_tile_temp_ = nullptr;
-    tile_ws_tiles_ = std::max(tile_ws_tiles_, n_tiles + n_tiles / 8 + 16);
+    tile_ws_tiles_ = std::max(tile_ws_tiles_, n_tiles + n_tiles / 8 + 32);
     tile_ws_cap_ = std::max(tile_ws_cap_, tile_cap);
     const size_t n = (size_t)tile_ws_tiles_ * tile_ws_cap_;
     dmalloc(d_tile_info_, n); dmalloc(d_tile_pos1_, n); dmalloc(d_tile_rec_, n);
@@ -426,10 +435,11 @@ void Mapper::ensure_tile_workspace(uint32_t n_tiles, uint32_t tile_cap)
 void Mapper::run_batch_direct_candidates(const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads, uint64_t n_bases,
     uint32_t* covg, uint32_t* prg_reads, hipStream_t stream)
 {
-    const uint32_t n_tiles = dev::sketch_n_tiles(n_bases, halo_);
-    if (n_tiles > tile_cap_) { // first read of every tile
+    const uint32_t n_tiles = dev::direct_candidate_tiles(n_bases, halo_, params_.k, params_.w, wide_hash_); // = slices
+    const uint32_t n_first = dev::direct_first_read_tiles(n_bases, halo_, params_.k, params_.w, wide_hash_);
+    if (n_first > tile_cap_) { // first read of every tile
         dfree(d_tile_first_);
-        tile_cap_ = n_tiles + n_tiles / 4 + 16;
+        tile_cap_ = n_first + n_first / 4 + 16;
         dmalloc(d_tile_first_, (size_t)tile_cap_);
     }
     ensure_lanes(1, std::min<uint64_t>(std::max<uint64_t>(1u << 20, n_bases / 16), (1ull << 31) - 1));
@@ -451,6 +461,7 @@ void Mapper::run_batch_direct_candidates(const uint8_t* d_bases, const uint64_t*
         a.tile_hits = d_tile_hits_;
         a.tile_nmin = d_tile_nmin_;
         a.prg_min_path_len = d_min_path_len_;
+        a.prg_thr = d_prg_thr_;
         a.fraction = params_.cluster_fraction();
         a.min_cluster_size = params_.min_cluster_size;
         dev::FilterBuffers fb { lane.raw_pos, lane.raw_grp, lane.cand_info, lane.cand_pos1, lane.cand_rec, lane.raw_capacity, lane.small,

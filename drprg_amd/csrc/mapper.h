@@ -111,6 +111,8 @@ private:
     uint32_t* d_rec_knode_ = nullptr;
     uint16_t* d_rec_prg_ = nullptr;
     uint32_t* d_min_path_len_ = nullptr;
+    uint32_t* d_prg_thr_ = nullptr;         // per PRG: floor(shortest k-mer path * cluster fraction), follows set_params
+    std::vector<uint32_t> h_min_path_len_;
     uint32_t* d_bloom_ = nullptr;
     uint32_t bloom_wbits_ = 0;
     uint32_t* d_pbloom_ = nullptr; // Bloom tier of the direct kernel (large indexes)

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(SK_THREADS) void sketch_probe_kernel(SketchArgs a)
         int64_t g = origin + (int64_t)v * 16;
         uint4 out;
         if (g >= 0 && g + 16 <= n_bases) {
-            uint4 in = *reinterpret_cast<const uint4*>(a.bases + g);
+            uint4 in = load_once_16(a.bases + g);
             out.x = encode4(in.x); out.y = encode4(in.y); out.z = encode4(in.z); out.w = encode4(in.w);
         } else {
             uint32_t tmp[4];
@@ -123,7 +123,14 @@ __global__ __launch_bounds__(SK_THREADS) void sketch_probe_kernel(SketchArgs a)
                 rev = (rev >> 2) | ((b ^ (HT)3) << shift1);
                 if (s >= k - 1) {
                     const int j = s - (k - 1);
-                    const HT hf = Tr::mix(fwd, mask), hr = Tr::mix(rev, mask);
+                    HT hf, hr;
+                    if constexpr (KC > 0 && sizeof(HT) == 4) {
+                        hf = mix_k<KC>((uint32_t)fwd);
+                        hr = mix_k<KC>((uint32_t)rev);
+                    } else {
+                        hf = Tr::mix(fwd, mask);
+                        hr = Tr::mix(rev, mask);
+                    }
                     strand_bits |= (uint32_t)(hf <= hr) << j;
                     s_hash[hpad(base0 + j)] = (hf < hr ? hf : hr) + 1;
                 }
@@ -267,7 +274,7 @@ __global__ __launch_bounds__(SK_THREADS) void sketch_probe_kernel(SketchArgs a)
                     maybe = (a.pbloom[pbloom_word(m, a.pbloom_wbits)] & need) == need;
                 }
                 if (maybe) {
-                    s = table_slot_dev((uint64_t)h, a.table_bits);
+                    s = table_slot_dev(h, a.table_bits);
                     while (true) {
                         const HT key = slot_key[s];
                         if (key == h) { found = true; break; }
@@ -329,7 +336,7 @@ __global__ __launch_bounds__(SK_THREADS) void sketch_probe_kernel(SketchArgs a)
                 continue;
             }
         }
-        uint32_t s = table_slot_dev((uint64_t)h, a.table_bits);
+        uint32_t s = table_slot_dev(h, a.table_bits);
         bool found = false;
         while (true) {
             const HT key = slot_key[s];
@@ -373,6 +380,13 @@ __global__ __launch_bounds__(SK_THREADS) void sketch_probe_kernel(SketchArgs a)
     if (tid == 0 && nmin) atomicAdd(a.n_minimizers, (unsigned long long)nmin);
 }
 
+hipError_t launch_tile_first_read(const uint64_t* offsets, uint32_t n_reads, int t_eval, int halo, uint32_t n_tiles, uint32_t* out,
+    hipStream_t stream)
+{
+    hipLaunchKernelGGL(tile_first_read_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, stream, offsets, n_reads, t_eval, halo, n_tiles, out);
+    return hipGetLastError();
+}
+
 uint32_t sketch_tile_eval(int halo) { return (uint32_t)(SK_NPOS - 2 * halo); }
 
 uint32_t sketch_n_tiles(uint64_t n_bases, int halo)
@@ -385,9 +399,7 @@ hipError_t launch_sketch_probe(const SketchArgs& a, bool wide_hash, hipStream_t 
 {
     if (a.n_bases == 0) return hipSuccess;
     const uint32_t grid = sketch_n_tiles(a.n_bases, a.halo); // positions past n_bases-k are invalid inside the kernel
-    hipLaunchKernelGGL(tile_first_read_kernel, dim3((grid + 255) / 256), dim3(256), 0, stream, a.offsets, a.n_reads,
-        (int)sketch_tile_eval(a.halo), a.halo, grid, a.tile_first_read);
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(launch_tile_first_read(a.offsets, a.n_reads, (int)sketch_tile_eval(a.halo), a.halo, grid, a.tile_first_read, stream));
     const dim3 g(grid), b(SK_THREADS);
     if (timer.begin) HIP_TRY(hipEventRecord(timer.begin, stream));
     if (wide_hash)

@@ -1,0 +1,425 @@
+// sketch_wave.hip -- K1+K2 for large indexes, register-resident form (gfx950): sketch_wave_kernel<K, W>.
+//
+// Same contract as the candidate form of sketch_probe_kernel (sketch_probe.hip): every k-mer of the concatenated base buffer
+// is hashed, the (w,k) window minimizers are found, the ones that are index keys leave the workgroup as candidate records in
+// position order in its slice (tile_info / tile_pos1 / tile_rec, tile_count / tile_hits / tile_nmin); scan + gather +
+// read_cluster_kernel take it from there.  It replaces, inside the external `pandora map` process that
+// /root/reference/src/lib.rs:580-642 spawns, Seq::minimizer_sketch + the index lookup of add_read_hits.
+//
+// What is different from sketch_probe_kernel: nothing goes through LDS on the way from bases to window minima, and no
+// workgroup barrier exists -- every WAVE owns a tile of 64 x 16 bases:
+//   * one 16-byte non-temporal load per lane; the 16 bases are packed to 2 bits twice (first base in the low bits / in the
+//     high bits) with v_dot4_u32_u8; the right neighbour's words arrive by a DPP wave shift;
+//   * k-mer j of a lane is ONE v_alignbit_b32 out of the high-first words (forward k-mer) and ONE out of the low-first words
+//     (whose complement is the reverse-complement k-mer, so that costs nothing): no rolling, no masks;
+//   * the hash is mix_k<K> (12 full-rate instructions, device_common.h); canonical hash + 1 (0 = invalid k-mer) stays in 16
+//     VGPRs; the W-1 values either side come from the neighbouring lanes by DPP wave shifts;
+//   * window minima by doubling in registers, as in sketch_probe_kernel;
+//   * lanes 0, 62 and 63 only supply neighbours (a tile evaluates 61 x 16 positions);
+//   * read boundaries and non-ACGT bases become a per-lane mask of invalid k-mer starts (a 64-word LDS array per wave, touched
+//     only by that wave);
+//   * the minimizers of the tile are compacted per wave (prefix over lanes with wave scans) and thinned in three passes with
+//     all lanes busy: Bloom tier -> exact table lookup -> record; the four tiles of a workgroup share one slice.
+#include "device_common.h"
+
+namespace drprg {
+namespace dev {
+
+constexpr int SW_G = 16;                    // k-mer positions (= bytes loaded) per lane
+constexpr int SW_LOAD = 64 * SW_G;          // bases staged per wave tile
+constexpr int SW_FIRST = 1, SW_LAST = 61;   // lanes that evaluate their positions
+constexpr int SW_EVAL = (SW_LAST - SW_FIRST + 1) * SW_G; // 976 positions per tile
+constexpr int SW_WAVES = 4;                 // independent waves (= tiles) per workgroup
+
+uint32_t wave_tile_eval() { return SW_EVAL; }
+uint32_t wave_n_tiles(uint64_t n_bases) { return (uint32_t)((n_bases + SW_EVAL - 1) / SW_EVAL); }
+bool wave_kernel_applies(int k, int w) { return k == 15 && (w == 11 || w == 14); }
+uint32_t wave_n_slices(uint64_t n_bases) { return (wave_n_tiles(n_bases) + SW_WAVES - 1) / SW_WAVES; } // one slice per workgroup
+
+__device__ __forceinline__ uint32_t from_next_lane(uint32_t v) // lane i <- lane i + 1 (lane 63 <- 0)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+}
+__device__ __forceinline__ uint32_t from_prev_lane(uint32_t v) // lane i <- lane i - 1 (lane 0 <- 0)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+}
+__device__ __forceinline__ uint32_t lanes_below(uint64_t m)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+// four ASCII bases -> selector bytes (A0 C1 T2 G3 = bits 2:1 of the letter); *diff receives a non-zero byte for every base
+// that is not ACGT / acgt
+__device__ __forceinline__ uint32_t select4(uint32_t word, uint32_t& diff_acc)
+{
+    const uint32_t sel = (word >> 1) & 0x03030303u;
+    const uint32_t expect = __builtin_amdgcn_perm(0u, 0x47544341u, sel); // the upper-case letter each selector stands for
+    diff_acc |= (word & 0xDFDFDFDFu) ^ expect;
+    return sel;
+}
+// bit i set iff byte i of x is non-zero
+__device__ __forceinline__ uint32_t nonzero_bytes4(uint32_t x)
+{
+    const uint32_t t = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
+    return ((t >> 7) | (t >> 14) | (t >> 21) | (t >> 28)) & 0xFu;
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(v), 63);
+}
+
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// LDS of one wave (nothing in it is shared between waves)
+struct alignas(16) WaveLds {
+    uint32_t hv[SW_LOAD];   // hash + 1 of every position of the wave's tile (0 = invalid); later the slot of a found one
+    uint16_t list[SW_LOAD]; // tile positions: minimizers -> those that pass the Bloom tier -> index keys (compacted in place)
+    uint32_t inv[64];       // per lane: k-mer starts invalidated by a read boundary
+    uint32_t strand[64];    // per lane: bit j = forward k-mer of position j is the canonical one
+    uint32_t rbits[64];     // per lane: bit j = a read starts at position j; bit 16 = several reads start at one position
+    uint32_t rcnt[64];      // per lane: reads that start in its 16 positions; later the read before its first position
+};
+
+template <int K, int W>
+__device__ __forceinline__ void sketch_wave_tile(const SketchArgs& a, uint32_t tile, bool active, WaveLds& lds, uint32_t* s_nb, uint32_t* s_sum, int lane, int wave)
+{
+    if (!active) { // a wave past the last tile still meets the workgroup's two barriers
+        if (lane == 0) s_nb[wave] = 0;
+        __syncthreads();
+        __syncthreads();
+        return;
+    }
+    const int64_t n_bases = (int64_t)a.n_bases;
+    const int64_t origin = (int64_t)tile * SW_EVAL - SW_G; // global position of lane 0's first base
+    const int64_t g0 = origin + (int64_t)lane * SW_G;
+
+    // ---- bases -> 2-bit words, low-first (le) and high-first (be) ----
+    uint4 in;
+    if (g0 >= 0 && g0 + SW_G <= n_bases) {
+        in = load_once_16(a.bases + g0);
+    } else { // the ends of the buffer: what lies outside is 'N'
+        uint32_t tmp[4];
+        for (int q = 0; q < 4; ++q) {
+            uint32_t wd = 0;
+            for (int b = 0; b < 4; ++b) {
+                const int64_t gg = g0 + q * 4 + b;
+                wd |= (uint32_t)((gg >= 0 && gg < n_bases) ? a.bases[gg] : (uint8_t)'N') << (8 * b);
+            }
+            tmp[q] = wd;
+        }
+        in = make_uint4(tmp[0], tmp[1], tmp[2], tmp[3]);
+    }
+    lds.inv[lane] = 0;
+    lds.rbits[lane] = 0;
+    lds.rcnt[lane] = 0;
+    uint32_t diff = 0;
+    const uint32_t s0 = select4(in.x, diff), s1 = select4(in.y, diff), s2 = select4(in.z, diff), s3 = select4(in.w, diff);
+    // v_dot4_u32_u8 packs four selectors into a byte: weights 1,4,16,64 (first base lowest) / 64,16,4,1 (first base highest)
+    uint32_t le = __builtin_amdgcn_udot4(s0, 0x40100401u, 0u, false) | (__builtin_amdgcn_udot4(s1, 0x40100401u, 0u, false) << 8)
+        | (__builtin_amdgcn_udot4(s2, 0x40100401u, 0u, false) << 16) | (__builtin_amdgcn_udot4(s3, 0x40100401u, 0u, false) << 24);
+    uint32_t be = (__builtin_amdgcn_udot4(s0, 0x01041040u, 0u, false) << 24) | (__builtin_amdgcn_udot4(s1, 0x01041040u, 0u, false) << 16)
+        | (__builtin_amdgcn_udot4(s2, 0x01041040u, 0u, false) << 8) | __builtin_amdgcn_udot4(s3, 0x01041040u, 0u, false);
+    le ^= (le >> 1) & 0x55555555u; // A0 C1 T2 G3 -> A0 C1 G2 T3 in every 2-bit field
+    be ^= (be >> 1) & 0x55555555u;
+    const uint32_t le_next = from_next_lane(le), be_next = from_next_lane(be);
+
+    // ---- read boundaries: a k-mer must not straddle two reads (invalid k-mer starts), and where reads start (read lookup) ----
+    const uint32_t first_read = a.tile_first_read[tile];
+    {
+        const int64_t end_pos = origin + SW_LOAD;
+        for (uint32_t r = first_read + (uint32_t)lane; r < a.n_reads; r += 64) {
+            const int64_t o = (int64_t)a.offsets[r];
+            if (o >= end_pos + K) break;
+            const int oc = (int)(o - origin); // the k-mers that start in [oc - K + 1, oc) end inside read r
+            if (oc >= 0 && oc < SW_LOAD) {
+                atomicOr(&lds.rbits[oc >> 4], 1u << (oc & 15));
+                atomicAdd(&lds.rcnt[oc >> 4], 1u);
+            }
+            int p0 = oc - K + 1, p1 = oc < SW_LOAD ? oc : SW_LOAD;
+            if (p0 < 0) p0 = 0;
+            if (p0 >= p1) continue;
+            const int l0 = p0 >> 4, l1 = (p1 - 1) >> 4; // at most two lanes (K - 1 <= 16 positions)
+            const uint32_t run = ((1u << (p1 - p0)) - 1u) << (p0 & 15);
+            atomicOr(&lds.inv[l0], run & 0xFFFFu);
+            if (l1 != l0) atomicOr(&lds.inv[l1], run >> 16);
+        }
+    }
+    // ---- ... and bases that are not ACGT (rare: the exact per-base test only runs when some lane saw one) ----
+    uint32_t inv = 0;
+    if (__any(diff != 0)) {
+        uint32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+        (void)select4(in.x, d0); (void)select4(in.y, d1); (void)select4(in.z, d2); (void)select4(in.w, d3);
+        const uint32_t bad = nonzero_bytes4(d0) | (nonzero_bytes4(d1) << 4) | (nonzero_bytes4(d2) << 8) | (nonzero_bytes4(d3) << 12);
+        const uint32_t win = bad | (from_next_lane(bad) << 16); // my 16 bases and the 16 after them
+        for (int d = 0; d < K; ++d) inv |= win >> d;           // k-mer j holds bases j .. j + K - 1
+    }
+    wave_lds_fence();
+    inv |= *reinterpret_cast<volatile uint32_t*>(&lds.inv[lane]);
+    const uint32_t validbits = ~inv & 0xFFFFu;
+    { // read that holds the base just before my first position = first_read - 1 + reads that start before it in this tile
+        const uint32_t c = *reinterpret_cast<volatile uint32_t*>(&lds.rcnt[lane]);
+        const uint32_t rb = *reinterpret_cast<volatile uint32_t*>(&lds.rbits[lane]);
+        const uint32_t before = wave_inclusive_scan(c) - c;
+        if (c != (uint32_t)__popc(rb)) lds.rbits[lane] = rb | 0x10000u; // empty reads: the popcount shortcut does not hold here
+        lds.rcnt[lane] = first_read - 1u + before;
+    }
+
+    // ---- canonical hash + 1 of my 16 k-mers (0 = invalid), strand bits ----
+    uint32_t hv[SW_G];
+    uint32_t strandbits = 0;
+#pragma unroll
+    for (int j = 0; j < SW_G; ++j) {
+        // low-first stream: bits [2j, 2j + 2K) = the k-mer read backwards; its complement is the reverse-complement k-mer
+        const uint32_t e = __builtin_amdgcn_alignbit(le_next, le, 2 * j);
+        // high-first stream (be : be_next): the forward k-mer sits at bits [64 - 2j - 2K, 64 - 2j)
+        constexpr int TOP = 64 - 2 * K;
+        const int sh = TOP - 2 * j;
+        const uint32_t f = sh >= 32 ? be >> (sh - 32) : __builtin_amdgcn_alignbit(be, be_next, sh);
+        const uint32_t hf = mix_k<K>(f), hr = mix_k<K>(~e);
+        strandbits |= (uint32_t)(hf <= hr) << j;
+        const uint32_t h1 = (hf < hr ? hf : hr) + 1u;
+        hv[j] = h1 & (uint32_t)__builtin_amdgcn_sbfe((int)validbits, j, 1);
+    }
+
+    // ---- window minimizers: position j is one iff some window of W consecutive valid k-mers containing it has no smaller
+    //      value (an invalid k-mer is 0: a window holding one has minimum 0, which no valid value equals) ----
+    uint32_t minbits = 0;
+    {
+        constexpr int N = SW_G + 2 * (W - 1);
+        uint32_t g[N];
+#pragma unroll
+        for (int i = 0; i < W - 1; ++i) g[i] = from_prev_lane(hv[SW_G - (W - 1) + i]);
+#pragma unroll
+        for (int j = 0; j < SW_G; ++j) g[W - 1 + j] = hv[j];
+#pragma unroll
+        for (int i = 0; i < W - 1; ++i) g[W - 1 + SW_G + i] = from_next_lane(hv[i]);
+        constexpr int NW = SW_G + W - 1; // window starts that matter: 0 .. NW - 1
+        uint32_t wm[NW];                  // wm[i] = min g[i .. i + W - 1]
+        if constexpr (W == 11 || W == 14) {
+            // three-input minima: runs of 3, of 9, then the window (11 = 9 + a run of 3 that overlaps it, 14 = 9 + two runs of 3)
+            uint32_t m3[N - 2], m9[N - 8];
+#pragma unroll
+            for (int i = 0; i < N - 2; ++i) m3[i] = min(min(g[i], g[i + 1]), g[i + 2]);
+#pragma unroll
+            for (int i = 0; i < N - 8; ++i) m9[i] = min(min(m3[i], m3[i + 3]), m3[i + 6]);
+#pragma unroll
+            for (int i = 0; i < NW; ++i) wm[i] = W == 11 ? min(m9[i], m3[i + 8]) : min(min(m9[i], m3[i + 9]), m3[i + 11]);
+            // the same shape with maxima over the W windows that hold position j: windows j .. j + W - 1
+            uint32_t x3[NW - 2], x9[NW - 8];
+#pragma unroll
+            for (int i = 0; i < NW - 2; ++i) x3[i] = max(max(wm[i], wm[i + 1]), wm[i + 2]);
+#pragma unroll
+            for (int i = 0; i < NW - 8; ++i) x9[i] = max(max(x3[i], x3[i + 3]), x3[i + 6]);
+#pragma unroll
+            for (int j = 0; j < SW_G; ++j) {
+                const uint32_t best = W == 11 ? max(x9[j], x3[j + 8]) : max(max(x9[j], x3[j + 9]), x3[j + 11]);
+                minbits |= (uint32_t)(best == hv[j]) << j;
+            }
+        } else {
+            constexpr int P = (W >= 16) ? 16 : (W >= 8) ? 8 : (W >= 4) ? 4 : 2; // largest power of two <= W
+#pragma unroll
+            for (int sp = 1; sp < P; sp *= 2) {
+#pragma unroll
+                for (int i = 0; i + sp < N; ++i) g[i] = g[i] < g[i + sp] ? g[i] : g[i + sp];
+            }
+#pragma unroll
+            for (int i = 0; i < NW; ++i) wm[i] = g[i] < g[i + W - P] ? g[i] : g[i + W - P];
+#pragma unroll
+            for (int sp = 1; sp < P; sp *= 2) {
+#pragma unroll
+                for (int i = 0; i + sp < NW; ++i) wm[i] = wm[i] > wm[i + sp] ? wm[i] : wm[i + sp];
+            }
+#pragma unroll
+            for (int j = 0; j < SW_G; ++j) {
+                const uint32_t best = wm[j] > wm[j + W - P] ? wm[j] : wm[j + W - P];
+                minbits |= (uint32_t)(best == hv[j]) << j;
+            }
+        }
+        minbits &= validbits;
+        if (lane < SW_FIRST || lane > SW_LAST) minbits = 0;
+    }
+
+    // ---- the tile's minimizers, compacted in position order; hashes and strands parked in LDS for the probe loops ----
+    {
+        uint4* dst = reinterpret_cast<uint4*>(&lds.hv[lane * SW_G]);
+        dst[0] = make_uint4(hv[0], hv[1], hv[2], hv[3]);
+        dst[1] = make_uint4(hv[4], hv[5], hv[6], hv[7]);
+        dst[2] = make_uint4(hv[8], hv[9], hv[10], hv[11]);
+        dst[3] = make_uint4(hv[12], hv[13], hv[14], hv[15]);
+        lds.strand[lane] = strandbits;
+    }
+    const uint32_t cnt = (uint32_t)__popc(minbits);
+    const uint32_t incl = wave_inclusive_scan(cnt);
+    const uint32_t nmin = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    {
+        uint32_t at = incl - cnt, bits = minbits;
+        while (bits) {
+            const int j = __ffs(bits) - 1;
+            bits &= bits - 1;
+            lds.list[at++] = (uint16_t)(lane * SW_G + j);
+        }
+    }
+    wave_lds_fence();
+    volatile uint16_t* list = lds.list;
+    volatile uint32_t* hvs = lds.hv;
+
+    // ---- stage A: the Bloom tier in front of a table that outgrows the L2 stops most minimizers at one word ----
+    uint32_t n_a = nmin;
+    if (a.pbloom) {
+        n_a = 0;
+        for (uint32_t i0 = 0; i0 < nmin; i0 += 64) {
+            const uint32_t i = i0 + (uint32_t)lane;
+            bool pass = false;
+            uint32_t p = 0;
+            if (i < nmin) {
+                p = list[i];
+                const uint32_t m = (hvs[p] - 1u) * 0x9E3779B1u, need = pbloom_bits(m); // (= pbloom_mix of a 32-bit key)
+                pass = (a.pbloom[pbloom_word(m, a.pbloom_wbits)] & need) == need;
+            }
+            const uint64_t pm = __ballot(pass);
+            if (pass) list[n_a + lanes_below(pm)] = (uint16_t)p; // (in place: nothing at or beyond i0 + 64 is overwritten)
+            n_a += (uint32_t)__popcll(pm);
+        }
+        wave_lds_fence();
+    }
+    // ---- stage B: exact lookup; the slot of a found key replaces its hash, the list shrinks to the index keys ----
+    const uint32_t tmask = (1u << a.table_bits) - 1;
+    const uint32_t* __restrict__ slot_key = reinterpret_cast<const uint32_t*>(a.slot_key);
+    uint32_t n_b = 0;
+    for (uint32_t i0 = 0; i0 < n_a; i0 += 64) {
+        const uint32_t i = i0 + (uint32_t)lane;
+        bool found = false;
+        uint32_t p = 0, s = 0;
+        if (i < n_a) {
+            p = list[i];
+            const uint32_t h = hvs[p] - 1u;
+            s = table_slot_dev(h, a.table_bits);
+            while (true) {
+                const uint32_t key = slot_key[s];
+                if (key == h) { found = true; break; }
+                if (key == 0xFFFFFFFFu) break;
+                s = (s + 1) & tmask;
+            }
+        }
+        const uint64_t fm = __ballot(found);
+        if (found) {
+            list[n_b + lanes_below(fm)] = (uint16_t)p;
+            hvs[p] = s;
+        }
+        n_b += (uint32_t)__popcll(fm);
+    }
+    wave_lds_fence();
+    // ---- where this tile's records go: the workgroup's four tiles share one slice, in tile order ----
+    if (lane == 0) s_nb[wave] = n_b;
+    __syncthreads();
+    uint32_t base = 0, wg_total = 0;
+#pragma unroll
+    for (int v = 0; v < SW_WAVES; ++v) {
+        const uint32_t x = *reinterpret_cast<volatile uint32_t*>(&s_nb[v]);
+        if (v < wave) base += x;
+        wg_total += x;
+    }
+    const size_t slice = (size_t)blockIdx.x * a.tile_cap;
+    // ---- stage C: one record per index minimizer ----
+    const uint32_t w1_magic = w1_reciprocal(W);
+    uint32_t my_hits = 0;
+    for (uint32_t i0 = 0; i0 < n_b; i0 += 64) {
+        const uint32_t i = i0 + (uint32_t)lane;
+        if (i >= n_b) break;
+        const uint32_t p = list[i], s = hvs[p];
+        const uint4 sf = a.slot_first[s]; // record offset, count, the first record's node << 1 | strand, its prg | shortest path << 12
+        const uint64_t gp = (uint64_t)(origin + (int64_t)p);
+        const uint32_t rb = *reinterpret_cast<volatile uint32_t*>(&lds.rbits[p >> 4]);
+        uint32_t read = *reinterpret_cast<volatile uint32_t*>(&lds.rcnt[p >> 4]) + (uint32_t)__popc(rb & ((2u << (p & 15)) - 1u));
+        uint64_t o0 = 0, o1 = 0;
+        bool ok = !(rb & 0x10000u) && read < a.n_reads;
+        if (ok) {
+            o0 = a.offsets[read];
+            o1 = a.offsets[read + 1];
+            ok = o0 <= gp && gp < o1;
+        }
+        if (!ok) { // empty reads around here: search from the tile's first read
+            read = find_read_from(a.offsets, a.n_reads, first_read ? first_read - 1 : 0, gp);
+            o0 = a.offsets[read];
+            o1 = a.offsets[read + 1];
+        }
+        const uint64_t pos = gp - o0;
+        const uint32_t strand = (*reinterpret_cast<volatile uint32_t*>(&lds.strand[p >> 4]) >> (p & 15)) & 1u;
+        my_hits += sf.y;
+        const uint32_t at = base + i;
+        if (pos >= (1ull << HIT_POS_BITS)) atomicOr(a.overflow, 2u);
+        else if (at < a.tile_cap) {
+            const uint32_t kn = sf.z, prg = sf.w & 0xFFFu;
+            const uint32_t rev = ((kn & 1u) == strand) ? 0u : 1u;
+            // size threshold of a cluster of this read on that PRG: floor(min(shortest path, expected) * fraction) =
+            // min(floor(shortest path * fraction) [per PRG, from the host], floor(expected * fraction)) -- floor(x * f) is monotone
+            const uint32_t by_len = (uint32_t)((double)expected_minimizers(o1 - o0, W, w1_magic) * a.fraction);
+            const uint32_t by_prg = a.prg_thr[prg];
+            const uint32_t length_based = by_len < by_prg ? by_len : by_prg;
+            uint32_t thr = length_based > a.min_cluster_size ? length_based : a.min_cluster_size;
+            if (thr > 0xFFFFu) thr = 0xFFFFu;
+            a.tile_info[slice + at] = ((uint64_t)s << 32) | ((uint64_t)strand << 31) | (uint64_t)read;
+            a.tile_pos1[slice + at] = (uint32_t)pos + 1;
+            a.tile_rec[slice + at] = make_uint4(sf.x, sf.y, (strand << 31) | (((prg << 1) | rev) << 16) | thr, (kn >> 1) * 2u + rev);
+        }
+    }
+    // ---- the workgroup's counters ----
+    const uint32_t tile_hits = wave_sum(my_hits);
+    if (lane == 0) {
+        atomicAdd(&s_sum[0], tile_hits);
+        atomicAdd(&s_sum[1], nmin);
+    }
+    __syncthreads();
+    if (wave == 0 && lane == 0) {
+        a.tile_count[blockIdx.x] = wg_total < a.tile_cap ? wg_total : a.tile_cap;
+        a.tile_hits[blockIdx.x] = s_sum[0];
+        a.tile_nmin[blockIdx.x] = s_sum[1];
+        if (wg_total > a.tile_cap) atomicOr(a.overflow, 4u);
+    }
+}
+
+// One tile per wave, tile = blockIdx.x * SW_WAVES + wave; the waves of a workgroup meet twice (slice offsets, counters).
+//
+// Tried and measured on 1.5 M tiles (10 M x 150 bp), writing the dense list from inside this kernel instead of slices +
+// gather: every tile needs the number of records of all tiles before it, i.e. a chained scan (decoupled look-back) with
+// waiting waves.  A ticket per tile from one device-wide counter: 18 ms (~12 ns per atomic, in series).  A ticket per
+// workgroup of 8 waves x 2 tiles: 1 s (a wave's second tile starts after its first one's wait, which serialises the groups).
+// A ticket per workgroup of 16 waves / 112 KB of LDS: 10 ms, 5.3 ms even without the scan (4 waves per SIMD).  No tickets,
+// tile = blockIdx order, two-level scan (64 tiles per group, look-back over groups): 13 ms against 3.8 ms without the scan --
+// a tile waited 48 us for its 63 group neighbours and 40 us for the previous group, four times its own 12 us.
+template <int K, int W>
+__global__ __launch_bounds__(SW_WAVES * 64) void sketch_wave_kernel(SketchArgs a, uint32_t n_tiles)
+{
+    __shared__ WaveLds s_lds[SW_WAVES];
+    __shared__ uint32_t s_nb[SW_WAVES], s_sum[2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x < 2) s_sum[threadIdx.x] = 0; // (read after the first barrier at the earliest)
+    const uint32_t tile = blockIdx.x * SW_WAVES + (uint32_t)wave;
+    sketch_wave_tile<K, W>(a, tile, tile < n_tiles, s_lds[wave], s_nb, s_sum, lane, wave);
+}
+
+hipError_t launch_sketch_wave(const SketchArgs& a, hipStream_t stream, KernelTimer timer)
+{
+    if (a.n_bases == 0 || !a.tile_cap || !a.prg_thr || !wave_kernel_applies(a.k, a.w)) return hipErrorInvalidValue;
+    const uint32_t n_tiles = wave_n_tiles(a.n_bases);
+    HIP_TRY(launch_tile_first_read(a.offsets, a.n_reads, SW_EVAL, SW_G, n_tiles, a.tile_first_read, stream));
+    const dim3 g(wave_n_slices(a.n_bases)), b(SW_WAVES * 64);
+    if (timer.begin) HIP_TRY(hipEventRecord(timer.begin, stream));
+    if (a.w == 11)
+        hipLaunchKernelGGL((sketch_wave_kernel<15, 11>), g, b, 0, stream, a, n_tiles);
+    else
+        hipLaunchKernelGGL((sketch_wave_kernel<15, 14>), g, b, 0, stream, a, n_tiles);
+    HIP_TRY(hipGetLastError());
+    if (timer.end) HIP_TRY(hipEventRecord(timer.end, stream));
+    return hipSuccess;
+}
+
+} // namespace dev
+} // namespace drprg
