@@ -34,7 +34,7 @@ $(OBJD)/%.o: $(SRC)/%.hip $(wildcard $(SRC)/*.h) include/drprg_hip.h
 
 $(LIB): $(OBJS)
 	@mkdir -p $(dir $@)
-	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $(OBJS) -lz
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $(OBJS) -lz -ldl
 
 $(BIN): $(SRC)/pandora_main.cpp $(LIB)
 	@mkdir -p $(dir $@)
@@ -56,6 +56,6 @@ asan:
 	@mkdir -p build/asan
 	for f in $(HOST_SRCS:.cpp=); do $(HIPCC) $(ASAN_FLAGS) -x hip --offload-arch=$(ARCH) -c $(SRC)/$$f.cpp -o build/asan/$$f.o || exit 1; done
 	for f in $(HIP_SRCS:.hip=); do $(HIPCC) $(ASAN_FLAGS) --offload-arch=$(ARCH) -c $(SRC)/$$f.hip -o build/asan/$$f.o || exit 1; done
-	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -fsanitize=address,undefined -fno-gpu-sanitize -o build/asan/libdrprg_hip.so build/asan/*.o -lz
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -fsanitize=address,undefined -fno-gpu-sanitize -o build/asan/libdrprg_hip.so build/asan/*.o -lz -ldl
 
 .PHONY: asan

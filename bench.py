@@ -196,6 +196,70 @@ def full_size_checks(torch, ctx, opts, bases, offsets, n_reads, covg, prg_reads,
     return shard_invariant, kernels_agree
 
 
+def write_bgzf(path, data, block=65280, level=1):
+    """bgzip's container (gzip members of <= 64 KB with a 'BC' extra field), written with zlib only"""
+    import struct
+    import zlib
+    with open(path, "wb") as fh:
+        for lo in list(range(0, len(data), block)) + [None]:
+            chunk = data[lo:lo + block] if lo is not None else b""
+            c = zlib.compressobj(level, zlib.DEFLATED, -15)
+            body = c.compress(chunk) + c.flush()
+            fh.write(b"\x1f\x8b\x08\x04" + b"\0" * 4 + b"\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 12 + 6 + len(body) + 8 - 1))
+            fh.write(body + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
+
+
+def e2e_leg(torch, ctx, synth, bases, n_reads, read_len, covg):
+    """End to end (SURVEY 8d "end-to-end and kernel-only"): the same reads as FASTQ text in the page cache (/dev/shm) -> parse
+    on host threads -> pinned blocks -> PCIe -> kernels -> coverage, through drprg_hip_map_fastx; outside the timed region.
+    Plain text: the whole batch, and its coverage must equal the HBM-resident result.  gzip (BGZF as bgzip writes it, and one
+    plain member as `gzip` writes it): the first 2 M reads."""
+    import gzip
+    import shutil
+    threads = max(1, min(os.cpu_count() or 1, 32))
+    d = tempfile.mkdtemp(prefix="drprg_e2e_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    res = {"threads": threads, "input": "FASTQ text in the page cache; wall time of drprg_hip_map_fastx (parse + pin + PCIe + kernels)"}
+    try:
+        host = bases.cpu().numpy()
+        fq = os.path.join(d, "reads.fq")
+        synth.write_fastq_fixed(fq, host, read_len)
+        ctx.set_threads(threads)
+        want = covg.cpu().numpy().view(np.uint32)
+
+        def run(path, n):
+            ctx.reset()
+            t0 = time.perf_counter()
+            ctx.map_fastx(path)
+            dt = time.perf_counter() - t0
+            got = ctx.coverage()[0]
+            return {"reads": n, "seconds": dt, "reads_per_s": n / dt, "file_GB_per_s": os.path.getsize(path) / dt / 1e9}, got
+
+        run(fq, n_reads)  # (first pass: pinned blocks and workspaces are allocated)
+        res["plain"], got = run(fq, n_reads)
+        res["plain"]["coverage_equals_hbm_resident_run"] = bool(np.array_equal(got, want))
+        n_gz = min(n_reads, 2_000_000)
+        rec = os.path.getsize(fq) // n_reads
+        text = open(fq, "rb").read(rec * n_gz)
+        ref = None
+        def write_gzip(p):
+            with gzip.open(p, "wb", compresslevel=1) as fh:
+                fh.write(text)
+
+        for name, writer in (("bgzf", lambda p: write_bgzf(p, text)), ("gzip", write_gzip)):
+            p = os.path.join(d, f"reads.{name}.fq.gz")
+            writer(p)
+            res[name], got = run(p, n_gz)
+            if ref is None:
+                sub = os.path.join(d, "sub.fq")
+                open(sub, "wb").write(text)
+                ref = run(sub, n_gz)[1]
+            res[name]["coverage_equals_plain_text_run"] = bool(np.array_equal(got, ref))
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+        ctx.reset()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -207,6 +271,8 @@ def main():
     ap.add_argument("--reads-per-gpu", type=int, default=0, help="0 = the workload's size")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--cpu-sample", type=int, default=-1, help="reads timed on the CPU oracle (0 = skip, -1 = ~10 s worth)")
+    ap.add_argument("--e2e", type=int, default=1, help="1: add the end-to-end leg (FASTQ text in /dev/shm -> coverage through map_fastx, "
+                                                       "plain and gzip) to the JSON line at N=1; 0: skip")
     ap.add_argument("--no-checks", action="store_true",
                     help="skip the full-size property checks after the timed region (profiling runs: every launch is then a "
                          "timed full-size one, so rocprofv3 per-kernel averages compare directly with avg_launch_ms)")
@@ -443,6 +509,8 @@ def main():
                                              f"(disjoint read ranges), {cpu_s:.1f}s",
                                    "single_thread_value": ns1 / cpu1_s, "single_thread_sample": f"first {ns1} reads, {cpu1_s:.1f}s",
                                    "host_cores_available": os.cpu_count(), "parity_vs_hip_on_sample": parity}
+        if args.e2e and world == 1 and args.workload != "nanopore" and not args.no_checks:
+            out["e2e"] = e2e_leg(torch, ctx, synth, bases, n_reads, args.read_len, covg)
         print(json.dumps(out), flush=True)
     ctx.close()
     if world > 1:

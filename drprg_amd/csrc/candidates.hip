@@ -93,6 +93,14 @@ __global__ __launch_bounds__(64) void cand_gather_kernel(FilterWork fw)
 // then the 2w-1 neighbouring k-mers are hashed one after the other out of a 96-bit shift register -- a third of the
 // instructions of giving every neighbour its own lane, each of which had to load and pack its own bases.  It is a read
 // minimizer iff the run of neighbours with hash >= its own (inside the read, no N) reaches w-1 across both sides.
+// KC: compile-time k (15: the mask-free 12-instruction hash mix_k) or 0 (any k <= 15)
+template <int KC> __device__ __forceinline__ uint32_t verify_mix(uint32_t x, uint32_t kmask)
+{
+    if constexpr (KC > 0) return mix_k<KC>(x);
+    else return HashTraits<uint32_t>::mix(x, kmask);
+}
+
+template <int KC>
 __global__ __launch_bounds__(EX_THREADS) void verify_count_kernel(SketchArgs a, FilterWork fw, ReadClusterArgs rc)
 {
     using Tr = HashTraits<uint32_t>;
@@ -137,7 +145,7 @@ __global__ __launch_bounds__(EX_THREADS) void verify_count_kernel(SketchArgs a, 
             if (!((bad >> oc) & 1u)) {
                 const uint32_t h0 = (oc & 16) ? r1w : r0w, h1 = (oc & 16) ? r2w : r1w;
                 const uint32_t f = __funnelshift_l(h1, h0, 2 * (oc & 15)) >> sh_k;
-                const uint32_t hf = Tr::mix(f, kmask), hr = Tr::mix(revcomp_code(f, k), kmask);
+                const uint32_t hf = verify_mix<KC>(f, kmask), hr = verify_mix<KC>(revcomp_code(f, k), kmask);
                 strand = hf <= hr ? 1u : 0u;
                 g = (hf < hr ? hf : hr) + 1;
             }
@@ -179,7 +187,7 @@ __global__ __launch_bounds__(EX_THREADS) void verify_count_kernel(SketchArgs a, 
                         r0w = __funnelshift_l(r1w, r0w, 2);
                         r1w = __funnelshift_l(r2w, r1w, 2);
                         r2w <<= 2;
-                        const uint32_t hf = Tr::mix(f, kmask), hr = Tr::mix(rcw, kmask);
+                        const uint32_t hf = verify_mix<KC>(f, kmask), hr = verify_mix<KC>(rcw, kmask);
                         const uint32_t x = (hf < hr ? hf : hr) + 1;
                         const bool ok = ((valid >> i) & 1u) && x >= g;
                         if (i < ic) streak = ok ? streak + 1 : 0;
@@ -464,7 +472,8 @@ hipError_t launch_candidate_stage(const SketchArgs& a, const FilterWork& fw, con
 {
     hipLaunchKernelGGL(cand_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, fw);
     hipLaunchKernelGGL(cand_gather_kernel, dim3(fw.n_slices), dim3(64), 0, stream, fw);
-    hipLaunchKernelGGL(verify_count_kernel, dim3(fw.ex_grid), dim3(EX_THREADS), 0, stream, a, fw, rc);
+    if (a.k == 15) hipLaunchKernelGGL(verify_count_kernel<15>, dim3(fw.ex_grid), dim3(EX_THREADS), 0, stream, a, fw, rc);
+    else hipLaunchKernelGGL(verify_count_kernel<0>, dim3(fw.ex_grid), dim3(EX_THREADS), 0, stream, a, fw, rc);
     hipLaunchKernelGGL(hit_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, a, fw, 0);
     return hipGetLastError();
 }

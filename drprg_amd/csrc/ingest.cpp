@@ -5,7 +5,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <dlfcn.h>
 #include <fcntl.h>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <sys/mman.h>
@@ -219,6 +221,34 @@ private:
     bool closed_ = false;
 };
 
+// Window buffers of the gzip path are recycled: a fresh 32 MB vector per window means an mmap, 8 k page faults and an munmap
+// (with its TLB shoot-downs on every parser thread) per window -- measured 4x slower with 8 threads than with 4.
+class BufferPool {
+public:
+    std::shared_ptr<std::vector<char>> acquire(size_t size)
+    {
+        std::unique_ptr<std::vector<char>> v;
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            if (!free_.empty()) {
+                v = std::move(free_.back());
+                free_.pop_back();
+            }
+        }
+        if (!v) v.reset(new std::vector<char>());
+        if (v->size() < size) v->resize(size);
+        std::vector<char>* raw = v.release();
+        return std::shared_ptr<std::vector<char>>(raw, [this](std::vector<char>* p) {
+            std::lock_guard<std::mutex> g(mu_);
+            free_.emplace_back(p);
+        });
+    }
+
+private:
+    std::mutex mu_;
+    std::vector<std::unique_ptr<std::vector<char>>> free_;
+};
+
 // multi-line FASTQ (sequence wrapped over several lines) is left to the serial reader
 void require_four_line_fastq(const char* p, const char* e)
 {
@@ -226,6 +256,78 @@ void require_four_line_fastq(const char* p, const char* e)
     const char* l1 = find_nl(p, e);
     const char* l2 = l1 ? find_nl(l1 + 1, e) : nullptr;
     if (l2 && l2 + 1 < e && l2[1] != '+') throw Error(DRPRG_EAGAIN_SERIAL, "multi-line FASTQ");
+}
+
+// ---- gzip input ----------------------------------------------------------------------------------------------------
+// libdeflate (whole-buffer inflate, 2-3x zlib's rate) is bound at run time: the image ships libdeflate.so.0 without its
+// header; a host without it falls back to zlib's streaming inflate.
+struct LibDeflate {
+    void* (*alloc)() = nullptr;
+    int (*gzip_ex)(void*, const void*, size_t, void*, size_t, size_t*, size_t*) = nullptr; // 0 = success, 3 = output too small
+    void (*release)(void*) = nullptr;
+    bool ok() const { return alloc && gzip_ex && release; }
+    static const LibDeflate& get()
+    {
+        static const LibDeflate inst = [] {
+            LibDeflate l;
+            if (std::getenv("DRPRG_HIP_NO_LIBDEFLATE")) return l; // (tests: force the zlib path)
+            void* h = nullptr;
+            for (const char* name : { "libdeflate.so.0", "libdeflate.so" })
+                if ((h = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+            if (!h) return l;
+            l.alloc = reinterpret_cast<void* (*)()>(dlsym(h, "libdeflate_alloc_decompressor"));
+            l.gzip_ex = reinterpret_cast<int (*)(void*, const void*, size_t, void*, size_t, size_t*, size_t*)>(dlsym(h, "libdeflate_gzip_decompress_ex"));
+            l.release = reinterpret_cast<void (*)(void*)>(dlsym(h, "libdeflate_free_decompressor"));
+            return l;
+        }();
+        return inst;
+    }
+};
+
+// BGZF (bgzip, the usual way sequencing centres ship .fastq.gz): a series of gzip members of <= 64 KB, each with a 'BC' extra
+// field that holds its compressed size -- the members can be located without inflating and inflated independently.
+struct BgzfBlock {
+    size_t in_off;
+    uint32_t in_len, out_len;
+    size_t out_off; // within its window
+};
+
+inline uint32_t le32(const unsigned char* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+
+// size of the BGZF member that starts at p, 0 if p is not one
+uint32_t bgzf_member_size(const unsigned char* p, size_t avail)
+{
+    if (avail < 18 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4)) return 0;
+    const uint32_t xlen = (uint32_t)p[10] | ((uint32_t)p[11] << 8);
+    if (12 + (size_t)xlen > avail) return 0;
+    for (uint32_t o = 0; o + 4 <= xlen;) {
+        const unsigned char* f = p + 12 + o;
+        const uint32_t slen = (uint32_t)f[2] | ((uint32_t)f[3] << 8);
+        if (f[0] == 'B' && f[1] == 'C' && slen == 2 && o + 6 <= xlen) return ((uint32_t)f[4] | ((uint32_t)f[5] << 8)) + 1;
+        o += 4 + slen;
+    }
+    return 0;
+}
+
+// every member of the file, or an empty list if it is not BGZF from start to end
+std::vector<BgzfBlock> bgzf_index(const unsigned char* data, size_t size)
+{
+    std::vector<BgzfBlock> blocks;
+    size_t off = 0;
+    while (off < size) {
+        const uint32_t n = bgzf_member_size(data + off, size - off);
+        if (n < 26 || off + n > size) return {};
+        blocks.push_back(BgzfBlock { off, n, le32(data + off + n - 4), 0 });
+        off += n;
+    }
+    return blocks;
+}
+
+void inflate_member(void* dec, const unsigned char* in, size_t in_len, char* out, size_t out_len, const std::string& path)
+{
+    size_t used = 0, got = 0;
+    const int rc = LibDeflate::get().gzip_ex(dec, in, in_len, out, out_len, &used, &got);
+    if (rc != 0 || got != out_len) throw Error(DRPRG_EIO, "corrupt gzip block in " + path);
 }
 
 bool detect_format(const char* p, const char* e, bool& fastq)
@@ -244,6 +346,7 @@ IngestStats ingest_fastx(const std::string& path, int threads, const IngestHooks
 {
     if (threads < 1) threads = 1;
     Shared sh(hooks);
+    BufferPool gz_pool; // (outlives the queue and the threads that hand window buffers back to it)
     IngestStats st;
     int fd = open(path.c_str(), O_RDONLY);
     if (fd < 0) throw Error(DRPRG_ENOENT, "cannot open reads file " + path);
@@ -309,31 +412,113 @@ IngestStats ingest_fastx(const std::string& path, int threads, const IngestHooks
                 cur = cut;
             }
         } else {
-            gzFile gzf = gzdopen(dup(fd), "rb");
-            if (!gzf) throw Error(DRPRG_EIO, "cannot read gzip stream " + path);
-            gzbuffer(gzf, 1 << 20);
+            // Three ways to inflate, fastest first: (1) BGZF: the members are located from their headers and inflated in
+            // parallel, a window of text at a time; (2) one plain gzip member whose size field can be trusted (< 4 GB of
+            // text): one libdeflate call into one buffer, then the parallel parser as for a plain file; (3) anything else,
+            // or no libdeflate on this host: zlib's streaming inflate on this thread.
+            const LibDeflate& ld = LibDeflate::get();
+            const size_t gz_len = (size_t)sb.st_size;
+            void* gz_map = ld.ok() && gz_len >= 18 ? mmap(nullptr, gz_len, PROT_READ, MAP_PRIVATE, fd, 0) : MAP_FAILED;
+            const unsigned char* gz_data = gz_map != MAP_FAILED ? (const unsigned char*)gz_map : nullptr;
+            struct Unmap {
+                void* p;
+                size_t n;
+                ~Unmap() { if (p && p != MAP_FAILED) munmap(p, n); }
+            } unmap { gz_map, gz_len };
+            std::vector<BgzfBlock> blocks;
+            if (gz_data) blocks = bgzf_index(gz_data, gz_len);
+            std::shared_ptr<std::vector<char>> whole; // way (2)
+            if (gz_data && blocks.empty() && gz_len < (size_t(1) << 30)) {
+                const size_t isize = le32(gz_data + gz_len - 4);
+                if (isize >= gz_len / 2) { // (a wrapped size field of a > 4 GB stream is most likely smaller than that)
+                    auto buf = std::make_shared<std::vector<char>>(isize + 1);
+                    void* dec = ld.alloc();
+                    size_t used = 0, got = 0;
+                    const int rc = dec ? ld.gzip_ex(dec, gz_data, gz_len, buf->data(), isize, &used, &got) : 1;
+                    if (dec) ld.release(dec);
+                    if (rc == 0 && used == gz_len && got == isize) {
+                        buf->resize(isize);
+                        whole = buf;
+                    } // (several members, or a wrapped size: the streaming reader takes it)
+                }
+            }
             for (int t = 0; t < threads; ++t) pool.emplace_back(worker);
+            // text source: fills dst with up to cap bytes of inflated text, returns the number written (0 = end)
+            gzFile gzf = nullptr;
+            size_t next_block = 0, whole_off = 0;
+            std::function<size_t(char*, size_t)> read_text;
+            if (!blocks.empty()) {
+                st.gz_mode = 1;
+                read_text = [&](char* dst, size_t cap) -> size_t {
+                    size_t first = next_block, total = 0;
+                    while (next_block < blocks.size() && total + blocks[next_block].out_len <= cap) {
+                        blocks[next_block].out_off = total;
+                        total += blocks[next_block].out_len;
+                        ++next_block;
+                    }
+                    if (next_block == first && next_block < blocks.size()) throw Error(DRPRG_EIO, "BGZF block larger than a slice in " + path);
+                    const size_t last = next_block;
+                    const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)threads, (last - first) / 64 + 1));
+                    std::vector<std::thread> infl;
+                    std::atomic<size_t> cursor { first };
+                    std::atomic<bool> bad { false };
+                    auto job = [&]() {
+                        void* dec = ld.alloc();
+                        if (!dec) { bad = true; return; }
+                        try {
+                            for (size_t b; (b = cursor.fetch_add(16)) < last;)
+                                for (size_t i = b; i < std::min(b + 16, last); ++i)
+                                    inflate_member(dec, gz_data + blocks[i].in_off, blocks[i].in_len, dst + blocks[i].out_off, blocks[i].out_len, path);
+                        } catch (const Error&) {
+                            bad = true;
+                        }
+                        ld.release(dec);
+                    };
+                    for (int t = 1; t < nt; ++t) infl.emplace_back(job);
+                    job();
+                    for (auto& t : infl) t.join();
+                    if (bad) throw Error(DRPRG_EIO, "corrupt gzip block in " + path);
+                    return total;
+                };
+            } else if (whole) {
+                st.gz_mode = 2;
+                read_text = [&](char* dst, size_t cap) -> size_t {
+                    const size_t n = std::min(cap, whole->size() - whole_off);
+                    std::memcpy(dst, whole->data() + whole_off, n);
+                    whole_off += n;
+                    return n;
+                };
+            } else {
+                st.gz_mode = 3;
+                gzf = gzdopen(dup(fd), "rb");
+                if (!gzf) throw Error(DRPRG_EIO, "cannot read gzip stream " + path);
+                gzbuffer(gzf, 1 << 20);
+                read_text = [&](char* dst, size_t cap) -> size_t {
+                    size_t have = 0;
+                    while (have < cap) {
+                        const int n = gzread(gzf, dst + have, (unsigned)std::min<size_t>(cap - have, 1u << 30));
+                        if (n < 0) throw Error(DRPRG_EIO, "gzip read error in " + path);
+                        if (n == 0) break;
+                        have += (size_t)n;
+                    }
+                    return have;
+                };
+            }
+            struct CloseGz {
+                gzFile& f;
+                ~CloseGz() { if (f) gzclose(f); }
+            } close_gz { gzf };
             std::vector<char> carry;
             bool eof = false;
             while (!eof && !sh.failed) {
-                auto buf = std::make_shared<std::vector<char>>();
-                buf->resize(carry.size() + SLICE_BYTES);
+                auto buf = gz_pool.acquire(carry.size() + SLICE_BYTES); // (may be larger than asked for: a recycled one)
                 if (!carry.empty()) std::memcpy(buf->data(), carry.data(), carry.size());
                 size_t have = carry.size();
                 carry.clear();
-                while (have < buf->size()) {
-                    int n = gzread(gzf, buf->data() + have, (unsigned)std::min<size_t>(buf->size() - have, 1u << 30));
-                    if (n < 0) {
-                        gzclose(gzf);
-                        throw Error(DRPRG_EIO, "gzip read error in " + path);
-                    }
-                    if (n == 0) {
-                        eof = true;
-                        break;
-                    }
-                    have += (size_t)n;
-                }
-                buf->resize(have);
+                const size_t got = read_text(buf->data() + have, SLICE_BYTES);
+                have += got;
+                if (got < SLICE_BYTES - (1u << 17)) // a short window: the source has nothing left (BGZF windows end up to 64 KB short)
+                    eof = blocks.empty() ? true : next_block >= blocks.size();
                 if (have == 0) break;
                 const char* b = buf->data();
                 const char* e = b + have;
@@ -354,7 +539,6 @@ IngestStats ingest_fastx(const std::string& path, int threads, const IngestHooks
                 }
                 queue.push(Slice { b, cut, buf });
             }
-            gzclose(gzf);
         }
     } catch (const Error& e) {
         sh.fail(e.code, e.what());

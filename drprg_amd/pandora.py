@@ -73,6 +73,10 @@ class Context:
         _check(lib.drprg_hip_set_opts(self._h, C.byref(o)), self._h)
 
     # ---- mapping -------------------------------------------------------------------------------
+    def set_threads(self, threads):
+        """parser threads of map_fastx (the -t drprg forwards to pandora)"""
+        _check(lib.drprg_hip_set_threads(self._h, int(threads)), self._h)
+
     def map_fastx(self, path):
         _check(lib.drprg_hip_map_fastx(self._h, os.fsencode(path)), self._h)
 

@@ -65,8 +65,9 @@ int drprg_hip_map_fastx(drprg_hip_ctx* ctx, const char* reads_path); /* fasta/fa
  * default 4.  The file is cut at record boundaries and parsed in parallel into pinned blocks. */
 int drprg_hip_set_threads(drprg_hip_ctx* ctx, int threads);
 /* Host-only self-check of that ingest: parses the file with `threads` parser threads and returns
- * out[0..3] = reads, bases, order-independent digest (sum of the FNV-1a hashes of the reads), batches. */
-int drprg_hip_parse_fastx(const char* reads_path, int threads, uint64_t out[4], char* err, size_t err_len);
+ * out[0..4] = reads, bases, order-independent digest (sum of the FNV-1a hashes of the reads), batches, and how gzip input
+ * was inflated (0 plain text, 1 BGZF members in parallel, 2 one member in one libdeflate call, 3 zlib streaming). */
+int drprg_hip_parse_fastx(const char* reads_path, int threads, uint64_t out[5], char* err, size_t err_len);
 int drprg_hip_map_host(drprg_hip_ctx* ctx, const uint8_t* bases, const uint64_t* offsets, uint64_t n_reads);
 /* Batch already resident in HBM.  d_bases: ASCII bases of all reads back to back, 16-byte aligned;
  * d_offsets: u64[n_reads+1], d_offsets[0] == 0, d_offsets[n_reads] == n_bases.  d_covg (u32[2*n_knodes]) and

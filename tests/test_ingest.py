@@ -7,14 +7,17 @@ import os
 import numpy as np
 import pytest
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 def _parse(path, threads):
     from drprg_amd._lib import lib
-    out = (C.c_uint64 * 4)()
+    out = (C.c_uint64 * 5)()
     err = C.create_string_buffer(512)
     rc = lib.drprg_hip_parse_fastx(os.fsencode(path), threads, out, err, len(err))
     if rc != 0:
         raise RuntimeError(f"{rc}: {err.value.decode()}")
+    _parse.gz_mode = int(out[4])
     return int(out[0]), int(out[1]), int(out[2]), int(out[3])
 
 
@@ -120,3 +123,72 @@ def test_malformed_inputs(tmp_path):
     empty = tmp_path / "empty.fq"
     empty.write_bytes(b"")
     assert _parse(str(empty), 2)[:2] == (0, 0)
+
+
+# ---- gzip input: BGZF members in parallel (libdeflate), one plain member in one call, zlib streaming as the fallback ------
+def _write_bgzf(path, data, block=65280, level=1):
+    """bgzip's container: gzip members of <= 64 KB with a 'BC' extra field holding the member size - 1, then the empty EOF member"""
+    import struct
+    import zlib
+    with open(path, "wb") as fh:
+        for lo in list(range(0, len(data), block)) + [None]:
+            chunk = data[lo:lo + block] if lo is not None else b""
+            c = zlib.compressobj(level, zlib.DEFLATED, -15)
+            body = c.compress(chunk) + c.flush()
+            bsize = 12 + 6 + len(body) + 8
+            fh.write(b"\x1f\x8b\x08\x04" + b"\0" * 4 + b"\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize - 1))
+            fh.write(body + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
+
+
+def _random_fastq(n, seed, max_len=300):
+    rng = np.random.default_rng(seed)
+    reads, parts = [], []
+    for i in range(n):
+        r = bytes(rng.choice(np.frombuffer(b"ACGTN", np.uint8), size=int(rng.integers(1, max_len)), p=[.24, .26, .26, .23, .01]))
+        reads.append(r)
+        parts.append(b"@r%d some text\n" % i + r + b"\n+\n" + b"I" * len(r) + b"\n")
+    return reads, b"".join(parts)
+
+
+@pytest.mark.parametrize("threads", [1, 4])
+def test_gzip_inputs_take_the_fast_paths_and_agree(tmp_path, threads):
+    import gzip
+    reads, text = _random_fastq(120_000, 5)  # ~36 MB of text: more than one 32 MB window
+    want = (len(reads), sum(len(r) for r in reads), _digest(reads))
+    plain = tmp_path / "r.fq"
+    plain.write_bytes(text)
+    assert _parse(str(plain), threads)[:3] == want and _parse.gz_mode == 0
+    bg = tmp_path / "r.bgzf.fq.gz"
+    _write_bgzf(str(bg), text)
+    assert _parse(str(bg), threads)[:3] == want and _parse.gz_mode == 1
+    gz = tmp_path / "r.fq.gz"
+    with gzip.open(gz, "wb", compresslevel=1) as fh:
+        fh.write(text)
+    assert _parse(str(gz), threads)[:3] == want and _parse.gz_mode == 2
+    multi = tmp_path / "multi.fq.gz"  # several plain members (cat a.gz b.gz): only the streaming reader follows them
+    with open(multi, "wb") as fh:
+        cut = text.index(b"\n@r60000 ") + 1
+        fh.write(gzip.compress(text[:cut], 1) + gzip.compress(text[cut:], 1))
+    assert _parse(str(multi), threads)[:3] == want and _parse.gz_mode == 3
+
+
+def test_gzip_without_libdeflate_and_corrupt_blocks(tmp_path):
+    import subprocess
+    import sys
+    reads, text = _random_fastq(3000, 9)
+    bg = tmp_path / "r.fq.gz"
+    _write_bgzf(str(bg), text)
+    want = (len(reads), sum(len(r) for r in reads), _digest(reads))
+    # a host without libdeflate: the same file through zlib (separate process: the library is bound once per process)
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_ingest as t; "
+            "r = t._parse(%r, 2); print(r[0], r[1], r[2], t._parse.gz_mode)" % (ROOT, os.path.join(ROOT, "tests"), str(bg)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, DRPRG_HIP_NO_LIBDEFLATE="1"))
+    assert out.returncode == 0, out.stderr
+    assert tuple(int(x) for x in out.stdout.split()) == want + (3,)
+    # a flipped byte inside a member's deflate data: refused (CRC), not silently mis-parsed
+    raw = bytearray(bg.read_bytes())
+    raw[len(raw) // 2] ^= 0x55
+    bad = tmp_path / "bad.fq.gz"
+    bad.write_bytes(bytes(raw))
+    with pytest.raises(RuntimeError):
+        _parse(str(bad), 2)
