@@ -47,6 +47,7 @@ SIGNATURES = {
     "drprg_hip_index": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int]),
     "drprg_hip_open": (C.c_void_p, [C.c_char_p, C.c_int, C.c_int, C.c_int]),
     "drprg_hip_open_prg": (C.c_void_p, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "drprg_hip_open_multi": (C.c_void_p, [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int]),
     "drprg_hip_close": (None, [C.c_void_p]),
     "drprg_hip_last_error": (C.c_char_p, [C.c_void_p]),
     "drprg_hip_set_opts": (C.c_int, [C.c_void_p, C.POINTER(MapOpts)]),

@@ -1,3 +1,5 @@
+#include <atomic>
+#include <mutex>
 #include <fstream>
 #include <cstdio>
 // capi.cpp -- the C ABI declared in include/drprg_hip.h.
@@ -15,7 +17,9 @@ using namespace drprg;
 
 struct drprg_hip_ctx {
     PrgIndex index;
-    std::unique_ptr<Mapper> mapper; // null for a host-only context
+    std::unique_ptr<Mapper> mapper; // null for a host-only context; device 0 of a multi-device context
+    std::vector<std::unique_ptr<Mapper>> extra; // devices 1 .. ndev-1 of drprg_hip_open_multi (map_fastx shards the reads over all)
+    MapCounters extra_counts;                   // what the extra devices counted (folded in when their coverage is)
     MapParams params;
     std::string prg_file;
     std::string last_error;
@@ -77,7 +81,8 @@ int drprg_hip_index(const char* prg_file, int w, int k, int threads)
     return DRPRG_OK;
 }
 
-static drprg_hip_ctx* open_impl(const char* prg_file, int w, int k, int device, bool from_files, int threads)
+static drprg_hip_ctx* open_impl(const char* prg_file, int w, int k, int device, bool from_files, int threads, const int* more_devices = nullptr,
+    int n_more = 0)
 {
     if (!prg_file) {
         g_last_error = "null PRG path";
@@ -105,6 +110,7 @@ static drprg_hip_ctx* open_impl(const char* prg_file, int w, int k, int device, 
         ctx->params.k = k;
         apply_defaults(ctx->params, nullptr);
         if (device >= 0) ctx->mapper.reset(new Mapper(ctx->index.flat, ctx->params, device));
+        for (int i = 0; i < n_more; ++i) ctx->extra.emplace_back(new Mapper(ctx->index.flat, ctx->params, more_devices[i]));
     } catch (const std::exception& e) {
         g_last_error = e.what();
         return nullptr;
@@ -122,6 +128,20 @@ drprg_hip_ctx* drprg_hip_open_prg(const char* prg_file, int w, int k, int device
     return open_impl(prg_file, w, k, device, false, threads);
 }
 
+drprg_hip_ctx* drprg_hip_open_multi(const char* prg_file, int w, int k, const int* devices, int ndev, int from_files)
+{
+    if (!devices || ndev < 1) {
+        g_last_error = "drprg_hip_open_multi needs at least one device";
+        return nullptr;
+    }
+    for (int i = 0; i < ndev; ++i)
+        if (devices[i] < 0) {
+            g_last_error = "drprg_hip_open_multi: negative device id";
+            return nullptr;
+        }
+    return open_impl(prg_file, w, k, devices[0], from_files != 0, 4, devices + 1, ndev - 1);
+}
+
 void drprg_hip_close(drprg_hip_ctx* ctx) { delete ctx; }
 
 const char* drprg_hip_last_error(const drprg_hip_ctx* ctx) { return ctx ? ctx->last_error.c_str() : g_last_error.c_str(); }
@@ -131,6 +151,7 @@ int drprg_hip_set_opts(drprg_hip_ctx* ctx, const drprg_hip_map_opts* opts)
     API_BEGIN(ctx)
     apply_defaults(ctx->params, opts);
     if (ctx->mapper) ctx->mapper->set_params(ctx->params);
+    for (auto& m : ctx->extra) m->set_params(ctx->params);
     API_END(ctx)
 }
 
@@ -150,12 +171,54 @@ int drprg_hip_map_fastx(drprg_hip_ctx* ctx, const char* reads_path)
     IngestHooks hooks;
     hooks.alloc = [](size_t n) { return Mapper::pinned_alloc(n); };
     hooks.release = [](void* p) { Mapper::pinned_free(p); };
-    hooks.submit = [&](const PinnedBatch& b) { m.map_host(b.bases, b.offsets, b.n_reads); };
+    // One device: one submitter at a time (the ingest serialises the calls).  Several devices (drprg_hip_open_multi): the
+    // reads shard by block -- a block goes to the first idle device, round robin from the one after the last choice --
+    // and the parser threads that carry the blocks are the submitters, one per device at a time.
+    const size_t ndev = 1 + ctx->extra.size();
+    std::vector<std::mutex> dev_mu(ndev);
+    std::atomic<size_t> next_dev { 0 };
+    auto mapper_of = [&](size_t d) -> Mapper& { return d == 0 ? m : *ctx->extra[d - 1]; };
+    if (ndev == 1) {
+        hooks.submit = [&](const PinnedBatch& b) { m.map_host(b.bases, b.offsets, b.n_reads); };
+    } else {
+        hooks.concurrent_submit = true;
+        hooks.submit = [&](const PinnedBatch& b) {
+            const size_t first = next_dev.fetch_add(1) % ndev;
+            for (size_t i = 0; i < ndev; ++i) {
+                const size_t d = (first + i) % ndev;
+                std::unique_lock<std::mutex> l(dev_mu[d], std::try_to_lock);
+                if (!l.owns_lock()) continue;
+                mapper_of(d).map_host(b.bases, b.offsets, b.n_reads);
+                return;
+            }
+            std::lock_guard<std::mutex> l(dev_mu[first]); // all busy: wait for the round-robin choice
+            mapper_of(first).map_host(b.bases, b.offsets, b.n_reads);
+        };
+    }
+    // the coverage vectors of the other devices are summed into device 0 (unsigned sums commute: the result does not
+    // depend on which device mapped which block), their counters folded into the context
+    auto fold = [&]() {
+        if (ctx->extra.empty()) return;
+        std::vector<uint32_t> total, prg_total, c, p;
+        m.download(total, prg_total);
+        for (auto& e : ctx->extra) {
+            e->download(c, p);
+            for (size_t i = 0; i < total.size(); ++i) total[i] += c[i];
+            for (size_t i = 0; i < prg_total.size(); ++i) prg_total[i] += p[i];
+            const MapCounters k = e->counters();
+            ctx->extra_counts.reads += k.reads; ctx->extra_counts.bases += k.bases; ctx->extra_counts.minimizers += k.minimizers;
+            ctx->extra_counts.hits += k.hits; ctx->extra_counts.clusters_kept += k.clusters_kept;
+            ctx->extra_counts.hits_kept += k.hits_kept; ctx->extra_counts.leftover_reads += k.leftover_reads;
+            e->reset_coverage();
+        }
+        m.upload(total, prg_total);
+    };
     try {
         IngestStats st = ingest_fastx(reads_path, ctx->threads, hooks);
         ctx->total_bases += st.bases;
+        fold();
     } catch (const Error& e) {
-        if (e.code != DRPRG_EAGAIN_SERIAL) throw;
+        if (e.code != DRPRG_EAGAIN_SERIAL) throw; // (a failed multi-device pass leaves partial vectors on the devices: reset before reuse)
         FastxReader rd(reads_path);
         ReadBatch batch;
         while (rd.next_batch(batch, 8u << 20, 1ull << 30)) {
@@ -256,6 +319,8 @@ int drprg_hip_reset(drprg_hip_ctx* ctx)
 {
     API_BEGIN(ctx)
     if (ctx->mapper) ctx->mapper->reset_coverage();
+    for (auto& m : ctx->extra) m->reset_coverage();
+    ctx->extra_counts = MapCounters();
     ctx->covg.clear();
     ctx->prg_reads.clear();
     ctx->host_coverage_valid = false;
@@ -270,8 +335,9 @@ int drprg_hip_counters(drprg_hip_ctx* ctx, uint64_t out[8])
     std::memset(out, 0, 8 * sizeof(uint64_t));
     if (ctx->mapper) {
         MapCounters c = ctx->mapper->counters();
-        out[0] = c.reads; out[1] = c.bases; out[2] = c.minimizers; out[3] = c.hits;
-        out[4] = c.clusters_kept; out[5] = c.hits_kept; out[6] = c.kernel; out[7] = c.leftover_reads;
+        const MapCounters& x = ctx->extra_counts; // (the other devices of a multi-device context)
+        out[0] = c.reads + x.reads; out[1] = c.bases + x.bases; out[2] = c.minimizers + x.minimizers; out[3] = c.hits + x.hits;
+        out[4] = c.clusters_kept + x.clusters_kept; out[5] = c.hits_kept + x.hits_kept; out[6] = c.kernel; out[7] = c.leftover_reads + x.leftover_reads;
     }
     API_END(ctx)
 }

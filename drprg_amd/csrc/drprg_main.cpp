@@ -179,7 +179,20 @@ int main(int argc, char** argv)
     if (const char* d = std::getenv("DRPRG_HIP_DEVICE")) device = std::atoi(d);
 
     const std::string prg = index + "/dr.prg";
-    drprg_hip_ctx* ctx = drprg_hip_open(prg.c_str(), w, k, device);
+    // DRPRG_HIP_DEVICES=0,1,2,3: one context over several GPUs of the node (the reads shard by ingest block, the coverage
+    // vectors are summed before the genotyping / report stages, which run once)
+    std::vector<int> devices;
+    if (const char* d = std::getenv("DRPRG_HIP_DEVICES"))
+        for (const char* p = d; *p;) {
+            char* end = nullptr;
+            const long v = std::strtol(p, &end, 10);
+            if (end == p) break;
+            devices.push_back((int)v);
+            p = *end ? end + 1 : end;
+        }
+    if (devices.size() == 1) device = devices[0];
+    drprg_hip_ctx* ctx = devices.size() > 1 ? drprg_hip_open_multi(prg.c_str(), w, k, devices.data(), (int)devices.size(), 1)
+                                            : drprg_hip_open(prg.c_str(), w, k, device);
     if (!ctx) die(std::string("cannot open the index: ") + drprg_hip_last_error(nullptr));
     drprg_hip_map_opts mo {};
     mo.illumina = illumina;

@@ -53,7 +53,8 @@ struct Shared {
     {
         if (b.n_reads == 0) return;
         PinnedBatch pb { b.bases, b.offsets, b.n_reads, b.n_bases };
-        {
+        if (hooks.concurrent_submit) hooks.submit(pb);
+        else {
             std::lock_guard<std::mutex> g(submit_mu);
             hooks.submit(pb);
         }

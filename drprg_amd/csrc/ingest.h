@@ -19,7 +19,8 @@ struct PinnedBatch {
 struct IngestHooks {
     std::function<void*(size_t)> alloc;            // pinned allocation (falls back to malloc when null)
     std::function<void(void*)> release;
-    std::function<void(const PinnedBatch&)> submit; // called by one thread at a time
+    std::function<void(const PinnedBatch&)> submit; // called by one thread at a time ...
+    bool concurrent_submit = false;                 // ... unless set: then by any parser thread, and submit does its own locking
 };
 
 struct IngestStats {

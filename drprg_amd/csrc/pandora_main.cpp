@@ -51,7 +51,7 @@ void usage()
         "  pandora map      [--genotype] [--local] [--gt-conf X] [-v] [-o DIR] [-g SIZE] [--max-covg N]\n"
         "                   [--vcf-refs FASTA] [-t N] [-w W] [-k K] [-c N] [-I] [-K] [-e RATE] [--max-diff N] <prg> <reads>\n"
         "  pandora discover [same mapping options] <prg> <query.tsv>\n"
-        "environment: DRPRG_HIP_DEVICE selects the GPU (default 0)\n");
+        "environment: DRPRG_HIP_DEVICE selects the GPU (default 0); DRPRG_HIP_DEVICES=0,1,.. maps on several GPUs of the node\n");
 }
 
 Args parse(int argc, char** argv)
@@ -112,7 +112,18 @@ double now_s()
 
 drprg_hip_ctx* open_ctx(const Args& a)
 {
-    drprg_hip_ctx* ctx = drprg_hip_open(a.positional[0].c_str(), a.w, a.k, a.device);
+    // DRPRG_HIP_DEVICES=0,1,2,3: one context over several GPUs of the node (the reads shard by ingest block)
+    std::vector<int> devices;
+    if (const char* d = std::getenv("DRPRG_HIP_DEVICES"))
+        for (const char* p = d; *p;) {
+            char* end = nullptr;
+            const long v = std::strtol(p, &end, 10);
+            if (end == p) break;
+            devices.push_back((int)v);
+            p = *end ? end + 1 : end;
+        }
+    drprg_hip_ctx* ctx = devices.size() > 1 ? drprg_hip_open_multi(a.positional[0].c_str(), a.w, a.k, devices.data(), (int)devices.size(), 1)
+                                            : drprg_hip_open(a.positional[0].c_str(), a.w, a.k, devices.size() == 1 ? devices[0] : a.device);
     if (!ctx) die(std::string("cannot open index for ") + a.positional[0] + ": " + drprg_hip_last_error(nullptr));
     drprg_hip_map_opts o {};
     o.illumina = a.illumina;

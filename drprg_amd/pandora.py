@@ -40,9 +40,15 @@ def _ptr(a):
 class Context:
     """One opened index (+ its HIP device).  device=-1: host-only (index export, genotyping)."""
 
-    def __init__(self, prg_file, w, k, device=0, from_files=True, threads=1):
+    def __init__(self, prg_file, w, k, device=0, from_files=True, threads=1, devices=None):
+        """devices: a list of HIP device ids -> one context over all of them (drprg_hip_open_multi: map_fastx shards the reads)"""
         p = os.fsencode(prg_file)
-        self._h = lib.drprg_hip_open(p, w, k, device) if from_files else lib.drprg_hip_open_prg(p, w, k, device, threads)
+        if devices is not None:
+            arr = (C.c_int * len(devices))(*devices)
+            self._h = lib.drprg_hip_open_multi(p, w, k, arr, len(devices), 1 if from_files else 0)
+            device = devices[0]
+        else:
+            self._h = lib.drprg_hip_open(p, w, k, device) if from_files else lib.drprg_hip_open_prg(p, w, k, device, threads)
         if not self._h:
             raise DependencyError("ProcessError", lib.drprg_hip_last_error(None).decode())
         self.w, self.k, self.device = w, k, device

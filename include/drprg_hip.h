@@ -52,6 +52,14 @@ drprg_hip_ctx* drprg_hip_open(const char* prg_file, int w, int k, int device);
 /* Same, but sketches the PRG in memory instead of reading .idx / kmer_prgs (no files needed or written). */
 drprg_hip_ctx* drprg_hip_open_prg(const char* prg_file, int w, int k, int device, int threads);
 
+/* One context over several HIP devices of a node (the reference is single-process): the index tables
+ * are replicated on every device, drprg_hip_map_fastx shards the reads by ingest block over the devices and sums their coverage
+ * vectors into devices[0] before it returns (unsigned integer sums: the result is the same whatever device mapped what), so
+ * coverage / counters / genotype then see the whole sample.  Every other call (map_host, map_device, device_coverage) uses
+ * devices[0].  from_files != 0: like drprg_hip_open, else like drprg_hip_open_prg.  A device may be listed more than once
+ * (two concurrent launch sequences on one GPU: what the single-GPU test uses). */
+drprg_hip_ctx* drprg_hip_open_multi(const char* prg_file, int w, int k, const int* devices, int ndev, int from_files);
+
 void drprg_hip_close(drprg_hip_ctx* ctx);
 const char* drprg_hip_last_error(const drprg_hip_ctx* ctx);
 

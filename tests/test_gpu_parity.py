@@ -502,3 +502,54 @@ def test_full_size_properties(tmp_path, name, illumina, n_reads):
     twice = covg.clone()
     bench.map_range(ctx, bases, offsets, 0, n_reads, twice, prg_reads, stream, torch)
     assert torch.equal(twice, 2 * covg)
+
+
+def test_multi_device_context_equals_single(tmp_path, oracle):
+    """drprg_hip_open_multi (native host path): map_fastx shards the ingest blocks over the listed devices and sums
+    their coverage vectors into the first.  On a one-GPU box the list names device 0 twice -- two mappers, two streams, the
+    same code path as two GPUs -- and the result must equal the single-device context and the oracle, counters included;
+    the CLI takes the list from DRPRG_HIP_DEVICES."""
+    import subprocess
+    from drprg_amd import Context, synth
+    from drprg_amd._lib import PANDORA_EXE
+    w, k = 11, 15
+    panel = synth.small_panel(seed=17, n_loci=5, length=900)
+    prg, genes = str(tmp_path / "dr.prg"), str(tmp_path / "genes.fa")
+    panel.write(prg, genes)
+    gen = synth.HaplotypeGenomes(panel, genome_size=60000, n_hap=4, seed=3)
+    bases, offs = synth.sample_short_reads(gen, 1_500_000, seed=4)  # ~10 ingest blocks
+    fq = str(tmp_path / "reads.fq")
+    synth.write_fastq_fixed(fq, bases, 150)
+    single = Context(prg, w, k, device=0, from_files=False)
+    single.set_opts(illumina=True, genome_size=60000)
+    single.set_threads(8)
+    single.map_fastx(fq)
+    want, want_prg = single.coverage()
+    multi = Context(prg, w, k, from_files=False, devices=[0, 0, 0])
+    multi.set_opts(illumina=True, genome_size=60000)
+    multi.set_threads(8)
+    multi.map_fastx(fq)
+    got, got_prg = multi.coverage()
+    assert np.array_equal(got, want) and np.array_equal(got_prg, want_prg)
+    cs, cm = single.counters(), multi.counters()
+    for key in ("reads", "bases", "hits", "clusters_kept", "hits_kept"):
+        assert cs[key] == cm[key], key
+    idx = oracle.build_index(panel.prgs, w, k)
+    ocov, oprg, _ = _oracle_map(oracle, idx, bases, offs, w, k, True, threads=ORACLE_THREADS)
+    assert np.array_equal(got, ocov) and np.array_equal(got_prg, oprg)
+    # a second file accumulates on top, and reset clears every device
+    multi.map_fastx(fq)
+    assert np.array_equal(multi.coverage()[0], 2 * want)
+    multi.reset()
+    assert multi.coverage()[0].sum() == 0 and multi.counters()["reads"] == 0
+    # the drop-in executable over "two devices"
+    r = subprocess.run([PANDORA_EXE, "index", "-t", "2", "-w", str(w), "-k", str(k), prg], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    outs = []
+    for devs in ("0", "0,0"):
+        out = tmp_path / f"out_{devs.replace(',', '_')}"
+        r = subprocess.run([PANDORA_EXE, "map", "--genotype", "--local", "-o", str(out), "-g", "60000", "--vcf-refs", genes, "-t", "8", "-w", str(w),
+                            "-k", str(k), "-c", "10", "-I", prg, fq], capture_output=True, text=True, env=dict(os.environ, DRPRG_HIP_DEVICES=devs))
+        assert r.returncode == 0, r.stderr
+        outs.append([l for l in open(out / "pandora_genotyped.vcf") if not l.startswith("##fileDate")])
+    assert outs[0] == outs[1] and len(outs[0]) > 30
