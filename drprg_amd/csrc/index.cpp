@@ -224,11 +224,27 @@ void PrgIndex::save(const std::string& prg_file) const
     std::ofstream out(idx_path(prg_file, w, k));
     if (!out) throw Error(DRPRG_EIO, "cannot write " + idx_path(prg_file, w, k));
     const FlatIndex& f = flat;
+    // pandora's .idx layout as SURVEY.md appendix A.3 records it [UPSTREAM-MEMORY]: first line = number of distinct minimizer
+    // keys, then per key: hash <TAB> n <TAB> n records "(prg_id, path, knode_id, strand)", the path printed like the S lines
+    // of the k-mer graphs, e.g. 2{[10, 20)[25, 30)}
+    auto path_string = [&](uint32_t prg, uint32_t node) {
+        std::ostringstream os;
+        const KPath& kp = kgs[prg].nodes[node].path;
+        os << kp.size() << "{";
+        for (const PathPiece& pp : kp) {
+            const uint32_t base = prgs[prg].nodes[pp.node].start;
+            os << "[" << base + pp.off_start << ", " << base + pp.off_end << ")";
+        }
+        os << "}";
+        return os.str();
+    };
     out << f.keys.size() << "\n";
     for (size_t i = 0; i < f.keys.size(); ++i) {
         out << f.keys[i] << "\t" << (f.rec_off[i + 1] - f.rec_off[i]);
-        for (uint32_t j = f.rec_off[i]; j < f.rec_off[i + 1]; ++j)
-            out << "\t" << f.rec_prg[j] << " " << (f.rec_knode_global[j] - f.knode_base[f.rec_prg[j]]) << " " << (int)f.rec_strand[j];
+        for (uint32_t j = f.rec_off[i]; j < f.rec_off[i + 1]; ++j) {
+            const uint32_t prg = f.rec_prg[j], node = f.rec_knode_global[j] - f.knode_base[prg];
+            out << "\t(" << prg << ", " << path_string(prg, node) << ", " << node << ", " << (int)f.rec_strand[j] << ")";
+        }
         out << "\n";
     }
     if (!out) throw Error(DRPRG_EIO, "short write to " + idx_path(prg_file, w, k));
@@ -258,6 +274,8 @@ void PrgIndex::load(const std::string& prg_file, int w_, int k_)
     std::getline(in, line);
     if (nkeys != flat.keys.size())
         throw Error(DRPRG_EFORMAT, idx_path(prg_file, w, k) + " does not match kmer_prgs/ (key count)");
+    // every record of the file must be a record the k-mer graphs imply: same key, same PRG, same node, same strand (the
+    // path is re-derived from the GFA; a file written by the previous layout of this build -- "prg node strand" -- parses too)
     for (size_t i = 0; i < nkeys; ++i) {
         if (!std::getline(in, line)) throw Error(DRPRG_EFORMAT, idx_path(prg_file, w, k) + " is truncated");
         std::istringstream is(line);
@@ -266,6 +284,21 @@ void PrgIndex::load(const std::string& prg_file, int w_, int k_)
         is >> key >> n;
         if (key != flat.keys[i] || n != flat.rec_off[i + 1] - flat.rec_off[i])
             throw Error(DRPRG_EFORMAT, idx_path(prg_file, w, k) + " does not match kmer_prgs/ (key " + std::to_string(i) + ")");
+        std::string field;
+        std::getline(is, field, '\t'); // rest of the count column
+        for (uint32_t j = flat.rec_off[i]; j < flat.rec_off[i + 1]; ++j) {
+            if (!std::getline(is, field, '\t')) throw Error(DRPRG_EFORMAT, idx_path(prg_file, w, k) + ": key " + std::to_string(i) + " lists too few records");
+            unsigned prg = 0, node = 0;
+            int strand = 0;
+            bool ok;
+            const size_t brace = field.find('}');
+            if (!field.empty() && field[0] == '(' && brace != std::string::npos)
+                ok = std::sscanf(field.c_str(), "(%u,", &prg) == 1 && std::sscanf(field.c_str() + brace + 1, ", %u, %d)", &node, &strand) == 2;
+            else
+                ok = std::sscanf(field.c_str(), "%u %u %d", &prg, &node, &strand) == 3;
+            if (!ok || prg != flat.rec_prg[j] || node != flat.rec_knode_global[j] - flat.knode_base[flat.rec_prg[j]] || strand != (int)flat.rec_strand[j])
+                throw Error(DRPRG_EFORMAT, idx_path(prg_file, w, k) + " does not match kmer_prgs/ (record " + std::to_string(j) + ")");
+        }
         nrec += n;
     }
     (void)nrec;

@@ -141,9 +141,11 @@ def test_written_kmer_graphs_equal_the_oracle_graphs(tmp_path, oracle):
         fh.write("".join(f">{n}\n{p}\n" for n, p in zip(names, prgs)))
     w, k = 11, 15
     assert lib.drprg_hip_index(prg.encode(), w, k, 2) == 0
+    graph_paths = []
     for n, p in zip(names, prgs):
         nodes, edges = _parse_gfa(str(tmp_path / "kmer_prgs" / f"{n}.k{k}.w{w}.gfa"))
         g = oracle.sketch_prg(p, w, k, paths=True)
+        graph_paths.append(g["paths"])
         assert len(nodes) == g["n_nodes"]
         assert nodes[0] == [] and nodes[-1] == []
         assert nodes[1:-1] == g["paths"]
@@ -158,9 +160,12 @@ def test_written_kmer_graphs_equal_the_oracle_graphs(tmp_path, oracle):
         lo, hi = int(idx["rec_off"][i]), int(idx["rec_off"][i + 1])
         assert int(f[1]) == hi - lo
         for j, rec in enumerate(f[2:]):
-            p, node, strand = (int(x) for x in rec.split())
+            m = re.fullmatch(r"\((\d+), (\d+\{(?:\[\d+, \d+\))+\}), (\d+), ([01])\)", rec)  # (prg_id, path, knode_id, strand)
+            assert m, rec
+            p, node, strand = int(m.group(1)), int(m.group(3)), int(m.group(4))
             assert p == idx["rec_prg"][lo + j] and strand == idx["rec_strand"][lo + j]
             assert node == idx["rec_knode"][lo + j] - idx["knode_base"][p]
+            assert [(int(a), int(b)) for a, b in re.findall(r"\[(\d+), (\d+)\)", m.group(2))] == graph_paths[p][node - 1]
 
 
 def test_every_read_side_minimizer_of_a_prg_walk_is_a_node(oracle):
