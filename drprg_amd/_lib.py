@@ -79,6 +79,7 @@ SIGNATURES = {
     "drprg_hip_prg_nodes": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32),
                                       C.POINTER(C.c_uint32)]),
     "drprg_hip_annotate": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(AnnotateOpts), C.c_char_p, C.c_size_t]),
+    "drprg_hip_vcf_to_bcf": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]),
     "drprg_hip_report_json": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_char_p,
                                         C.c_size_t]),
     "drprg_hip_kernel_timing": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),

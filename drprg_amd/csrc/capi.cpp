@@ -628,6 +628,12 @@ int drprg_hip_report_json(const char* index_dir, const char* annotated_vcf, cons
 } // extern "C"
 
 // ---- ingest self-check (host only) ---------------------------------------------------------------------------
+extern "C" int drprg_hip_vcf_to_bcf(const char* vcf_path, const char* bcf_path, char* err, size_t err_len)
+{
+    if (!vcf_path || !bcf_path) return DRPRG_EINVAL;
+    return report_guard(err, err_len, [&]() { report::vcf_to_bcf(vcf_path, bcf_path); });
+}
+
 extern "C" int drprg_hip_parse_fastx(const char* reads_path, int threads, uint64_t out[5], char* err, size_t err_len)
 {
     if (!reads_path || !out) return DRPRG_EINVAL;

@@ -229,6 +229,8 @@ int main(int argc, char** argv)
     char err[1024] = { 0 };
     const std::string out_vcf = outdir + "/" + sample + ".drprg.vcf", out_json = outdir + "/" + sample + ".drprg.json";
     if (int rc = drprg_hip_annotate(index.c_str(), pandora_vcf.c_str(), out_vcf.c_str(), &ao, err, sizeof err)) die(err, -rc);
+    // <sample>.drprg.bcf: the file the reference leaves (/root/reference/src/predict.rs:429-431); the text VCF stays beside it
+    if (int rc = drprg_hip_vcf_to_bcf(out_vcf.c_str(), (outdir + "/" + sample + ".drprg.bcf").c_str(), err, sizeof err)) die(err, -rc);
     if (int rc = drprg_hip_report_json(index.c_str(), out_vcf.c_str(), out_json.c_str(), sample.c_str(), -1, nullptr, err, sizeof err)) die(err, -rc);
     if (verbose) std::fprintf(stderr, "[drprg-hip] wrote %s\n", out_json.c_str());
     return 0;

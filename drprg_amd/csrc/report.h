@@ -53,6 +53,9 @@ struct VcfFile {
     std::vector<std::string> contigs() const;
 };
 VcfFile read_vcf(const std::string& path); // plain or gz text VCF
+// BCF2.2 in BGZF, what the reference writes through rust-htslib (/root/reference/src/predict.rs:429-431); bcfout.cpp
+void write_bcf(const std::string& path, const VcfFile& vcf);
+void vcf_to_bcf(const std::string& vcf_path, const std::string& bcf_path);
 VcfRecord parse_vcf_line(const std::string& line);
 
 // ---- panel.bcf (BCF2 in BGZF) -------------------------------------------------------------------

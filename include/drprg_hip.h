@@ -167,6 +167,9 @@ typedef struct drprg_hip_annotate_opts {
  * Deviation: the output is VCF text, not BCF.  err receives the message on failure (may be NULL). */
 int drprg_hip_annotate(const char* index_dir, const char* pandora_vcf, const char* out_vcf,
     const drprg_hip_annotate_opts* opts, char* err, size_t err_len);
+/* The annotated VCF as BCF2.2 in BGZF: the format and file name (<sample>.drprg.bcf) the reference writes through rust-htslib
+ * (/root/reference/src/predict.rs:429-431).  `drprg predict` of this build writes both the text VCF and this. */
+int drprg_hip_vcf_to_bcf(const char* vcf_path, const char* bcf_path, char* err, size_t err_len);
 /* Replaces Predict::vcf_to_json (/root/reference/src/predict.rs:716-1086).  padding < 0 / index_version NULL: taken from
  * <index_dir>/.config.toml. */
 int drprg_hip_report_json(const char* index_dir, const char* annotated_vcf, const char* out_json, const char* sample,

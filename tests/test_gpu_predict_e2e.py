@@ -89,6 +89,14 @@ def test_reference_sample_is_susceptible_and_resistant_sample_is_called(tmp_path
             alt_calls.add((t[0], int(t[1])))
     expect_calls = {(gene, sites[gene][k][1] + 1) for gene, (k, _) in want.items()}
     assert expect_calls <= alt_calls and len(alt_calls) <= len(expect_calls) + 2, (alt_calls, expect_calls)
+    # the report surface of the reference: <sample>.drprg.bcf (/root/reference/src/predict.rs:429-431) beside the text VCF,
+    # same records; discover's outputs (/root/reference/src/predict.rs:247-256) with the loud warning on stderr
+    from bcf_decode import decode
+    _, recs = decode(str(out / "mut.drprg.bcf"))
+    text = [l.split("\t") for l in open(out / "mut.drprg.vcf") if not l.startswith("#")]
+    assert [(r["chrom"], r["pos"] + 1, r["alleles"][0]) for r in recs] == [(t[0], int(t[1]), t[3]) for t in text] and len(recs) > 100
+    assert [dict(r["info"]).get("PREDICT") for r in recs] == [dict(kv.split("=", 1) for kv in t[7].split(";") if "=" in kv).get("PREDICT") for t in text]
+    assert (out / "discover" / "denovo_paths.txt").exists() and (out / "discover" / "candidate_regions.tsv").exists()
 
 
 def test_absent_gene_is_reported(tmp_path):
