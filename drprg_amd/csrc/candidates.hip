@@ -442,10 +442,15 @@ __global__ __launch_bounds__(TG_THREADS) void tile_gather_kernel(SketchArgs a, F
         return;
     }
     const uint32_t t0 = blockIdx.x * TG_TILES, t1 = t0 + TG_TILES < n_tiles ? t0 + TG_TILES : n_tiles;
-    uint32_t my_hits = 0, my_nmin = 0;
+    uint32_t my_hits = 0, my_nmin = 0, my_fc = 0, my_fh = 0;
     for (uint32_t t = t0 + (uint32_t)tid; t < t1; t += TG_THREADS) {
         my_hits += a.tile_hits[t];
         my_nmin += a.tile_nmin[t];
+        if (a.fuse > 0) { // what sketch_wave_kernel clustered itself
+            const uint32_t f = a.tile_fast[t];
+            my_fc += f & 0xFFFFu;
+            my_fh += f >> 16;
+        }
     }
     for (uint32_t t = t0 + (uint32_t)wave; t < t1; t += TG_THREADS / 64) {
         const uint32_t n = a.tile_count[t], dst = tile_prefix[t];
@@ -456,12 +461,16 @@ __global__ __launch_bounds__(TG_THREADS) void tile_gather_kernel(SketchArgs a, F
             fw.cand_rec[dst + i] = a.tile_rec[src + i];
         }
     }
-    uint32_t hits, nmin;
+    uint32_t hits, nmin, fc, fh;
     (void)block_exclusive_scan<TG_THREADS / 64>(my_hits, s_w, &hits);
     (void)block_exclusive_scan<TG_THREADS / 64>(my_nmin, s_w, &nmin);
+    (void)block_exclusive_scan<TG_THREADS / 64>(my_fc, s_w, &fc);
+    (void)block_exclusive_scan<TG_THREADS / 64>(my_fh, s_w, &fh);
     if (tid == 0) {
         if (hits) atomicAdd(a.n_hits, (unsigned long long)hits);
         if (nmin) atomicAdd(a.n_minimizers, (unsigned long long)nmin);
+        if (fc) atomicAdd(a.n_clusters_kept, (unsigned long long)fc);
+        if (fh) atomicAdd(a.n_hits_kept, (unsigned long long)fh);
     }
 }
 
@@ -487,6 +496,8 @@ static bool use_wave_form(int k, int w, bool wide_hash)
     }();
     return !wide_hash && !forced_lds && wave_kernel_applies(k, w);
 }
+
+bool direct_uses_wave_form(int k, int w, bool wide_hash) { return use_wave_form(k, w, wide_hash); }
 
 uint32_t direct_candidate_tiles(uint64_t n_bases, int halo, int k, int w, bool wide_hash)
 {

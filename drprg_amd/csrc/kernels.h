@@ -70,6 +70,15 @@ struct SketchArgs {
     uint32_t *tile_count, *tile_hits, *tile_nmin;
     const uint32_t* prg_min_path_len; // for the size threshold stored in the records
     const uint32_t* prg_thr;          // per PRG: floor(shortest k-mer path * fraction) (sketch_wave_kernel)
+    // in-kernel clustering of the reads that lie inside one tile (sketch_wave_kernel stage C1): 0 off, 1 on, -1 undo
+    int fuse;
+    int max_diff;
+    uint32_t* covg;      // the batch's accumulators (stage C1 adds to them directly)
+    uint32_t* prg_reads;
+    uint32_t* tile_fast; // per slice: hits kept << 16 | clusters kept by stage C1
+    unsigned long long* n_clusters_kept;
+    unsigned long long* n_hits_kept;
+    unsigned long long* dbg; // 8 words, DRPRG_WAVE_DEBUG only: why stage C1 left entries behind
     double fraction;
     uint32_t min_cluster_size;
 };
@@ -116,6 +125,7 @@ uint32_t wave_n_slices(uint64_t n_bases); // one slice of tile_cap records per w
 hipError_t launch_sketch_wave(const SketchArgs& a, hipStream_t stream, KernelTimer timer = {});
 // tiles of the candidate form of the direct sequence for these parameters (whichever kernel serves them)
 uint32_t direct_candidate_tiles(uint64_t n_bases, int halo, int k, int w, bool wide_hash); // = slices
+bool direct_uses_wave_form(int k, int w, bool wide_hash); // sketch_wave_kernel serves these parameters
 uint32_t direct_first_read_tiles(uint64_t n_bases, int halo, int k, int w, bool wide_hash); // entries of tile_first_read
 // filtered form (k <= 15, w <= 16): bloom = 2^bloom_wbits words of index k-mer codes
 uint32_t filter_n_tiles(uint64_t n_bases);

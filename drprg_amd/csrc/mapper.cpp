@@ -122,6 +122,15 @@ Mapper::Mapper(const FlatIndex& idx, const MapParams& p, int device) : device_(d
     }
     HIPCHK(hipDeviceGetAttribute(&n_cus_, hipDeviceAttributeMultiprocessorCount, device_));
     set_params(p); // again: the kernel choice depends on the filter being available
+    {
+        const char* f = std::getenv("DRPRG_WAVE_FUSE");
+        const char* d = std::getenv("DRPRG_FT_DEBUG");
+        // opt-in (DRPRG_WAVE_FUSE=1; 2 = single-record minimizers only): measured on the 500-locus workload the in-kernel
+        // clustering takes 84 % of the candidates away from gather + read_cluster_kernel (2.7 -> 2.1 ms) but costs
+        // sketch_wave_kernel 1.65 ms (3.84 -> 5.50 ms): 7.6 ms per 10 M reads against 6.9 ms without it
+        fuse_in_kernel_ = f && std::atoi(f) != 0 && !(d && (std::atoi(d) & 8));
+        fuse_mode_ = f && std::atoi(f) == 2 ? 2 : 1;
+    }
     if (const char* e = std::getenv("DRPRG_HIP_LANES")) max_lanes_ = std::min(4, std::max(1, std::atoi(e)));
     if (const char* e = std::getenv("DRPRG_HIP_LANES_MIN_BASES")) lanes_min_bases_ = std::strtoull(e, nullptr, 10); // (tests: 0)
     dmalloc(d_covg_, 2 * (size_t)n_knodes_);
@@ -143,7 +152,7 @@ Mapper::~Mapper()
     dfree(d_key_a_); dfree(d_key_b_); dfree(d_val_a_); dfree(d_val_b_);
     dfree(d_head_); dfree(d_scan_); dfree(d_cstart_); dfree(d_order_); dfree(d_clusters_);
     if (d_temp_) (void)hipFree(d_temp_);
-    dfree(d_tile_info_); dfree(d_tile_pos1_); dfree(d_tile_count_); dfree(d_tile_hits_); dfree(d_tile_nmin_); dfree(d_tile_prefix_); dfree(d_tile_rec_);
+    dfree(d_tile_info_); dfree(d_tile_pos1_); dfree(d_tile_count_); dfree(d_tile_hits_); dfree(d_tile_nmin_); dfree(d_tile_prefix_); dfree(d_tile_fast_); dfree(d_tile_rec_);
     if (d_tile_temp_) (void)hipFree(d_tile_temp_);
     dfree(d_bases_); dfree(d_offsets_); dfree(d_tile_first_); dfree(d_bloom_); dfree(d_bloom0_); dfree(d_bloomr_); dfree(d_pbloom_);
     for (Lane& lane : lanes_) free_lane(lane);
@@ -417,14 +426,14 @@ void Mapper::leftovers(Lane& lane, const uint8_t* d_bases, const uint64_t* d_off
 void Mapper::ensure_tile_workspace(uint32_t n_tiles, uint32_t tile_cap)
 {
     if (n_tiles <= tile_ws_tiles_ && tile_cap <= tile_ws_cap_) return;
-    dfree(d_tile_info_); dfree(d_tile_pos1_); dfree(d_tile_count_); dfree(d_tile_hits_); dfree(d_tile_nmin_); dfree(d_tile_prefix_); dfree(d_tile_rec_);
+    dfree(d_tile_info_); dfree(d_tile_pos1_); dfree(d_tile_count_); dfree(d_tile_hits_); dfree(d_tile_nmin_); dfree(d_tile_prefix_); dfree(d_tile_fast_); dfree(d_tile_rec_);
     if (d_tile_temp_) (void)hipFree(d_tile_temp_);
     d_tile_temp_ = nullptr;
     tile_ws_tiles_ = std::max(tile_ws_tiles_, n_tiles + n_tiles / 8 + 32);
     tile_ws_cap_ = std::max(tile_ws_cap_, tile_cap);
     const size_t n = (size_t)tile_ws_tiles_ * tile_ws_cap_;
     dmalloc(d_tile_info_, n); dmalloc(d_tile_pos1_, n); dmalloc(d_tile_rec_, n);
-    dmalloc(d_tile_count_, (size_t)tile_ws_tiles_ + 1); dmalloc(d_tile_hits_, (size_t)tile_ws_tiles_ + 1); dmalloc(d_tile_nmin_, (size_t)tile_ws_tiles_ + 1); dmalloc(d_tile_prefix_, (size_t)tile_ws_tiles_ + 1);
+    dmalloc(d_tile_count_, (size_t)tile_ws_tiles_ + 1); dmalloc(d_tile_hits_, (size_t)tile_ws_tiles_ + 1); dmalloc(d_tile_nmin_, (size_t)tile_ws_tiles_ + 1); dmalloc(d_tile_prefix_, (size_t)tile_ws_tiles_ + 1); dmalloc(d_tile_fast_, (size_t)tile_ws_tiles_ + 1);
     tile_temp_bytes_ = dev::scan_temp_bytes(tile_ws_tiles_ + 1);
     HIPCHK(hipMalloc(&d_tile_temp_, tile_temp_bytes_ ? tile_temp_bytes_ : 1));
 }
@@ -460,8 +469,18 @@ void Mapper::run_batch_direct_candidates(const uint8_t* d_bases, const uint64_t*
         a.tile_count = d_tile_count_;
         a.tile_hits = d_tile_hits_;
         a.tile_nmin = d_tile_nmin_;
+        a.tile_fast = d_tile_fast_;
         a.prg_min_path_len = d_min_path_len_;
         a.prg_thr = d_prg_thr_;
+        // sketch_wave_kernel can cluster the reads that lie inside one tile itself and add their coverage on the spot
+        // (opt-in: DRPRG_WAVE_FUSE=1; never with DRPRG_FT_DEBUG=8, "every read through the generic pipeline")
+        a.fuse = fuse_in_kernel_ && dev::direct_uses_wave_form(params_.k, params_.w, wide_hash_) ? fuse_mode_ : 0;
+        a.max_diff = params_.max_diff;
+        a.covg = covg;
+        a.prg_reads = prg_reads;
+        a.n_clusters_kept = &d_counters_[C_CLUSTERS_KEPT];
+        a.n_hits_kept = &d_counters_[C_HITS_KEPT];
+        a.dbg = std::getenv("DRPRG_WAVE_DEBUG") ? &d_counters_[C_CHUNK] : nullptr; // (words C_CHUNK.. are unused by this sequence)
         a.fraction = params_.cluster_fraction();
         a.min_cluster_size = params_.min_cluster_size;
         dev::FilterBuffers fb { lane.raw_pos, lane.raw_grp, lane.cand_info, lane.cand_pos1, lane.cand_rec, lane.raw_capacity, lane.small,
@@ -498,8 +517,16 @@ void Mapper::run_batch_direct_candidates(const uint8_t* d_bases, const uint64_t*
         if (ovf & 2u) throw Error(DRPRG_EOVERFLOW, "a read is longer than 2^" + std::to_string(dev::HIT_POS_BITS) + " bases");
         if (!(ovf & 4u)) break;
         // a tile slice or the dense list was too small: nothing was counted except the minimizers, and those only in this
-        // attempt's scratch block; grow both and run again
+        // attempt's scratch block; grow both and run again.  What sketch_wave_kernel already added to the coverage vector for the
+        // reads it clusters itself is taken back first: the same launch with fuse = -1 repeats exactly those additions as
+        // subtractions (same input, same slice capacity, so the same reads take that path).
         if (attempt > 6) throw Error(DRPRG_EOVERFLOW, "candidate buffer overflow after regrow");
+        if (a.fuse > 0) {
+            dev::SketchArgs undo = a;
+            undo.fuse = -a.fuse;
+            HIPCHK(dev::launch_sketch_wave(undo, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+        }
         tile_slice_cap_ = std::min<uint32_t>(tile_slice_cap_ * 2, 4096);
         grow_lane(lane, std::min<uint64_t>(lane.raw_capacity * 2, (1ull << 31) - 1));
     }
@@ -669,6 +696,9 @@ MapCounters Mapper::counters()
     HIPCHK(hipStreamSynchronize(stream_));
     unsigned long long c[C_N];
     HIPCHK(hipMemcpy(c, d_counters_, sizeof(c), hipMemcpyDeviceToHost));
+    if (std::getenv("DRPRG_WAVE_DEBUG"))
+        std::fprintf(stderr, "[sketch_wave] entries %llu: several records out of group %llu, other group than the read's first %llu, read not inside the tile %llu, "
+                             "more than 64 entries %llu; entries left to the records path %llu\n", c[C_CHUNK], c[C_CHUNK + 1], c[C_CHUNK + 2], c[C_CHUNK + 3], c[C_CHUNK + 4], c[C_CHUNK + 5]);
     MapCounters m;
     m.reads = tot_reads_;
     m.bases = tot_bases_;

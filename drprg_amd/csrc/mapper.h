@@ -122,6 +122,8 @@ private:
     uint32_t* d_bloomr_ = nullptr; // second stage of the level-0 form
     int n_cus_ = 256;
     bool use_filter_ = false;
+    bool fuse_in_kernel_ = false; // sketch_wave_kernel clusters the reads inside one tile itself (DRPRG_WAVE_FUSE=1)
+    int fuse_mode_ = 1;          // 2: only reads whose minimizers all have one index record (DRPRG_WAVE_FUSE=2)
     bool use_direct_cands_ = false; // direct sketch kernel in its candidate form (read_cluster_kernel instead of sort + cluster kernels)
     // accumulators
     uint32_t* d_covg_ = nullptr;
@@ -150,7 +152,7 @@ private:
     // candidate form of the direct sequence: one slice of tile_cap_ records per tile
     uint32_t tile_slice_cap_ = 256, tile_ws_tiles_ = 0, tile_ws_cap_ = 0;
     uint64_t* d_tile_info_ = nullptr;
-    uint32_t *d_tile_pos1_ = nullptr, *d_tile_count_ = nullptr, *d_tile_hits_ = nullptr, *d_tile_nmin_ = nullptr, *d_tile_prefix_ = nullptr;
+    uint32_t *d_tile_pos1_ = nullptr, *d_tile_count_ = nullptr, *d_tile_hits_ = nullptr, *d_tile_nmin_ = nullptr, *d_tile_prefix_ = nullptr, *d_tile_fast_ = nullptr;
     uint4* d_tile_rec_ = nullptr;
     void* d_tile_temp_ = nullptr;
     size_t tile_temp_bytes_ = 0;

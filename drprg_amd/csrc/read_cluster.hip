@@ -34,7 +34,7 @@ constexpr int RC_SLOTS = RC_THREADS * RC_PER; // staged candidates
 constexpr int RC_AHEAD = 512;                 // look-ahead: a read belongs to the chunk that owns its first candidate
 constexpr int RC_OWN = RC_SLOTS - RC_AHEAD;
 constexpr int RC_HCAP = 3072;                 // staged hits
-constexpr int RC_POOL = 64;                   // reads per chunk that may take the wave path
+constexpr int RC_POOL = 512;                  // reads per chunk that may take the wave path (sketch_wave_kernel clusters the plain reads itself: what is left is rich in these)
 constexpr uint32_t RC_IRREGULAR = 2u, RC_COMPLEX = 1u;
 
 // later (read start << 16 | segment start) pair: the read start decides, then the segment start.  A gap inside a read

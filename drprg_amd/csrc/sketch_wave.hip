@@ -18,8 +18,9 @@
 //   * lanes 0, 62 and 63 only supply neighbours (a tile evaluates 61 x 16 positions);
 //   * read boundaries and non-ACGT bases become a per-lane mask of invalid k-mer starts (a 64-word LDS array per wave, touched
 //     only by that wave);
-//   * the minimizers of the tile are compacted per wave (prefix over lanes with wave scans) and thinned in three passes with
-//     all lanes busy: Bloom tier -> exact table lookup -> record; the four tiles of a workgroup share one slice.
+//   * the minimizers of the tile are compacted per wave (prefix over lanes with wave scans) and thinned in passes with all
+//     lanes busy: Bloom tier -> exact table lookup -> reads that lie inside the tile are clustered on the spot and their
+//     coverage added (stage C1) -> a record for what is left; the four tiles of a workgroup share one slice.
 #include "device_common.h"
 
 namespace drprg {
@@ -91,6 +92,7 @@ template <int K, int W>
 __device__ __forceinline__ void sketch_wave_tile(const SketchArgs& a, uint32_t tile, bool active, WaveLds& lds, uint32_t* s_nb, uint32_t* s_sum, int lane, int wave)
 {
     if (!active) { // a wave past the last tile still meets the workgroup's two barriers
+        (void)s_sum;
         if (lane == 0) s_nb[wave] = 0;
         __syncthreads();
         __syncthreads();
@@ -316,8 +318,152 @@ __device__ __forceinline__ void sketch_wave_tile(const SketchArgs& a, uint32_t t
         n_b += (uint32_t)__popcll(fm);
     }
     wave_lds_fence();
+    // everything a record, or a hit of the in-kernel clustering, needs of list entry i
+    struct Entry {
+        uint32_t p, slot, read, strand, kn, prg, rev, thr;
+        uint4 sf; // record offset, count, the first record's node << 1 | strand, its prg | shortest path << 12
+        uint64_t o0, o1, pos;
+    };
+    const uint32_t w1_magic = w1_reciprocal(W);
+    auto decode = [&](uint32_t i) -> Entry {
+        Entry e;
+        e.p = list[i] & 0x7FFFu;
+        e.slot = hvs[e.p];
+        e.sf = a.slot_first[e.slot];
+        const uint64_t gp = (uint64_t)(origin + (int64_t)e.p);
+        const uint32_t rb = *reinterpret_cast<volatile uint32_t*>(&lds.rbits[e.p >> 4]);
+        e.read = *reinterpret_cast<volatile uint32_t*>(&lds.rcnt[e.p >> 4]) + (uint32_t)__popc(rb & ((2u << (e.p & 15)) - 1u));
+        e.o0 = e.o1 = 0;
+        bool ok = !(rb & 0x10000u) && e.read < a.n_reads;
+        if (ok) {
+            e.o0 = a.offsets[e.read];
+            e.o1 = a.offsets[e.read + 1];
+            ok = e.o0 <= gp && gp < e.o1;
+        }
+        if (!ok) { // empty reads around here: search from the tile's first read
+            e.read = find_read_from(a.offsets, a.n_reads, first_read ? first_read - 1 : 0, gp);
+            e.o0 = a.offsets[e.read];
+            e.o1 = a.offsets[e.read + 1];
+        }
+        e.pos = gp - e.o0;
+        e.strand = (*reinterpret_cast<volatile uint32_t*>(&lds.strand[e.p >> 4]) >> (e.p & 15)) & 1u;
+        e.kn = e.sf.z;
+        e.prg = e.sf.w & 0xFFFu;
+        e.rev = ((e.kn & 1u) == e.strand) ? 0u : 1u;
+        // size threshold of a cluster of this read on that PRG: floor(min(shortest path, expected) * fraction) =
+        // min(floor(shortest path * fraction) [per PRG, from the host], floor(expected * fraction)) -- floor(x * f) is monotone
+        const uint32_t by_len = (uint32_t)((double)expected_minimizers(e.o1 - e.o0, W, w1_magic) * a.fraction);
+        const uint32_t by_prg = a.prg_thr[e.prg];
+        const uint32_t length_based = by_len < by_prg ? by_len : by_prg;
+        e.thr = length_based > a.min_cluster_size ? length_based : a.min_cluster_size;
+        if (e.thr > 0xFFFFu) e.thr = 0xFFFFu;
+        return e;
+    };
+
+    // ---- stage C1: reads that lie inside this tile are clustered here (pandora define_clusters / filter_clusters /
+    // add_hits_to_kmergraphs, as read_cluster_kernel's segment path does them).  Such a read has every one of its index
+    // minimizers in this wave's list, next to each other and in position order.  If each has exactly one index record and
+    // all of them fall into ONE (prg, strand) group, its clusters are the runs without a position gap > max_diff, a cluster is
+    // kept iff it has more hits than the size threshold, and the overlap sweep cannot drop a kept one (same group, disjoint
+    // ranges): every hit of a kept cluster adds 1 to its k-mer node's coverage right here.  Every other read -- it crosses the
+    // tile's edge, a minimizer with several records, hits in two groups, more than 64 index minimizers -- keeps its entries
+    // for stage C2 (records -> gather -> read_cluster_kernel).  a.fuse: 0 off (the default: see Mapper), 1 on, -1 take the same
+    // additions back (the host's undo pass before it re-runs a batch whose record slices overflowed).
+    uint32_t n_f = n_b, fast_clusters = 0, fast_hits = 0, my_hits = 0;
+    if (a.fuse) {
+        n_f = 0;
+        uint32_t cont_read = 0xFFFFFFFFu; // a read with more entries than one pass holds: never clustered here
+        for (uint32_t c = 0; c < n_b;) {
+            const uint32_t i = c + (uint32_t)lane;
+            const bool valid = i < n_b;
+            Entry e {};
+            if (valid) e = decode(i);
+            const uint32_t r_prev = from_prev_lane(e.read), pos_prev = from_prev_lane((uint32_t)e.pos);
+            const bool head = valid && (lane == 0 || e.read != r_prev);
+            const uint64_t hm = __ballot(head);
+            uint32_t take = n_b - c < 64u ? n_b - c : 64u;
+            bool oversized = false;
+            if (c + 64 < n_b) { // entries follow: the last read of this pass may run on -- leave it to the next pass
+                const int last_head = 63 - __clzll((long long)hm);
+                if (last_head > 0) take = (uint32_t)last_head;
+                else oversized = true; // one read fills the pass
+            }
+            const bool active = valid && (uint32_t)lane < take;
+            const uint64_t upto = lane == 63 ? ~0ull : ((2ull << lane) - 1ull); // bits 0 .. lane
+            // my read: entries [rs, re)
+            const int rs = 63 - __clzll((long long)((hm & upto) | 1ull));
+            const uint64_t h_after = lane == 63 ? 0ull : (hm >> (lane + 1));
+            uint32_t re = h_after ? (uint32_t)lane + (uint32_t)__ffsll((long long)h_after) : 64u;
+            if (re > take) re = take;
+            const uint32_t g = (e.prg << 1) | e.rev;
+            const uint32_t g0 = (uint32_t)__shfl((int)g, rs);
+            const int64_t s_loc = (int64_t)e.o0 - origin, e_loc = (int64_t)e.o1 - origin;
+            const bool owned = s_loc >= SW_FIRST * SW_G && e_loc <= (SW_LAST + 1) * SW_G - 1 + K; // every k-mer of the read starts in an evaluated lane
+            // a minimizer with several index records (the same k-mer on several paths of a PRG): all of them must be in the group
+            bool records_ok = e.sf.y >= 1u && e.sf.y <= ((a.fuse == 2 || a.fuse == -2) ? 1u : 8u); // (fuse +-2: single-record minimizers only, for A/B runs)
+            if (active && records_ok)
+                for (uint32_t q = 1; q < e.sf.y; ++q) {
+                    const uint32_t kq = a.rec_knode[e.sf.x + q], pq = a.rec_prg[e.sf.x + q];
+                    records_ok &= pq == e.prg && (((kq & 1u) == e.strand) ? 0u : 1u) == e.rev;
+                }
+            const bool bad = active && (!records_ok || g != g0 || !owned || e.read == cont_read || oversized);
+            if (a.dbg && a.fuse > 0) { // why entries stay behind (DRPRG_WAVE_DEBUG)
+                const uint64_t b0 = __ballot(active), b1 = __ballot(active && !records_ok), b2 = __ballot(active && records_ok && g != g0),
+                               b3 = __ballot(active && !owned), b4 = __ballot(active && (e.read == cont_read || oversized));
+                if (lane == 0) {
+                    atomicAdd(&a.dbg[0], (unsigned long long)__popcll(b0));
+                    atomicAdd(&a.dbg[1], (unsigned long long)__popcll(b1));
+                    atomicAdd(&a.dbg[2], (unsigned long long)__popcll(b2));
+                    atomicAdd(&a.dbg[3], (unsigned long long)__popcll(b3));
+                    atomicAdd(&a.dbg[4], (unsigned long long)__popcll(b4));
+                }
+            }
+            const uint64_t bm = __ballot(bad);
+            const uint64_t seg = (re >= 64u ? ~0ull : ((1ull << re) - 1ull)) & ~((1ull << rs) - 1ull);
+            const bool read_bad = (bm & seg) != 0;
+            // my cluster: entries [cs, ce)
+            const bool chead = active && (head || (uint32_t)e.pos - pos_prev > (uint32_t)a.max_diff);
+            const uint64_t cm = __ballot(chead);
+            const int cs = 63 - __clzll((long long)((cm & upto) | 1ull));
+            const uint64_t c_after = lane == 63 ? 0ull : (cm >> (lane + 1));
+            uint32_t ce = c_after ? (uint32_t)lane + (uint32_t)__ffsll((long long)c_after) : 64u;
+            if (ce > take) ce = take;
+            const bool fast = active && !read_bad;
+            // hits of my cluster = sum of the record counts of its entries (differences of an inclusive scan over the lanes)
+            const uint32_t cnt_incl = wave_inclusive_scan(active ? e.sf.y : 0u);
+            // (both shuffles by every lane: a lane that sits out a shuffle reads as 0 to the lanes that ask for its value)
+            const uint32_t upto_end = (uint32_t)__shfl((int)cnt_incl, ce > 0 ? (int)ce - 1 : 0);
+            const uint32_t at_prev = (uint32_t)__shfl((int)cnt_incl, cs > 0 ? cs - 1 : 0);
+            const uint32_t before = cs > 0 ? at_prev : 0u;
+            const bool kept = fast && (upto_end - before) > e.thr;
+            if (kept) {
+                for (uint32_t q = 0; q < e.sf.y; ++q) {
+                    const uint32_t kq = q ? a.rec_knode[e.sf.x + q] : e.kn;
+                    if (a.fuse > 0) atomicAdd(&a.covg[(kq >> 1) * 2u + e.rev], 1u);
+                    else atomicSub(&a.covg[(kq >> 1) * 2u + e.rev], 1u);
+                }
+                if (lane == cs) {
+                    if (a.fuse > 0) atomicAdd(&a.prg_reads[e.prg], 1u);
+                    else atomicSub(&a.prg_reads[e.prg], 1u);
+                }
+            }
+            fast_hits += wave_sum(kept ? e.sf.y : 0u);
+            fast_clusters += (uint32_t)__popcll(__ballot(kept && lane == cs));
+            if (active) my_hits += e.sf.y;
+            if (fast) list[i] = (uint16_t)(e.p | 0x8000u); // done
+            n_f += (uint32_t)__popcll(__ballot(active && read_bad));
+            if (a.dbg && a.fuse > 0) {
+                const uint64_t left = __ballot(active && read_bad);
+                if (lane == 0) atomicAdd(&a.dbg[5], (unsigned long long)__popcll(left));
+            }
+            if (oversized) cont_read = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.read);
+            c += take;
+        }
+        wave_lds_fence();
+    }
+
     // ---- where this tile's records go: the workgroup's four tiles share one slice, in tile order ----
-    if (lane == 0) s_nb[wave] = n_b;
+    if (lane == 0) s_nb[wave] = n_f;
     __syncthreads();
     uint32_t base = 0, wg_total = 0;
 #pragma unroll
@@ -327,60 +473,39 @@ __device__ __forceinline__ void sketch_wave_tile(const SketchArgs& a, uint32_t t
         wg_total += x;
     }
     const size_t slice = (size_t)blockIdx.x * a.tile_cap;
-    // ---- stage C: one record per index minimizer ----
-    const uint32_t w1_magic = w1_reciprocal(W);
-    uint32_t my_hits = 0;
-    for (uint32_t i0 = 0; i0 < n_b; i0 += 64) {
+    // ---- stage C2: one record per index minimizer that stage C1 left ----
+    uint32_t written = 0;
+    for (uint32_t i0 = 0; i0 < n_b && a.fuse >= 0; i0 += 64) {
         const uint32_t i = i0 + (uint32_t)lane;
-        if (i >= n_b) break;
-        const uint32_t p = list[i], s = hvs[p];
-        const uint4 sf = a.slot_first[s]; // record offset, count, the first record's node << 1 | strand, its prg | shortest path << 12
-        const uint64_t gp = (uint64_t)(origin + (int64_t)p);
-        const uint32_t rb = *reinterpret_cast<volatile uint32_t*>(&lds.rbits[p >> 4]);
-        uint32_t read = *reinterpret_cast<volatile uint32_t*>(&lds.rcnt[p >> 4]) + (uint32_t)__popc(rb & ((2u << (p & 15)) - 1u));
-        uint64_t o0 = 0, o1 = 0;
-        bool ok = !(rb & 0x10000u) && read < a.n_reads;
-        if (ok) {
-            o0 = a.offsets[read];
-            o1 = a.offsets[read + 1];
-            ok = o0 <= gp && gp < o1;
+        const bool todo = i < n_b && !(list[i] & 0x8000u);
+        const uint64_t tm = __ballot(todo);
+        if (todo) {
+            const Entry e = decode(i);
+            if (!a.fuse) my_hits += e.sf.y;
+            const uint32_t at = base + written + lanes_below(tm);
+            if (e.pos >= (1ull << HIT_POS_BITS)) atomicOr(a.overflow, 2u);
+            else if (at < a.tile_cap) {
+                a.tile_info[slice + at] = ((uint64_t)e.slot << 32) | ((uint64_t)e.strand << 31) | (uint64_t)e.read;
+                a.tile_pos1[slice + at] = (uint32_t)e.pos + 1;
+                a.tile_rec[slice + at] = make_uint4(e.sf.x, e.sf.y, (e.strand << 31) | (((e.prg << 1) | e.rev) << 16) | e.thr, (e.kn >> 1) * 2u + e.rev);
+            }
         }
-        if (!ok) { // empty reads around here: search from the tile's first read
-            read = find_read_from(a.offsets, a.n_reads, first_read ? first_read - 1 : 0, gp);
-            o0 = a.offsets[read];
-            o1 = a.offsets[read + 1];
-        }
-        const uint64_t pos = gp - o0;
-        const uint32_t strand = (*reinterpret_cast<volatile uint32_t*>(&lds.strand[p >> 4]) >> (p & 15)) & 1u;
-        my_hits += sf.y;
-        const uint32_t at = base + i;
-        if (pos >= (1ull << HIT_POS_BITS)) atomicOr(a.overflow, 2u);
-        else if (at < a.tile_cap) {
-            const uint32_t kn = sf.z, prg = sf.w & 0xFFFu;
-            const uint32_t rev = ((kn & 1u) == strand) ? 0u : 1u;
-            // size threshold of a cluster of this read on that PRG: floor(min(shortest path, expected) * fraction) =
-            // min(floor(shortest path * fraction) [per PRG, from the host], floor(expected * fraction)) -- floor(x * f) is monotone
-            const uint32_t by_len = (uint32_t)((double)expected_minimizers(o1 - o0, W, w1_magic) * a.fraction);
-            const uint32_t by_prg = a.prg_thr[prg];
-            const uint32_t length_based = by_len < by_prg ? by_len : by_prg;
-            uint32_t thr = length_based > a.min_cluster_size ? length_based : a.min_cluster_size;
-            if (thr > 0xFFFFu) thr = 0xFFFFu;
-            a.tile_info[slice + at] = ((uint64_t)s << 32) | ((uint64_t)strand << 31) | (uint64_t)read;
-            a.tile_pos1[slice + at] = (uint32_t)pos + 1;
-            a.tile_rec[slice + at] = make_uint4(sf.x, sf.y, (strand << 31) | (((prg << 1) | rev) << 16) | thr, (kn >> 1) * 2u + rev);
-        }
+        written += (uint32_t)__popcll(tm);
     }
     // ---- the workgroup's counters ----
     const uint32_t tile_hits = wave_sum(my_hits);
     if (lane == 0) {
         atomicAdd(&s_sum[0], tile_hits);
         atomicAdd(&s_sum[1], nmin);
+        atomicAdd(&s_sum[2], fast_clusters);
+        atomicAdd(&s_sum[3], fast_hits);
     }
     __syncthreads();
-    if (wave == 0 && lane == 0) {
+    if (wave == 0 && lane == 0 && a.fuse >= 0) {
         a.tile_count[blockIdx.x] = wg_total < a.tile_cap ? wg_total : a.tile_cap;
         a.tile_hits[blockIdx.x] = s_sum[0];
         a.tile_nmin[blockIdx.x] = s_sum[1];
+        a.tile_fast[blockIdx.x] = (s_sum[3] << 16) | s_sum[2]; // hits and clusters kept by stage C1 (<= 3904 each)
         if (wg_total > a.tile_cap) atomicOr(a.overflow, 4u);
     }
 }
@@ -398,9 +523,9 @@ template <int K, int W>
 __global__ __launch_bounds__(SW_WAVES * 64) void sketch_wave_kernel(SketchArgs a, uint32_t n_tiles)
 {
     __shared__ WaveLds s_lds[SW_WAVES];
-    __shared__ uint32_t s_nb[SW_WAVES], s_sum[2];
+    __shared__ uint32_t s_nb[SW_WAVES], s_sum[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x < 2) s_sum[threadIdx.x] = 0; // (read after the first barrier at the earliest)
+    if (threadIdx.x < 4) s_sum[threadIdx.x] = 0; // (added to after the first barrier at the earliest)
     const uint32_t tile = blockIdx.x * SW_WAVES + (uint32_t)wave;
     sketch_wave_tile<K, W>(a, tile, tile < n_tiles, s_lds[wave], s_nb, s_sum, lane, wave);
 }

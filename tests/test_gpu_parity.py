@@ -553,3 +553,31 @@ def test_multi_device_context_equals_single(tmp_path, oracle):
         assert r.returncode == 0, r.stderr
         outs.append([l for l in open(out / "pandora_genotyped.vcf") if not l.startswith("##fileDate")])
     assert outs[0] == outs[1] and len(outs[0]) > 30
+
+
+def test_in_kernel_clustering_of_sketch_wave_kernel(tmp_path, oracle, monkeypatch):
+    """DRPRG_WAVE_FUSE=1 (opt-in): sketch_wave_kernel clusters the reads that lie inside one of its tiles itself -- single
+    (prg, strand) group, minimizers with up to eight index records -- and only the others (reads across a tile edge, hits in
+    several groups, more than 64 index minimizers) leave records for gather + read_cluster_kernel.  Same coverage vector and
+    counters as the oracle on the 500-locus index and on a nested / indel panel with duplicated loci; a tiny record slice
+    forces the overflow + undo + regrow path."""
+    from drprg_amd import synth
+    monkeypatch.setenv("DRPRG_WAVE_FUSE", "1")
+    panel, genomes = _baseline_panel("big")
+    bases, offs = _baseline_reads("big", False, 600_000)
+    ctx = _ctx(tmp_path, panel, 11, 15, True, genome_size=synth.MTB_GENOME_SIZE, kernel=3)
+    cnt = _compare(ctx, oracle, bases, offs, 11, 15, True, 3, threads=ORACLE_THREADS)
+    assert cnt["clusters_kept"] > 50_000 and ctx.counters()["leftover_reads"] == 0
+    ctx.close()
+    rng = np.random.default_rng(23)
+    a = synth.make_locus(rng, 900, site_every=35, nested_frac=0.3, indel_frac=0.2)
+    b = synth.make_locus(rng, 700, site_every=35, nested_frac=0.3, indel_frac=0.2)
+    small = synth.Panel(["a", "a_copy", "b"], [a, a, b])
+    seqs = [synth.sample_haplotype(rng, t).encode() for t in (a, b) for _ in range(4)] + [synth.random_seq(rng, 3000).encode()]
+    parts = [_reads_from(rng, seqs, 6000, 150), _reads_from(rng, seqs, 500, 400), _reads_from(rng, seqs, 60, 2500)]
+    sb = np.concatenate([p[0] for p in parts])
+    so = np.concatenate([np.zeros(1, np.uint64)] + [p[1][1:] + sum(int(q[1][-1]) for q in parts[:i]) for i, p in enumerate(parts)])
+    for illumina in (True, False):
+        ctx = _ctx(tmp_path, small, 11, 15, illumina, kernel=3)
+        _compare(ctx, oracle, sb, so, 11, 15, illumina, 3)
+        ctx.close()
