@@ -216,7 +216,7 @@ def e2e_leg(torch, ctx, synth, bases, n_reads, read_len, covg):
     plain member as `gzip` writes it): the first 2 M reads."""
     import gzip
     import shutil
-    threads = max(1, min(os.cpu_count() or 1, 32))
+    threads = max(1, min(os.cpu_count() or 1, 32))  # parser / inflate threads (the ingest itself caps the block-pinning parser workers)
     d = tempfile.mkdtemp(prefix="drprg_e2e_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     res = {"threads": threads, "input": "FASTQ text in the page cache; wall time of drprg_hip_map_fastx (parse + pin + PCIe + kernels)"}
     try:

@@ -30,6 +30,14 @@ struct drprg_hip_ctx {
     int threads = 4; // parser threads of drprg_hip_map_fastx
     uint32_t ginfo[4] = { 0, 0, 0, 0 };
     std::vector<VcfRecord> last_records; // of the last drprg_hip_genotype (drprg_hip_genotype_alleles)
+    // page-locked ingest blocks of drprg_hip_map_fastx, recycled between calls
+    std::mutex pin_mu;
+    std::vector<std::pair<void*, size_t>> pin_free, pin_busy;
+    ~drprg_hip_ctx()
+    {
+        for (auto& b : pin_free) Mapper::pinned_free(b.first);
+        for (auto& b : pin_busy) Mapper::pinned_free(b.first);
+    }
 };
 
 static thread_local std::string g_last_error;
@@ -169,8 +177,35 @@ int drprg_hip_map_fastx(drprg_hip_ctx* ctx, const char* reads_path)
     ctx->host_coverage_valid = false;
     // multi-threaded ingest into pinned blocks (ingest.cpp); multi-line FASTQ falls back to the serial reader
     IngestHooks hooks;
-    hooks.alloc = [](size_t n) { return Mapper::pinned_alloc(n); };
-    hooks.release = [](void* p) { Mapper::pinned_free(p); };
+    // pinned ingest blocks are kept by the context between calls (pinning 32 MB costs milliseconds of driver time)
+    hooks.alloc = [ctx](size_t n) -> void* {
+        {
+            std::lock_guard<std::mutex> g(ctx->pin_mu);
+            for (size_t i = 0; i < ctx->pin_free.size(); ++i)
+                if (ctx->pin_free[i].second == n) {
+                    void* p = ctx->pin_free[i].first;
+                    ctx->pin_free.erase(ctx->pin_free.begin() + (long)i);
+                    ctx->pin_busy.emplace_back(p, n);
+                    return p;
+                }
+        }
+        void* p = Mapper::pinned_alloc(n);
+        if (p) {
+            std::lock_guard<std::mutex> g(ctx->pin_mu);
+            ctx->pin_busy.emplace_back(p, n);
+        }
+        return p;
+    };
+    hooks.release = [ctx](void* p) {
+        std::lock_guard<std::mutex> g(ctx->pin_mu);
+        for (size_t i = 0; i < ctx->pin_busy.size(); ++i)
+            if (ctx->pin_busy[i].first == p) {
+                ctx->pin_free.push_back(ctx->pin_busy[i]);
+                ctx->pin_busy.erase(ctx->pin_busy.begin() + (long)i);
+                return;
+            }
+        Mapper::pinned_free(p);
+    };
     // One device: one submitter at a time (the ingest serialises the calls).  Several devices (drprg_hip_open_multi): the
     // reads shard by block -- a block goes to the first idle device, round robin from the one after the last choice --
     // and the parser threads that carry the blocks are the submitters, one per device at a time.

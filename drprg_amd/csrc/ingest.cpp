@@ -403,7 +403,9 @@ IngestStats ingest_fastx(const std::string& path, int threads, const IngestHooks
                 return st;
             }
             if (fastq) require_four_line_fastq(text, end);
-            const int n_workers = (int)std::min<size_t>((size_t)threads, map_len / SLICE_BYTES + 1);
+            // (a worker pins its own block -- a few milliseconds of driver time, serialised -- so every worker should have several
+            // slices to fill it with: measured on 4 M reads, 8 workers 50 ms, 32 workers 139 ms)
+            const int n_workers = (int)std::min<size_t>((size_t)threads, map_len / (3 * SLICE_BYTES) + 1);
             for (int t = 0; t < n_workers; ++t) pool.emplace_back(worker);
             const char* cur = text;
             while (cur < end && !sh.failed) {
@@ -443,7 +445,7 @@ IngestStats ingest_fastx(const std::string& path, int threads, const IngestHooks
                     } // (several members, or a wrapped size: the streaming reader takes it)
                 }
             }
-            for (int t = 0; t < threads; ++t) pool.emplace_back(worker);
+            for (int t = 0; t < std::min(threads, 8); ++t) pool.emplace_back(worker); // (the inflater feeds them: more only pin more blocks)
             // text source: fills dst with up to cap bytes of inflated text, returns the number written (0 = end)
             gzFile gzf = nullptr;
             size_t next_block = 0, whole_off = 0;
@@ -459,7 +461,7 @@ IngestStats ingest_fastx(const std::string& path, int threads, const IngestHooks
                     }
                     if (next_block == first && next_block < blocks.size()) throw Error(DRPRG_EIO, "BGZF block larger than a slice in " + path);
                     const size_t last = next_block;
-                    const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)threads, (last - first) / 64 + 1));
+                    const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)threads, (last - first + 15) / 16)); // >= 16 members (1 MB of text) per thread
                     std::vector<std::thread> infl;
                     std::atomic<size_t> cursor { first };
                     std::atomic<bool> bad { false };
@@ -467,8 +469,8 @@ IngestStats ingest_fastx(const std::string& path, int threads, const IngestHooks
                         void* dec = ld.alloc();
                         if (!dec) { bad = true; return; }
                         try {
-                            for (size_t b; (b = cursor.fetch_add(16)) < last;)
-                                for (size_t i = b; i < std::min(b + 16, last); ++i)
+                            for (size_t b; (b = cursor.fetch_add(8)) < last;)
+                                for (size_t i = b; i < std::min(b + 8, last); ++i)
                                     inflate_member(dec, gz_data + blocks[i].in_off, blocks[i].in_len, dst + blocks[i].out_off, blocks[i].out_len, path);
                         } catch (const Error&) {
                             bad = true;
