@@ -12,6 +12,20 @@ namespace dev {
         if (e_ != hipSuccess) return e_;                                                             \
     } while (0)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to (kernel, device): a process that drives several devices
+// (drprg_hip_open_multi) has to set it once on each.  cache: one slot per device, owned by the call site.
+constexpr int MAX_HIP_DEVICES = 64;
+inline hipError_t ensure_dynamic_lds(const void* kernel, size_t bytes, size_t (&cache)[MAX_HIP_DEVICES])
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < MAX_HIP_DEVICES && bytes <= cache[dev]) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess && dev >= 0 && dev < MAX_HIP_DEVICES) cache[dev] = bytes;
+    return e;
+}
+
 // ---------------------------------------------------------------------------------------------
 // hash
 // ---------------------------------------------------------------------------------------------

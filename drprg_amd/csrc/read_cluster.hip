@@ -394,11 +394,8 @@ hipError_t launch_read_cluster(const SketchArgs& a, const FilterWork& fw, const 
         return hipGetLastError();
     }
     const size_t dyn = (size_t)rc.n_prgs * sizeof(uint32_t); // the per-PRG histogram, behind ~70 KB of static LDS
-    static size_t configured = 0;
-    if (dyn > configured) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&read_cluster_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-        configured = dyn;
-    }
+    static size_t configured[MAX_HIP_DEVICES] = {};
+    HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&read_cluster_kernel), dyn, configured));
     hipLaunchKernelGGL(read_cluster_kernel, dim3((uint32_t)n_cus * 2), dim3(RC_THREADS), dyn, stream, a, fw, rc);
     return hipGetLastError();
 }

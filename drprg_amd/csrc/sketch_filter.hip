@@ -408,22 +408,16 @@ hipError_t launch_sketch_filter(const SketchArgs& a, uint32_t read_begin, uint32
             : which == 1                 ? &sketch_filter_kernel<true, false>
                                          : &sketch_filter_kernel<false, false>;
         const size_t dyn = level0 ? (size_t)FT_L0_WORDS * 4 : ((size_t)4 << bt.bloom_wbits);
-        static size_t configured[3] = { 0, 0, 0 };
-        if (dyn > configured[which]) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-            configured[which] = dyn;
-        }
+        static size_t configured[3][MAX_HIP_DEVICES] = {};
+        HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), dyn, configured[which]));
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(FT_THREADS), dyn, stream, a, fw);
     }
     HIP_TRY(hipGetLastError());
     if (timer.end) HIP_TRY(hipEventRecord(timer.end, stream));
     if (level0) {
-        static size_t refine_configured = 0;
+        static size_t refine_configured[MAX_HIP_DEVICES] = {};
         const size_t dyn = (size_t)4 << BLOOMR_WBITS;
-        if (dyn > refine_configured) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&refine_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-            refine_configured = dyn;
-        }
+        HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&refine_kernel), dyn, refine_configured));
         hipLaunchKernelGGL(refine_kernel, dim3(std::min<uint32_t>((fw.n_slices + RF_THREADS / 64 - 1) / (RF_THREADS / 64), (uint32_t)n_cus * 2)), dim3(RF_THREADS), dyn, stream, a, fw);
         HIP_TRY(hipGetLastError());
     }
