@@ -581,3 +581,41 @@ def test_in_kernel_clustering_of_sketch_wave_kernel(tmp_path, oracle, monkeypatc
         ctx = _ctx(tmp_path, small, 11, 15, illumina, kernel=3)
         _compare(ctx, oracle, sb, so, 11, 15, illumina, 3)
         ctx.close()
+
+
+@pytest.mark.parametrize("fuse", ["0", "1"])
+def test_wave_tile_geometry_edges(tmp_path, oracle, monkeypatch, fuse):
+    """sketch_wave_kernel evaluates 61 lanes x 16 positions per tile (976), loads 1024 bases, and a read is clustered in-kernel
+    (DRPRG_WAVE_FUSE=1) only if all its k-mers start inside one tile: reads whose lengths sit on those edges (15, 16, 17, 31,
+    960 ... 1007, 1024, 1952), runs of empty reads (several reads starting at one position), N runs that cross lane and tile
+    borders, all drawn from loci so that they carry hits"""
+    from drprg_amd import synth
+    monkeypatch.setenv("DRPRG_WAVE_FUSE", fuse)
+    rng = np.random.default_rng(41)
+    loci = [synth.make_locus(rng, 2600, site_every=45, nested_frac=0.2, indel_frac=0.1) for _ in range(3)]
+    panel = synth.Panel(["x", "y", "z"], loci)
+    haps = [np.frombuffer(synth.sample_haplotype(rng, t).encode(), np.uint8) for t in loci for _ in range(2)]
+    lengths = [0, 0, 0, 1, 14, 15, 16, 17, 30, 31, 32, 150, 150, 150, 959, 960, 961, 975, 976, 977, 990, 991, 992, 1005, 1006, 1007, 1008, 1023, 1024,
+               1025, 1951, 1952, 1953]
+    reads = []
+    for i in range(9000):
+        L = int(lengths[int(rng.integers(0, len(lengths)))])
+        h = haps[i % len(haps)]
+        s = int(rng.integers(0, len(h) - L + 1))
+        r = h[s:s + L].copy()
+        if L and rng.random() < 0.15:  # an N run of 1..40 bases somewhere
+            a0 = int(rng.integers(0, L))
+            r[a0:a0 + int(rng.integers(1, 41))] = ord("N")
+        if L and rng.random() < 0.5:
+            r = synth._COMP[r[::-1]]
+        reads.append(r)
+    offs = np.zeros(len(reads) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(r) for r in reads])
+    bases = np.concatenate(reads)
+    for illumina in (True, False):
+        ctx = _ctx(tmp_path, panel, 11, 15, illumina, kernel=3)
+        cnt = _compare(ctx, oracle, bases, offs, 11, 15, illumina, 3)
+        assert cnt["clusters_kept"] > 1000
+        ctx.close()
+    ctx = _ctx(tmp_path, panel, 14, 15, True, kernel=3)  # the other instantiation of the kernel
+    _compare(ctx, oracle, bases, offs, 14, 15, True, 3)
