@@ -88,7 +88,7 @@ struct alignas(16) WaveLds {
     uint32_t rcnt[64];      // per lane: reads that start in its 16 positions; later the read before its first position
 };
 
-template <int K, int W>
+template <int K, int W, bool FUSE>
 __device__ __forceinline__ void sketch_wave_tile(const SketchArgs& a, uint32_t tile, bool active, WaveLds& lds, uint32_t* s_nb, uint32_t* s_sum, int lane, int wave)
 {
     if (!active) { // a wave past the last tile still meets the workgroup's two barriers
@@ -370,7 +370,7 @@ __device__ __forceinline__ void sketch_wave_tile(const SketchArgs& a, uint32_t t
     // for stage C2 (records -> gather -> read_cluster_kernel).  a.fuse: 0 off (the default: see Mapper), 1 on, -1 take the same
     // additions back (the host's undo pass before it re-runs a batch whose record slices overflowed).
     uint32_t n_f = n_b, fast_clusters = 0, fast_hits = 0, my_hits = 0;
-    if (a.fuse) {
+    if constexpr (FUSE) {
         n_f = 0;
         uint32_t cont_read = 0xFFFFFFFFu; // a read with more entries than one pass holds: never clustered here
         for (uint32_t c = 0; c < n_b;) {
@@ -475,13 +475,13 @@ __device__ __forceinline__ void sketch_wave_tile(const SketchArgs& a, uint32_t t
     const size_t slice = (size_t)blockIdx.x * a.tile_cap;
     // ---- stage C2: one record per index minimizer that stage C1 left ----
     uint32_t written = 0;
-    for (uint32_t i0 = 0; i0 < n_b && a.fuse >= 0; i0 += 64) {
+    for (uint32_t i0 = 0; i0 < n_b && (!FUSE || a.fuse >= 0); i0 += 64) {
         const uint32_t i = i0 + (uint32_t)lane;
-        const bool todo = i < n_b && !(list[i] & 0x8000u);
+        const bool todo = i < n_b && (!FUSE || !(list[i] & 0x8000u));
         const uint64_t tm = __ballot(todo);
         if (todo) {
             const Entry e = decode(i);
-            if (!a.fuse) my_hits += e.sf.y;
+            if (!FUSE) my_hits += e.sf.y;
             const uint32_t at = base + written + lanes_below(tm);
             if (e.pos >= (1ull << HIT_POS_BITS)) atomicOr(a.overflow, 2u);
             else if (at < a.tile_cap) {
@@ -501,7 +501,7 @@ __device__ __forceinline__ void sketch_wave_tile(const SketchArgs& a, uint32_t t
         atomicAdd(&s_sum[3], fast_hits);
     }
     __syncthreads();
-    if (wave == 0 && lane == 0 && a.fuse >= 0) {
+    if (wave == 0 && lane == 0 && (!FUSE || a.fuse >= 0)) {
         a.tile_count[blockIdx.x] = wg_total < a.tile_cap ? wg_total : a.tile_cap;
         a.tile_hits[blockIdx.x] = s_sum[0];
         a.tile_nmin[blockIdx.x] = s_sum[1];
@@ -519,7 +519,7 @@ __device__ __forceinline__ void sketch_wave_tile(const SketchArgs& a, uint32_t t
 // A ticket per workgroup of 16 waves / 112 KB of LDS: 10 ms, 5.3 ms even without the scan (4 waves per SIMD).  No tickets,
 // tile = blockIdx order, two-level scan (64 tiles per group, look-back over groups): 13 ms against 3.8 ms without the scan --
 // a tile waited 48 us for its 63 group neighbours and 40 us for the previous group, four times its own 12 us.
-template <int K, int W>
+template <int K, int W, bool FUSE>
 __global__ __launch_bounds__(SW_WAVES * 64) void sketch_wave_kernel(SketchArgs a, uint32_t n_tiles)
 {
     __shared__ WaveLds s_lds[SW_WAVES];
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(SW_WAVES * 64) void sketch_wave_kernel(SketchArgs a
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x < 4) s_sum[threadIdx.x] = 0; // (added to after the first barrier at the earliest)
     const uint32_t tile = blockIdx.x * SW_WAVES + (uint32_t)wave;
-    sketch_wave_tile<K, W>(a, tile, tile < n_tiles, s_lds[wave], s_nb, s_sum, lane, wave);
+    sketch_wave_tile<K, W, FUSE>(a, tile, tile < n_tiles, s_lds[wave], s_nb, s_sum, lane, wave);
 }
 
 hipError_t launch_sketch_wave(const SketchArgs& a, hipStream_t stream, KernelTimer timer)
@@ -537,10 +537,10 @@ hipError_t launch_sketch_wave(const SketchArgs& a, hipStream_t stream, KernelTim
     HIP_TRY(launch_tile_first_read(a.offsets, a.n_reads, SW_EVAL, SW_G, n_tiles, a.tile_first_read, stream));
     const dim3 g(wave_n_slices(a.n_bases)), b(SW_WAVES * 64);
     if (timer.begin) HIP_TRY(hipEventRecord(timer.begin, stream));
-    if (a.w == 11)
-        hipLaunchKernelGGL((sketch_wave_kernel<15, 11>), g, b, 0, stream, a, n_tiles);
-    else
-        hipLaunchKernelGGL((sketch_wave_kernel<15, 14>), g, b, 0, stream, a, n_tiles);
+    if (a.w == 11 && !a.fuse) hipLaunchKernelGGL((sketch_wave_kernel<15, 11, false>), g, b, 0, stream, a, n_tiles);
+    else if (a.w == 11) hipLaunchKernelGGL((sketch_wave_kernel<15, 11, true>), g, b, 0, stream, a, n_tiles);
+    else if (!a.fuse) hipLaunchKernelGGL((sketch_wave_kernel<15, 14, false>), g, b, 0, stream, a, n_tiles);
+    else hipLaunchKernelGGL((sketch_wave_kernel<15, 14, true>), g, b, 0, stream, a, n_tiles);
     HIP_TRY(hipGetLastError());
     if (timer.end) HIP_TRY(hipEventRecord(timer.end, stream));
     return hipSuccess;
