@@ -133,6 +133,16 @@ WORKLOADS = {
 }
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def make_panel(synth, which):
     return {"mtb_8d": synth.mtb_8d_panel, "mtb_like": synth.mtb_like_panel, "big": synth.big_panel}[which]()
 
@@ -508,7 +518,7 @@ def main():
                                    "sample": f"first {ns} reads ({nb} bases) of rank 0's shard, oracle/oracle.c on {threads} threads "
                                              f"(disjoint read ranges), {cpu_s:.1f}s",
                                    "single_thread_value": ns1 / cpu1_s, "single_thread_sample": f"first {ns1} reads, {cpu1_s:.1f}s",
-                                   "host_cores_available": os.cpu_count(), "parity_vs_hip_on_sample": parity}
+                                   "host_cores_available": os.cpu_count(), "cpu_model": cpu_model(), "parity_vs_hip_on_sample": parity}
         if args.e2e and world == 1 and args.workload != "nanopore" and not args.no_checks:
             try:
                 out["e2e"] = e2e_leg(torch, ctx, synth, bases, n_reads, args.read_len, covg)

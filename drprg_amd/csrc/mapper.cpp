@@ -307,19 +307,22 @@ void Mapper::launch_lane(Lane& lane, hipStream_t stream, const uint8_t* d_bases,
     lane.scratch_zero = true;
 }
 
-// The wait polls the stream: an interrupt-driven hipStreamSynchronize wakes up tens of microseconds late, which is
-// visible at 0.6 ms per batch.
+// The wait polls the stream for a short while first: an interrupt-driven hipStreamSynchronize wakes up tens of microseconds late,
+// which is visible at 0.7 ms per batch.  Only for a short while (~2 ms of polls): a longer batch does not notice the late wake-up,
+// and a host core that spins for it is a core the FASTQ parser threads (or the other ranks of a node) do not have.
+// DRPRG_HIP_SPIN=0: never poll.
 void Mapper::wait_stream(hipStream_t stream)
 {
-    for (int spins = 0;; ++spins) {
+    static const bool spin = [] {
+        const char* e = std::getenv("DRPRG_HIP_SPIN");
+        return !(e && std::atoi(e) == 0);
+    }();
+    for (int spins = 0; spin && spins < 2048; ++spins) {
         const hipError_t e = hipStreamQuery(stream);
         if (e == hipSuccess) return;
         if (e != hipErrorNotReady) HIPCHK(e);
-        if (spins > (1 << 22)) { // something is badly late (a multi-second batch): stop burning the core
-            HIPCHK(hipStreamSynchronize(stream));
-            return;
-        }
     }
+    HIPCHK(hipStreamSynchronize(stream));
 }
 
 // hits in d_key_a_/d_val_a_ -> clusters -> coverage (the generic pipeline).  ordered: the hits are ordered by
