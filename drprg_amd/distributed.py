@@ -33,8 +33,18 @@ def reduce_coverage(covg, prg_reads, total_bases, group=None):
 
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return int(total_bases)
-    dist.all_reduce(covg, op=dist.ReduceOp.SUM, group=group)
-    dist.all_reduce(prg_reads, op=dist.ReduceOp.SUM, group=group)
-    t = torch.tensor([int(total_bases)], dtype=torch.int64, device=covg.device)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-    return int(t.item())
+    # ONE collective: coverage, per-PRG cluster counts and the base count travel in one int32 buffer --
+    # the message is a few hundred KB at most, so the exchange is latency-bound and every extra collective costs a round trip
+    tb = int(total_bases)
+    n_c, n_p = covg.numel(), prg_reads.numel()
+    buf = torch.empty(n_c + n_p + 4, dtype=torch.int32, device=covg.device)
+    buf[:n_c] = covg.reshape(-1)
+    buf[n_c:n_c + n_p] = prg_reads.reshape(-1)
+    # the 64-bit base count as four 16-bit pieces (int32 lanes do not carry into each other)
+    pieces = torch.tensor([tb & 0xFFFF, (tb >> 16) & 0xFFFF, (tb >> 32) & 0xFFFF, tb >> 48], dtype=torch.int32, device=covg.device)
+    buf[n_c + n_p:] = pieces
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    covg.reshape(-1).copy_(buf[:n_c])
+    prg_reads.reshape(-1).copy_(buf[n_c:n_c + n_p])
+    p = [int(x) for x in buf[n_c + n_p:].tolist()]  # each piece summed over <= 2^15 ranks stays below 2^31
+    return p[0] + (p[1] << 16) + (p[2] << 32) + (p[3] << 48)
