@@ -1,3 +1,4 @@
+#include <set>
 #include <atomic>
 #include <mutex>
 #include <fstream>
@@ -7,6 +8,7 @@
 #include "fastx.h"
 #include "genotype.h"
 #include "ingest.h"
+#include "denovo.h"
 #include "mapper.h"
 #include <cstdlib>
 #include <cstring>
@@ -30,6 +32,9 @@ struct drprg_hip_ctx {
     int threads = 4; // parser threads of drprg_hip_map_fastx
     uint32_t ginfo[4] = { 0, 0, 0, 0 };
     std::vector<VcfRecord> last_records; // of the last drprg_hip_genotype (drprg_hip_genotype_alleles)
+    // the last drprg_hip_discover_reads: what drprg_hip_update_prg applies
+    GenotypeResult last_discover;
+    std::vector<NovelVariant> last_variants;
     // page-locked ingest blocks of drprg_hip_map_fastx, recycled between calls
     std::mutex pin_mu;
     std::vector<std::pair<void*, size_t>> pin_free, pin_busy;
@@ -417,6 +422,55 @@ int drprg_hip_discover(drprg_hip_ctx* ctx, const char* vcf_refs, const char* out
         std::ofstream f(dir + "/denovo_sequences.fa");
     }
     if (n_candidates) *n_candidates = (uint32_t)r.candidates.size();
+    API_END(ctx)
+}
+
+int drprg_hip_discover_reads(drprg_hip_ctx* ctx, const char* reads_path, const char* vcf_refs, const char* out_dir, const char* sample,
+    int list_loci, uint32_t out[3])
+{
+    API_BEGIN(ctx)
+    if (!out_dir || !reads_path) throw Error(DRPRG_EINVAL, "null argument");
+    sync_host_coverage(ctx);
+    const DiscoverParams dp;
+    GenotypeResult r = genotype(ctx->index, ctx->covg, ctx->prg_reads, ctx->total_bases, ctx->params, vcf_refs ? vcf_refs : "", dp);
+    const std::string dir = out_dir, smp = sample && *sample ? sample : "sample";
+    {
+        std::ofstream o(dir + "/candidate_regions.tsv");
+        o << "#locus\tstart\tend\tlow_start\tlow_end\tmax_covg\tconsensus\n";
+        for (const CandidateRegion& c : r.candidates)
+            o << c.chrom << "\t" << c.start << "\t" << c.end << "\t" << c.low_start << "\t" << c.low_end << "\t" << c.max_covg << "\t" << c.seq << "\n";
+        if (!o) throw Error(DRPRG_EIO, "cannot write " + dir + "/candidate_regions.tsv");
+    }
+    // accurate reads only: the exact-anchor pile-up needs reads whose bases between two 15-mers can be taken at face value
+    std::vector<NovelVariant> variants;
+    if (ctx->params.illumina) variants = assemble_candidate_regions(r, reads_path, ctx->threads, dp);
+    write_denovo_paths(dir, smp, r, variants, list_loci != 0);
+    if (out) {
+        out[0] = (uint32_t)r.candidates.size();
+        out[1] = (uint32_t)variants.size();
+        std::set<std::string> loci;
+        for (const NovelVariant& v : variants) loci.insert(v.chrom);
+        out[2] = (uint32_t)loci.size();
+    }
+    ctx->last_discover = std::move(r);
+    ctx->last_variants = std::move(variants);
+    API_END(ctx)
+}
+
+int drprg_hip_update_prg(drprg_hip_ctx* ctx, const char* out_prg, uint32_t* n_applied)
+{
+    API_BEGIN(ctx)
+    if (!out_prg) throw Error(DRPRG_EINVAL, "null output path");
+    std::vector<std::pair<std::string, std::string>> prgs;
+    for (const LocalGraph& g : ctx->index.prgs) prgs.emplace_back(g.name, g.prg);
+    std::vector<std::string> skipped;
+    const uint32_t n = update_prgs(prgs, ctx->last_discover, ctx->last_variants, &skipped);
+    for (const std::string& s : skipped)
+        std::fprintf(stderr, "drprg-hip: novel variant at %s overlaps an existing site of the PRG and is not added to it\n", s.c_str());
+    std::ofstream o(out_prg);
+    for (auto& p : prgs) o << ">" << p.first << "\n" << p.second << "\n";
+    if (!o) throw Error(DRPRG_EIO, std::string("cannot write ") + out_prg);
+    if (n_applied) *n_applied = n;
     API_END(ctx)
 }
 

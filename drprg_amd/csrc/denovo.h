@@ -1,0 +1,28 @@
+// denovo.h -- novel variants inside the candidate regions of `discover`, and the PRG update they lead to.  See denovo.cpp.
+#pragma once
+#include "genotype.h"
+
+namespace drprg {
+
+struct NovelVariant {
+    std::string chrom;
+    uint32_t prg = 0;
+    uint32_t pos = 0; // 0-based on the locus' called consensus
+    std::string ref, alt; // either may be empty (insertion / deletion)
+    uint32_t support = 0, spanning = 0; // reads that spell alt between the anchors / reads that hold both anchors
+};
+
+// second pass over the reads file (host threads): exact-anchor pile-up over every candidate region of `gr`
+std::vector<NovelVariant> assemble_candidate_regions(const GenotypeResult& gr, const std::string& reads_path, int threads, const DiscoverParams& dp);
+
+// <dir>/denovo_paths.txt (+ denovo_sequences.fa, denovo_variants.tsv).  list_loci = false keeps the "0 loci" line: the
+// variants are then reported in denovo_variants.tsv only and the caller's make_prg step is not triggered.
+void write_denovo_paths(const std::string& dir, const std::string& sample, const GenotypeResult& gr, const std::vector<NovelVariant>& variants,
+    bool list_loci);
+
+// prgs: (name, PRG string) per locus in file order; every variant that lies strictly inside one local node of its locus'
+// called path becomes a new site.  Returns the number applied; `skipped` (may be null) receives locus:pos of the others.
+uint32_t update_prgs(std::vector<std::pair<std::string, std::string>>& prgs, const GenotypeResult& gr, const std::vector<NovelVariant>& variants,
+    std::vector<std::string>* skipped);
+
+} // namespace drprg

@@ -101,7 +101,7 @@ void usage()
         "drprg predict -x <index dir | species[@version]> -i <reads.fq[.gz]> [-o DIR] [-s SAMPLE] [-I] [-S]\n"
         "              [-f MAF] [-d MIN_COVG] [-D MAX_COVG] [-b MIN_STRAND_BIAS] [-g MIN_GT_CONF] [-L MAX_INDEL] [-K MIN_FRS]\n"
         "              [-C MIN_CLUSTER_SIZE] [--debug] [-v] [-t THREADS]\n"
-        "MI355X-native hot path; -p/-m/-M (external tools) are accepted and ignored.\n");
+        "MI355X-native hot path; -p/-m/-M (external tools) are accepted and not needed: novel variants update the PRG in process.\n");
 }
 
 } // namespace
@@ -204,16 +204,37 @@ int main(int argc, char** argv)
     // discover + map share ONE pass over the reads (the reference runs two, /root/reference/src/predict.rs:248-302)
     if (int rc = drprg_hip_map_fastx(ctx, input.c_str())) die(drprg_hip_last_error(ctx), -rc);
     {
-        // discover's outputs (/root/reference/src/predict.rs:247-256): candidate regions are located, but there is no local
-        // assembly, so no novel variant is ever added to the PRG (MakePrg::update keeps it, src/lib.rs:299-301)
+        // discover (/root/reference/src/predict.rs:247-256): candidate regions of every locus' called consensus, then -- accurate
+        // reads only -- a host-side pile-up of the reads over them.  Novel variants update the PRG (what MakePrg::update does with
+        // make_prg + mafft in the reference, src/predict.rs:260-284, here a new site per variant: -m/-M are not needed), the updated
+        // PRG is indexed in the output directory and the reads are mapped again against it.
         std::string ddir = outdir + "/discover";
         mkdir(ddir.c_str(), 0777);
-        uint32_t n_cand = 0;
-        if (int rc = drprg_hip_discover(ctx, (index + "/genes.fa").c_str(), ddir.c_str(), sample.c_str(), &n_cand)) die(drprg_hip_last_error(ctx), -rc);
-        std::fprintf(stderr,
-            "drprg (hip): WARNING: de novo variant discovery is not implemented: %u low-coverage candidate region(s) in "
-            "%s/candidate_regions.tsv, no local assembly, the PRG is used unchanged (-m/-M are ignored). Variants absent from the "
-            "index will not be called.\n", n_cand, ddir.c_str());
+        uint32_t found[3] = { 0, 0, 0 };
+        if (int rc = drprg_hip_discover_reads(ctx, input.c_str(), (index + "/genes.fa").c_str(), ddir.c_str(), sample.c_str(), 1, found))
+            die(drprg_hip_last_error(ctx), -rc);
+        if (!illumina)
+            std::fprintf(stderr,
+                "drprg (hip): WARNING: de novo variant discovery needs accurate reads (-I): %u low-coverage candidate region(s) are listed in "
+                "%s/candidate_regions.tsv but not assembled; variants absent from the index will not be called.\n", found[0], ddir.c_str());
+        else if (verbose || found[1])
+            std::fprintf(stderr, "[drprg-hip] discover: %u candidate region(s), %u novel variant(s) in %u locus/loci\n", found[0], found[1], found[2]);
+        if (found[1]) {
+            const std::string updated = outdir + "/updated.dr.prg";
+            uint32_t applied = 0;
+            if (int rc = drprg_hip_update_prg(ctx, updated.c_str(), &applied)) die(drprg_hip_last_error(ctx), -rc);
+            if (applied) {
+                if (int rc = drprg_hip_index(updated.c_str(), w, k, threads)) die(drprg_hip_last_error(nullptr), -rc);
+                drprg_hip_close(ctx);
+                ctx = devices.size() > 1 ? drprg_hip_open_multi(updated.c_str(), w, k, devices.data(), (int)devices.size(), 1)
+                                         : drprg_hip_open(updated.c_str(), w, k, device);
+                if (!ctx) die(std::string("cannot open the updated PRG: ") + drprg_hip_last_error(nullptr));
+                if (int rc = drprg_hip_set_opts(ctx, &mo)) die(drprg_hip_last_error(ctx), -rc);
+                drprg_hip_set_threads(ctx, threads);
+                if (int rc = drprg_hip_map_fastx(ctx, input.c_str())) die(drprg_hip_last_error(ctx), -rc);
+                if (verbose) std::fprintf(stderr, "[drprg-hip] %u novel site(s) added to %s; reads mapped again\n", applied, updated.c_str());
+            }
+        }
     }
     const std::string pandora_vcf = outdir + "/pandora_genotyped.vcf";
     if (int rc = drprg_hip_genotype(ctx, (index + "/genes.fa").c_str(), pandora_vcf.c_str(), "sample")) die(drprg_hip_last_error(ctx), -rc);

@@ -305,7 +305,7 @@ struct LocusGenotyper {
 
     // per-base coverage of the consensus (a base takes the largest fwd+rev coverage among the path's k-mer nodes that
     // cover it), low-coverage runs, merged and padded (pandora discover's candidate regions)
-    void candidate_regions(const DiscoverParams& dp, std::vector<CandidateRegion>& regions) const
+    void candidate_regions(const DiscoverParams& dp, uint32_t prg_index, std::vector<CandidateRegion>& regions, std::vector<LocusConsensus>& consensus) const
     {
         Route path;
         consensus_chain(0, path);
@@ -338,9 +338,18 @@ struct LocusGenotyper {
             if (!merged.empty() && r.first <= merged.back().second + dp.merge_dist) merged.back().second = r.second;
             else merged.push_back(r);
         }
+        {
+            LocusConsensus lc;
+            lc.chrom = g.name;
+            lc.prg = prg_index;
+            lc.seq = cons;
+            for (uint32_t n : path) lc.nodes.push_back(ConsensusNode { n, g.nodes[n].start, g.nodes[n].end, g.nodes[n].seq });
+            consensus.push_back(std::move(lc));
+        }
         for (auto& r : merged) {
             CandidateRegion cr;
             cr.chrom = g.name;
+            cr.prg = prg_index;
             cr.low_start = r.first;
             cr.low_end = r.second;
             cr.start = r.first > dp.padding ? r.first - dp.padding : 0;
@@ -348,6 +357,8 @@ struct LocusGenotyper {
             for (uint32_t b = r.first; b < r.second; ++b)
                 if (covered[b]) cr.max_covg = std::max(cr.max_covg, base[b]);
             cr.seq = cons.substr(cr.start, cr.end - cr.start);
+            if (cr.start >= dp.anchor_len) cr.left_anchor = cons.substr(cr.start - dp.anchor_len, dp.anchor_len);
+            if (cr.end + dp.anchor_len <= L) cr.right_anchor = cons.substr(cr.end, dp.anchor_len);
             regions.push_back(std::move(cr));
         }
     }
@@ -423,7 +434,7 @@ GenotypeResult genotype(const PrgIndex& idx, const std::vector<uint32_t>& covg, 
         lg.init();
         uint32_t refpos = 0;
         lg.walk_chain(0, refpos);
-        lg.candidate_regions(dp, res.candidates);
+        lg.candidate_regions(dp, (uint32_t)pi, res.candidates, res.consensus);
     }
     std::sort(res.present.begin(), res.present.end());
     std::sort(res.absent.begin(), res.absent.end());

@@ -31,16 +31,34 @@ struct VcfRecord {
 // (/root/reference/src/lib.rs:513-578) ends with these; pandora then assembles the reads over each region locally.
 struct CandidateRegion {
     std::string chrom;
+    uint32_t prg = 0;              // index of the locus in the PRG file
     uint32_t start = 0, end = 0;   // 0-based half-open on the consensus sequence, padding included
     uint32_t low_start = 0, low_end = 0; // the low-coverage bases themselves
     uint32_t max_covg = 0;         // largest per-base coverage inside [low_start, low_end)
     std::string seq;               // consensus[start, end)
+    std::string left_anchor, right_anchor; // the anchor_len bases of the consensus before `start` / after `end` (empty at a locus end)
+};
+
+// the called consensus of a locus as a walk through its local graph (what pandora's denovo_paths.txt lists as "nodes")
+struct ConsensusNode {
+    uint32_t id, start, end; // local node, its [start, end) in the PRG string
+    std::string seq;
+};
+struct LocusConsensus {
+    std::string chrom;
+    uint32_t prg = 0;
+    std::vector<ConsensusNode> nodes;
+    std::string seq;
 };
 
 // pandora discover's candidate-region options [UPSTREAM-MEMORY: --min-candidate-covg 3, --min-candidate-len 1,
 // --max-candidate-len 50, --pad 22, --merge 22]
 struct DiscoverParams {
     uint32_t min_candidate_covg = 3, min_candidate_len = 1, max_candidate_len = 50, padding = 22, merge_dist = 22;
+    uint32_t anchor_len = 15;     // exact-match anchors either side of a region (denovo.cpp)
+    uint32_t min_support = 3;     // reads that must spell the novel allele ...
+    double min_fraction = 0.5;    // ... and their share of the reads that span the region
+    uint32_t max_len_change = 30; // longest insertion / deletion accepted between the anchors
 };
 
 struct GenotypeResult {
@@ -50,6 +68,7 @@ struct GenotypeResult {
     std::vector<std::string> absent;
     std::vector<VcfRecord> records;   // sorted by (chrom, pos, ref, alts)
     std::vector<CandidateRegion> candidates; // low-coverage regions of the called consensus of every present locus
+    std::vector<LocusConsensus> consensus;   // of the loci that have candidate regions
 };
 
 // per-allele statistics from the k-mer coverages of one allele (SampleInfo)

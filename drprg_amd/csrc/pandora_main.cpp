@@ -216,20 +216,30 @@ int cmd_discover(const Args& a)
     double t0 = now_s();
     if (int rc = drprg_hip_map_fastx(ctx, reads.c_str())) die(drprg_hip_last_error(ctx), -rc);
     report_counters(ctx, now_s() - t0);
-    // The mapping half of discover is the same kernels as `map`; its product here is (1) the candidate regions -- stretches
-    // of each locus' called consensus that the reads do not support -- and (2) the coverage vector, kept for the `map` call
-    // drprg issues next.  De novo local assembly of those regions is NOT implemented (NEXT-2):
-    // denovo_paths.txt reports no locus with novel variation, which makes drprg keep the index PRG unchanged
-    // (/root/reference/src/lib.rs:299-301).
-    uint32_t n_cand = 0;
-    if (int rc = drprg_hip_discover(ctx, nullptr, a.outdir.c_str(), sample.c_str(), &n_cand)) die(drprg_hip_last_error(ctx), -rc);
+    // The mapping half of discover is the same kernels as `map`; its products are (1) the candidate regions -- stretches of each
+    // locus' called consensus that the reads do not support --, (2) for accurate reads (-I) the novel variants a host-side pile-up of
+    // the reads finds in them, and (3) the coverage vector, kept for the `map` call drprg issues next on the unchanged PRG.
+    // denovo_paths.txt lists the loci with novel variants only when DRPRG_HIP_DENOVO_PATHS=1: the caller then runs make_prg on this
+    // file, and its layout is written from the one example in the reference tree (/root/reference/src/lib.rs:3010-3038) without a
+    // make_prg here to try it on; by default the file reports 0 loci (drprg keeps the index PRG, /root/reference/src/lib.rs:299-301)
+    // and the findings are in denovo_variants.tsv.
+    const char* paths_env = std::getenv("DRPRG_HIP_DENOVO_PATHS");
+    const int list_loci = paths_env && std::atoi(paths_env) != 0;
+    uint32_t found[3] = { 0, 0, 0 };
+    if (int rc = drprg_hip_discover_reads(ctx, reads.c_str(), nullptr, a.outdir.c_str(), sample.c_str(), list_loci, found))
+        die(drprg_hip_last_error(ctx), -rc);
     if (drprg_hip_save_coverage(ctx, (a.outdir + "/" + COVERAGE_CACHE).c_str(), run_tag(a, reads).c_str()) != 0)
         std::fprintf(stderr, "pandora (drprg-hip): warning: could not keep the coverage vector for `map`: %s\n", drprg_hip_last_error(ctx));
-    std::fprintf(stderr,
-        "pandora (drprg-hip): WARNING: de novo variant discovery is not implemented in this build: %u low-coverage candidate "
-        "region(s) written to %s/candidate_regions.tsv, no local assembly, denovo_paths.txt reports 0 loci. Variants that are "
-        "not in the PRG will not be called.\n", n_cand, a.outdir.c_str());
-    std::printf("[pandora-hip] discover: %u candidate regions; 0 loci with denovo variants (local assembly not implemented)\n", n_cand);
+    if (!a.illumina)
+        std::fprintf(stderr,
+            "pandora (drprg-hip): WARNING: de novo variant discovery needs accurate reads (-I) in this build: %u low-coverage candidate "
+            "region(s) written to %s/candidate_regions.tsv, not assembled; denovo_paths.txt reports 0 loci.\n", found[0], a.outdir.c_str());
+    else if (found[1] && !list_loci)
+        std::fprintf(stderr,
+            "pandora (drprg-hip): WARNING: %u novel variant(s) in %u locus/loci found (%s/denovo_variants.tsv) but denovo_paths.txt reports 0 "
+            "loci, so the PRG will not be updated: set DRPRG_HIP_DENOVO_PATHS=1 to list them for make_prg.\n", found[1], found[2], a.outdir.c_str());
+    std::printf("[pandora-hip] discover: %u candidate regions, %u novel variants in %u loci%s\n", found[0], found[1], found[2],
+        list_loci ? "" : " (not listed in denovo_paths.txt)");
     drprg_hip_close(ctx);
     return 0;
 }

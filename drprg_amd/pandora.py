@@ -143,6 +143,25 @@ class Context:
         assert len(regions) == n.value
         return regions
 
+    def discover_reads(self, reads, vcf_refs, out_dir, sample="sample", list_loci=True):
+        """candidate regions + the pile-up of the reads over them; returns the novel variants [(locus, pos1, ref, alt, support, spanning)]"""
+        out = (C.c_uint32 * 3)()
+        _check(lib.drprg_hip_discover_reads(self._h, os.fsencode(reads), os.fsencode(vcf_refs) if vcf_refs else None, os.fsencode(out_dir),
+                                            sample.encode(), 1 if list_loci else 0, out), self._h)
+        variants = []
+        for line in open(os.path.join(out_dir, "denovo_variants.tsv")):
+            if not line.startswith("#"):
+                f = line.rstrip("\n").split("\t")
+                variants.append((f[0], int(f[1]), "" if f[2] == "." else f[2], "" if f[3] == "." else f[3], int(f[4]), int(f[5])))
+        assert len(variants) == out[1]
+        return variants
+
+    def update_prg(self, out_prg):
+        """the PRG file with the novel variants of the last discover_reads added as sites; returns how many were added"""
+        n = C.c_uint32()
+        _check(lib.drprg_hip_update_prg(self._h, os.fsencode(out_prg), C.byref(n)), self._h)
+        return int(n.value)
+
     def save_coverage(self, path, tag):
         _check(lib.drprg_hip_save_coverage(self._h, os.fsencode(path), tag.encode()), self._h)
 
@@ -278,22 +297,25 @@ class Pandora:
 
     COVERAGE_CACHE = ".drprg_hip_coverage"
 
-    def discover_with(self, prg, query_idx, outdir, args=()):
+    def discover_with(self, prg, query_idx, outdir, args=(), list_loci=False):
         """Pandora::discover_with, /root/reference/src/lib.rs:513-578.  Returns the denovo_paths.txt path.
 
-        Behavioural difference from pandora: the mapping half runs (and its coverage vector is kept under `outdir` for the
-        genotype_with call that follows), low-coverage candidate regions are written to candidate_regions.tsv, but there is
-        no local assembly: denovo_paths.txt always says "0 loci with denovo variants"."""
+        The mapping half runs (its coverage vector is kept under `outdir` for the genotype_with call that follows), candidate
+        regions go to candidate_regions.tsv, and with accurate reads (-I) the reads are piled up over them: novel variants go to
+        denovo_variants.tsv.  list_loci=True also lists them in denovo_paths.txt (the caller's make_prg update then runs on it;
+        the layout follows the one example in the reference tree and could not be tried on make_prg here); the default keeps
+        "0 loci with denovo variants"."""
         import warnings
         os.makedirs(outdir, exist_ok=True)
         with open(query_idx) as fh:
             sample, reads = fh.readline().split()[:2]
         with self._mapped_context(prg, reads, args) as ctx:
-            regions = ctx.discover(None, outdir, sample)
+            ctx.set_threads(self._parse_args(args)["threads"])
+            self.novel_variants = ctx.discover_reads(reads, None, outdir, sample, list_loci=list_loci)
             ctx.save_coverage(os.path.join(outdir, self.COVERAGE_CACHE), self._run_tag(prg, reads, args))
-        if regions:
-            warnings.warn(f"discover: {len(regions)} low-coverage candidate region(s) in {len({r['locus'] for r in regions})} "
-                          "locus/loci; de novo local assembly is not implemented, novel variants are NOT added to the PRG")
+        if self.novel_variants and not list_loci:
+            warnings.warn(f"discover: {len(self.novel_variants)} novel variant(s) found (denovo_variants.tsv) but not listed in "
+                          "denovo_paths.txt: the PRG will not be updated")
         path = os.path.join(outdir, "denovo_paths.txt")
         if not os.path.exists(path):
             raise DependencyError("MissingExpectedOutput", path)

@@ -111,6 +111,20 @@ int drprg_hip_genotype_info(const drprg_hip_ctx* ctx, uint32_t out[4]);
  * /root/reference/src/lib.rs:648-697 parses), so a sample's off-panel variants are located but never added to the PRG.
  * *n_candidates (may be NULL) receives the number of candidate regions. */
 int drprg_hip_discover(drprg_hip_ctx* ctx, const char* vcf_refs, const char* out_dir, const char* sample, uint32_t* n_candidates);
+/* drprg_hip_discover + the second half of `pandora discover`: a host-side pass over the reads file piles up, per candidate
+ * region, what the reads spell between the exact 15-base anchors either side of it; the most frequent allele that differs
+ * from the called consensus (>= 3 reads, >= half of the spanning reads) is a novel variant (accurate reads only: with
+ * illumina = 0 in the map options regions are reported, not assembled).  Writes candidate_regions.tsv, denovo_variants.tsv,
+ * denovo_sequences.fa and denovo_paths.txt; list_loci != 0 lists the loci and their variants in denovo_paths.txt in pandora's
+ * layout (/root/reference/src/lib.rs:3010-3038) so that the caller's make_prg update runs, 0 keeps "0 loci with denovo
+ * variants".  out[0..2] = candidate regions, novel variants, loci with novel variants. */
+int drprg_hip_discover_reads(drprg_hip_ctx* ctx, const char* reads_path, const char* vcf_refs, const char* out_dir, const char* sample,
+    int list_loci, uint32_t out[3]);
+/* What MakePrg::update does in the reference (/root/reference/src/lib.rs:279-456) for a host without make_prg / mafft: writes the
+ * context's PRG file again with every novel variant of the last drprg_hip_discover_reads that lies inside one local node of its
+ * locus' called path added as a new site (index it with drprg_hip_index, open it, map again).  *n_applied: sites added. */
+int drprg_hip_update_prg(drprg_hip_ctx* ctx, const char* out_prg, uint32_t* n_applied);
+
 /* Coverage hand-over between `discover` and the `map` that follows it on the same reads and PRG
  * (/root/reference/src/predict.rs:248-255, :296-302): save writes vector + counters under `tag`; load returns 0 and installs
  * them only if the file exists, is intact and carries the same tag and index shape (-ENOENT otherwise: map the reads). */

@@ -352,7 +352,7 @@ def test_cli_map_end_to_end(tmp_path, oracle):
     r = subprocess.run([PANDORA_EXE, "discover", "-g", "4411532", "--max-covg", "4294967295", "-v", "-o", str(out2 / "discover"),
                         "-t", "1", "-w", str(w), "-k", str(k), "-c", "10", "-I", prg, str(q)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    assert "WARNING: de novo variant discovery is not implemented" in r.stderr
+    assert "discover:" in r.stdout and (out2 / "discover" / "denovo_variants.tsv").exists()
     from drprg_amd import Pandora
     assert Pandora.list_prgs_with_novel_variants(str(out2 / "discover" / "denovo_paths.txt")) == []
     assert (out2 / "discover" / "candidate_regions.tsv").exists()

@@ -111,3 +111,53 @@ def test_absent_gene_is_reported(tmp_path):
     assert res["genes"]["absent"] == ["pncA"]
     pza = res["susceptibility"]["Pyrazinamide"]
     assert pza["predict"] == "R" and pza["evidence"][0]["variant"] == "gene_absent" and pza["evidence"][0]["gene"] == "pncA"
+
+
+def test_off_panel_variant_is_discovered_and_reported_as_unknown(tmp_path):
+    """The reference's reason for running discover (/root/reference/src/predict.rs:247-302): a non-synonymous variant that is
+    NOT in the panel must come out as an unknown (`U`) call, not as susceptible.  The sample carries a missense SNP in the
+    middle of katG's coding sequence at a position the panel holds no site for: discover finds it in the reads, the PRG in
+    the output directory gains the site, the reads are mapped again, the VCF calls the new allele and the report holds the
+    evidence with prediction U for katG's drug; the same reads with discovery impossible (no -I) stay S."""
+    from drprg_amd import synth
+    idx, panel, sites = _make_index(tmp_path)
+    g = panel.names.index("katG")
+    ref = panel.refs[g]
+    # a codon of katG (padding 100: the CDS starts at offset 100) whose neighbourhood holds no panel site
+    taken = [p for _, p, r, _ in sites["katG"] for p in range(p - 40, p + len(r) + 40)]
+    pos = next(p for p in range(100 + 3 * 250, len(ref) - 400, 3) if p not in taken and p + 1 not in taken and p + 2 not in taken)
+    codon = ref[pos:pos + 3]
+    # second base of the codon -> a change that is never synonymous for the standard table except ... pick one that alters the residue
+    alt_base = next(b for b in "ACGT" if b != codon[1] and _aa(codon[0] + b + codon[2]) not in (_aa(codon), "*"))
+    mutated = ref[:pos + 1] + alt_base + ref[pos + 2:]
+    rng = np.random.default_rng(7)
+    spacer = synth.random_seq(rng, 300)
+    genome = spacer + spacer.join(mutated if gi == g else r for gi, r in enumerate(panel.refs)) + spacer
+    gn = np.frombuffer(genome.encode(), np.uint8)
+    starts = rng.integers(0, len(gn) - 150, size=16000)
+    block = gn[starts[:, None] + np.arange(150)]
+    rev = rng.random(len(starts)) < 0.5
+    block[rev] = synth._COMP[block[rev][:, ::-1]]
+    bases, offs = block.reshape(-1), np.arange(len(starts) + 1, dtype=np.uint64) * np.uint64(150)
+    res, out = _predict(tmp_path, idx, bases, offs, "novel")
+    variants = [l.split("\t") for l in open(out / "discover" / "denovo_variants.tsv") if not l.startswith("#")]
+    assert len(variants) == 1 and variants[0][0] == "katG" and int(variants[0][1]) == pos + 2 and variants[0][2:4] == [codon[1], alt_base]
+    assert (out / "updated.dr.prg").exists() and (out / "updated.dr.prg.k15.w11.idx").exists()
+    calls = [t.split("\t") for t in open(out / "pandora_genotyped.vcf") if t.startswith("katG\t")]
+    alt_calls = [t for t in calls if t[9].split(":")[0] not in ("0", ".")]
+    assert len(alt_calls) == 1 and int(alt_calls[0][1]) == pos + 2 and alt_calls[0][3] == codon[1] and alt_calls[0][4] == alt_base
+    evid = [(d, e["variant"], v["predict"]) for d, v in res["susceptibility"].items() for e in v["evidence"] if e["gene"] == "katG"]
+    aa_pos = (pos - 100) // 3 + 1
+    assert evid and all(p == "U" for _, _, p in evid), res["susceptibility"]
+    assert all(var == f"{_aa(codon)}{aa_pos}{_aa(codon[0] + alt_base + codon[2])}" for _, var, _ in evid), evid
+    assert {d for d, _, _ in evid} == {"Isoniazid"}
+    # every other drug stays susceptible
+    assert all(v["predict"] == "S" for d, v in res["susceptibility"].items() if d != "Isoniazid")
+
+
+_CODONS = {a + b + c: aa for (a, b, c), aa in zip(((x, y, z) for x in "TCAG" for y in "TCAG" for z in "TCAG"),
+                                                  "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG")}
+
+
+def _aa(codon):
+    return _CODONS[codon]

@@ -456,3 +456,129 @@ def test_coverage_hand_over_between_discover_and_map(tmp_path, oracle):
     open(cache, "r+b").truncate(100)
     with pytest.raises(Exception):
         ctx.load_coverage(cache, "tag-A")
+
+
+# ---- discover, second half: novel variants from the reads over the candidate regions, PRG update, re-genotyping ----------
+def _denovo_sample(tmp_path, oracle, kind):
+    """reads (FASTQ on disk + arrays) of a sample whose locus g1 differs from every PRG path at one place (kind: snp / del / ins),
+    well inside a site-free stretch; the locus sits inside flanks so that coverage does not thin out at its ends"""
+    from drprg_amd import Context, synth
+    w, k = 11, 15
+    panel = synth.small_panel(seed=31, n_loci=3, length=900, site_every=60)
+    prg, genes = str(tmp_path / "dr.prg"), str(tmp_path / "genes.fa")
+    panel.write(prg, genes)
+    rng = np.random.default_rng(4)
+    tree = panel.trees[1]
+    cur, best = 0, (0, 0)
+    for seg in tree:
+        if isinstance(seg, str):
+            if len(seg) > best[0]:
+                best = (len(seg), cur + len(seg) // 2)
+            cur += len(seg)
+        else:
+            cur += len(seg.alleles[0][0]) if isinstance(seg.alleles[0][0], str) else 0
+    pos = best[1]
+    ref1 = panel.refs[1]
+    if kind == "snp":
+        want = (pos, ref1[pos], "ACGT".replace(ref1[pos], "")[0])
+        mutated = ref1[:pos] + want[2] + ref1[pos + 1:]
+    elif kind == "del":
+        want = (pos, ref1[pos:pos + 3], "")
+        mutated = ref1[:pos] + ref1[pos + 3:]
+    else:
+        ins = "ACGTA".replace(ref1[pos], "")[:2] + "T"
+        want = (pos, "", ins)
+        mutated = ref1[:pos] + ins + ref1[pos:]
+    reads = []
+    for locus in range(3):
+        hap = mutated if locus == 1 else panel.refs[locus]
+        h = np.frombuffer((synth.random_seq(rng, 200) + hap + synth.random_seq(rng, 200)).encode(), np.uint8)
+        for s in rng.integers(0, len(h) - 150, size=900):
+            r = h[s:s + 150]
+            reads.append(synth._COMP[r[::-1]] if rng.random() < 0.5 else r)
+    offs = np.arange(len(reads) + 1, dtype=np.uint64) * np.uint64(150)
+    bases = np.concatenate(reads)
+    fq = str(tmp_path / "reads.fq")
+    synth.write_fastq(fq, bases, offs)
+    ctx = Context(prg, w, k, device=-1, from_files=False)
+    ctx.set_opts(illumina=True, genome_size=4000)
+    md, er = map_params(k, True)
+    covg, prg_reads, _ = oracle.map_reads(bases, offs, oracle.build_index(panel.prgs, w, k), w, k, md, cluster_fraction(er, k), 10)
+    ctx.set_coverage(covg, prg_reads, int(offs[-1]))
+    return ctx, panel, genes, fq, bases, offs, want
+
+
+def _same_variant(got, want, ref):
+    """(pos, ref, alt) equal up to the left/right shift an indel in a repeat allows"""
+    apply = lambda v: ref[:v[0]] + v[2] + ref[v[0] + len(v[1]):]
+    return apply(got) == apply(want) and len(got[1]) - len(got[2]) == len(want[1]) - len(want[2])
+
+
+@pytest.mark.parametrize("kind", ["snp", "del", "ins"])
+def test_discover_finds_the_novel_variant_and_the_updated_prg_calls_it(tmp_path, oracle, kind):
+    """/root/reference/src/predict.rs:247-302 in one piece: discover -> (update PRG) -> index -> map -> genotype.  The reads carry a
+    variant no PRG path holds: discover reports the locus with that variant in denovo_paths.txt (the layout of
+    /root/reference/src/lib.rs:3010-3038, parsed by list_prgs_with_novel_variants), the updated PRG holds one more site, and
+    mapping the same reads against it calls the new allele (here through the oracle; the GPU e2e test does it on the device)."""
+    from drprg_amd import Context, Pandora
+    ctx, panel, genes, fq, bases, offs, want = _denovo_sample(tmp_path, oracle, kind)
+    out = tmp_path / "discover"
+    out.mkdir()
+    ctx.set_threads(4)
+    variants = ctx.discover_reads(fq, genes, str(out))
+    assert len(variants) == 1, variants
+    locus, pos1, ref, alt, support, spanning = variants[0]
+    assert locus == "g1" and support >= 10 and support >= 0.8 * spanning
+    assert _same_variant((pos1 - 1, ref, alt), want, panel.refs[1])
+    assert Pandora.list_prgs_with_novel_variants(str(out / "denovo_paths.txt")) == ["g1"]
+    text = (out / "denovo_paths.txt").read_text()
+    assert "\n1 denovo variants for this locus\n" in text and f"\n{pos1}\t{ref}\t{alt}\n" in text
+    nodes = re.findall(r"\((\d+) \[(\d+), (\d+)\) ([ACGT]*)\)", text)
+    assert len(nodes) >= 3 and all(int(b) - int(a) == len(s) for _, a, b, s in nodes)
+    assert "".join(s for *_, s in nodes) == panel.refs[1]  # the called path of a sample that follows the first alleles
+    # ---- the PRG with the novel allele as a site ----
+    new_prg = str(tmp_path / "updated.dr.prg")
+    assert ctx.update_prg(new_prg) == 1
+    prgs = [l.rstrip("\n") for l in open(new_prg) if not l.startswith(">")]
+    assert prgs[0] == panel.prgs[0] and prgs[2] == panel.prgs[2] and prgs[1] != panel.prgs[1]
+    assert len(re.findall(r" (\d+) ", prgs[1])) == len(re.findall(r" (\d+) ", panel.prgs[1])) + 3  # marker, separator, marker
+    w, k = 11, 15
+    ctx2 = Context(new_prg, w, k, device=-1, from_files=False)
+    ctx2.set_opts(illumina=True, genome_size=4000)
+    md, er = map_params(k, True)
+    covg, prg_reads, _ = oracle.map_reads(bases, offs, oracle.build_index(prgs, w, k), w, k, md, cluster_fraction(er, k), 10)
+    ctx2.set_coverage(covg, prg_reads, int(offs[-1]))
+    vcf = str(tmp_path / "updated.vcf")
+    ctx2.genotype(genes, vcf)
+    called = [(t[0], int(t[1]), t[3], t[4], fmt["GT"]) for t, fmt in _parse_vcf(vcf) if fmt["GT"] not in ("0", ".")]
+    assert len(called) == 1 and called[0][0] == "g1"
+    _, vpos, vref, valt, gt = called[0]
+    assert _same_variant((vpos - 1, vref, valt.split(",")[int(gt) - 1]), want, panel.refs[1])
+    # ... and nothing is left to discover on the updated PRG
+    out2 = tmp_path / "discover2"
+    out2.mkdir()
+    assert ctx2.discover_reads(fq, genes, str(out2)) == []
+
+
+def test_discover_reports_no_novel_variant_for_a_sample_the_panel_explains(tmp_path, oracle):
+    ctx, panel, genes, fq, bases, offs, _ = _denovo_sample(tmp_path, oracle, "snp")
+    # the same reads against a context whose coverage comes from reference-only reads: no candidate region, nothing assembled
+    from drprg_amd import Context, Pandora, synth
+    rng = np.random.default_rng(5)
+    reads = []
+    for locus in range(3):
+        h = np.frombuffer((synth.random_seq(rng, 200) + panel.refs[locus] + synth.random_seq(rng, 200)).encode(), np.uint8)
+        reads += [h[s:s + 150] for s in rng.integers(0, len(h) - 150, size=700)]
+    offs2 = np.arange(len(reads) + 1, dtype=np.uint64) * np.uint64(150)
+    b2 = np.concatenate(reads)
+    fq2 = str(tmp_path / "wt.fq")
+    synth.write_fastq(fq2, b2, offs2)
+    md, er = map_params(15, True)
+    covg, prg_reads, _ = oracle.map_reads(b2, offs2, oracle.build_index(panel.prgs, 11, 15), 11, 15, md, cluster_fraction(er, 15), 10)
+    ctx.set_coverage(covg, prg_reads, int(offs2[-1]))
+    out = tmp_path / "d"
+    out.mkdir()
+    assert ctx.discover_reads(fq2, genes, str(out)) == []
+    assert Pandora.list_prgs_with_novel_variants(str(out / "denovo_paths.txt")) == []
+    assert ctx.update_prg(str(tmp_path / "same.prg")) == 0
+    assert [l.rstrip("\n") for l in open(tmp_path / "same.prg") if not l.startswith(">")] == panel.prgs
