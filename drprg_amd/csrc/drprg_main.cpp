@@ -2,7 +2,8 @@
 //
 // Mirrors the CLI surface of /root/reference/src/predict.rs:134-202 (+ Filterer src/filter.rs:165-197, MinorAllele
 // src/minor.rs:19-49, global -v/-t src/cli.rs:81-93) and the sequence of Predict::run (src/predict.rs:204-317):
-// validate index -> [discover: the mapping pass is shared, no novel loci are reported] -> map + genotype on the GPU
+// validate index -> map on the GPU -> discover from that same pass (candidate regions; novel variants from a pile-up of the reads;
+// PRG update + index + second mapping pass only if there are any) -> genotype
 // -> pandora_genotyped.vcf -> <sample>.drprg.vcf -> <sample>.drprg.json.  Host orchestration is C++ here because
 // the image has no Rust toolchain; a Rust drprg binds the same ABI.
 #include "../../include/drprg_hip.h"

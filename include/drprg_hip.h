@@ -107,8 +107,8 @@ int drprg_hip_genotype_info(const drprg_hip_ctx* ctx, uint32_t out[4]);
 /* The tail of `pandora discover` (Pandora::discover_with, /root/reference/src/lib.rs:513-578) on the coverage accumulated so
  * far: calls every site, walks the called consensus of every present locus and writes <out_dir>/candidate_regions.tsv (the
  * low-coverage regions pandora would hand to its local assembler), <out_dir>/denovo_paths.txt and denovo_sequences.fa.
- * Local assembly is NOT implemented: denovo_paths.txt always reports "0 loci with denovo variants" (the format
- * /root/reference/src/lib.rs:648-697 parses), so a sample's off-panel variants are located but never added to the PRG.
+ * This entry does not look at the reads again: denovo_paths.txt reports "0 loci with denovo variants" (the format
+ * /root/reference/src/lib.rs:648-697 parses); drprg_hip_discover_reads below also finds the novel variants.
  * *n_candidates (may be NULL) receives the number of candidate regions. */
 int drprg_hip_discover(drprg_hip_ctx* ctx, const char* vcf_refs, const char* out_dir, const char* sample, uint32_t* n_candidates);
 /* drprg_hip_discover + the second half of `pandora discover`: a host-side pass over the reads file piles up, per candidate
