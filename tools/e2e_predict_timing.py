@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Process start -> JSON timing of `drprg predict` (C++ front end) on the SURVEY 8d index with synthetic 150 bp reads, plain
+FASTQ in /dev/shm, on the GPU box: a wild-type sample and a sample with one off-panel SNP (second mapping pass).
+Usage: python tools/e2e_predict_timing.py [n_reads] [threads]"""
+import json, os, shutil, subprocess, sys, tempfile, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from drprg_amd import synth
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
+threads = sys.argv[2] if len(sys.argv) > 2 else "16"
+DS = os.path.join(ROOT, "tests", "golden", "downstream")
+tmp = tempfile.mkdtemp(prefix="drprg_predict_", dir="/dev/shm")
+idx = os.path.join(tmp, "idx")
+os.makedirs(os.path.join(idx, "msas"))
+for f in (".config.toml", "genes.fa", "genes.fa.fai", "panel.bcf", "panel.bcf.csi", "rules.csv"):
+    shutil.copy(os.path.join(DS, f), os.path.join(idx, f))
+panel = synth.mtb_8d_panel(DS)
+panel.write(os.path.join(idx, "dr.prg"))
+exe = os.path.join(ROOT, "drprg_amd", "bin")
+subprocess.run([os.path.join(exe, "pandora"), "index", "-t", "8", "-w", "11", "-k", "15", os.path.join(idx, "dr.prg")], check=True, stdout=subprocess.DEVNULL)
+g = panel.names.index("katG")
+for label in ("wild_type", "off_panel_snp"):
+    trees = list(panel.trees)
+    refs = list(panel.refs)
+    if label == "off_panel_snp":
+        p = 100 + 3 * 300 + 1
+        refs[g] = refs[g][:p] + ("A" if refs[g][p] != "A" else "C") + refs[g][p + 1:]
+    # background genome with the first-allele loci implanted (the mutated katG for the second sample)
+    rng = np.random.default_rng(4411532)
+    total = sum(len(r) for r in refs)
+    spacer = (synth.MTB_GENOME_SIZE - total) // (len(refs) + 1)
+    genome = "".join(synth.random_seq(rng, spacer) + r for r in refs) + synth.random_seq(rng, spacer)
+    class G:  # the two attributes sample_short_reads needs
+        haps = [np.frombuffer(genome.encode(), np.uint8)]
+        lens = np.array([len(genome)], dtype=np.int64)
+    bases, offs = synth.sample_short_reads(G, n, seed=2)
+    fq = os.path.join(tmp, label + ".fq")
+    synth.write_fastq_fixed(fq, bases, 150)
+    out = os.path.join(tmp, "out_" + label)
+    t = time.time()
+    r = subprocess.run([os.path.join(exe, "drprg"), "predict", "-x", idx, "-i", fq, "-o", out, "-s", label, "-I", "-t", threads, "-v"], capture_output=True, text=True)
+    dt = time.time() - t
+    assert r.returncode == 0, r.stderr
+    res = json.load(open(os.path.join(out, label + ".drprg.json")))
+    calls = {d: v["predict"] for d, v in res["susceptibility"].items() if v["predict"] != "S"}
+    print(f"{label}: {n} reads ({os.path.getsize(fq) / 1e9:.2f} GB FASTQ), process start -> JSON {dt:.2f}s = {n / dt / 1e6:.1f} M reads/s; non-S: {calls}", flush=True)
+    print("   " + " | ".join(l for l in r.stderr.splitlines() if "discover" in l or "novel" in l), flush=True)
+    os.remove(fq)
+shutil.rmtree(tmp)
