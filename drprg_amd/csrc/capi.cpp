@@ -441,9 +441,13 @@ int drprg_hip_discover_reads(drprg_hip_ctx* ctx, const char* reads_path, const c
             o << c.chrom << "\t" << c.start << "\t" << c.end << "\t" << c.low_start << "\t" << c.low_end << "\t" << c.max_covg << "\t" << c.seq << "\n";
         if (!o) throw Error(DRPRG_EIO, "cannot write " + dir + "/candidate_regions.tsv");
     }
-    // accurate reads only: the exact-anchor pile-up needs reads whose bases between two 15-mers can be taken at face value
-    std::vector<NovelVariant> variants;
-    if (ctx->params.illumina) variants = assemble_candidate_regions(r, reads_path, ctx->threads, dp);
+    // accurate reads (-I): whole strings between the anchors are counted; noisy reads: column-wise majority of their alignments
+    DiscoverParams adp = dp;
+    if (!ctx->params.illumina) {
+        adp.min_support = 4;
+        adp.min_fraction = 0.6;
+    }
+    std::vector<NovelVariant> variants = assemble_candidate_regions(r, reads_path, ctx->threads, adp, ctx->params.illumina);
     write_denovo_paths(dir, smp, r, variants, list_loci != 0);
     if (out) {
         out[0] = (uint32_t)r.candidates.size();

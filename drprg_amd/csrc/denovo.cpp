@@ -8,7 +8,8 @@
 // either orientation, in every read of the file (a second, host-side pass over the reads: the mapping pass keeps no
 // reads); a read that holds both anchors of a region in the right order spells one allele between them; the most
 // frequent allele that is not the consensus, with at least min_support reads and min_fraction of the spanning reads, is
-// a novel variant.  Noisy long reads need a real multiple alignment and are left alone (regions are still reported).
+// a novel variant.  Noisy long reads (no -I) spell the allele with their own errors: their strings are aligned to the consensus
+// slice and the majority is taken column by column instead (column_consensus).
 //
 // Outputs: denovo_paths.txt in the layout the reference's parser and make_prg read (/root/reference/src/lib.rs:648-697 and
 // the example at :3010-3038: locus, "<n> nodes", one "(id [start, end) seq)" line per local node of the called path,
@@ -18,8 +19,11 @@
 #include "denovo.h"
 #include "ingest.h"
 #include <algorithm>
+#include <array>
 #include <atomic>
+#include <cmath>
 #include <fstream>
+#include <map>
 #include <mutex>
 #include <sstream>
 #include <unordered_map>
@@ -32,6 +36,7 @@ struct AnchorRef {
     uint32_t region;
     uint8_t right;   // 0 = left anchor, 1 = right anchor
     uint8_t reverse; // the reverse complement of the anchor (the read runs against the consensus)
+    uint8_t j;       // 0 = the anchor next to the region, 1, 2 = the fallback anchors further out (noisy reads only)
 };
 
 bool pack_kmer(const char* s, uint32_t k, uint64_t& out)
@@ -44,6 +49,18 @@ bool pack_kmer(const char* s, uint32_t k, uint64_t& out)
     }
     out = v;
     return true;
+}
+
+uint32_t edit_distance(const std::string& a, const std::string& b)
+{
+    std::vector<uint32_t> prev(b.size() + 1), cur(b.size() + 1);
+    for (size_t j = 0; j <= b.size(); ++j) prev[j] = (uint32_t)j;
+    for (size_t i = 1; i <= a.size(); ++i) {
+        cur[0] = (uint32_t)i;
+        for (size_t j = 1; j <= b.size(); ++j) cur[j] = std::min(prev[j - 1] + (a[i - 1] != b[j - 1]), std::min(prev[j], cur[j - 1]) + 1);
+        prev.swap(cur);
+    }
+    return prev[b.size()];
 }
 
 std::string revcomp(const std::string& s)
@@ -66,26 +83,129 @@ struct RegionVotes {
     std::unordered_map<std::string, uint32_t> alleles;
 };
 
+// votes are keyed by two digits (which left / right anchor the read held: 0 = the one next to the region) + the string spelled
+// between the two anchors; the consensus that string is to be compared with is the region plus the skipped anchors
+std::string extended(const CandidateRegion& c, uint32_t A, uint32_t jl, uint32_t jr, const std::string& core)
+{
+    return c.left_context.substr(c.left_context.size() - (size_t)A * jl) + core + c.right_context.substr(0, (size_t)A * jr);
+}
+
+// Noisy reads (no -I): the strings the reads spell between the anchors differ from each other by their own errors, so they
+// are not counted as whole strings but column by column: every string is aligned to the consensus slice (global, unit costs),
+// a column of the region collects votes for A / C / G / T / "deleted", the gap before a column collects the inserted strings,
+// and the majority of every column -- if it has min_support reads and min_fraction of the spanning reads -- makes the allele.
+std::string column_consensus(const CandidateRegion& cr, const std::string& core, uint32_t A, const std::unordered_map<std::string, uint32_t>& alleles,
+    uint32_t spanning, const DiscoverParams& dp)
+{
+    const size_t R = core.size();
+    std::vector<std::array<uint32_t, 5>> col(R, std::array<uint32_t, 5> { 0, 0, 0, 0, 0 }); // A C G T deleted
+    std::vector<std::unordered_map<std::string, uint32_t>> ins(R + 1);                        // inserted before column i
+    std::vector<uint16_t> dpm;
+    for (auto& kv : alleles) {
+        const uint32_t jl = (uint32_t)(kv.first[0] - '0'), jr = (uint32_t)(kv.first[1] - '0');
+        const std::string ref = extended(cr, A, jl, jr, core), s = kv.first.substr(2);
+        const size_t E = ref.size(), S = s.size(), shift = (size_t)A * jl; // region column = extended column - shift
+        dpm.assign((E + 1) * (S + 1), 0);
+        auto D = [&](size_t i, size_t j) -> uint16_t& { return dpm[i * (S + 1) + j]; };
+        for (size_t i = 0; i <= E; ++i) D(i, 0) = (uint16_t)i;
+        for (size_t j = 0; j <= S; ++j) D(0, j) = (uint16_t)j;
+        for (size_t i = 1; i <= E; ++i)
+            for (size_t j = 1; j <= S; ++j) {
+                const uint16_t sub = (uint16_t)(D(i - 1, j - 1) + (ref[i - 1] != s[j - 1])), del = (uint16_t)(D(i - 1, j) + 1), in = (uint16_t)(D(i, j - 1) + 1);
+                D(i, j) = std::min(sub, std::min(del, in));
+            }
+        // traceback from the end; on ties prefer the diagonal, then a deletion: gaps end up as far left as the costs allow
+        size_t i = E, j = S;
+        std::string pending; // bases inserted before extended column i (collected right to left)
+        auto flush_ins = [&](size_t before_col) {
+            if (pending.empty()) return;
+            if (before_col >= shift && before_col - shift <= R) {
+                std::reverse(pending.begin(), pending.end());
+                ins[before_col - shift][pending] += kv.second;
+            }
+            pending.clear();
+        };
+        auto in_region = [&](size_t ext_col) { return ext_col >= shift && ext_col - shift < R; };
+        while (i > 0 || j > 0) {
+            if (i > 0 && j > 0 && D(i, j) == D(i - 1, j - 1) + (ref[i - 1] != s[j - 1])) {
+                flush_ins(i);
+                const int c = nt4((unsigned char)s[j - 1]);
+                if (c < 4 && in_region(i - 1)) col[i - 1 - shift][(size_t)c] += kv.second;
+                --i;
+                --j;
+            } else if (i > 0 && D(i, j) == D(i - 1, j) + 1) {
+                flush_ins(i);
+                if (in_region(i - 1)) col[i - 1 - shift][4] += kv.second;
+                --i;
+            } else {
+                pending.push_back(s[j - 1]);
+                --j;
+            }
+        }
+        flush_ins(0);
+    }
+    const uint32_t need = std::max<uint32_t>(dp.min_support, (uint32_t)std::ceil(dp.min_fraction * (double)spanning));
+    std::string out;
+    for (size_t i = 0; i <= R; ++i) {
+        // an insertion: enough reads insert SOMETHING here; its length is the most frequent one, its bases the majority per place
+        uint32_t any = 0;
+        std::map<size_t, uint32_t> by_len;
+        for (auto& kv : ins[i]) {
+            any += kv.second;
+            by_len[kv.first.size()] += kv.second;
+        }
+        if (any >= need) {
+            size_t len = 0;
+            uint32_t len_n = 0;
+            for (auto& kv : by_len)
+                if (kv.second > len_n) {
+                    len_n = kv.second;
+                    len = kv.first;
+                }
+            for (size_t p = 0; p < len; ++p) {
+                uint32_t n[4] = { 0, 0, 0, 0 };
+                for (auto& kv : ins[i])
+                    if (kv.first.size() == len && nt4((unsigned char)kv.first[p]) < 4) n[nt4((unsigned char)kv.first[p])] += kv.second;
+                out.push_back("ACGT"[std::max_element(n, n + 4) - n]);
+            }
+        }
+        if (i == R) break;
+        const size_t ref_c = (size_t)nt4((unsigned char)core[i]);
+        size_t arg = ref_c > 3 ? 0 : ref_c;
+        for (size_t c = 0; c < 5; ++c)
+            if (col[i][c] > col[i][arg]) arg = c;
+        if (arg != ref_c && col[i][arg] < need) arg = ref_c; // a change needs the support; otherwise the consensus base stays
+        if (arg < 4) out.push_back("ACGT"[arg]);
+    }
+    return out;
+}
+
 } // namespace
 
-std::vector<NovelVariant> assemble_candidate_regions(const GenotypeResult& gr, const std::string& reads_path, int threads, const DiscoverParams& dp)
+std::vector<NovelVariant> assemble_candidate_regions(const GenotypeResult& gr, const std::string& reads_path, int threads, const DiscoverParams& dp,
+    bool accurate_reads)
 {
     std::vector<NovelVariant> out;
     const uint32_t A = dp.anchor_len;
     if (gr.candidates.empty() || A == 0 || A > 31) return out;
-    // anchor k-mers of every region that has both (a region at the very end of a locus has no room for one: left alone)
+    // anchor k-mers of every region that has both (a region at the very end of a locus has no room for one: left alone).
+    // Accurate reads: the one anchor on each side; noisy reads: up to three on each side, because a read with 5 % errors holds a
+    // given 15-mer intact only half of the time
+    const uint32_t max_anchors = accurate_reads ? 1 : 3;
     std::unordered_multimap<uint64_t, AnchorRef> anchors;
     for (uint32_t r = 0; r < gr.candidates.size(); ++r) {
         const CandidateRegion& c = gr.candidates[r];
         if (c.left_anchor.size() != A || c.right_anchor.size() != A) continue;
-        uint64_t l, rr, lrc, rrc;
-        if (!pack_kmer(c.left_anchor.data(), A, l) || !pack_kmer(c.right_anchor.data(), A, rr)) continue;
-        const std::string lr = revcomp(c.left_anchor), rrs = revcomp(c.right_anchor);
-        if (!pack_kmer(lr.data(), A, lrc) || !pack_kmer(rrs.data(), A, rrc)) continue;
-        anchors.insert({ l, AnchorRef { r, 0, 0 } });
-        anchors.insert({ rr, AnchorRef { r, 1, 0 } });
-        anchors.insert({ lrc, AnchorRef { r, 0, 1 } });
-        anchors.insert({ rrc, AnchorRef { r, 1, 1 } });
+        const uint32_t nl = std::min<uint32_t>(max_anchors, (uint32_t)c.left_context.size() / A), nr = std::min<uint32_t>(max_anchors, (uint32_t)c.right_context.size() / A);
+        for (uint32_t side = 0; side < 2; ++side)
+            for (uint32_t j = 0; j < (side ? nr : nl); ++j) {
+                const std::string fwd = side ? c.right_context.substr((size_t)A * j, A) : c.left_context.substr(c.left_context.size() - (size_t)A * (j + 1), A);
+                const std::string rev = revcomp(fwd);
+                uint64_t f, rc;
+                if (!pack_kmer(fwd.data(), A, f) || !pack_kmer(rev.data(), A, rc)) continue;
+                anchors.insert({ f, AnchorRef { r, (uint8_t)side, 0, (uint8_t)j } });
+                anchors.insert({ rc, AnchorRef { r, (uint8_t)side, 1, (uint8_t)j } });
+            }
     }
     if (anchors.empty()) return out;
     std::vector<uint8_t> prefilter(1u << 16, 0); // low 16 bits of the packed k-mer: most read k-mers stop here
@@ -95,10 +215,15 @@ std::vector<NovelVariant> assemble_candidate_regions(const GenotypeResult& gr, c
 
     struct Hit {
         uint32_t region, pos;
-        uint8_t right, reverse;
+        uint8_t right, reverse, j;
+    };
+    struct Span { // the best pair of anchors of one (region, orientation) in one read: the innermost ones
+        uint32_t region, from, len;
+        uint8_t reverse, jl, jr;
     };
     auto scan_batch = [&](const PinnedBatch& b) {
         std::vector<Hit> hits;
+        std::vector<Span> spans;
         for (uint64_t i = 0; i < b.n_reads; ++i) {
             const char* s = (const char*)b.bases + b.offsets[i];
             const uint64_t len = b.offsets[i + 1] - b.offsets[i];
@@ -116,25 +241,38 @@ std::vector<NovelVariant> assemble_candidate_regions(const GenotypeResult& gr, c
                 if (++run < A || !prefilter[v & 0xFFFF]) continue;
                 auto range = anchors.equal_range(v);
                 for (auto it = range.first; it != range.second; ++it)
-                    hits.push_back(Hit { it->second.region, (uint32_t)(p + 1 - A), it->second.right, it->second.reverse });
+                    hits.push_back(Hit { it->second.region, (uint32_t)(p + 1 - A), it->second.right, it->second.reverse, it->second.j });
             }
             if (hits.size() < 2) continue;
             // forward read: left anchor, allele, right anchor; reverse read: rc(right anchor), rc(allele), rc(left anchor)
+            spans.clear();
             for (const Hit& x : hits)
                 for (const Hit& y : hits) {
                     if (x.region != y.region || x.reverse != y.reverse) continue;
                     const bool first_is_x = x.reverse ? (x.right == 1 && y.right == 0) : (x.right == 0 && y.right == 1);
                     if (!first_is_x || y.pos < x.pos + A) continue;
                     const CandidateRegion& c = gr.candidates[x.region];
-                    const uint32_t got = y.pos - (x.pos + A), want = c.end - c.start;
+                    const uint8_t jl = x.reverse ? y.j : x.j, jr = x.reverse ? x.j : y.j;
+                    const uint32_t got = y.pos - (x.pos + A), want = c.end - c.start + A * ((uint32_t)jl + jr);
                     if (got > want + dp.max_len_change || got + dp.max_len_change < want) continue;
-                    std::string allele(s + x.pos + A, got);
-                    for (char& ch : allele) ch = (char)std::toupper((unsigned char)ch);
-                    if (x.reverse) allele = revcomp(allele);
-                    if (allele.find('N') != std::string::npos) continue;
-                    std::lock_guard<std::mutex> g(votes[x.region].mu);
-                    votes[x.region].alleles[allele] += 1;
+                    Span sp { x.region, x.pos + A, got, x.reverse, jl, jr };
+                    bool placed = false;
+                    for (Span& o : spans)
+                        if (o.region == sp.region && o.reverse == sp.reverse) {
+                            if ((uint32_t)sp.jl + sp.jr < (uint32_t)o.jl + o.jr) o = sp;
+                            placed = true;
+                        }
+                    if (!placed) spans.push_back(sp);
                 }
+            for (const Span& sp : spans) {
+                std::string allele(s + sp.from, sp.len);
+                for (char& ch : allele) ch = (char)std::toupper((unsigned char)ch);
+                if (sp.reverse) allele = revcomp(allele);
+                if (allele.find('N') != std::string::npos) continue;
+                const char key[3] = { (char)('0' + sp.jl), (char)('0' + sp.jr), 0 };
+                std::lock_guard<std::mutex> g(votes[sp.region].mu);
+                votes[sp.region].alleles[key + allele] += 1;
+            }
         }
     };
     IngestHooks hooks;
@@ -149,15 +287,38 @@ std::vector<NovelVariant> assemble_candidate_regions(const GenotypeResult& gr, c
     for (uint32_t r = 0; r < gr.candidates.size(); ++r) {
         const CandidateRegion& c = gr.candidates[r];
         uint32_t spanning = 0, best_n = 0;
-        const std::string* best = nullptr;
+        const std::string* best_key = nullptr;
         for (auto& kv : votes[r].alleles) {
             spanning += kv.second;
-            if (kv.second > best_n || (kv.second == best_n && best && kv.first < *best)) {
+            if (kv.second > best_n || (kv.second == best_n && best_key && kv.first < *best_key)) {
                 best_n = kv.second;
-                best = &kv.first;
+                best_key = &kv.first;
             }
         }
-        if (!best || *best == c.seq || best_n < dp.min_support || (double)best_n < dp.min_fraction * (double)spanning) continue;
+        std::string allele;
+        if (!accurate_reads) { // noisy reads: the allele is the column-wise majority of the aligned strings
+            if (spanning < dp.min_support) continue;
+            // a change the first alignment spreads over neighbouring columns (a deletion inside a repeat) is gathered by aligning again,
+            // to the result: at most three rounds, normally the second one changes nothing
+            allele = c.seq;
+            for (int round = 0; round < 3; ++round) {
+                std::string next = column_consensus(c, allele, A, votes[r].alleles, spanning, dp);
+                if (next == allele) break;
+                allele.swap(next);
+            }
+            if (allele == c.seq) continue;
+            best_n = 0;
+            for (auto& kv : votes[r].alleles) { // reported support: reads that are closer to the new allele than to the consensus
+                const uint32_t jl = (uint32_t)(kv.first[0] - '0'), jr = (uint32_t)(kv.first[1] - '0');
+                const std::string s = kv.first.substr(2);
+                best_n += kv.second * (edit_distance(s, extended(c, A, jl, jr, allele)) < edit_distance(s, extended(c, A, jl, jr, c.seq)));
+            }
+        } else {
+            if (!best_key || best_n < dp.min_support || (double)best_n < dp.min_fraction * (double)spanning) continue;
+            allele = best_key->substr(2); // one anchor per side: the key is "00" + the string
+            if (allele == c.seq) continue;
+        }
+        const std::string* best = &allele;
         // trim what the allele shares with the consensus on both sides
         const std::string& ref = c.seq;
         const std::string& alt = *best;

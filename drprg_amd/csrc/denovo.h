@@ -12,8 +12,10 @@ struct NovelVariant {
     uint32_t support = 0, spanning = 0; // reads that spell alt between the anchors / reads that hold both anchors
 };
 
-// second pass over the reads file (host threads): exact-anchor pile-up over every candidate region of `gr`
-std::vector<NovelVariant> assemble_candidate_regions(const GenotypeResult& gr, const std::string& reads_path, int threads, const DiscoverParams& dp);
+// second pass over the reads file (host threads): exact-anchor pile-up over every candidate region of `gr`; accurate_reads:
+// whole strings are counted (Illumina), otherwise the strings are aligned to the consensus and counted column by column
+std::vector<NovelVariant> assemble_candidate_regions(const GenotypeResult& gr, const std::string& reads_path, int threads, const DiscoverParams& dp,
+    bool accurate_reads);
 
 // <dir>/denovo_paths.txt (+ denovo_sequences.fa, denovo_variants.tsv).  list_loci = false keeps the "0 loci" line: the
 // variants are then reported in denovo_variants.tsv only and the caller's make_prg step is not triggered.

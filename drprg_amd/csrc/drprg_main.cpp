@@ -205,8 +205,8 @@ int main(int argc, char** argv)
     // discover + map share ONE pass over the reads (the reference runs two, /root/reference/src/predict.rs:248-302)
     if (int rc = drprg_hip_map_fastx(ctx, input.c_str())) die(drprg_hip_last_error(ctx), -rc);
     {
-        // discover (/root/reference/src/predict.rs:247-256): candidate regions of every locus' called consensus, then -- accurate
-        // reads only -- a host-side pile-up of the reads over them.  Novel variants update the PRG (what MakePrg::update does with
+        // discover (/root/reference/src/predict.rs:247-256): candidate regions of every locus' called consensus, then a host-side
+        // pile-up of the reads over them (whole strings with -I, column-wise majority of aligned strings without).  Novel variants update the PRG (what MakePrg::update does with
         // make_prg + mafft in the reference, src/predict.rs:260-284, here a new site per variant: -m/-M are not needed), the updated
         // PRG is indexed in the output directory and the reads are mapped again against it.
         std::string ddir = outdir + "/discover";
@@ -214,11 +214,7 @@ int main(int argc, char** argv)
         uint32_t found[3] = { 0, 0, 0 };
         if (int rc = drprg_hip_discover_reads(ctx, input.c_str(), (index + "/genes.fa").c_str(), ddir.c_str(), sample.c_str(), 1, found))
             die(drprg_hip_last_error(ctx), -rc);
-        if (!illumina)
-            std::fprintf(stderr,
-                "drprg (hip): WARNING: de novo variant discovery needs accurate reads (-I): %u low-coverage candidate region(s) are listed in "
-                "%s/candidate_regions.tsv but not assembled; variants absent from the index will not be called.\n", found[0], ddir.c_str());
-        else if (verbose || found[1])
+        if (verbose || found[1])
             std::fprintf(stderr, "[drprg-hip] discover: %u candidate region(s), %u novel variant(s) in %u locus/loci\n", found[0], found[1], found[2]);
         if (found[1]) {
             const std::string updated = outdir + "/updated.dr.prg";

@@ -359,6 +359,11 @@ struct LocusGenotyper {
             cr.seq = cons.substr(cr.start, cr.end - cr.start);
             if (cr.start >= dp.anchor_len) cr.left_anchor = cons.substr(cr.start - dp.anchor_len, dp.anchor_len);
             if (cr.end + dp.anchor_len <= L) cr.right_anchor = cons.substr(cr.end, dp.anchor_len);
+            if (dp.anchor_len) {
+                const uint32_t nl = std::min<uint32_t>(3, cr.start / dp.anchor_len), nr = std::min<uint32_t>(3, (uint32_t)(L - cr.end) / dp.anchor_len);
+                cr.left_context = cons.substr(cr.start - nl * dp.anchor_len, nl * dp.anchor_len);
+                cr.right_context = cons.substr(cr.end, nr * dp.anchor_len);
+            }
             regions.push_back(std::move(cr));
         }
     }

@@ -37,6 +37,7 @@ struct CandidateRegion {
     uint32_t max_covg = 0;         // largest per-base coverage inside [low_start, low_end)
     std::string seq;               // consensus[start, end)
     std::string left_anchor, right_anchor; // the anchor_len bases of the consensus before `start` / after `end` (empty at a locus end)
+    std::string left_context, right_context; // up to 3 anchor_len bases before / after: fallback anchors for noisy reads (whole multiples of anchor_len)
 };
 
 // the called consensus of a locus as a walk through its local graph (what pandora's denovo_paths.txt lists as "nodes")

@@ -217,7 +217,7 @@ int cmd_discover(const Args& a)
     if (int rc = drprg_hip_map_fastx(ctx, reads.c_str())) die(drprg_hip_last_error(ctx), -rc);
     report_counters(ctx, now_s() - t0);
     // The mapping half of discover is the same kernels as `map`; its products are (1) the candidate regions -- stretches of each
-    // locus' called consensus that the reads do not support --, (2) for accurate reads (-I) the novel variants a host-side pile-up of
+    // locus' called consensus that the reads do not support --, (2) the novel variants a host-side pile-up of
     // the reads finds in them, and (3) the coverage vector, kept for the `map` call drprg issues next on the unchanged PRG.
     // denovo_paths.txt lists the loci with novel variants only when DRPRG_HIP_DENOVO_PATHS=1: the caller then runs make_prg on this
     // file, and its layout is written from the one example in the reference tree (/root/reference/src/lib.rs:3010-3038) without a
@@ -230,11 +230,7 @@ int cmd_discover(const Args& a)
         die(drprg_hip_last_error(ctx), -rc);
     if (drprg_hip_save_coverage(ctx, (a.outdir + "/" + COVERAGE_CACHE).c_str(), run_tag(a, reads).c_str()) != 0)
         std::fprintf(stderr, "pandora (drprg-hip): warning: could not keep the coverage vector for `map`: %s\n", drprg_hip_last_error(ctx));
-    if (!a.illumina)
-        std::fprintf(stderr,
-            "pandora (drprg-hip): WARNING: de novo variant discovery needs accurate reads (-I) in this build: %u low-coverage candidate "
-            "region(s) written to %s/candidate_regions.tsv, not assembled; denovo_paths.txt reports 0 loci.\n", found[0], a.outdir.c_str());
-    else if (found[1] && !list_loci)
+    if (found[1] && !list_loci)
         std::fprintf(stderr,
             "pandora (drprg-hip): WARNING: %u novel variant(s) in %u locus/loci found (%s/denovo_variants.tsv) but denovo_paths.txt reports 0 "
             "loci, so the PRG will not be updated: set DRPRG_HIP_DENOVO_PATHS=1 to list them for make_prg.\n", found[1], found[2], a.outdir.c_str());

@@ -301,7 +301,7 @@ class Pandora:
         """Pandora::discover_with, /root/reference/src/lib.rs:513-578.  Returns the denovo_paths.txt path.
 
         The mapping half runs (its coverage vector is kept under `outdir` for the genotype_with call that follows), candidate
-        regions go to candidate_regions.tsv, and with accurate reads (-I) the reads are piled up over them: novel variants go to
+        regions go to candidate_regions.tsv, and the reads are piled up over them: novel variants go to
         denovo_variants.tsv.  list_loci=True also lists them in denovo_paths.txt (the caller's make_prg update then runs on it;
         the layout follows the one example in the reference tree and could not be tried on make_prg here); the default keeps
         "0 loci with denovo variants"."""

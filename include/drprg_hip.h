@@ -113,8 +113,8 @@ int drprg_hip_genotype_info(const drprg_hip_ctx* ctx, uint32_t out[4]);
 int drprg_hip_discover(drprg_hip_ctx* ctx, const char* vcf_refs, const char* out_dir, const char* sample, uint32_t* n_candidates);
 /* drprg_hip_discover + the second half of `pandora discover`: a host-side pass over the reads file piles up, per candidate
  * region, what the reads spell between the exact 15-base anchors either side of it; the most frequent allele that differs
- * from the called consensus (>= 3 reads, >= half of the spanning reads) is a novel variant (accurate reads only: with
- * illumina = 0 in the map options regions are reported, not assembled).  Writes candidate_regions.tsv, denovo_variants.tsv,
+ * from the called consensus (>= 3 reads, >= half of the spanning reads) is a novel variant (with illumina = 0 in
+ * the map options the strings are aligned to the consensus and counted column by column: >= 4 reads, >= 60 %).  Writes candidate_regions.tsv, denovo_variants.tsv,
  * denovo_sequences.fa and denovo_paths.txt; list_loci != 0 lists the loci and their variants in denovo_paths.txt in pandora's
  * layout (/root/reference/src/lib.rs:3010-3038) so that the caller's make_prg update runs, 0 keeps "0 loci with denovo
  * variants".  out[0..2] = candidate regions, novel variants, loci with novel variants. */

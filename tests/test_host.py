@@ -582,3 +582,37 @@ def test_discover_reports_no_novel_variant_for_a_sample_the_panel_explains(tmp_p
     assert Pandora.list_prgs_with_novel_variants(str(out / "denovo_paths.txt")) == []
     assert ctx.update_prg(str(tmp_path / "same.prg")) == 0
     assert [l.rstrip("\n") for l in open(tmp_path / "same.prg") if not l.startswith(">")] == panel.prgs
+
+
+@pytest.mark.parametrize("kind", ["snp", "del", "ins"])
+def test_discover_with_noisy_long_reads(tmp_path, oracle, kind):
+    """the same off-panel variant under Nanopore-like reads (5 % errors, no -I): the reads' strings between the anchors are
+    aligned to the consensus and counted column by column; exactly the planted variant comes out, and no read error does"""
+    from types import SimpleNamespace
+    from drprg_amd import Context, synth
+    ctx_i, panel, genes, _, _, _, want = _denovo_sample(tmp_path, oracle, kind)
+    ref1 = panel.refs[1]
+    mutated = ref1[:want[0]] + want[2] + ref1[want[0] + len(want[1]):]
+    rng = np.random.default_rng(8)
+    parts = [synth.random_seq(rng, 300)]
+    for locus in range(3):
+        parts += [mutated if locus == 1 else panel.refs[locus], synth.random_seq(rng, 300)]
+    genome = np.frombuffer("".join(parts).encode(), np.uint8)
+    g = SimpleNamespace(haps=[genome], lens=np.array([genome.size], dtype=np.int64))
+    bases, offs = synth.sample_long_reads(g, 45 * genome.size // 1500, seed=12, mean_len=1500, min_len=400, max_len=genome.size - 1)
+    fq = str(tmp_path / "long.fq")
+    synth.write_fastq(fq, bases, offs)
+    w, k = 11, 15
+    ctx = Context(str(tmp_path / "dr.prg"), w, k, device=-1, from_files=False)
+    ctx.set_opts(illumina=False, genome_size=int(genome.size))
+    md, er = map_params(k, False)
+    covg, prg_reads, _ = oracle.map_reads(bases, offs, oracle.build_index(panel.prgs, w, k), w, k, md, cluster_fraction(er, k), 10)
+    ctx.set_coverage(covg, prg_reads, int(offs[-1]))
+    out = tmp_path / "discover_long"
+    out.mkdir()
+    ctx.set_threads(4)
+    variants = ctx.discover_reads(fq, genes, str(out))
+    assert len(variants) == 1, variants
+    locus, pos1, ref, alt, support, spanning = variants[0]
+    assert locus == "g1" and support >= 4 and spanning >= support
+    assert _same_variant((pos1 - 1, ref, alt), want, ref1)
