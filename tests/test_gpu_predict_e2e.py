@@ -44,13 +44,13 @@ def _reads(panel, choose, n_reads, seed):
     return block.reshape(-1), np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(150)
 
 
-def _predict(tmp_path, idx, bases, offs, name):
+def _predict(tmp_path, idx, bases, offs, name, illumina=True):
     from drprg_amd import synth
     fq = str(tmp_path / f"{name}.fq")
     synth.write_fastq(fq, bases, offs)
     out = tmp_path / f"out_{name}"
-    r = subprocess.run([os.path.join(BIN, "drprg"), "predict", "-x", str(idx), "-i", fq, "-o", str(out), "-s", name, "-I", "-v"],
-                       capture_output=True, text=True)
+    r = subprocess.run([os.path.join(BIN, "drprg"), "predict", "-x", str(idx), "-i", fq, "-o", str(out), "-s", name, "-v"]
+                       + (["-I"] if illumina else []), capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     for f in ("pandora_genotyped.vcf", f"{name}.drprg.vcf", f"{name}.drprg.json", "discover/denovo_paths.txt"):
         assert (out / f).exists(), f
@@ -113,12 +113,14 @@ def test_absent_gene_is_reported(tmp_path):
     assert pza["predict"] == "R" and pza["evidence"][0]["variant"] == "gene_absent" and pza["evidence"][0]["gene"] == "pncA"
 
 
-def test_off_panel_variant_is_discovered_and_reported_as_unknown(tmp_path):
+@pytest.mark.parametrize("tech", ["illumina", "nanopore"])
+def test_off_panel_variant_is_discovered_and_reported_as_unknown(tmp_path, tech):
     """The reference's reason for running discover (/root/reference/src/predict.rs:247-302): a non-synonymous variant that is
     NOT in the panel must come out as an unknown (`U`) call, not as susceptible.  The sample carries a missense SNP in the
     middle of katG's coding sequence at a position the panel holds no site for: discover finds it in the reads, the PRG in
     the output directory gains the site, the reads are mapped again, the VCF calls the new allele and the report holds the
-    evidence with prediction U for katG's drug; the same reads with discovery impossible (no -I) stay S."""
+    evidence with prediction U for katG's drug.  Both technologies: 150-base accurate reads with -I, and 2-kb reads with 5 %
+    errors without (the pile-up then takes the column-wise majority of the aligned reads)."""
     from drprg_amd import synth
     idx, panel, sites = _make_index(tmp_path)
     g = panel.names.index("katG")
@@ -134,12 +136,17 @@ def test_off_panel_variant_is_discovered_and_reported_as_unknown(tmp_path):
     spacer = synth.random_seq(rng, 300)
     genome = spacer + spacer.join(mutated if gi == g else r for gi, r in enumerate(panel.refs)) + spacer
     gn = np.frombuffer(genome.encode(), np.uint8)
-    starts = rng.integers(0, len(gn) - 150, size=16000)
-    block = gn[starts[:, None] + np.arange(150)]
-    rev = rng.random(len(starts)) < 0.5
-    block[rev] = synth._COMP[block[rev][:, ::-1]]
-    bases, offs = block.reshape(-1), np.arange(len(starts) + 1, dtype=np.uint64) * np.uint64(150)
-    res, out = _predict(tmp_path, idx, bases, offs, "novel")
+    if tech == "illumina":
+        starts = rng.integers(0, len(gn) - 150, size=16000)
+        block = gn[starts[:, None] + np.arange(150)]
+        rev = rng.random(len(starts)) < 0.5
+        block[rev] = synth._COMP[block[rev][:, ::-1]]
+        bases, offs = block.reshape(-1), np.arange(len(starts) + 1, dtype=np.uint64) * np.uint64(150)
+    else:
+        from types import SimpleNamespace
+        bases, offs = synth.sample_long_reads(SimpleNamespace(haps=[gn], lens=np.array([gn.size], dtype=np.int64)), 60 * gn.size // 2000,
+                                              seed=21, mean_len=2000, min_len=500, max_len=gn.size - 1)
+    res, out = _predict(tmp_path, idx, bases, offs, "novel", illumina=tech == "illumina")
     variants = [l.split("\t") for l in open(out / "discover" / "denovo_variants.tsv") if not l.startswith("#")]
     assert len(variants) == 1 and variants[0][0] == "katG" and int(variants[0][1]) == pos + 2 and variants[0][2:4] == [codon[1], alt_base]
     assert (out / "updated.dr.prg").exists() and (out / "updated.dr.prg.k15.w11.idx").exists()
