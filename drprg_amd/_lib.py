@@ -54,6 +54,7 @@ SIGNATURES = {
     "drprg_hip_map_fastx": (C.c_int, [C.c_void_p, C.c_char_p]),
     "drprg_hip_set_threads": (C.c_int, [C.c_void_p, C.c_int]),
     "drprg_hip_parse_fastx": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_uint64), C.c_char_p, C.c_size_t]),
+    "drprg_hip_gunzip_file": (C.c_int, [C.c_char_p, C.c_int, C.c_uint64, C.c_char_p, C.POINTER(C.c_uint64), C.c_char_p, C.c_size_t]),
     "drprg_hip_map_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "drprg_hip_map_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),

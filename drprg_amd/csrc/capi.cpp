@@ -8,11 +8,16 @@
 #include "fastx.h"
 #include "genotype.h"
 #include "ingest.h"
+#include "pgunzip.h"
 #include "denovo.h"
 #include "mapper.h"
 #include <cstdlib>
 #include <cstring>
+#include <fcntl.h>
 #include <functional>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <memory>
 
 using namespace drprg;
@@ -725,6 +730,38 @@ extern "C" int drprg_hip_vcf_to_bcf(const char* vcf_path, const char* bcf_path, 
 {
     if (!vcf_path || !bcf_path) return DRPRG_EINVAL;
     return report_guard(err, err_len, [&]() { report::vcf_to_bcf(vcf_path, bcf_path); });
+}
+
+extern "C" int drprg_hip_gunzip_file(const char* gz_path, int threads, uint64_t chunk_bytes, const char* out_path, uint64_t out[3], char* err, size_t err_len)
+{
+    if (!gz_path || !out_path || !out) return DRPRG_EINVAL;
+    return report_guard(err, err_len, [&]() {
+        const int fd = open(gz_path, O_RDONLY);
+        if (fd < 0) throw Error(DRPRG_ENOENT, std::string("cannot open ") + gz_path);
+        struct stat sb;
+        void* map = fstat(fd, &sb) == 0 && sb.st_size > 0 ? mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0) : MAP_FAILED;
+        close(fd);
+        if (map == MAP_FAILED) throw Error(DRPRG_EIO, std::string("cannot map ") + gz_path);
+        struct Unmap {
+            void* p;
+            size_t n;
+            ~Unmap() { munmap(p, n); }
+        } unmap { map, (size_t)sb.st_size };
+        FILE* o = std::fopen(out_path, "wb");
+        if (!o) throw Error(DRPRG_EIO, std::string("cannot write ") + out_path);
+        struct Close {
+            FILE* f;
+            ~Close() { std::fclose(f); }
+        } close_o { o };
+        ParallelGunzip pg((const unsigned char*)map, (size_t)sb.st_size, threads, (size_t)chunk_bytes);
+        std::vector<char> buf(size_t(8) << 20);
+        uint64_t total = 0;
+        for (size_t n; (n = pg.read(buf.data(), buf.size())) > 0; total += n)
+            if (std::fwrite(buf.data(), 1, n, o) != n) throw Error(DRPRG_EIO, std::string("cannot write ") + out_path);
+        out[0] = total;
+        out[1] = pg.chunks_accepted();
+        out[2] = pg.chunks_redone();
+    });
 }
 
 extern "C" int drprg_hip_parse_fastx(const char* reads_path, int threads, uint64_t out[5], char* err, size_t err_len)

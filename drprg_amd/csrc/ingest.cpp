@@ -1,5 +1,6 @@
 // ingest.cpp -- see ingest.h
 #include "ingest.h"
+#include "pgunzip.h"
 #include <atomic>
 #include <condition_variable>
 #include <cstdlib>
@@ -415,13 +416,17 @@ IngestStats ingest_fastx(const std::string& path, int threads, const IngestHooks
                 cur = cut;
             }
         } else {
-            // Three ways to inflate, fastest first: (1) BGZF: the members are located from their headers and inflated in
-            // parallel, a window of text at a time; (2) one plain gzip member whose size field can be trusted (< 4 GB of
-            // text): one libdeflate call into one buffer, then the parallel parser as for a plain file; (3) anything else,
-            // or no libdeflate on this host: zlib's streaming inflate on this thread.
+            // Four ways to inflate: (1) BGZF: the members are located from their headers and inflated in parallel, a window
+            // of text at a time; (4) a plain gzip file of some size with several threads to spend: all threads inflate the one
+            // stream, entering it at block boundaries found in the compressed data (pgunzip.h); (2) a small plain gzip member
+            // whose size field can be trusted: one libdeflate call into one buffer; (3) anything else, or no libdeflate on
+            // this host: zlib's streaming inflate on this thread.
             const LibDeflate& ld = LibDeflate::get();
             const size_t gz_len = (size_t)sb.st_size;
-            void* gz_map = ld.ok() && gz_len >= 18 ? mmap(nullptr, gz_len, PROT_READ, MAP_PRIVATE, fd, 0) : MAP_FAILED;
+            const char* par_env = std::getenv("DRPRG_GZ_PARALLEL"); // 0: never way 4; 1: also for small files (tests)
+            const bool par_forced = par_env && std::atoi(par_env) > 0;
+            const bool par_ok = !(par_env && std::atoi(par_env) == 0) && threads >= 2 && (par_forced || gz_len >= (size_t(4) << 20));
+            void* gz_map = (ld.ok() || par_ok) && gz_len >= 18 ? mmap(nullptr, gz_len, PROT_READ, MAP_PRIVATE, fd, 0) : MAP_FAILED;
             const unsigned char* gz_data = gz_map != MAP_FAILED ? (const unsigned char*)gz_map : nullptr;
             struct Unmap {
                 void* p;
@@ -429,9 +434,14 @@ IngestStats ingest_fastx(const std::string& path, int threads, const IngestHooks
                 ~Unmap() { if (p && p != MAP_FAILED) munmap(p, n); }
             } unmap { gz_map, gz_len };
             std::vector<BgzfBlock> blocks;
-            if (gz_data) blocks = bgzf_index(gz_data, gz_len);
+            if (gz_data && ld.ok()) blocks = bgzf_index(gz_data, gz_len);
+            std::unique_ptr<ParallelGunzip> pgz; // way (4)
+            if (gz_data && blocks.empty() && par_ok) {
+                const char* chunk_env = std::getenv("DRPRG_GZ_CHUNK");
+                pgz.reset(new ParallelGunzip(gz_data, gz_len, threads, chunk_env ? (size_t)std::atoll(chunk_env) : 0));
+            }
             std::shared_ptr<std::vector<char>> whole; // way (2)
-            if (gz_data && blocks.empty() && gz_len < (size_t(1) << 30)) {
+            if (gz_data && ld.ok() && blocks.empty() && !pgz && gz_len < (size_t(1) << 30)) {
                 const size_t isize = le32(gz_data + gz_len - 4);
                 if (isize >= gz_len / 2) { // (a wrapped size field of a > 4 GB stream is most likely smaller than that)
                     auto buf = std::make_shared<std::vector<char>>(isize + 1);
@@ -482,6 +492,17 @@ IngestStats ingest_fastx(const std::string& path, int threads, const IngestHooks
                     for (auto& t : infl) t.join();
                     if (bad) throw Error(DRPRG_EIO, "corrupt gzip block in " + path);
                     return total;
+                };
+            } else if (pgz) {
+                st.gz_mode = 4;
+                read_text = [&](char* dst, size_t cap) -> size_t {
+                    size_t have = 0;
+                    while (have < cap) { // (a call hands over what one round of chunks left; a short window would read as the end)
+                        const size_t n = pgz->read(dst + have, cap - have);
+                        if (n == 0) break;
+                        have += n;
+                    }
+                    return have;
                 };
             } else if (whole) {
                 st.gz_mode = 2;

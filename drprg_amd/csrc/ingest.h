@@ -3,7 +3,7 @@
 // The kernels map 10 M reads in under 2 ms; end to end the path is bound by text parsing and the host->device copy.
 // A plain file is memory-mapped and cut at record boundaries into slices that worker threads parse straight into
 // pinned buffers (so the H2D copy runs at DMA speed); gzip input is inflated window by window -- BGZF members in
-// parallel with libdeflate, a single plain member in one libdeflate call, anything else by zlib -- and cut the same way.  Read order is irrelevant to the result (coverage is a sum), so workers submit batches independently.
+// parallel with libdeflate, a plain gzip stream by all threads at once (pgunzip.h), a small one in one libdeflate call, anything else by zlib -- and cut the same way.  Read order is irrelevant to the result (coverage is a sum), so workers submit batches independently.
 #pragma once
 #include "common.h"
 #include <functional>
@@ -26,7 +26,8 @@ struct IngestHooks {
 struct IngestStats {
     uint64_t reads = 0, bases = 0, batches = 0;
     bool parallel = false;
-    int gz_mode = 0; // 0 plain text, 1 BGZF (members inflated in parallel), 2 one gzip member in one libdeflate call, 3 zlib streaming
+    int gz_mode = 0; // 0 plain text, 1 BGZF (members inflated in parallel), 2 one gzip member in one libdeflate call, 3 zlib streaming,
+                     // 4 one plain gzip stream inflated by all threads (pgunzip.h)
 };
 
 // Parses `path` (fasta/fastq, plain or .gz) with `threads` parser threads and feeds every batch to hooks.submit.

@@ -74,8 +74,13 @@ int drprg_hip_map_fastx(drprg_hip_ctx* ctx, const char* reads_path); /* fasta/fa
 int drprg_hip_set_threads(drprg_hip_ctx* ctx, int threads);
 /* Host-only self-check of that ingest: parses the file with `threads` parser threads and returns
  * out[0..4] = reads, bases, order-independent digest (sum of the FNV-1a hashes of the reads), batches, and how gzip input
- * was inflated (0 plain text, 1 BGZF members in parallel, 2 one member in one libdeflate call, 3 zlib streaming). */
+ * was inflated (0 plain text, 1 BGZF members in parallel, 2 one member in one libdeflate call, 3 zlib streaming, 4 one plain
+ * gzip stream inflated by all threads: chunks entered at block boundaries found in the compressed data, csrc/pgunzip.h). */
 int drprg_hip_parse_fastx(const char* reads_path, int threads, uint64_t out[5], char* err, size_t err_len);
+/* Host-only self-check of way 4 on any gzip file (not only FASTQ): inflates gz_path with `threads` threads and chunks of
+ * chunk_bytes compressed bytes (0 = automatic) into out_path; out[0..2] = bytes written, chunks accepted as their threads
+ * inflated them, chunks inflated again from the known position.  Member CRC-32s and lengths are checked as gzip does. */
+int drprg_hip_gunzip_file(const char* gz_path, int threads, uint64_t chunk_bytes, const char* out_path, uint64_t out[3], char* err, size_t err_len);
 int drprg_hip_map_host(drprg_hip_ctx* ctx, const uint8_t* bases, const uint64_t* offsets, uint64_t n_reads);
 /* Batch already resident in HBM.  d_bases: ASCII bases of all reads back to back, 16-byte aligned;
  * d_offsets: u64[n_reads+1], d_offsets[0] == 0, d_offsets[n_reads] == n_bases.  d_covg (u32[2*n_knodes]) and

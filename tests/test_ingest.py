@@ -164,12 +164,39 @@ def test_gzip_inputs_take_the_fast_paths_and_agree(tmp_path, threads):
     gz = tmp_path / "r.fq.gz"
     with gzip.open(gz, "wb", compresslevel=1) as fh:
         fh.write(text)
-    assert _parse(str(gz), threads)[:3] == want and _parse.gz_mode == 2
-    multi = tmp_path / "multi.fq.gz"  # several plain members (cat a.gz b.gz): only the streaming reader follows them
+    # a plain gzip file of some size: with threads to spend all of them inflate the one stream (way 4), else one libdeflate call
+    assert os.path.getsize(gz) > (4 << 20)
+    assert _parse(str(gz), threads)[:3] == want and _parse.gz_mode == (4 if threads > 1 else 2)
+    multi = tmp_path / "multi.fq.gz"  # several plain members (cat a.gz b.gz): way 4 follows them, and so does the streaming reader
     with open(multi, "wb") as fh:
         cut = text.index(b"\n@r60000 ") + 1
         fh.write(gzip.compress(text[:cut], 1) + gzip.compress(text[cut:], 1))
-    assert _parse(str(multi), threads)[:3] == want and _parse.gz_mode == 3
+    assert _parse(str(multi), threads)[:3] == want and _parse.gz_mode == (4 if threads > 1 else 3)
+
+
+def test_parallel_gunzip_can_be_switched_off_and_forced(tmp_path, monkeypatch):
+    import gzip
+    reads, text = _random_fastq(60_000, 6)
+    want = (len(reads), sum(len(r) for r in reads), _digest(reads))
+    gz = tmp_path / "r.fq.gz"
+    gz.write_bytes(gzip.compress(text, 6))
+    small = tmp_path / "small.fq.gz"
+    small.write_bytes(gzip.compress(text[:text.index(b"\n@r2000 ") + 1], 6))
+    assert _parse(str(small), 4)[0] == 2000 and _parse.gz_mode == 2      # too small to be worth the threads
+    monkeypatch.setenv("DRPRG_GZ_PARALLEL", "1")
+    monkeypatch.setenv("DRPRG_GZ_CHUNK", "30000")
+    assert _parse(str(small), 4)[0] == 2000 and _parse.gz_mode == 4
+    assert _parse(str(gz), 3)[:3] == want and _parse.gz_mode == 4
+    monkeypatch.setenv("DRPRG_GZ_PARALLEL", "0")
+    assert _parse(str(gz), 4)[:3] == want and _parse.gz_mode == 2
+    # a damaged stream is refused on the parallel path too
+    monkeypatch.setenv("DRPRG_GZ_PARALLEL", "1")
+    raw = bytearray(gz.read_bytes())
+    raw[len(raw) // 2] ^= 0x10
+    bad = tmp_path / "bad.fq.gz"
+    bad.write_bytes(bytes(raw))
+    with pytest.raises(RuntimeError):
+        _parse(str(bad), 4)
 
 
 def test_gzip_without_libdeflate_and_corrupt_blocks(tmp_path):
