@@ -180,10 +180,11 @@ void parse_slice(const char* p, const char* e, bool fastq, Block& blk, Shared& s
     }
 }
 
+struct TextBuffer;
 struct Slice {
     const char* begin = nullptr;
     const char* end = nullptr;
-    std::shared_ptr<std::vector<char>> owner; // inflated gzip text; null for a memory-mapped file
+    std::shared_ptr<TextBuffer> owner; // inflated gzip text; null for a memory-mapped file
 };
 
 class SliceQueue {
@@ -223,13 +224,32 @@ private:
     bool closed_ = false;
 };
 
-// Window buffers of the gzip path are recycled: a fresh 32 MB vector per window means an mmap, 8 k page faults and an munmap
-// (with its TLB shoot-downs on every parser thread) per window -- measured 4x slower with 8 threads than with 4.
+// Window buffers of the gzip path are recycled: a fresh 32 MB buffer per window means an mmap, 8 k page faults and an munmap
+// (with its TLB shoot-downs on every parser thread) per window -- measured 4x slower with 8 threads than with 4.  They are raw
+// (not value-initialised: a std::vector would write 32 MB of zeros first), 2 MB-aligned and advised as huge pages.
+struct TextBuffer {
+    char* p = nullptr;
+    size_t n = 0;
+    explicit TextBuffer(size_t size)
+    {
+        constexpr size_t HUGE = size_t(2) << 20;
+        n = (size + HUGE - 1) / HUGE * HUGE;
+        p = (char*)std::aligned_alloc(HUGE, n);
+        if (!p) throw Error(DRPRG_EIO, "out of memory for a text window");
+        madvise(p, n, MADV_HUGEPAGE);
+    }
+    ~TextBuffer() { std::free(p); }
+    TextBuffer(const TextBuffer&) = delete;
+    TextBuffer& operator=(const TextBuffer&) = delete;
+    char* data() { return p; }
+    size_t size() const { return n; }
+};
+
 class BufferPool {
 public:
-    std::shared_ptr<std::vector<char>> acquire(size_t size)
+    std::shared_ptr<TextBuffer> acquire(size_t size)
     {
-        std::unique_ptr<std::vector<char>> v;
+        std::unique_ptr<TextBuffer> v;
         {
             std::lock_guard<std::mutex> g(mu_);
             if (!free_.empty()) {
@@ -237,10 +257,9 @@ public:
                 free_.pop_back();
             }
         }
-        if (!v) v.reset(new std::vector<char>());
-        if (v->size() < size) v->resize(size);
-        std::vector<char>* raw = v.release();
-        return std::shared_ptr<std::vector<char>>(raw, [this](std::vector<char>* p) {
+        if (!v || v->size() < size) v.reset(new TextBuffer(size));
+        TextBuffer* raw = v.release();
+        return std::shared_ptr<TextBuffer>(raw, [this](TextBuffer* p) {
             std::lock_guard<std::mutex> g(mu_);
             free_.emplace_back(p);
         });
@@ -248,7 +267,7 @@ public:
 
 private:
     std::mutex mu_;
-    std::vector<std::unique_ptr<std::vector<char>>> free_;
+    std::vector<std::unique_ptr<TextBuffer>> free_;
 };
 
 // multi-line FASTQ (sequence wrapped over several lines) is left to the serial reader
@@ -359,7 +378,8 @@ IngestStats ingest_fastx(const std::string& path, int threads, const IngestHooks
     }
     unsigned char magic[2] = { 0, 0 };
     const bool gz = pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
-    SliceQueue queue((size_t)threads + 2);
+    // (gzip: at most 8 parser threads; every queued window is a 32 MB buffer that is recycled only once parsed, so a short queue keeps the same few buffers -- and their pages -- going round)
+    SliceQueue queue(gz ? (size_t)std::min(threads, 8) + 2 : (size_t)threads + 2);
     bool fastq = true;
     std::atomic<bool> format_known { false };
 
@@ -535,7 +555,8 @@ IngestStats ingest_fastx(const std::string& path, int threads, const IngestHooks
             std::vector<char> carry;
             bool eof = false;
             while (!eof && !sh.failed) {
-                auto buf = gz_pool.acquire(carry.size() + SLICE_BYTES); // (may be larger than asked for: a recycled one)
+                // (one size for every window -- the carry is at most the 1 MB the cut is looked for in --, so a recycled buffer always fits)
+                auto buf = gz_pool.acquire(std::max(carry.size(), size_t(1) << 20) + SLICE_BYTES);
                 if (!carry.empty()) std::memcpy(buf->data(), carry.data(), carry.size());
                 size_t have = carry.size();
                 carry.clear();

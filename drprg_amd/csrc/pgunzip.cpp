@@ -3,12 +3,15 @@
 #include "pgunzip.h"
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <condition_variable>
 #include <deque>
 #include <mutex>
 #include <dlfcn.h>
+#include <sys/mman.h>
 #include <emmintrin.h>
 #include <thread>
 #include <vector>
@@ -248,6 +251,17 @@ bool read_dynamic_lengths(BitReader& br, uint8_t* lens /* [320] */, unsigned& hl
     return lens[256] != 0; // a block without an end-of-block code never ends
 }
 
+// Symbol buffers are tens of MB written once front to back: 2 MB-aligned and advised as huge pages, so that filling them costs
+// one page fault per 2 MB instead of 512 (with every thread of a round faulting at once the kernel serialises them).
+constexpr size_t HUGE = size_t(2) << 20;
+uint16_t* alloc_symbols(size_t n)
+{
+    const size_t bytes = (n * sizeof(uint16_t) + HUGE - 1) / HUGE * HUGE;
+    void* p = std::aligned_alloc(HUGE, bytes);
+    if (p) madvise(p, bytes, MADV_HUGEPAGE);
+    return (uint16_t*)p;
+}
+
 struct MemberEnd {
     size_t at;      // symbols of the segment that belong to members ended so far
     uint32_t crc, isize;
@@ -303,8 +317,10 @@ struct Inflater {
         size_t cap = std::max<size_t>(s.cap * 2, want + (want >> 1));
         if (cap > HARD_CAP + WINDOW + (1u << 20)) cap = HARD_CAP + WINDOW + (1u << 20);
         if (cap < want) return false;
-        uint16_t* nb = (uint16_t*)std::realloc(s.buf, cap * sizeof(uint16_t));
+        uint16_t* nb = alloc_symbols(cap);
         if (!nb) return false;
+        std::memcpy(nb, s.buf, (WINDOW + s.n) * sizeof(uint16_t));
+        std::free(s.buf);
         s.buf = nb;
         s.cap = cap;
         return true;
@@ -321,7 +337,7 @@ struct Inflater {
         s.ok = s.eof = s.hit_cap = false;
         if (!s.buf) {
             s.cap = WINDOW + std::max<size_t>(expect_symbols, 1u << 16);
-            s.buf = (uint16_t*)std::malloc(s.cap * sizeof(uint16_t));
+            s.buf = alloc_symbols(s.cap);
             if (!s.buf) {
                 s.error = "out of memory";
                 return Status::FAILED;
@@ -578,7 +594,7 @@ struct ParallelGunzip::Impl {
     uint64_t next_bit = 0;        // where the stitched stream stands (a block boundary, or a member header when at_header)
     bool at_header = true, done = false;
     size_t next_chunk = 0;        // the chunk whose range [next_chunk * chunk, ...) comes next
-    // the rounds run on a producer thread, up to two rounds ahead of read(): inflating the next chunks overlaps resolving
+    // the rounds run on a producer thread, up to a round ahead of read(): inflating the next chunks overlaps resolving
     // and parsing the previous ones
     std::deque<std::unique_ptr<Segment>> ready; // guarded by mu, like done_pub / failed / stop
     std::mutex mu;
@@ -590,6 +606,9 @@ struct ParallelGunzip::Impl {
     uint32_t run_crc = 0;
     uint64_t run_len = 0;
     std::atomic<uint64_t> accepted { 0 }, redone { 0 };
+    double t_decode = 0, t_stitch = 0, t_resolve = 0, t_wait = 0; // wall seconds (DRPRG_GZ_DEBUG=1 prints them)
+    uint64_t n_rounds = 0, n_reads = 0;
+    static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
     // symbol buffers go round: a fresh 20 MB allocation per chunk is 5000 page faults, serialised between the threads by the kernel
     std::mutex pool_mu;
     std::vector<std::pair<uint16_t*, size_t>> pool;
@@ -613,10 +632,14 @@ struct ParallelGunzip::Impl {
     ~Impl()
     {
         shutdown();
+        if (std::getenv("DRPRG_GZ_DEBUG"))
+            std::fprintf(stderr, "[pgunzip] threads %d chunk %zu: %llu rounds decode %.3f s stitch %.3f s | %llu reads resolve %.3f s wait-for-producer %.3f s | accepted %llu redone %llu\n",
+                threads, chunk, (unsigned long long)n_rounds, t_decode, t_stitch, (unsigned long long)n_reads, t_resolve, t_wait,
+                (unsigned long long)accepted.load(), (unsigned long long)redone.load());
         for (auto& b : pool) std::free(b.first);
     }
 
-    size_t expect_symbols() const { return chunk * 5; }
+    size_t expect_symbols() const { return chunk * 10; } // (address space: only what is written gets pages)
     size_t soft_cap() const { return std::max<size_t>(chunk * 48, size_t(1) << 24); }
 
     // one round: `threads` chunks inflated at once, then stitched onto `ready`
@@ -641,9 +664,18 @@ struct ParallelGunzip::Impl {
             }
         };
         const int nt = (int)std::min<size_t>((size_t)threads, seg.size());
+        const double t0 = now();
         for (int t = 1; t < nt; ++t) pool.emplace_back(job);
         job();
         for (auto& t : pool) t.join();
+        const double t1 = now();
+        t_decode += t1 - t0;
+        ++n_rounds;
+        struct Tick {
+            double& acc;
+            double from;
+            ~Tick() { acc += now() - from; }
+        } tick { t_stitch, t1 };
         // ---- stitch ----
         std::unique_ptr<Inflater> inf;
         for (size_t j = 0; j < seg.size() && !done; ++j) {
@@ -711,7 +743,7 @@ struct ParallelGunzip::Impl {
             while (!done) {
                 {
                     std::unique_lock<std::mutex> g(mu);
-                    cv.wait(g, [&] { return stop || ready.size() < 2 * (size_t)threads; });
+                    cv.wait(g, [&] { return stop || ready.size() < (size_t)threads; });
                     if (stop) return;
                 }
                 round();
@@ -779,7 +811,9 @@ struct ParallelGunzip::Impl {
             std::unique_lock<std::mutex> g(mu);
             if (ready.empty()) {
                 if (total > 0) break; // (hand over what there is)
+                const double w0 = now();
                 cv.wait(g, [&] { return !ready.empty() || done_pub; });
+                t_wait += now() - w0;
                 if (ready.empty()) {
                     if (!failed.empty()) throw Error(DRPRG_EIO, failed);
                     break;
@@ -835,10 +869,13 @@ struct ParallelGunzip::Impl {
             }
         };
         const int nt = (int)std::min<size_t>((size_t)threads, (jobs.size() + 1) / 2);
+        const double r0 = now();
         std::vector<std::thread> pool;
         for (int t = 1; t < nt; ++t) pool.emplace_back(work);
         work();
         for (auto& t : pool) t.join();
+        t_resolve += now() - r0;
+        ++n_reads;
         for (auto& u : used) recycle(*u);
         for (const Job& j : jobs) {
             if (j.count) {
@@ -861,7 +898,8 @@ ParallelGunzip::ParallelGunzip(const unsigned char* data, size_t len, int thread
     impl_->data = data;
     impl_->len = len;
     impl_->threads = std::max(1, threads);
-    if (!chunk_bytes) chunk_bytes = std::min<size_t>(size_t(2) << 20, std::max<size_t>(size_t(128) << 10, len / ((size_t)impl_->threads * 4)));
+    // (every chunk in flight holds ~12x its size in symbols, memory the kernel has to zero first: 1 MB chunks are as fast as 4 MB ones)
+    if (!chunk_bytes) chunk_bytes = std::min<size_t>(size_t(1) << 20, std::max<size_t>(size_t(128) << 10, len / ((size_t)impl_->threads * 8)));
     impl_->chunk = std::max<size_t>(chunk_bytes, 1024);
     if (!gzip_header(data, len, 0)) throw Error(DRPRG_EIO, "not a gzip file");
 }
