@@ -351,11 +351,19 @@ def main():
     # every reduce before the next step starts.
     n_acc = 2 * ctx.n_knodes + ctx.n_prgs
     overlap = world > 1 and os.environ.get("DRPRG_BENCH_SYNC_REDUCE", "0") in ("", "0")
-    accs = [torch.zeros(n_acc, dtype=torch.int32, device=device) for _ in range(2 if overlap else 1)]
+    # Steps are queued without the host waiting for them (drprg_hip_map_device_async): the read-back a batch ends with is looked
+    # at while the next batch runs, so the device never idles between steps.  A batch's accumulator must stay untouched until
+    # the call after the next one, hence buffers in rotation: 2 at N = 1; 3 at N > 1, where the all-reduce of batch i is issued
+    # once batch i is known to be complete -- right after batch i+1 has been queued -- and runs on RCCL's stream while batch
+    # i+1 / i+2 map into the other buffers (every step's collective completes inside the timed region: drain() before the
+    # closing barrier).  DRPRG_BENCH_SYNC_REDUCE=1: one buffer, synchronous calls, the stream waits for every reduce.
+    deferred = (world == 1 or overlap) and os.environ.get("DRPRG_BENCH_SYNC", "0") in ("", "0")  # DRPRG_BENCH_SYNC=1: the host waits for every batch
+    accs = [torch.zeros(n_acc, dtype=torch.int32, device=device) for _ in range((3 if world > 1 else 2) if deferred else 1)]
     pending = [None] * len(accs)
     stream = torch.cuda.Stream(device)  # the hot path runs on this stream; the collective is ordered behind it
     torch.cuda.synchronize()
     step_no = [0]
+    unreduced = [None]  # N > 1: the buffer of the batch queued last, not reduced yet
 
     def step():
         b = step_no[0] % len(accs)
@@ -366,17 +374,26 @@ def main():
                 pending[b].wait()  # (the stream waits, not the host)
                 pending[b] = None
             acc.zero_()
-            ctx.map_device(bases.data_ptr(), offsets.data_ptr(), n_reads, n_bases, acc.data_ptr(),
-                           acc.data_ptr() + 8 * ctx.n_knodes, stream.cuda_stream)
-            if world > 1:
-                if overlap:
-                    pending[b] = dist.all_reduce(acc, async_op=True)
-                else:
+            if deferred:
+                ctx.map_device_async(bases.data_ptr(), offsets.data_ptr(), n_reads, n_bases, acc.data_ptr(),
+                                     acc.data_ptr() + 8 * ctx.n_knodes, stream.cuda_stream)
+                if world > 1:
+                    if unreduced[0] is not None:  # the batch before this one is complete now
+                        pending[unreduced[0]] = dist.all_reduce(accs[unreduced[0]], async_op=True)
+                    unreduced[0] = b
+            else:
+                ctx.map_device(bases.data_ptr(), offsets.data_ptr(), n_reads, n_bases, acc.data_ptr(),
+                               acc.data_ptr() + 8 * ctx.n_knodes, stream.cuda_stream)
+                if world > 1:
                     dist.all_reduce(acc)
         return acc
 
     def drain():
+        ctx.sync()
         with torch.cuda.stream(stream):
+            if unreduced[0] is not None:
+                pending[unreduced[0]] = dist.all_reduce(accs[unreduced[0]], async_op=True)
+                unreduced[0] = None
             for b, w in enumerate(pending):
                 if w is not None:
                     w.wait()

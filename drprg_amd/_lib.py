@@ -58,6 +58,9 @@ SIGNATURES = {
     "drprg_hip_map_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "drprg_hip_map_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),
+    "drprg_hip_map_device_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p,
+                                             C.c_void_p, C.c_void_p]),
+    "drprg_hip_sync": (C.c_int, [C.c_void_p]),
     "drprg_hip_coverage_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "drprg_hip_coverage": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]),
     "drprg_hip_set_coverage": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64]),

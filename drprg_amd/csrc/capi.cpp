@@ -306,6 +306,25 @@ int drprg_hip_map_device(drprg_hip_ctx* ctx, const void* d_bases, const void* d_
     API_END(ctx)
 }
 
+int drprg_hip_map_device_async(drprg_hip_ctx* ctx, const void* d_bases, const void* d_offsets, uint64_t n_reads, uint64_t n_bases,
+    void* d_covg, void* d_prg_reads, void* hip_stream)
+{
+    API_BEGIN(ctx)
+    Mapper& m = need_mapper(ctx);
+    m.map_device_async((const uint8_t*)d_bases, (const uint64_t*)d_offsets, n_reads, n_bases, (uint32_t*)d_covg,
+        (uint32_t*)d_prg_reads, (hipStream_t)hip_stream);
+    ctx->total_bases += n_bases;
+    ctx->host_coverage_valid = false;
+    API_END(ctx)
+}
+
+int drprg_hip_sync(drprg_hip_ctx* ctx)
+{
+    API_BEGIN(ctx)
+    if (ctx->mapper) ctx->mapper->sync();
+    API_END(ctx)
+}
+
 int drprg_hip_coverage_size(const drprg_hip_ctx* ctx, uint64_t* n_covg, uint64_t* n_prgs)
 {
     if (!ctx) return DRPRG_EINVAL;
@@ -648,6 +667,7 @@ int drprg_hip_kernel_timing(drprg_hip_ctx* ctx, int enable, int reset, double* m
 {
     API_BEGIN(ctx)
     Mapper& m = need_mapper(ctx);
+    m.sync(); // (a batch in flight carries the events of the setting it was launched with)
     m.enable_kernel_timing(enable != 0);
     if (ms_total) *ms_total = m.sketch_ms_total();
     if (launches) *launches = m.sketch_launches();

@@ -145,6 +145,12 @@ Mapper::Mapper(const FlatIndex& idx, const MapParams& p, int device) : device_(d
 Mapper::~Mapper()
 {
     (void)hipSetDevice(device_);
+    try {
+        sync();
+    } catch (...) { // (nothing to report to from a destructor)
+    }
+    (void)hipDeviceSynchronize();
+    for (Lane& lane : pipe_lanes_) free_lane(lane);
     if (stream_) (void)hipStreamSynchronize(stream_);
     dfree(d_slot_rec_); dfree(d_slot_first_); dfree(d_rec_knode_); dfree(d_rec_prg_); dfree(d_min_path_len_); dfree(d_prg_thr_);
     if (d_slot_key_) (void)hipFree(d_slot_key_);
@@ -181,6 +187,7 @@ void Mapper::pinned_free(void* p)
 
 void Mapper::set_params(const MapParams& p)
 {
+    sync(); // (a batch in flight was launched with the previous parameters)
     // validate everything before any state changes: a refused call leaves the previous parameters in force
     if (p.k < 1 || p.k > 31) throw Error(DRPRG_EINVAL, "k must be in [1,31]");
     if (p.w < 1 || p.w > 1024) throw Error(DRPRG_EINVAL, "w must be in [1,1024]");
@@ -204,6 +211,7 @@ void Mapper::set_params(const MapParams& p)
 
 void Mapper::reset_coverage()
 {
+    sync();
     HIPCHK(hipSetDevice(device_));
     HIPCHK(hipMemsetAsync(d_covg_, 0, 2 * (size_t)n_knodes_ * sizeof(uint32_t), stream_));
     HIPCHK(hipMemsetAsync(d_prg_reads_, 0, (size_t)n_prgs_ * sizeof(uint32_t), stream_));
@@ -539,6 +547,118 @@ void Mapper::run_batch_direct_candidates(const uint8_t* d_bases, const uint64_t*
     leftovers(lane, d_bases, d_offsets, n_reads, n_bases, covg, prg_reads, stream);
 }
 
+// What the host does with a lane's read-back once its sequence has finished: a candidate slice that was too small -> the range
+// again with larger buffers; the totals; the reads read_cluster_kernel left over -> the generic pipeline on their hits.
+void Mapper::finish_lane(Lane& lane, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads, uint64_t n_bases, uint32_t* covg,
+    uint32_t* prg_reads, hipStream_t stream)
+{
+    for (int attempt = 0;; ++attempt) {
+        const uint32_t ovf = (uint32_t)lane.h_scratch[L_OVERFLOW];
+        if (ovf & 8u) throw Error(DRPRG_EIO, "sketch_filter_kernel: dynamic LDS does not start at address 0");
+        if (ovf & 2u) throw Error(DRPRG_EOVERFLOW, "a read is longer than 2^" + std::to_string(dev::HIT_POS_BITS) + " bases");
+        if (!(ovf & 4u)) break;
+        // a candidate slice of this range was too small: its sequence counted nothing and touched no coverage
+        // (hit_scan_kernel / read_cluster_kernel check the flag); grow the lane and run the range again, alone
+        if (attempt > 8) throw Error(DRPRG_EOVERFLOW, "candidate buffer overflow after regrow");
+        grow_lane(lane, lane.raw_capacity * 4);
+        launch_lane(lane, stream, d_bases, d_offsets, n_reads, n_bases, covg, prg_reads);
+        wait_stream(stream);
+    }
+    tot_minimizers_ += lane.h_scratch[L_MINIMIZERS];
+    tot_hits_ += lane.h_scratch[L_HITS];
+    tot_leftover_ += lane.h_scratch[L_COMPLEX];
+    leftovers(lane, d_bases, d_offsets, n_reads, n_bases, covg, prg_reads, stream);
+}
+
+void Mapper::map_device_async(const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n_reads, uint64_t n_bases, uint32_t* covg,
+    uint32_t* prg_reads, hipStream_t stream)
+{
+    if (n_reads == 0) return;
+    if (!use_filter_ || max_lanes_ > 1 || n_bases == 0) { // (no deferred form of the other sequences)
+        map_device(d_bases, d_offsets, n_reads, n_bases, covg, prg_reads, stream);
+        return;
+    }
+    if (!d_bases || !d_offsets) throw Error(DRPRG_EINVAL, "null device pointer");
+    if ((reinterpret_cast<uintptr_t>(d_bases) & 15u) != 0) throw Error(DRPRG_EINVAL, "d_bases must be 16-byte aligned");
+    if (n_reads > dev::MAX_BATCH_READS)
+        throw Error(DRPRG_EOVERFLOW, "at most " + std::to_string(dev::MAX_BATCH_READS) + " reads per batch");
+    HIPCHK(hipSetDevice(device_));
+    if (!stream) stream = stream_;
+    if (!covg) covg = d_covg_;
+    if (!prg_reads) prg_reads = d_prg_reads_;
+    if (pipe_lanes_.empty()) {
+        for (int j = 0; j < 2; ++j) {
+            pipe_lanes_.emplace_back();
+            Lane& lane = pipe_lanes_.back();
+            HIPCHK(hipEventCreateWithFlags(&lane.done, hipEventDisableTiming));
+            HIPCHK(hipEventCreate(&lane.t0));
+            HIPCHK(hipEventCreate(&lane.t1));
+            dmalloc(lane.small, dev::filter_small_words());
+            dmalloc(lane.d_scratch, (size_t)L_N);
+            HIPCHK(hipHostMalloc((void**)&lane.h_scratch, L_N * sizeof(unsigned long long), hipHostMallocDefault));
+            HIPCHK(hipMemset(lane.d_scratch, 0, L_N * sizeof(unsigned long long)));
+            lane.scratch_zero = true;
+        }
+    }
+    Lane& lane = pipe_lanes_[(size_t)pipe_next_];
+    // (this lane's previous batch was completed by the call before this one; growing frees its buffers, which waits for the device)
+    grow_lane(lane, std::max<uint64_t>(1u << 20, n_bases / 64));
+    lane.r0 = 0;
+    lane.r1 = (uint32_t)n_reads;
+    launch_lane(lane, stream, d_bases, d_offsets, (uint32_t)n_reads, n_bases, covg, prg_reads);
+    HIPCHK(hipEventRecord(lane.done, stream));
+    Pending cur;
+    cur.active = true;
+    cur.lane = pipe_next_;
+    cur.d_bases = d_bases;
+    cur.d_offsets = d_offsets;
+    cur.n_reads = (uint32_t)n_reads;
+    cur.n_bases = n_bases;
+    cur.covg = covg;
+    cur.prg_reads = prg_reads;
+    cur.stream = stream;
+    complete_pending(); // the batch before this one, while this one runs
+    pending_ = cur;
+    static const bool one_lane_experiment = std::getenv("DRPRG_PIPE_ONE_LANE") != nullptr; // (measurement only: unsafe with leftovers)
+    if (!one_lane_experiment) pipe_next_ ^= 1;
+    tot_reads_ += n_reads;
+    tot_bases_ += n_bases;
+}
+
+void Mapper::complete_pending()
+{
+    if (!pending_.active) return;
+    const Pending p = pending_;
+    pending_.active = false;
+    HIPCHK(hipSetDevice(device_));
+    Lane& lane = pipe_lanes_[(size_t)p.lane];
+    static const bool spin = [] {
+        const char* e = std::getenv("DRPRG_HIP_SPIN");
+        return !(e && std::atoi(e) == 0);
+    }();
+    bool ready = false;
+    for (int spins = 0; spin && spins < 2048 && !ready; ++spins) {
+        const hipError_t e = hipEventQuery(lane.done);
+        if (e == hipSuccess) ready = true;
+        else if (e != hipErrorNotReady) HIPCHK(e);
+    }
+    if (!ready) HIPCHK(hipEventSynchronize(lane.done));
+    if (timing_) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, lane.t0, lane.t1));
+        sketch_ms_ += ms;
+        sketch_launches_ += 1;
+    }
+    finish_lane(lane, p.d_bases, p.d_offsets, p.n_reads, p.n_bases, p.covg, p.prg_reads, p.stream);
+}
+
+void Mapper::sync()
+{
+    const hipStream_t last = pending_.active ? pending_.stream : nullptr;
+    complete_pending();
+    if (last) HIPCHK(hipStreamSynchronize(last));
+}
+
 void Mapper::run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads, uint64_t n_bases,
     uint32_t* covg, uint32_t* prg_reads, hipStream_t stream)
 {
@@ -574,27 +694,7 @@ void Mapper::run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32
                 sketch_launches_ += 1;
             }
         }
-        for (int j = 0; j < n_lanes; ++j) {
-            Lane& lane = lanes_[j];
-            for (int attempt = 0;; ++attempt) {
-                const uint32_t ovf = (uint32_t)lane.h_scratch[L_OVERFLOW];
-                if (ovf & 8u) throw Error(DRPRG_EIO, "sketch_filter_kernel: dynamic LDS does not start at address 0");
-                if (ovf & 2u) throw Error(DRPRG_EOVERFLOW, "a read is longer than 2^" + std::to_string(dev::HIT_POS_BITS) + " bases");
-                if (!(ovf & 4u)) break;
-                // a candidate slice of this range was too small: its sequence counted nothing and touched no coverage
-                // (hit_scan_kernel / read_cluster_kernel check the flag); grow the lane and run the range again, alone
-                if (attempt > 8) throw Error(DRPRG_EOVERFLOW, "candidate buffer overflow after regrow");
-                grow_lane(lane, lane.raw_capacity * 4);
-                launch_lane(lane, stream, d_bases, d_offsets, n_reads, n_bases, covg, prg_reads);
-                wait_stream(stream);
-            }
-            tot_minimizers_ += lane.h_scratch[L_MINIMIZERS];
-            tot_hits_ += lane.h_scratch[L_HITS];
-            tot_leftover_ += lane.h_scratch[L_COMPLEX];
-        }
-        // ---- reads that did not fit read_cluster_kernel (long reads, many clusters): the generic pipeline on their hits,
-        // one range after the other ----
-        for (int j = 0; j < n_lanes; ++j) leftovers(lanes_[j], d_bases, d_offsets, n_reads, n_bases, covg, prg_reads, stream);
+        for (int j = 0; j < n_lanes; ++j) finish_lane(lanes_[j], d_bases, d_offsets, n_reads, n_bases, covg, prg_reads, stream);
         return;
     }
     if (use_direct_cands_) {
@@ -639,6 +739,7 @@ void Mapper::map_device(const uint8_t* d_bases, const uint64_t* d_offsets, uint6
     if (n_reads > dev::MAX_BATCH_READS)
         throw Error(DRPRG_EOVERFLOW, "at most " + std::to_string(dev::MAX_BATCH_READS) + " reads per batch");
     HIPCHK(hipSetDevice(device_));
+    complete_pending();
     run_batch(d_bases, d_offsets, (uint32_t)n_reads, n_bases, covg ? covg : d_covg_, prg_reads ? prg_reads : d_prg_reads_,
         stream ? stream : stream_);
     tot_reads_ += n_reads;
@@ -648,6 +749,7 @@ void Mapper::map_device(const uint8_t* d_bases, const uint64_t* d_offsets, uint6
 void Mapper::map_host(const uint8_t* bases, const uint64_t* offsets, uint64_t n_reads)
 {
     if (n_reads == 0) return;
+    sync();
     HIPCHK(hipSetDevice(device_));
     if (offsets[0] != 0) throw Error(DRPRG_EINVAL, "offsets[0] must be 0");
     const uint64_t n_bases = offsets[n_reads];
@@ -669,6 +771,7 @@ void Mapper::map_host(const uint8_t* bases, const uint64_t* offsets, uint64_t n_
 
 void Mapper::download(std::vector<uint32_t>& covg, std::vector<uint32_t>& prg_reads)
 {
+    sync();
     HIPCHK(hipSetDevice(device_));
     HIPCHK(hipStreamSynchronize(stream_));
     covg.resize(2 * (size_t)n_knodes_);
@@ -680,6 +783,7 @@ void Mapper::download(std::vector<uint32_t>& covg, std::vector<uint32_t>& prg_re
 void Mapper::upload(const std::vector<uint32_t>& covg, const std::vector<uint32_t>& prg_reads)
 {
     if (covg.size() != 2 * (size_t)n_knodes_ || prg_reads.size() != n_prgs_) throw Error(DRPRG_EINVAL, "coverage size mismatch");
+    sync();
     HIPCHK(hipSetDevice(device_));
     HIPCHK(hipMemcpy(d_covg_, covg.data(), covg.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_prg_reads_, prg_reads.data(), prg_reads.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -695,6 +799,7 @@ void Mapper::device_tables(uint64_t out[4]) const
 
 MapCounters Mapper::counters()
 {
+    sync();
     HIPCHK(hipSetDevice(device_));
     HIPCHK(hipStreamSynchronize(stream_));
     unsigned long long c[C_N];

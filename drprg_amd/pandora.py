@@ -95,6 +95,14 @@ class Context:
         """Pointers are integer device addresses (e.g. torch.Tensor.data_ptr())."""
         _check(lib.drprg_hip_map_device(self._h, d_bases, d_offsets, n_reads, n_bases, d_covg, d_prg_reads, stream), self._h)
 
+    def map_device_async(self, d_bases, d_offsets, n_reads, n_bases, d_covg=None, d_prg_reads=None, stream=None):
+        """map_device without the host waiting: the batch is queued and completed by the next call (or sync(), or anything
+        that reads results); its buffers must stay valid and unchanged until then (drprg_hip_map_device_async)."""
+        _check(lib.drprg_hip_map_device_async(self._h, d_bases, d_offsets, n_reads, n_bases, d_covg, d_prg_reads, stream), self._h)
+
+    def sync(self):
+        _check(lib.drprg_hip_sync(self._h), self._h)
+
     # ---- coverage ------------------------------------------------------------------------------
     def coverage(self):
         covg = np.zeros(2 * self.n_knodes, dtype=np.uint32)

@@ -87,6 +87,14 @@ int drprg_hip_map_host(drprg_hip_ctx* ctx, const uint8_t* bases, const uint64_t*
  * d_prg_reads (u32[n_prgs]) may be NULL to use the context's accumulators; hip_stream may be NULL. */
 int drprg_hip_map_device(drprg_hip_ctx* ctx, const void* d_bases, const void* d_offsets, uint64_t n_reads,
     uint64_t n_bases, void* d_covg, void* d_prg_reads, void* hip_stream);
+/* The same without the host waiting for the batch: the launch sequence is queued and the call returns; the read-back the
+ * sequence ends with (overflow flags, reads left to the generic pipeline, counters) is looked at while the NEXT batch runs
+ * -- by the next call, by drprg_hip_sync, or by anything that reads results -- so back-to-back batches leave no gap on the
+ * device.  The buffers of a batch (bases, offsets, accumulators) stay valid and unchanged until the call after the next
+ * one returns or drprg_hip_sync does.  An error of a batch is reported by the call that completes it. */
+int drprg_hip_map_device_async(drprg_hip_ctx* ctx, const void* d_bases, const void* d_offsets, uint64_t n_reads,
+    uint64_t n_bases, void* d_covg, void* d_prg_reads, void* hip_stream);
+int drprg_hip_sync(drprg_hip_ctx* ctx); /* completes the batch in flight and waits for its stream */
 
 /* The per-k-mer-node coverage vector (what gets sum-reduced across GPUs):
  * covg[2g] forward, covg[2g+1] reverse coverage of global k-mer node g; prg_reads[p] clusters on PRG p. */

@@ -619,3 +619,67 @@ def test_wave_tile_geometry_edges(tmp_path, oracle, monkeypatch, fuse):
         ctx.close()
     ctx = _ctx(tmp_path, panel, 14, 15, True, kernel=3)  # the other instantiation of the kernel
     _compare(ctx, oracle, bases, offs, 14, 15, True, 3)
+
+
+@pytest.mark.parametrize("kernel", [0, 1])
+def test_deferred_batches_equal_synchronous_ones(tmp_path, oracle, kernel):
+    """drprg_hip_map_device_async: a batch is queued and its read-back is looked at while the next one runs.  Batches that need the
+    host afterwards -- dense reads that overflow the candidate slices (run again with larger buffers), reads of a 70-copy locus
+    that read_cluster_kernel leaves to the generic pipeline -- come out exactly as through the synchronous call and as the oracle
+    has them; kernel=1 (no deferred form) falls back to the synchronous path behind the same entry."""
+    import torch
+    from drprg_amd import synth
+    rng = np.random.default_rng(21)
+    rep = synth.make_locus(rng, 400, site_every=70)
+    single = synth.make_locus(rng, 900, site_every=50)
+    other = synth.make_locus(rng, 1200, site_every=40)
+    panel = synth.Panel([f"rep{i}" for i in range(70)] + ["single", "other"], [rep] * 70 + [single, other])
+    hap = lambda t: synth.sample_haplotype(rng, t).encode()
+    background = synth.random_seq(rng, 30000).encode()
+    batches = [
+        _reads_from(rng, [hap(single), hap(other)], 6000, 150),                       # dense: every read inside the panel
+        _reads_from(rng, [hap(rep), hap(single), background], 1500, 150),             # leftovers of the repeated locus
+        _reads_from(rng, [background, hap(other)], 20000, 150),                       # mostly off-panel
+        _reads_from(rng, [hap(other), hap(single), hap(rep)], 9000, 150),             # dense again, larger than the first
+        _reads_from(rng, [hap(other)], 10, 150),                                      # a tiny last batch
+    ]
+    dev = torch.device("cuda", 0)
+    tens = [(torch.from_numpy(np.ascontiguousarray(b)).to(dev), torch.from_numpy(o.astype(np.int64)).to(dev), len(o) - 1, int(o[-1]))
+            for b, o in batches]
+    torch.cuda.synchronize()
+    ctx = _ctx(tmp_path, panel, 11, 15, True, kernel=kernel)
+    for tb, to, n, nb in tens:
+        ctx.map_device(tb.data_ptr(), to.data_ptr(), n, nb)
+    want, want_prg = ctx.coverage()
+    want_cnt = ctx.counters()
+    ctx.reset()
+    for tb, to, n, nb in tens:
+        ctx.map_device_async(tb.data_ptr(), to.data_ptr(), n, nb)
+    got, got_prg = ctx.coverage()  # (reading results completes the batch in flight)
+    cnt = ctx.counters()
+    assert np.array_equal(got, want) and np.array_equal(got_prg, want_prg)
+    for key in ("reads", "bases", "minimizers", "hits", "clusters_kept", "hits_kept", "leftover_reads"):
+        assert cnt[key] == want_cnt[key], key
+    if kernel == 0 and not FORCED_GENERIC:
+        assert cnt["kernel"] == 2 and cnt["leftover_reads"] > 300
+    # ... and as the oracle has them
+    bases = np.concatenate([b for b, _ in batches])
+    offs = np.concatenate([[0]] + [o[1:] + sum(int(p[-1]) for _, p in batches[:i]) for i, (_, o) in enumerate(batches)]).astype(np.uint64)
+    idx = _oracle_index(oracle, ctx.prg_strings, 11, 15)
+    ocov, oprg, _ = _oracle_map(oracle, idx, bases, offs, 11, 15, True)
+    assert np.array_equal(got, ocov) and np.array_equal(got_prg, oprg)
+    # a second round into caller-owned accumulators that alternate, with explicit sync
+    ctx.reset()
+    accs = [torch.zeros(2 * ctx.n_knodes + ctx.n_prgs, dtype=torch.int32, device=dev) for _ in range(2)]
+    sums = np.zeros(2 * ctx.n_knodes, dtype=np.int64)
+    for i, (tb, to, n, nb) in enumerate(tens):
+        a = accs[i % 2]
+        if i >= 2:
+            sums += a[:2 * ctx.n_knodes].cpu().numpy()  # batch i-2 was completed by call i-1
+        a.zero_()
+        torch.cuda.synchronize()
+        ctx.map_device_async(tb.data_ptr(), to.data_ptr(), n, nb, a.data_ptr(), a.data_ptr() + 8 * ctx.n_knodes)
+    ctx.sync()
+    for a in accs:
+        sums += a[:2 * ctx.n_knodes].cpu().numpy()
+    assert np.array_equal(sums.astype(np.uint32), want)
