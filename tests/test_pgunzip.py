@@ -180,3 +180,16 @@ def test_header_look_alikes_do_not_mislead(tmp_path):
     blob = gzip.compress(data, 6)
     for chunk in (2048, 10000, 50000):
         _check(tmp_path, blob, data, chunk=chunk, name="alike.gz")
+
+
+def test_bgzf_file_as_a_plain_multi_member_stream(tmp_path, text):
+    """a bgzip file is hundreds of 64 KB members (each with an extra field) and an empty one at the end: the ingest has a
+    faster way for those, but this decoder must take them too (a host without libdeflate sends them here)"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    p = tmp_path / "t.bgzf.gz"
+    bench.write_bgzf(str(p), text[:8_000_000])
+    for chunk in (20000, 300000):
+        n, accepted, redone = _gunzip(p, tmp_path / "o", 4, chunk)
+        assert n == 8_000_000 and (tmp_path / "o").read_bytes() == text[:8_000_000]
