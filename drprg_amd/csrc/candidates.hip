@@ -181,7 +181,8 @@ __global__ __launch_bounds__(EX_THREADS) void verify_count_kernel(SketchArgs a, 
                     const uint32_t valid = ((2u << i_hi) - 1u) & ~((1u << i_lo) - 1u) & ~(uint32_t)(bad >> of);
                     uint32_t streak = 0, right = 0, alive = 1;
                     uint32_t rcw = revcomp_code(r0w >> sh_k, k) << 2; // the reverse complement rolls along: one base in, one out
-                    for (int i = 0; i < 2 * w - 1; ++i) {
+                    const int n_steps = (fw.debug & 16u) ? 0 : 2 * w - 1; // (DRPRG_FT_DEBUG=16: measurement only, no window test)
+                    for (int i = 0; i < n_steps; ++i) {
                         const uint32_t f = r0w >> sh_k;
                         rcw = (rcw >> 2) | ((~f & 3u) << (2 * k - 2));
                         r0w = __funnelshift_l(r1w, r0w, 2);
