@@ -47,5 +47,21 @@ for label in ("wild_type", "off_panel_snp"):
     calls = {d: v["predict"] for d, v in res["susceptibility"].items() if v["predict"] != "S"}
     print(f"{label}: {n} reads ({os.path.getsize(fq) / 1e9:.2f} GB FASTQ), process start -> JSON {dt:.2f}s = {n / dt / 1e6:.1f} M reads/s; non-S: {calls}", flush=True)
     print("   " + " | ".join(l for l in r.stderr.splitlines() if "discover" in l or "novel" in l), flush=True)
+    if label == "wild_type" and os.environ.get("E2E_GZ", "1") != "0":
+        # the same sample as one plain gzip stream (what `gzip` writes; inflated by all -t threads, csrc/pgunzip.cpp)
+        gz = fq + ".gz"
+        with open(gz, "wb") as fh:
+            subprocess.run(["gzip", "-1", "-c", fq], stdout=fh, check=True)
+        out = os.path.join(tmp, "out_gz")
+        for th in (threads, "32"):
+            shutil.rmtree(out, ignore_errors=True)
+            t = time.time()
+            r = subprocess.run([os.path.join(exe, "drprg"), "predict", "-x", idx, "-i", gz, "-o", out, "-s", "gz", "-I", "-t", th], capture_output=True, text=True)
+            dt = time.time() - t
+            assert r.returncode == 0, r.stderr
+            same = json.load(open(os.path.join(out, "gz.drprg.json")))["susceptibility"] == res["susceptibility"]
+            print(f"wild_type as .fq.gz ({os.path.getsize(gz) / 1e9:.2f} GB), -t {th}: process start -> JSON {dt:.2f}s = {n / dt / 1e6:.1f} M reads/s; "
+                  f"same calls as from plain text: {same}", flush=True)
+        os.remove(gz)
     os.remove(fq)
 shutil.rmtree(tmp)
