@@ -619,8 +619,7 @@ void Mapper::map_device_async(const uint8_t* d_bases, const uint64_t* d_offsets,
     cur.stream = stream;
     complete_pending(); // the batch before this one, while this one runs
     pending_ = cur;
-    static const bool one_lane_experiment = std::getenv("DRPRG_PIPE_ONE_LANE") != nullptr; // (measurement only: unsafe with leftovers)
-    if (!one_lane_experiment) pipe_next_ ^= 1;
+    pipe_next_ ^= 1;
     tot_reads_ += n_reads;
     tot_bases_ += n_bases;
 }

@@ -653,14 +653,17 @@ struct ParallelGunzip::Impl {
         const uint64_t stand = next_bit;
         const bool stand_header = at_header;
         auto job = [&]() {
-            std::unique_ptr<Inflater> inf(new Inflater { data, len, {} });
-            for (size_t j; (j = cursor.fetch_add(1)) < seg.size();) {
-                const size_t c = first + j;
-                seg[j].reset(new_segment());
-                const uint64_t lo = (uint64_t)c * chunk * 8, hi = (uint64_t)(c + 1) * chunk * 8;
-                if (j == 0) { // the stream stands at a known position: no search
-                    if (inf->run(*seg[j], stand, stand_header, hi, soft_cap(), false, expect_symbols()) != Status::OK) seg[j]->ok = false;
-                } else if (stand > lo || !inf->find_and_run(*seg[j], lo, hi, hi, soft_cap(), expect_symbols())) seg[j]->ok = false;
+            try {
+                std::unique_ptr<Inflater> inf(new Inflater { data, len, {} });
+                for (size_t j; (j = cursor.fetch_add(1)) < seg.size();) {
+                    const size_t c = first + j;
+                    seg[j].reset(new_segment());
+                    const uint64_t lo = (uint64_t)c * chunk * 8, hi = (uint64_t)(c + 1) * chunk * 8;
+                    if (j == 0) { // the stream stands at a known position: no search
+                        if (inf->run(*seg[j], stand, stand_header, hi, soft_cap(), false, expect_symbols()) != Status::OK) seg[j]->ok = false;
+                    } else if (stand > lo || !inf->find_and_run(*seg[j], lo, hi, hi, soft_cap(), expect_symbols())) seg[j]->ok = false;
+                }
+            } catch (const std::exception&) { // (out of memory: the chunks this thread did not finish are inflated again by the stitcher)
             }
         };
         const int nt = (int)std::min<size_t>((size_t)threads, seg.size());
