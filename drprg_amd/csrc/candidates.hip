@@ -125,7 +125,8 @@ __global__ __launch_bounds__(EX_THREADS) void verify_count_kernel(SketchArgs a, 
         if (gp >= win_lo && gp < win_hi && gp + k <= n_bases) { // (the boundary tiles of a read range reach past it)
             // the read of every candidate, index k-mer or not: read_cluster_kernel finds the first candidate of a read by
             // comparing neighbours (interpolated first guess: exact for fixed-length reads, a short gallop otherwise)
-            read = find_read_near(a.offsets, a.n_reads, (uint32_t)((double)gp * reads_per_base), (uint64_t)gp);
+            if (!(fw.debug & 64u)) // (DRPRG_FT_DEBUG=64: timing only, no read lookup)
+                read = find_read_near(a.offsets, a.n_reads, (uint32_t)((double)gp * reads_per_base), (uint64_t)gp);
             // ---- the 64 bases [a0, a0+64) hold the candidate and all its neighbours (w <= 16, k <= 15) ----
             const int64_t a0 = (gp > 15 ? gp - 15 : 0) & ~(int64_t)15;
             uint32_t r0w, r1w, r2w, r3w, n0, n1, n2, n3;
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(EX_THREADS) void verify_count_kernel(SketchArgs a, 
                 g = (hf < hr ? hf : hr) + 1;
             }
             bool found = false;
-            if (g) {
+            if (g && !(fw.debug & 32u)) { // (DRPRG_FT_DEBUG=32: timing only, no table probe and nothing after it)
                 const uint32_t h = g - 1;
                 uint32_t sl = table_slot_dev(h, a.table_bits);
                 while (true) {
