@@ -36,6 +36,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdlib>
+#include <string>
 
 namespace drprg {
 namespace dev {
@@ -78,11 +79,22 @@ __device__ __forceinline__ uint32_t bloom_test(uint32_t word, uint32_t h, uint32
 }
 
 // SHORT_K: k < 12, the level-1 key must be masked to 2k bits.  LEVEL0: the level-0 array is present (k = 15).
-template <bool SHORT_K, bool LEVEL0>
+// FUSED (with LEVEL0; opt-in, DRPRG_FILTER_FORM=fused): the second stage runs in this kernel as well.  The groups that pass level 0 are staged in the wave's own
+// 2 KB of LDS and, 64 at a time, put through the second-stage filter one lane per group -- dense lanes, as in refine_kernel --
+// so that only surviving POSITIONS leave for global memory.  Why: the 16-byte group records of the
+// two-kernel form are 104 MB of scattered writes per 10 M reads, and those writes -- not their instructions: staging them in
+// LDS and copying them out coalesced once in twelve tiles changed nothing, sending them nowhere saved 65 us -- slow the
+// streaming reads down.  LDS: level 0 128 KB + stage 32 KB; the 64 KB second-stage array does not fit
+// and is read from global memory (L2-resident) -- which is what makes this form lose: with the words taken from LDS (wrong
+// results, timing only) the kernel ran in 0.319 ms, with the 26 M four-byte loads from global memory in 0.449 ms whether
+// they are waited for at once or a tile later.
+template <bool SHORT_K, bool LEVEL0, bool FUSED = false>
 __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a, FilterWork fw)
 {
-    extern __shared__ uint32_t s_dyn[]; // [level 0: FT_L0_WORDS] [levels 1+2: 2^bloom_wbits words]
+    static_assert(!FUSED || LEVEL0, "the fused second stage belongs to the level-0 form");
+    extern __shared__ uint32_t s_dyn[]; // [level 0: FT_L0_WORDS] then [levels 1+2: 2^bloom_wbits words] or, FUSED, [stage: 2 KB per wave]
     constexpr uint32_t L12_BASE = LEVEL0 ? FT_L0_WORDS * 4u : 0u;
+    constexpr uint32_t STAGE_RECORDS = 128, STAGE_BASE_WORDS = FT_L0_WORDS;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int k = a.k;
@@ -96,6 +108,7 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
 
     if (LEVEL0)
         for (uint32_t i = tid; i < (1u << fw.bloom0_wbits); i += FT_THREADS) s_dyn[i] = fw.bloom0[i];
+
     if (!LEVEL0) // (the level-0 form leaves levels 1+2 to refine_kernel)
         for (uint32_t i = tid; i < n_words; i += FT_THREADS) s_dyn[L12_BASE / 4 + i] = fw.bloom[i];
     if (tid == 0 && (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)s_dyn != 0u) atomicOr(a.overflow, 8u);
@@ -146,9 +159,81 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
     uint4* grp_out = LEVEL0 ? fw.raw_grp + (size_t)slice * fw.raw_slice : nullptr;
     (void)grp_out;
     uint32_t wcur = 0; // candidates in the current slice so far (wave-uniform)
+    // FUSED: the groups that passed level 0 wait in the wave's 2 KB of LDS, 64 to a half.  When the half being filled cannot take
+    // the next tile, every lane takes one of its groups and requests the four second-stage words of its four positions from
+    // global memory (phase A) -- and only one tile later, just before that tile's own groups are staged, tests them and appends
+    // the surviving positions in order (phase B): by then the words have arrived, and waiting for them does not wait for the
+    // base loads issued since (waiting right away cost 130 us per 10 M reads: every such wait drained the prefetched tiles).
+    // (Macros, not closures or functions taking the counters by reference: those kept the counters in scratch memory, whose
+    // accesses count on vmcnt like every other VMEM instruction.)
+    constexpr uint32_t HALF = STAGE_RECORDS / 2;
+    uint4* const stage = FUSED ? reinterpret_cast<uint4*>(s_dyn + STAGE_BASE_WORDS) + (tid >> 6) * STAGE_RECORDS : nullptr;
+    uint32_t lcnt = 0, fill = 0, pcnt = 0; // groups in the half being filled, which half that is, groups of the half that waits for its words
+    uint32_t sw0 = 0, sw1 = 0, sw2 = 0, sw3 = 0; // the four words of this lane's group of the waiting half
+    (void)stage;
+    auto mb_below = [](uint64_t m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); };
+    (void)mb_below;
+#define DRPRG_STAGE_KEY(r, q) ((((q) ? __funnelshift_r((r).z, (r).w, 2 * (q)) : (r).z) & kmask) * BLOOM_CR)
+#define DRPRG_PHASE_A(w0, w1, w2, w3)                                                                                       \
+    do {                                                                                                                    \
+        __builtin_amdgcn_wave_barrier(); /* the wave's own LDS writes come before these reads in program order */           \
+        if ((uint32_t)lane < lcnt) {                                                                                        \
+            const uint4 ra = stage[fill * HALF + (uint32_t)lane];                                                           \
+            w0 = fw.bloomr[DRPRG_STAGE_KEY(ra, 0) >> (32 - BLOOMR_WBITS)];                                                  \
+            w1 = fw.bloomr[DRPRG_STAGE_KEY(ra, 1) >> (32 - BLOOMR_WBITS)];                                                  \
+            w2 = fw.bloomr[DRPRG_STAGE_KEY(ra, 2) >> (32 - BLOOMR_WBITS)];                                                  \
+            w3 = fw.bloomr[DRPRG_STAGE_KEY(ra, 3) >> (32 - BLOOMR_WBITS)];                                                  \
+        }                                                                                                                   \
+        pcnt = lcnt;                                                                                                        \
+        lcnt = 0;                                                                                                           \
+        fill ^= 1u;                                                                                                         \
+    } while (0)
+#define DRPRG_STAGE_TEST(word, h) (((word) >> ((h) & 31)) & ((word) >> (((h) >> 5) & 31)) & ((word) >> (((h) >> 10) & 31)) & ((word) >> (((h) >> 15) & 31)) & 1u)
+#define DRPRG_PHASE_B(w0, w1, w2, w3)                                                                                       \
+    do {                                                                                                                    \
+        if (pcnt) {                                                                                                         \
+            uint32_t cand2 = 0;                                                                                             \
+            uint4 rb = make_uint4(0, 0, 0, 0);                                                                              \
+            if ((uint32_t)lane < pcnt) {                                                                                    \
+                rb = stage[(fill ^ 1u) * HALF + (uint32_t)lane];                                                            \
+                cand2 = DRPRG_STAGE_TEST(w0, DRPRG_STAGE_KEY(rb, 0)) | (DRPRG_STAGE_TEST(w1, DRPRG_STAGE_KEY(rb, 1)) << 1)    \
+                    | (DRPRG_STAGE_TEST(w2, DRPRG_STAGE_KEY(rb, 2)) << 2) | (DRPRG_STAGE_TEST(w3, DRPRG_STAGE_KEY(rb, 3)) << 3); \
+            }                                                                                                               \
+            /* ordered append: exclusive prefix of the per-lane counts (0..4) from three ballots */                         \
+            const uint32_t c2 = (uint32_t)__popc(cand2);                                                                    \
+            const uint64_t e0 = __ballot(c2 & 1u), e1 = __ballot(c2 & 2u), e2 = __ballot(c2 & 4u);                          \
+            if (e0 | e1 | e2) {                                                                                             \
+                uint32_t at2 = wcur + mb_below(e0) + 2u * mb_below(e1) + 4u * mb_below(e2);                                 \
+                const uint64_t pos2 = ((uint64_t)rb.y << 32) | rb.x;                                                        \
+                while (cand2) {                                                                                             \
+                    const int q2 = __ffs(cand2) - 1;                                                                        \
+                    cand2 &= cand2 - 1;                                                                                     \
+                    if (at2 < fw.raw_slice) out[at2] = pos2 + (uint64_t)q2;                                                 \
+                    ++at2;                                                                                                  \
+                }                                                                                                           \
+                wcur += (uint32_t)(__popcll(e0) + 2 * __popcll(e1) + 4 * __popcll(e2));                                     \
+            }                                                                                                               \
+            __builtin_amdgcn_wave_barrier(); /* the half may be written again */                                            \
+            pcnt = 0;                                                                                                       \
+        }                                                                                                                   \
+    } while (0)
+    // both phases at once for the half being filled (end of a slice, dense tiles): words in registers of their own, so that the
+    // compiler's count of what is in flight for sw0..sw3 -- requested a tile before they are needed -- stays exact
+#define DRPRG_FLUSH_NOW()                         \
+    do {                                          \
+        if (lcnt) {                               \
+            uint32_t tw0 = 0, tw1 = 0, tw2 = 0, tw3 = 0; \
+            DRPRG_PHASE_A(tw0, tw1, tw2, tw3);    \
+            DRPRG_PHASE_B(tw0, tw1, tw2, tw3);    \
+        }                                         \
+    } while (0)
     auto close_slice = [&]() {
+        if constexpr (FUSED) { // everything staged leaves now
+            DRPRG_PHASE_B(sw0, sw1, sw2, sw3);
+            DRPRG_FLUSH_NOW();
+        }
         if (lane == 0) {
-            (LEVEL0 ? fw.grp_count : fw.slice_count)[slice] = wcur;
+            (LEVEL0 && !FUSED ? fw.grp_count : fw.slice_count)[slice] = wcur;
             if (wcur > fw.raw_slice) atomicOr(a.overflow, 4u);
         }
     };
@@ -182,23 +267,57 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
 #pragma unroll
             for (int g = FT_G / 4 - 1; g >= 0; --g) grp = __builtin_amdgcn_alignbit(grp, bloom_test(ws[g], hs[g], xs[g]), 31);
             if (lane == 63 || (fw.debug & 1u)) grp = 0;
+            if constexpr (FUSED) DRPRG_PHASE_B(sw0, sw1, sw2, sw3); // the half whose words were requested while the previous tile was staged
             // ---- append in (lane, group) = position order: exclusive prefix of the per-lane counts (0..8) from four ballots ----
             const uint32_t cnt = (uint32_t)__popc(grp);
             const uint64_t b0 = __ballot(cnt & 1u), b1 = __ballot(cnt & 2u), b2 = __ballot(cnt & 4u), b3 = __ballot(cnt & 8u);
             if (b0 | b1 | b2 | b3) {
                 auto below = [&](uint64_t m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); };
-                uint32_t at = wcur + below(b0) + 2u * below(b1) + 4u * below(b2) + 8u * below(b3);
                 const uint64_t base = (uint64_t)t * FT_WPOS + (uint64_t)lane * FT_G;
-                while (grp) {
-                    const int g = __ffs(grp) - 1;
-                    grp &= grp - 1;
+                auto record = [&](int g) {
                     const uint32_t lo = g < 4 ? wa : wb, hi = g < 4 ? wb : wc;
                     const uint32_t sh = (8u * (uint32_t)g) & 31u;
                     const uint64_t pos = base + 4u * (uint32_t)g;
-                    if (at < fw.raw_slice) grp_out[at] = make_uint4((uint32_t)pos, (uint32_t)(pos >> 32), __funnelshift_r(lo, hi, sh), hi >> sh);
-                    ++at;
+                    return make_uint4((uint32_t)pos, (uint32_t)(pos >> 32), __funnelshift_r(lo, hi, sh), hi >> sh);
+                };
+                if constexpr (FUSED) {
+                    const uint32_t total = (uint32_t)(__popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2) + 8 * __popcll(b3));
+                    if (total <= HALF) {
+                        if (lcnt + total > HALF) DRPRG_PHASE_A(sw0, sw1, sw2, sw3); // wave-uniform; the other half is free: phase B ran above
+                        uint32_t at = fill * HALF + lcnt + below(b0) + 2u * below(b1) + 4u * below(b2) + 8u * below(b3);
+                        while (grp) {
+                            const int g = __ffs(grp) - 1;
+                            grp &= grp - 1;
+                            stage[at++] = record(g);
+                        }
+                        lcnt += total;
+                    } else { // a tile dense with index k-mers (amplicon reads): eight lanes (<= 64 groups) at a time, in lane order,
+                             // each lot through both phases at once
+                        DRPRG_FLUSH_NOW();
+                        for (int part = 0; part < 8; ++part) {
+                            uint32_t gq = (lane >> 3) == part ? grp : 0u;
+                            const uint32_t cq = (uint32_t)__popc(gq);
+                            const uint64_t q0 = __ballot(cq & 1u), q1 = __ballot(cq & 2u), q2 = __ballot(cq & 4u), q3 = __ballot(cq & 8u);
+                            uint32_t at = fill * HALF + below(q0) + 2u * below(q1) + 4u * below(q2) + 8u * below(q3);
+                            while (gq) {
+                                const int g = __ffs(gq) - 1;
+                                gq &= gq - 1;
+                                stage[at++] = record(g);
+                            }
+                            lcnt = (uint32_t)(__popcll(q0) + 2 * __popcll(q1) + 4 * __popcll(q2) + 8 * __popcll(q3));
+                            DRPRG_FLUSH_NOW();
+                        }
+                    }
+                } else {
+                    uint32_t at = wcur + below(b0) + 2u * below(b1) + 4u * below(b2) + 8u * below(b3);
+                    while (grp) {
+                        const int g = __ffs(grp) - 1;
+                        grp &= grp - 1;
+                        if (at < fw.raw_slice) grp_out[at] = record(g);
+                        ++at;
+                    }
+                    wcur += (uint32_t)(__popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2) + 8 * __popcll(b3));
                 }
-                wcur += (uint32_t)(__popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2) + 8 * __popcll(b3));
             }
             return;
         }
@@ -279,8 +398,13 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
     }
     close_slice();
     for (++slice; slice < (gw + 1) * FT_SUB; ++slice) // slices this wave never reached (the last waves of a short batch)
-        if (lane == 0) (LEVEL0 ? fw.grp_count : fw.slice_count)[slice] = 0;
+        if (lane == 0) (LEVEL0 && !FUSED ? fw.grp_count : fw.slice_count)[slice] = 0;
 }
+#undef DRPRG_PHASE_A
+#undef DRPRG_FLUSH_NOW
+#undef DRPRG_PHASE_B
+#undef DRPRG_STAGE_KEY
+#undef DRPRG_STAGE_TEST
 
 // Second stage of the filter for the groups that passed level 0 (level-0 form of sketch_filter_kernel): one lane per
 // group tests its four k-mer codes against a 64 KB LDS-resident filter (four bits per code, < 15 % full); every wave
@@ -382,6 +506,10 @@ hipError_t launch_sketch_filter(const SketchArgs& a, uint32_t read_begin, uint32
     if (const char* dbg = std::getenv("DRPRG_FT_DEBUG")) fw.debug = (uint32_t)std::atoi(dbg); // 1 no filter test, 4 no level 0, 8 no read_cluster_kernel
     const bool level0 = bt.bloom0 != nullptr && a.k == 15 && ((size_t)4 << bt.bloom_wbits) + (size_t)FT_L0_WORDS * 4 <= 160 * 1024
         && !(fw.debug & 4u);
+    // the second stage as refine_kernel behind the streaming kernel (default) or inside it (DRPRG_FILTER_FORM=fused: measured
+    // slower, 0.449 against 0.378 + 0.045 ms per 10 M reads; kept for the measurement and its tests)
+    const char* form = std::getenv("DRPRG_FILTER_FORM");
+    const bool fused = level0 && form && std::string(form) == "fused";
     fw.bloom = bt.bloom;
     fw.bloom_wbits = bt.bloom_wbits;
     fw.bloomr = bt.bloomr;
@@ -403,18 +531,19 @@ hipError_t launch_sketch_filter(const SketchArgs& a, uint32_t read_begin, uint32
     if (timer.begin) HIP_TRY(hipEventRecord(timer.begin, stream));
     {
         using Kernel = void (*)(SketchArgs, FilterWork);
-        const int which = level0 ? 2 : (a.k < 12 ? 1 : 0);
-        const Kernel kernel = which == 2 ? &sketch_filter_kernel<false, true>
+        const int which = level0 ? (fused ? 3 : 2) : (a.k < 12 ? 1 : 0);
+        const Kernel kernel = which == 3 ? &sketch_filter_kernel<false, true, true>
+            : which == 2                 ? &sketch_filter_kernel<false, true>
             : which == 1                 ? &sketch_filter_kernel<true, false>
                                          : &sketch_filter_kernel<false, false>;
-        const size_t dyn = level0 ? (size_t)FT_L0_WORDS * 4 : ((size_t)4 << bt.bloom_wbits);
-        static size_t configured[3][MAX_HIP_DEVICES] = {};
+        const size_t dyn = level0 ? (size_t)FT_L0_WORDS * 4 + (fused ? (size_t)FT_WAVES * 2048 : 0) : ((size_t)4 << bt.bloom_wbits);
+        static size_t configured[4][MAX_HIP_DEVICES] = {};
         HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), dyn, configured[which]));
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(FT_THREADS), dyn, stream, a, fw);
     }
     HIP_TRY(hipGetLastError());
     if (timer.end) HIP_TRY(hipEventRecord(timer.end, stream));
-    if (level0) {
+    if (level0 && !fused) {
         static size_t refine_configured[MAX_HIP_DEVICES] = {};
         const size_t dyn = (size_t)4 << BLOOMR_WBITS;
         HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&refine_kernel), dyn, refine_configured));

@@ -683,3 +683,24 @@ def test_deferred_batches_equal_synchronous_ones(tmp_path, oracle, kernel):
     for a in accs:
         sums += a[:2 * ctx.n_knodes].cpu().numpy()
     assert np.array_equal(sums.astype(np.uint32), want)
+
+
+def test_second_stage_inside_the_streaming_kernel(tmp_path, oracle, monkeypatch):
+    """DRPRG_FILTER_FORM=fused: sketch_filter_kernel stages the level-0 survivors in LDS and runs the second-stage filter itself,
+    64 groups at a time, one tile after it requested their filter words (no refine_kernel, no group records in global memory).
+    Opt-in (slower on MI355X) -- but it has to give the same vector: sparse reads, dense reads whose tiles
+    hold more groups than a stage half, and reads that cross slice ends."""
+    from drprg_amd import synth
+    monkeypatch.setenv("DRPRG_FILTER_FORM", "fused")
+    panel = synth.small_panel(seed=6, n_loci=3, length=900)
+    rng = np.random.default_rng(5)
+    haps = [synth.sample_haplotype(rng, t).encode() for t in panel.trees]
+    dense = _reads_from(rng, haps, 6000, 150)
+    sparse = _reads_from(rng, haps + [synth.random_seq(rng, 200000).encode()] * 9, 60000, 150)
+    for bases, offs in (dense, sparse):
+        ctx = _ctx(tmp_path, panel, 11, 15, True, kernel=2)
+        cnt = _compare(ctx, oracle, bases, offs, 11, 15, True, 2)
+        assert cnt["clusters_kept"] > 3000
+    monkeypatch.setenv("DRPRG_FILTER_FORM", "refine")
+    ctx = _ctx(tmp_path, panel, 11, 15, True, kernel=2)
+    _compare(ctx, oracle, sparse[0], sparse[1], 11, 15, True, 2)
