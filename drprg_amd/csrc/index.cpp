@@ -125,6 +125,7 @@ void PrgIndex::flatten()
         if (level0) {
             f.bloom0_wbits = L0_WBITS;
             f.bloom0.assign(size_t(1) << L0_WBITS, 0);
+            f.bloom0f.assign(size_t(1) << L0_WBITS, 0);
             f.bloomr.assign(size_t(1) << BLOOMR_WBITS, 0);
         }
         const uint32_t wmask0 = (1u << L0_WBITS) - 1;
@@ -137,12 +138,19 @@ void PrgIndex::flatten()
             if (level0) { // second stage: one word, four bits (fill < 15 %: one in a few thousand false positives)
                 const uint32_t hr = code * BLOOM_CR;
                 f.bloomr[hr >> (32 - BLOOMR_WBITS)] |= (1u << (hr & 31)) | (1u << ((hr >> 5) & 31)) | (1u << ((hr >> 10) & 31)) | (1u << ((hr >> 15) & 31));
+                // the same stage inside the level-0 array: word = top 15 bits of the hash, three bits from its low 15, three from a
+                // second hash (six bits: the array is a third full, and every false positive is a candidate verify_count_kernel pays for)
+                const uint32_t hs = code * BLOOM_C2;
+                f.bloom0f[hr >> (32 - L0_WBITS)] |= (1u << (hr & 31)) | (1u << ((hr >> 5) & 31)) | (1u << ((hr >> 10) & 31)) | (1u << (hs >> 27))
+                    | (1u << ((hs >> 22) & 31)) | (1u << ((hs >> 17) & 31));
             }
             if (level0)
                 for (int o = 0; o < 4; ++o) {
                     const uint32_t y = (code >> (2 * o)) & 0xFFFFFFu;
                     const uint32_t g = (uint32_t)((uint64_t)y * BLOOM_C0);
-                    f.bloom0[(g >> 17) & wmask0] |= (1u << (31 - (g & 31))) | (1u << (31 - ((g >> 8) & 31))) | (1u << (31 - ((y >> 16) & 31)));
+                    const uint32_t bits0 = (1u << (31 - (g & 31))) | (1u << (31 - ((g >> 8) & 31))) | (1u << (31 - ((y >> 16) & 31)));
+                    f.bloom0[(g >> 17) & wmask0] |= bits0;
+                    f.bloom0f[(g >> 17) & wmask0] |= bits0;
                 }
         };
         for (size_t p = 0; p < prgs.size(); ++p) {
@@ -184,6 +192,18 @@ void PrgIndex::filter_selfcheck(uint64_t out[8]) const
             out[1] += any_miss;
             const uint32_t hr = code * BLOOM_CR, word = f.bloomr[hr >> (32 - BLOOMR_WBITS)];
             out[3] += !((word >> (hr & 31)) & (word >> ((hr >> 5) & 31)) & (word >> ((hr >> 10) & 31)) & (word >> ((hr >> 15) & 31)) & 1u);
+            // the shared array of the fused form: both tests
+            bool miss_f = false;
+            for (int o = 0; o < 4; ++o) {
+                const uint32_t y = (code >> (2 * o)) & 0xFFFFFFu;
+                const uint32_t g = (uint32_t)((uint64_t)y * BLOOM_C0);
+                miss_f |= !three(f.bloom0f[(g >> 17) & wmask0], g, y);
+            }
+            const uint32_t wf = f.bloom0f[hr >> (32 - f.bloom0_wbits)];
+            const uint32_t hs = code * BLOOM_C2;
+            miss_f |= !((wf >> (hr & 31)) & (wf >> ((hr >> 5) & 31)) & (wf >> ((hr >> 10) & 31)) & (wf >> (hs >> 27)) & (wf >> ((hs >> 22) & 31))
+                & (wf >> ((hs >> 17) & 31)) & 1u);
+            out[7] += miss_f;
         }
         const uint32_t x = code & kmask & 0xFFFFFFu;
         const uint32_t h = (uint32_t)((uint64_t)x * BLOOM_C1);

@@ -37,6 +37,7 @@ struct FlatIndex {
     // level 0 of that filter (k = 15, small indexes): the 12-mers at offsets 0..3 of every index k-mer; 0 = absent
     uint32_t bloom0_wbits = 0;
     std::vector<uint32_t> bloom0;
+    std::vector<uint32_t> bloom0f; // bloom0 plus the second-stage bits of every code (four per code, in the word its BLOOM_CR hash selects)
     // with level 0: the second stage (refine_kernel), 2^14 words keyed on the whole k-mer code, four bits per code
     std::vector<uint32_t> bloomr;
     uint32_t total_knodes() const { return knode_base.empty() ? 0 : knode_base.back(); }

@@ -137,6 +137,7 @@ struct BloomTables {
     const uint32_t* bloom0;
     uint32_t bloom0_wbits;
     const uint32_t* bloomr; // second stage of the level-0 form (2^BLOOMR_WBITS words)
+    const uint32_t* bloom0f; // level 0 and the second-stage bits in one array (the form with the second stage inside the streaming kernel)
 };
 // Scratch of the filtered launch sequence.  raw_pos: raw_capacity candidate positions (one slice per filter wave);
 // cand_info / cand_pos1: raw_capacity entries each; small: filter_small_words() u32; max_len: device scalar that

@@ -117,6 +117,8 @@ Mapper::Mapper(const FlatIndex& idx, const MapParams& p, int device) : device_(d
     if (bloom0_wbits_) {
         dmalloc(d_bloom0_, idx.bloom0.size());
         HIPCHK(hipMemcpy(d_bloom0_, idx.bloom0.data(), idx.bloom0.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        dmalloc(d_bloom0f_, idx.bloom0f.size());
+        HIPCHK(hipMemcpy(d_bloom0f_, idx.bloom0f.data(), idx.bloom0f.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         dmalloc(d_bloomr_, idx.bloomr.size());
         HIPCHK(hipMemcpy(d_bloomr_, idx.bloomr.data(), idx.bloomr.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
@@ -160,7 +162,7 @@ Mapper::~Mapper()
     if (d_temp_) (void)hipFree(d_temp_);
     dfree(d_tile_info_); dfree(d_tile_pos1_); dfree(d_tile_count_); dfree(d_tile_hits_); dfree(d_tile_nmin_); dfree(d_tile_prefix_); dfree(d_tile_fast_); dfree(d_tile_rec_);
     if (d_tile_temp_) (void)hipFree(d_tile_temp_);
-    dfree(d_bases_); dfree(d_offsets_); dfree(d_tile_first_); dfree(d_bloom_); dfree(d_bloom0_); dfree(d_bloomr_); dfree(d_pbloom_);
+    dfree(d_bases_); dfree(d_offsets_); dfree(d_tile_first_); dfree(d_bloom_); dfree(d_bloom0_); dfree(d_bloom0f_); dfree(d_bloomr_); dfree(d_pbloom_);
     for (Lane& lane : lanes_) free_lane(lane);
     if (ev_begin_) (void)hipEventDestroy(ev_begin_);
     if (h_counters_) (void)hipHostFree(h_counters_);
@@ -291,7 +293,7 @@ void Mapper::launch_lane(Lane& lane, hipStream_t stream, const uint8_t* d_bases,
     a.overflow = reinterpret_cast<uint32_t*>(&lane.d_scratch[L_OVERFLOW]);
     dev::FilterBuffers fb { lane.raw_pos, lane.raw_grp, lane.cand_info, lane.cand_pos1, lane.cand_rec, lane.raw_capacity, lane.small,
         &lane.d_scratch[L_MAXLEN] };
-    dev::BloomTables bt { d_bloom_, bloom_wbits_, d_bloom0_, bloom0_wbits_, d_bloomr_ };
+    dev::BloomTables bt { d_bloom_, bloom_wbits_, d_bloom0_, bloom0_wbits_, d_bloomr_, d_bloom0f_ };
     dev::ReadClusterArgs rc {};
     rc.prg_min_path_len = d_min_path_len_;
     rc.fraction = params_.cluster_fraction();

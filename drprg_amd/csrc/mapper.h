@@ -146,6 +146,7 @@ private:
     uint32_t* d_pbloom_ = nullptr; // Bloom tier of the direct kernel (large indexes)
     uint32_t pbloom_wbits_ = 0;
     uint32_t* d_bloom0_ = nullptr; // level 0 of the filter (k = 15, small indexes)
+    uint32_t* d_bloom0f_ = nullptr; // level 0 + second-stage bits in one array
     uint32_t bloom0_wbits_ = 0;
     uint32_t* d_bloomr_ = nullptr; // second stage of the level-0 form
     int n_cus_ = 256;

@@ -11,9 +11,11 @@
 //                          per four positions against a 128 KB array).  Survivors are appended in position order to the
 //                          wave's own slices (cursor in a scalar register: no atomics, no barriers).  Two tiles of bases
 //                          are in flight per wave in a register ring, the right neighbour's packed word arrives through
-//                          a DPP wave shift.
-//   refine_kernel          level-0 form: one lane per surviving group of four positions, second-stage filter in LDS,
-//                          ordered compaction of the surviving positions per slice.
+//                          a DPP wave shift.  Level-0 form, default: the groups that pass wait in the wave's 2 KB of LDS
+//                          and go through the second-stage filter -- its bits share the level-0 array -- 64 at a time,
+//                          one lane per group; only surviving positions leave the kernel.
+//   refine_kernel          level-0 form with DRPRG_FILTER_FORM=refine: the groups leave sketch_filter_kernel as 16-byte
+//                          records; one lane per group, second-stage filter in LDS, ordered compaction per slice.
 //   candidates.hip
 //   cand_scan_kernel       one workgroup: exclusive scan of the slice counts; cand_gather_kernel copies the slices into
 //                          one dense, ordered candidate list.
@@ -79,15 +81,15 @@ __device__ __forceinline__ uint32_t bloom_test(uint32_t word, uint32_t h, uint32
 }
 
 // SHORT_K: k < 12, the level-1 key must be masked to 2k bits.  LEVEL0: the level-0 array is present (k = 15).
-// FUSED (with LEVEL0; opt-in, DRPRG_FILTER_FORM=fused): the second stage runs in this kernel as well.  The groups that pass level 0 are staged in the wave's own
+// FUSED (with LEVEL0): the second stage runs in this kernel as well.  The groups that pass level 0 are staged in the wave's own
 // 2 KB of LDS and, 64 at a time, put through the second-stage filter one lane per group -- dense lanes, as in refine_kernel --
 // so that only surviving POSITIONS leave for global memory.  Why: the 16-byte group records of the
 // two-kernel form are 104 MB of scattered writes per 10 M reads, and those writes -- not their instructions: staging them in
 // LDS and copying them out coalesced once in twelve tiles changed nothing, sending them nowhere saved 65 us -- slow the
-// streaming reads down.  LDS: level 0 128 KB + stage 32 KB; the 64 KB second-stage array does not fit
-// and is read from global memory (L2-resident) -- which is what makes this form lose: with the words taken from LDS (wrong
-// results, timing only) the kernel ran in 0.319 ms, with the 26 M four-byte loads from global memory in 0.449 ms whether
-// they are waited for at once or a tile later.
+// streaming reads down.  LDS: level 0 128 KB + stage 32 KB.  A second-stage array of its own (64 KB) does
+// not fit, and read from global memory (26 M four-byte loads per batch) it made this form slower than the two kernels, whether
+// the words were waited for at once or a tile later; so the second-stage bits share the level-0 array (FlatIndex::bloom0f): both
+// tests see a fuller array and let more through, which costs less than the records did.
 template <bool SHORT_K, bool LEVEL0, bool FUSED = false>
 __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a, FilterWork fw)
 {
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
     const uint32_t kmask24 = kmask & 0xFFFFFFu;
     const int sh_w = 32 - (int)fw.bloom_wbits;
 
-    if (LEVEL0)
+    if (LEVEL0) // (FUSED: fw.bloom0 is the array that also holds the second-stage bits)
         for (uint32_t i = tid; i < (1u << fw.bloom0_wbits); i += FT_THREADS) s_dyn[i] = fw.bloom0[i];
 
     if (!LEVEL0) // (the level-0 form leaves levels 1+2 to refine_kernel)
@@ -159,79 +161,55 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
     uint4* grp_out = LEVEL0 ? fw.raw_grp + (size_t)slice * fw.raw_slice : nullptr;
     (void)grp_out;
     uint32_t wcur = 0; // candidates in the current slice so far (wave-uniform)
-    // FUSED: the groups that passed level 0 wait in the wave's 2 KB of LDS, 64 to a half.  When the half being filled cannot take
-    // the next tile, every lane takes one of its groups and requests the four second-stage words of its four positions from
-    // global memory (phase A) -- and only one tile later, just before that tile's own groups are staged, tests them and appends
-    // the surviving positions in order (phase B): by then the words have arrived, and waiting for them does not wait for the
-    // base loads issued since (waiting right away cost 130 us per 10 M reads: every such wait drained the prefetched tiles).
-    // (Macros, not closures or functions taking the counters by reference: those kept the counters in scratch memory, whose
-    // accesses count on vmcnt like every other VMEM instruction.)
-    constexpr uint32_t HALF = STAGE_RECORDS / 2;
+    // FUSED: the groups that passed level 0 wait in the wave's 2 KB of LDS; when the next tile might not fit, they go through the
+    // second stage, 64 at a time and one lane each, and the surviving positions are appended in order.  The second-stage bits live
+    // in the same 128 KB array as level 0 (FlatIndex::bloom0f: there is no room for an array of their own, and reading one from
+    // global memory is what made this form lose).  (A macro, not a closure or a function taking the counters by reference: those
+    // kept the counters in scratch memory, whose accesses count on vmcnt like every other VMEM instruction.)
     uint4* const stage = FUSED ? reinterpret_cast<uint4*>(s_dyn + STAGE_BASE_WORDS) + (tid >> 6) * STAGE_RECORDS : nullptr;
-    uint32_t lcnt = 0, fill = 0, pcnt = 0; // groups in the half being filled, which half that is, groups of the half that waits for its words
-    uint32_t sw0 = 0, sw1 = 0, sw2 = 0, sw3 = 0; // the four words of this lane's group of the waiting half
+    uint32_t lcnt = 0; // groups staged (wave-uniform)
     (void)stage;
     auto mb_below = [](uint64_t m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); };
     (void)mb_below;
-#define DRPRG_STAGE_KEY(r, q) ((((q) ? __funnelshift_r((r).z, (r).w, 2 * (q)) : (r).z) & kmask) * BLOOM_CR)
-#define DRPRG_PHASE_A(w0, w1, w2, w3)                                                                                       \
-    do {                                                                                                                    \
-        __builtin_amdgcn_wave_barrier(); /* the wave's own LDS writes come before these reads in program order */           \
-        if ((uint32_t)lane < lcnt) {                                                                                        \
-            const uint4 ra = stage[fill * HALF + (uint32_t)lane];                                                           \
-            w0 = fw.bloomr[DRPRG_STAGE_KEY(ra, 0) >> (32 - BLOOMR_WBITS)];                                                  \
-            w1 = fw.bloomr[DRPRG_STAGE_KEY(ra, 1) >> (32 - BLOOMR_WBITS)];                                                  \
-            w2 = fw.bloomr[DRPRG_STAGE_KEY(ra, 2) >> (32 - BLOOMR_WBITS)];                                                  \
-            w3 = fw.bloomr[DRPRG_STAGE_KEY(ra, 3) >> (32 - BLOOMR_WBITS)];                                                  \
-        }                                                                                                                   \
-        pcnt = lcnt;                                                                                                        \
-        lcnt = 0;                                                                                                           \
-        fill ^= 1u;                                                                                                         \
-    } while (0)
-#define DRPRG_STAGE_TEST(word, h) (((word) >> ((h) & 31)) & ((word) >> (((h) >> 5) & 31)) & ((word) >> (((h) >> 10) & 31)) & ((word) >> (((h) >> 15) & 31)) & 1u)
-#define DRPRG_PHASE_B(w0, w1, w2, w3)                                                                                       \
-    do {                                                                                                                    \
-        if (pcnt) {                                                                                                         \
-            uint32_t cand2 = 0;                                                                                             \
-            uint4 rb = make_uint4(0, 0, 0, 0);                                                                              \
-            if ((uint32_t)lane < pcnt) {                                                                                    \
-                rb = stage[(fill ^ 1u) * HALF + (uint32_t)lane];                                                            \
-                cand2 = DRPRG_STAGE_TEST(w0, DRPRG_STAGE_KEY(rb, 0)) | (DRPRG_STAGE_TEST(w1, DRPRG_STAGE_KEY(rb, 1)) << 1)    \
-                    | (DRPRG_STAGE_TEST(w2, DRPRG_STAGE_KEY(rb, 2)) << 2) | (DRPRG_STAGE_TEST(w3, DRPRG_STAGE_KEY(rb, 3)) << 3); \
-            }                                                                                                               \
-            /* ordered append: exclusive prefix of the per-lane counts (0..4) from three ballots */                         \
-            const uint32_t c2 = (uint32_t)__popc(cand2);                                                                    \
-            const uint64_t e0 = __ballot(c2 & 1u), e1 = __ballot(c2 & 2u), e2 = __ballot(c2 & 4u);                          \
-            if (e0 | e1 | e2) {                                                                                             \
-                uint32_t at2 = wcur + mb_below(e0) + 2u * mb_below(e1) + 4u * mb_below(e2);                                 \
-                const uint64_t pos2 = ((uint64_t)rb.y << 32) | rb.x;                                                        \
-                while (cand2) {                                                                                             \
-                    const int q2 = __ffs(cand2) - 1;                                                                        \
-                    cand2 &= cand2 - 1;                                                                                     \
-                    if (at2 < fw.raw_slice) out[at2] = pos2 + (uint64_t)q2;                                                 \
-                    ++at2;                                                                                                  \
-                }                                                                                                           \
-                wcur += (uint32_t)(__popcll(e0) + 2 * __popcll(e1) + 4 * __popcll(e2));                                     \
-            }                                                                                                               \
-            __builtin_amdgcn_wave_barrier(); /* the half may be written again */                                            \
-            pcnt = 0;                                                                                                       \
-        }                                                                                                                   \
-    } while (0)
-    // both phases at once for the half being filled (end of a slice, dense tiles): words in registers of their own, so that the
-    // compiler's count of what is in flight for sw0..sw3 -- requested a tile before they are needed -- stays exact
-#define DRPRG_FLUSH_NOW()                         \
-    do {                                          \
-        if (lcnt) {                               \
-            uint32_t tw0 = 0, tw1 = 0, tw2 = 0, tw3 = 0; \
-            DRPRG_PHASE_A(tw0, tw1, tw2, tw3);    \
-            DRPRG_PHASE_B(tw0, tw1, tw2, tw3);    \
-        }                                         \
+#define DRPRG_SECOND_STAGE()                                                                                                          \
+    do {                                                                                                                              \
+        if (lcnt) {                                                                                                                   \
+            __builtin_amdgcn_wave_barrier(); /* the wave's own LDS writes come before these reads in program order */                 \
+            for (uint32_t c0 = 0; c0 < lcnt; c0 += 64) {                                                                              \
+                const uint32_t ri = c0 + (uint32_t)lane;                                                                              \
+                uint32_t cand2 = 0;                                                                                                   \
+                uint4 r = make_uint4(0, 0, 0, 0);                                                                                     \
+                if (ri < lcnt) {                                                                                                      \
+                    r = stage[ri];                                                                                                    \
+                    _Pragma("unroll") for (int q = 0; q < 4; ++q) { /* four bits of one word, keyed on the whole code at position q */ \
+                        const uint32_t f = (q ? __funnelshift_r(r.z, r.w, 2 * q) : r.z) & kmask;                                      \
+                        const uint32_t h = f * BLOOM_CR, h2 = f * BLOOM_C2;                                                           \
+                        const uint32_t word = lds_at((h >> 17) << 2);                                                                 \
+                        cand2 |= ((word >> (h & 31)) & (word >> ((h >> 5) & 31)) & (word >> ((h >> 10) & 31)) & (word >> (h2 >> 27))      \
+                                     & (word >> ((h2 >> 22) & 31)) & (word >> ((h2 >> 17) & 31)) & 1u) << q;                           \
+                    }                                                                                                                 \
+                }                                                                                                                     \
+                /* ordered append: exclusive prefix of the per-lane counts (0..4) from three ballots */                               \
+                const uint32_t c2 = (uint32_t)__popc(cand2);                                                                          \
+                const uint64_t e0 = __ballot(c2 & 1u), e1 = __ballot(c2 & 2u), e2 = __ballot(c2 & 4u);                                \
+                if (e0 | e1 | e2) {                                                                                                   \
+                    uint32_t at2 = wcur + mb_below(e0) + 2u * mb_below(e1) + 4u * mb_below(e2);                                       \
+                    const uint64_t pos2 = ((uint64_t)r.y << 32) | r.x;                                                                \
+                    while (cand2) {                                                                                                   \
+                        const int q2 = __ffs(cand2) - 1;                                                                              \
+                        cand2 &= cand2 - 1;                                                                                           \
+                        if (at2 < fw.raw_slice) out[at2] = pos2 + (uint64_t)q2;                                                       \
+                        ++at2;                                                                                                        \
+                    }                                                                                                                 \
+                    wcur += (uint32_t)(__popcll(e0) + 2 * __popcll(e1) + 4 * __popcll(e2));                                           \
+                }                                                                                                                     \
+            }                                                                                                                         \
+            __builtin_amdgcn_wave_barrier();                                                                                          \
+            lcnt = 0;                                                                                                                 \
+        }                                                                                                                             \
     } while (0)
     auto close_slice = [&]() {
-        if constexpr (FUSED) { // everything staged leaves now
-            DRPRG_PHASE_B(sw0, sw1, sw2, sw3);
-            DRPRG_FLUSH_NOW();
-        }
+        if constexpr (FUSED) DRPRG_SECOND_STAGE(); // everything staged leaves now
         if (lane == 0) {
             (LEVEL0 && !FUSED ? fw.grp_count : fw.slice_count)[slice] = wcur;
             if (wcur > fw.raw_slice) atomicOr(a.overflow, 4u);
@@ -267,7 +245,6 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
 #pragma unroll
             for (int g = FT_G / 4 - 1; g >= 0; --g) grp = __builtin_amdgcn_alignbit(grp, bloom_test(ws[g], hs[g], xs[g]), 31);
             if (lane == 63 || (fw.debug & 1u)) grp = 0;
-            if constexpr (FUSED) DRPRG_PHASE_B(sw0, sw1, sw2, sw3); // the half whose words were requested while the previous tile was staged
             // ---- append in (lane, group) = position order: exclusive prefix of the per-lane counts (0..8) from four ballots ----
             const uint32_t cnt = (uint32_t)__popc(grp);
             const uint64_t b0 = __ballot(cnt & 1u), b1 = __ballot(cnt & 2u), b2 = __ballot(cnt & 4u), b3 = __ballot(cnt & 8u);
@@ -282,30 +259,28 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
                 };
                 if constexpr (FUSED) {
                     const uint32_t total = (uint32_t)(__popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2) + 8 * __popcll(b3));
-                    if (total <= HALF) {
-                        if (lcnt + total > HALF) DRPRG_PHASE_A(sw0, sw1, sw2, sw3); // wave-uniform; the other half is free: phase B ran above
-                        uint32_t at = fill * HALF + lcnt + below(b0) + 2u * below(b1) + 4u * below(b2) + 8u * below(b3);
+                    if (lcnt + total > STAGE_RECORDS) DRPRG_SECOND_STAGE(); // wave-uniform
+                    if (total <= STAGE_RECORDS) {
+                        uint32_t at = lcnt + below(b0) + 2u * below(b1) + 4u * below(b2) + 8u * below(b3);
                         while (grp) {
                             const int g = __ffs(grp) - 1;
                             grp &= grp - 1;
                             stage[at++] = record(g);
                         }
                         lcnt += total;
-                    } else { // a tile dense with index k-mers (amplicon reads): eight lanes (<= 64 groups) at a time, in lane order,
-                             // each lot through both phases at once
-                        DRPRG_FLUSH_NOW();
-                        for (int part = 0; part < 8; ++part) {
-                            uint32_t gq = (lane >> 3) == part ? grp : 0u;
+                    } else { // a tile dense with index k-mers (amplicon reads): sixteen lanes (<= 128 groups) at a time, in lane order
+                        for (int part = 0; part < 4; ++part) {
+                            uint32_t gq = (lane >> 4) == part ? grp : 0u;
                             const uint32_t cq = (uint32_t)__popc(gq);
                             const uint64_t q0 = __ballot(cq & 1u), q1 = __ballot(cq & 2u), q2 = __ballot(cq & 4u), q3 = __ballot(cq & 8u);
-                            uint32_t at = fill * HALF + below(q0) + 2u * below(q1) + 4u * below(q2) + 8u * below(q3);
+                            uint32_t at = below(q0) + 2u * below(q1) + 4u * below(q2) + 8u * below(q3);
                             while (gq) {
                                 const int g = __ffs(gq) - 1;
                                 gq &= gq - 1;
                                 stage[at++] = record(g);
                             }
                             lcnt = (uint32_t)(__popcll(q0) + 2 * __popcll(q1) + 4 * __popcll(q2) + 8 * __popcll(q3));
-                            DRPRG_FLUSH_NOW();
+                            DRPRG_SECOND_STAGE();
                         }
                     }
                 } else {
@@ -400,11 +375,7 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
     for (++slice; slice < (gw + 1) * FT_SUB; ++slice) // slices this wave never reached (the last waves of a short batch)
         if (lane == 0) (LEVEL0 && !FUSED ? fw.grp_count : fw.slice_count)[slice] = 0;
 }
-#undef DRPRG_PHASE_A
-#undef DRPRG_FLUSH_NOW
-#undef DRPRG_PHASE_B
-#undef DRPRG_STAGE_KEY
-#undef DRPRG_STAGE_TEST
+#undef DRPRG_SECOND_STAGE
 
 // Second stage of the filter for the groups that passed level 0 (level-0 form of sketch_filter_kernel): one lane per
 // group tests its four k-mer codes against a 64 KB LDS-resident filter (four bits per code, < 15 % full); every wave
@@ -502,18 +473,18 @@ hipError_t launch_sketch_filter(const SketchArgs& a, uint32_t read_begin, uint32
     if (a.n_bases == 0) return hipSuccess;
     if ((1u << bt.bloom_wbits) > (uint32_t)FT_BLOOM_WORDS) return hipErrorInvalidValue;
     if (bt.bloom0 && (1u << bt.bloom0_wbits) != (uint32_t)FT_L0_WORDS) return hipErrorInvalidValue;
-    if (bt.bloom0 && (!b.raw_grp || !bt.bloomr)) return hipErrorInvalidValue;
+    if (bt.bloom0 && (!b.raw_grp || !bt.bloomr || !bt.bloom0f)) return hipErrorInvalidValue;
     if (const char* dbg = std::getenv("DRPRG_FT_DEBUG")) fw.debug = (uint32_t)std::atoi(dbg); // 1 no filter test, 4 no level 0, 8 no read_cluster_kernel
     const bool level0 = bt.bloom0 != nullptr && a.k == 15 && ((size_t)4 << bt.bloom_wbits) + (size_t)FT_L0_WORDS * 4 <= 160 * 1024
         && !(fw.debug & 4u);
-    // the second stage as refine_kernel behind the streaming kernel (default) or inside it (DRPRG_FILTER_FORM=fused: measured
-    // slower, 0.449 against 0.378 + 0.045 ms per 10 M reads; kept for the measurement and its tests)
+    // the second stage inside the streaming kernel (default; its bits share the level-0 array) or as refine_kernel behind it
+    // (DRPRG_FILTER_FORM=refine): 0.64 against 0.69 ms per 10 M reads, DESIGN.md section 6
     const char* form = std::getenv("DRPRG_FILTER_FORM");
-    const bool fused = level0 && form && std::string(form) == "fused";
+    const bool fused = level0 && !(form && std::string(form) == "refine");
     fw.bloom = bt.bloom;
     fw.bloom_wbits = bt.bloom_wbits;
     fw.bloomr = bt.bloomr;
-    fw.bloom0 = level0 ? bt.bloom0 : nullptr;
+    fw.bloom0 = level0 ? (fused ? bt.bloom0f : bt.bloom0) : nullptr;
     fw.bloom0_wbits = level0 ? bt.bloom0_wbits : 0;
     const uint32_t grid = filter_grid(level0, n_cus, filter_n_tiles(a.n_bases));
     fw.n_slices = grid * FT_WAVES * FT_SUB;

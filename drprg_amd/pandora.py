@@ -197,7 +197,7 @@ class Context:
         out = (C.c_uint64 * 8)()
         _check(lib.drprg_hip_filter_selfcheck(self._h, out), self._h)
         names = ("codes", "level0_false_negatives", "level12_false_negatives", "stage2_false_negatives", "level0_fill_permille",
-                 "level12_fill_permille", "stage2_fill_permille")
+                 "level12_fill_permille", "stage2_fill_permille", "shared_array_false_negatives")
         return dict(zip(names, (int(x) for x in out)))
 
     def table_tier(self):

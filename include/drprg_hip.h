@@ -156,7 +156,8 @@ int drprg_hip_genotype_alleles(drprg_hip_ctx* ctx, const char* out_tsv);
 
 /* Host-side check of the Bloom filters of the prefiltered kernel (no device needed): out[0] = index k-mer codes tested
  * (both orientations), out[1..3] = codes that level 0 / levels 1+2 / the second stage would wrongly reject (false
- * negatives: must be 0), out[4..6] = bits set per thousand in those three arrays.  All zero: the index has no filter. */
+ * negatives: must be 0), out[4..6] = bits set per thousand in those three arrays, out[7] = codes that the array holding level 0
+ * and the second-stage bits together (second stage inside the streaming kernel) would wrongly reject.  All zero: no filter. */
 int drprg_hip_filter_selfcheck(const drprg_hip_ctx* ctx, uint64_t out[8]);
 /* Index introspection for harnesses: sizes[0..4] = keys, records, prgs, k-mer nodes, table slots. */
 int drprg_hip_index_sizes(const drprg_hip_ctx* ctx, uint64_t sizes[5]);

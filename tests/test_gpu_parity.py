@@ -686,10 +686,9 @@ def test_deferred_batches_equal_synchronous_ones(tmp_path, oracle, kernel):
 
 
 def test_second_stage_inside_the_streaming_kernel(tmp_path, oracle, monkeypatch):
-    """DRPRG_FILTER_FORM=fused: sketch_filter_kernel stages the level-0 survivors in LDS and runs the second-stage filter itself,
-    64 groups at a time, one tile after it requested their filter words (no refine_kernel, no group records in global memory).
-    Opt-in (slower on MI355X) -- but it has to give the same vector: sparse reads, dense reads whose tiles
-    hold more groups than a stage half, and reads that cross slice ends."""
+    """sketch_filter_kernel stages the level-0 survivors in LDS and runs the second-stage filter itself, 64 groups at a time
+    (no refine_kernel, no group records in global memory: the default; DRPRG_FILTER_FORM=refine is the two-kernel form).  Both
+    give the oracle's vector: sparse reads, dense reads whose tiles hold more groups than the stage, reads across slice ends."""
     from drprg_amd import synth
     monkeypatch.setenv("DRPRG_FILTER_FORM", "fused")
     panel = synth.small_panel(seed=6, n_loci=3, length=900)
