@@ -47,6 +47,10 @@ __device__ __forceinline__ uint32_t pack_max(uint32_t earlier, uint32_t later)
 }
 // LDS traffic only: global loads, stores and atomics stay in flight across the barrier
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// the same, and the thread index comes out of it as a value the compiler knows nothing about: the LDS addresses derived from
+// it are computed again after every barrier instead of being kept in registers across the whole chunk loop (at 64 VGPRs --
+// two 1024-thread workgroups per CU -- the kernel spilled twelve of them to scratch memory)
+__device__ __forceinline__ void lds_barrier(int& t) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+v"(t) : : "memory"); }
 
 __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs a, FilterWork fw, ReadClusterArgs rc)
 {
@@ -68,7 +72,9 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
     __shared__ uint32_t s_prev_read, s_n_irr, s_chunk;
     __shared__ unsigned long long s_tot[3];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int tid = threadIdx.x;
+#define lane (tid & 63)
+#define wave (tid >> 6)
     if (*reinterpret_cast<volatile uint32_t*>(a.overflow) & 4u) return; // a candidate slice overflowed: the host re-runs the batch
     const uint32_t total = *fw.cand_total;
     for (uint32_t i = tid; i < rc.n_prgs; i += RC_THREADS) s_hist[i] = 0;
@@ -80,13 +86,13 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
     // the workgroups idle for the last round); the next chunk number is fetched while the current one is processed
     if (tid == 0) s_chunk = atomicAdd(rc.chunk_counter, 1u);
     for (;;) {
-        lds_barrier(); // LDS of the previous chunk is free, s_chunk is there
+        lds_barrier(tid); // LDS of the previous chunk is free, s_chunk is there
         const uint64_t base64 = (uint64_t)s_chunk * RC_OWN;
         if (base64 >= total) break;
         const uint32_t base = (uint32_t)base64;
         const uint32_t n_loaded = total - base < (uint32_t)RC_SLOTS ? total - base : (uint32_t)RC_SLOTS;
         const uint32_t n_own = total - base < (uint32_t)RC_OWN ? total - base : (uint32_t)RC_OWN;
-        lds_barrier(); // everybody has read s_chunk
+        lds_barrier(tid); // everybody has read s_chunk
         if (tid == 0) s_chunk = atomicAdd(rc.chunk_counter, 1u);
         // ---- A: stage the candidates: three coalesced loads per slot, nothing depends on them but LDS work ----
         uint4 crec[RC_PER];
@@ -115,7 +121,7 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
                                                                                            : 0xFFFFFFFFu;
             s_n_irr = 0;
         }
-        lds_barrier();
+        lds_barrier(tid);
         // ---- B: exclusive sum scan of the hit counts and ONE inclusive max scan of (read start << 16 | segment start), in slot
         // order: both starts only grow along the slots and a read start is a segment start, so the packed maximum is the pair ----
         {
@@ -154,7 +160,7 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
                 s_w[1][wave] = imx;
             }
             const uint32_t excl_mx_in_wave = __shfl_up(imx, 1);
-            lds_barrier();
+            lds_barrier(tid);
             uint32_t before = incl - run, mx_before = lane ? excl_mx_in_wave : 0u, sum = 0;
 #pragma unroll
             for (int i = 0; i < RC_WAVES; ++i) {
@@ -175,7 +181,7 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
             }
             if (tid == 0) s_hstart[RC_SLOTS] = sum;
         }
-        lds_barrier();
+        lds_barrier(tid);
         // ---- C: the hits (one per index record of every minimizer); every segment start closes the segment before it; a
         // minimizer whose group differs from the previous one of its read makes the read irregular; the first minimizer of a
         // segment names the segment's group and threshold ----
@@ -218,7 +224,7 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
             const uint32_t lead = s_lead[RC_SLOTS - 1];
             if (lead && lead <= n_own) s_cplx[lead - 1] = 1;
         }
-        lds_barrier();
+        lds_barrier(tid);
         // ---- E: the first slot of every segment decides for the segment; reads with several groups queue for the wave path ----
 #pragma unroll
         for (int q = 0; q < RC_PER; ++q) {
@@ -250,7 +256,7 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
             }
             s_dec[i] = (uint8_t)dec;
         }
-        lds_barrier();
+        lds_barrier(tid);
         // ---- F: the minimizers of the kept segments ----
         {
 #pragma unroll
@@ -380,6 +386,8 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
         if (s_tot[2]) atomicAdd(rc.n_complex, s_tot[2]);
     }
 }
+#undef lane
+#undef wave
 
 // DRPRG_FT_DEBUG=8: no read_cluster_kernel; the generic pipeline runs iff there is a hit
 __global__ void flag_complex_kernel(const unsigned long long* n_hits, unsigned long long* n_complex)
