@@ -118,22 +118,49 @@ __global__ __launch_bounds__(EX_THREADS) void verify_count_kernel(SketchArgs a, 
     const uint32_t w1_magic = w1_reciprocal(w);
     const int64_t win_lo = (int64_t)a.offsets[fw.read_begin], win_hi = (int64_t)a.offsets[fw.read_end];
     uint32_t my_hits = 0, my_nmin = 0, my_maxlen = 0;
+    // (the position of this thread's next candidate is requested one round early: one round trip less in the chain of each)
+    int64_t gp_next = t_begin + tid < t_end ? (int64_t)fw.cand_info[t_begin + tid] : 0;
     for (uint32_t t = t_begin + tid; t < t_end; t += EX_THREADS) {
-        const int64_t gp = (int64_t)fw.cand_info[t]; // position now, (slot, strand, read) when this lane is done
+        const int64_t gp = gp_next; // position now, (slot, strand, read) when this lane is done
+        if (t + EX_THREADS < t_end) gp_next = (int64_t)fw.cand_info[t + EX_THREADS];
         uint32_t pos1 = 0, slot = 0, read = READ_NONE, strand = 0;
         uint4 crec = make_uint4(0, 0, 0, 0);
         if (gp >= win_lo && gp < win_hi && gp + k <= n_bases) { // (the boundary tiles of a read range reach past it)
-            // the read of every candidate, index k-mer or not: read_cluster_kernel finds the first candidate of a read by
-            // comparing neighbours (interpolated first guess: exact for fixed-length reads, a short gallop otherwise)
-            if (!(fw.debug & 64u)) // (DRPRG_FT_DEBUG=64: timing only, no read lookup)
-                read = find_read_near(a.offsets, a.n_reads, (uint32_t)((double)gp * reads_per_base), (uint64_t)gp);
-            // ---- the 64 bases [a0, a0+64) hold the candidate and all its neighbours (w <= 16, k <= 15) ----
+            // Everything the candidate needs from memory that does not depend on other loads is requested before anything is
+            // waited for: the two read offsets around the interpolated read index and the four 16-byte words of the 64 bases
+            // [a0, a0+64) that hold the candidate and all its neighbours (w <= 16, k <= 15).  (One guarded load after the other,
+            // each behind its own branch, was four round trips in a row, and the read lookup two more.)
+            uint32_t guess = (uint32_t)((double)gp * reads_per_base);
+            if (guess >= a.n_reads) guess = a.n_reads - 1;
+            const uint64_t o0 = a.offsets[guess], o1 = a.offsets[guess + 1];
             const int64_t a0 = (gp > 15 ? gp - 15 : 0) & ~(int64_t)15;
+            uint4 b0, b1, b2, b3;
+            if (a0 + 64 <= n_bases) {
+                const uint4* __restrict__ bp = reinterpret_cast<const uint4*>(a.bases + a0);
+                b0 = bp[0];
+                b1 = bp[1];
+                b2 = bp[2];
+                b3 = bp[3];
+            } else { // the last bytes of the buffer
+                b0 = load16_guarded(a.bases, n_bases, a0);
+                b1 = load16_guarded(a.bases, n_bases, a0 + 16);
+                b2 = load16_guarded(a.bases, n_bases, a0 + 32);
+                b3 = load16_guarded(a.bases, n_bases, a0 + 48);
+            }
+            // the read of every candidate, index k-mer or not: read_cluster_kernel finds the first candidate of a read by
+            // comparing neighbours (the interpolated index is exact for fixed-length reads; a short gallop otherwise)
+            int64_t r0 = (int64_t)o0, r1 = (int64_t)o1;
+            if (o0 <= (uint64_t)gp && (uint64_t)gp < o1) read = guess;
+            else {
+                read = find_read_near(a.offsets, a.n_reads, guess, (uint64_t)gp);
+                r0 = (int64_t)a.offsets[read];
+                r1 = (int64_t)a.offsets[read + 1];
+            }
             uint32_t r0w, r1w, r2w, r3w, n0, n1, n2, n3;
-            pack16n(load16_guarded(a.bases, n_bases, a0), r0w, n0);
-            pack16n(load16_guarded(a.bases, n_bases, a0 + 16), r1w, n1);
-            pack16n(load16_guarded(a.bases, n_bases, a0 + 32), r2w, n2);
-            pack16n(load16_guarded(a.bases, n_bases, a0 + 48), r3w, n3);
+            pack16n(b0, r0w, n0);
+            pack16n(b1, r1w, n1);
+            pack16n(b2, r2w, n2);
+            pack16n(b3, r3w, n3);
             uint64_t bad = (uint64_t)(n0 | (n1 << 16)) | ((uint64_t)(n2 | (n3 << 16)) << 32); // bit i: base a0+i is not ACGT
             if (bad) { // -> bit i: the k-mer starting at a0+i holds such a base
                 uint64_t m = bad;
@@ -163,8 +190,9 @@ __global__ __launch_bounds__(EX_THREADS) void verify_count_kernel(SketchArgs a, 
                 slot = sl;
             }
             if (found) {
-                const int64_t r0 = (int64_t)a.offsets[read], r1 = (int64_t)a.offsets[read + 1];
                 if (gp + k <= r1) { // the k-mer lies inside one read
+                    // (requested before the window scan that decides whether it is needed: the scan hides the round trip)
+                    const uint4 sf = a.slot_first[slot]; // record offset, count, first record's node, its prg and that prg's shortest path
                     // ---- scan q = q_first .. q_first + 2w-2; steps outside [gp-(w-1), gp+(w-1)] or the read are invalid ----
                     const int64_t q_lo = gp - (w - 1);
                     const int64_t q_first = q_lo > a0 ? q_lo : a0; // a0 <= max(q_lo, 0)
@@ -203,7 +231,6 @@ __global__ __launch_bounds__(EX_THREADS) void verify_count_kernel(SketchArgs a, 
                         if (pos >= (1ull << HIT_POS_BITS)) atomicOr(a.overflow, 2u);
                         else {
                             pos1 = (uint32_t)pos + 1;
-                            const uint4 sf = a.slot_first[slot]; // record offset, count, first record's node, its prg and that prg's shortest path
                             const uint2 rec = make_uint2(sf.x, sf.y);
                             my_hits += rec.y;
                             my_nmin += 1;

@@ -180,8 +180,8 @@ struct FilterWork {
     uint32_t *wg_hits, *wg_nmin, *wg_maxlen, *wg_base; // [ex_grid]
     unsigned long long* max_len; // longest read that holds a minimizer hit (this batch)
     uint32_t debug;          // ablation switches for profiling (DRPRG_FT_DEBUG): 1 = skip the Bloom test, 8 = every read through the
-                             // generic pipeline, 16 / 32 / 64 = verify_count_kernel without its window scan / table probe and
-                             // everything after it / read lookup (wrong results: timing only, tools/dbg16.sh)
+                             // generic pipeline, 16 / 32 = verify_count_kernel without its window scan / table probe and
+                             // everything after it (wrong results: timing only, tools/dbg16.sh)
 };
 constexpr uint32_t READ_NONE = 0x7FFFFFFFu; // "read" of a candidate that lies past the last whole k-mer of the buffer
 
