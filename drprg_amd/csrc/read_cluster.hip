@@ -96,17 +96,32 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
         if (tid == 0) s_chunk = atomicAdd(rc.chunk_counter, 1u);
         // ---- A: stage the candidates: three coalesced loads per slot, nothing depends on them but LDS work ----
         uint4 crec[RC_PER];
+        uint32_t st_read[RC_PER], st_pos1[RC_PER];
+#pragma unroll
+        for (int q = 0; q < RC_PER; ++q) { // (all six loads first and without a branch -- a slot past the end reads the chunk's first
+                                           // candidate and drops it --, then the LDS stores: one round trip instead of one per slot)
+            const uint32_t i = (uint32_t)tid + (uint32_t)q * RC_THREADS;
+            const uint32_t src = base + (i < n_loaded ? i : 0u);
+            st_read[q] = (uint32_t)fw.cand_info[src];
+            st_pos1[q] = fw.cand_pos1[src];
+            crec[q] = fw.cand_rec[src];
+        }
+        // (the two neighbours of the staged range, for thread 0, in the same round trip: uniform addresses)
+        const bool has_next = n_loaded == (uint32_t)RC_SLOTS && base + n_loaded < total;
+        const uint32_t edge_prev = (uint32_t)fw.cand_info[base ? base - 1 : 0u], edge_next = (uint32_t)fw.cand_info[has_next ? base + n_loaded : base];
 #pragma unroll
         for (int q = 0; q < RC_PER; ++q) {
             const uint32_t i = (uint32_t)tid + (uint32_t)q * RC_THREADS;
-            uint32_t read = READ_NONE, pos1 = 0;
-            crec[q] = make_uint4(0, 0, 0, 0);
-            if (i < n_loaded) {
-                read = (uint32_t)fw.cand_info[base + i] & 0x7FFFFFFFu;
-                pos1 = fw.cand_pos1[base + i];
-                crec[q] = fw.cand_rec[base + i];
-                if (!pos1) crec[q].y = 0; // handled by another chunk in the meantime (look-ahead slots only)
-            }
+            const bool in = i < n_loaded;
+            st_read[q] = in ? st_read[q] & 0x7FFFFFFFu : READ_NONE;
+            st_pos1[q] = in ? st_pos1[q] : 0u;
+            if (!in) crec[q] = make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < RC_PER; ++q) {
+            const uint32_t i = (uint32_t)tid + (uint32_t)q * RC_THREADS;
+            const uint32_t read = st_read[q], pos1 = st_pos1[q];
+            if (!pos1) crec[q].y = 0; // handled by another chunk in the meantime (look-ahead slots only)
             s_read[i] = read;
             s_pos1[i] = (uint16_t)(pos1 < 0xFFFFu ? pos1 : 0xFFFFu);
             s_hstart[i] = crec[q].y;
@@ -115,10 +130,9 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
             s_irrf[i] = 0;
         }
         if (tid == 0) {
-            s_prev_read = base ? ((uint32_t)fw.cand_info[base - 1] & 0x7FFFFFFFu) : 0xFFFFFFFFu;
+            s_prev_read = base ? (edge_prev & 0x7FFFFFFFu) : 0xFFFFFFFFu;
             // the candidate after the staged range: a read that runs on into it does not fit
-            s_read[RC_SLOTS] = (n_loaded == (uint32_t)RC_SLOTS && base + n_loaded < total) ? ((uint32_t)fw.cand_info[base + n_loaded] & 0x7FFFFFFFu)
-                                                                                           : 0xFFFFFFFFu;
+            s_read[RC_SLOTS] = has_next ? (edge_next & 0x7FFFFFFFu) : 0xFFFFFFFFu;
             s_n_irr = 0;
         }
         lds_barrier(tid);
