@@ -13,8 +13,11 @@ all-reduce of the u32 coverage vector per step.
 `python -m torch.distributed.run --nproc-per-node N bench.py ...`, spawned before this process touches
 the GPU) and relays rank 0's line and the exit code; it refuses to run with fewer than N devices.
 
+Steps are queued back to back (drprg_hip_map_device_async: the read-back a batch ends with is looked at
+while the next batch runs); DRPRG_BENCH_SYNC=1 makes the host wait for every batch instead.
+
 Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (sketch_filter_kernel for the
-mtb-sized indexes, sketch_probe_kernel for the 500-locus one) against HBM bandwidth using the
+mtb-sized indexes, sketch_wave_kernel for the 500-locus one) against HBM bandwidth using the
 algorithmic bytes of SURVEY.md section 8d, with its duration measured live with HIP events on the
 launch stream; `cpu_baseline` times the CPU oracle (oracle/oracle.c + oracle_index.c, a scalar port) on a
 bounded sample of the same workload, on one thread and on the host's cores (up to 64 threads).
