@@ -276,18 +276,27 @@ __device__ __forceinline__ void sketch_wave_tile(const SketchArgs& a, uint32_t t
     uint32_t n_a = nmin;
     if (a.pbloom) {
         n_a = 0;
-        for (uint32_t i0 = 0; i0 < nmin; i0 += 64) {
-            const uint32_t i = i0 + (uint32_t)lane;
-            bool pass = false;
-            uint32_t p = 0;
-            if (i < nmin) {
-                p = list[i];
-                const uint32_t m = (hvs[p] - 1u) * 0x9E3779B1u, need = pbloom_bits(m); // (= pbloom_mix of a 32-bit key)
-                pass = (a.pbloom[pbloom_word(m, a.pbloom_wbits)] & need) == need;
+        // (three rounds of 64 minimizers at a time -- a tile has about 160 --, their three filter words requested before the first
+        // one is looked at: one round trip to the L2 instead of three)
+        for (uint32_t i0 = 0; i0 < nmin; i0 += 192) {
+            uint32_t p[3] = { 0, 0, 0 }, need[3] = { 0, 0, 0 }, word[3] = { 0, 0, 0 };
+            bool in[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const uint32_t i = i0 + 64u * (uint32_t)u + (uint32_t)lane;
+                in[u] = i < nmin;
+                p[u] = list[in[u] ? i : 0u];
+                const uint32_t m = (hvs[p[u]] - 1u) * 0x9E3779B1u; // (= pbloom_mix of a 32-bit key)
+                need[u] = pbloom_bits(m);
+                word[u] = a.pbloom[pbloom_word(m, a.pbloom_wbits)];
             }
-            const uint64_t pm = __ballot(pass);
-            if (pass) list[n_a + lanes_below(pm)] = (uint16_t)p; // (in place: nothing at or beyond i0 + 64 is overwritten)
-            n_a += (uint32_t)__popcll(pm);
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const bool pass = in[u] && (word[u] & need[u]) == need[u];
+                const uint64_t pm = __ballot(pass);
+                if (pass) list[n_a + lanes_below(pm)] = (uint16_t)p[u]; // (in place: nothing at or beyond the entries read above is overwritten)
+                n_a += (uint32_t)__popcll(pm);
+            }
         }
         wave_lds_fence();
     }
@@ -329,17 +338,16 @@ __device__ __forceinline__ void sketch_wave_tile(const SketchArgs& a, uint32_t t
         Entry e;
         e.p = list[i] & 0x7FFFu;
         e.slot = hvs[e.p];
-        e.sf = a.slot_first[e.slot];
         const uint64_t gp = (uint64_t)(origin + (int64_t)e.p);
         const uint32_t rb = *reinterpret_cast<volatile uint32_t*>(&lds.rbits[e.p >> 4]);
         e.read = *reinterpret_cast<volatile uint32_t*>(&lds.rcnt[e.p >> 4]) + (uint32_t)__popc(rb & ((2u << (e.p & 15)) - 1u));
-        e.o0 = e.o1 = 0;
         bool ok = !(rb & 0x10000u) && e.read < a.n_reads;
-        if (ok) {
-            e.o0 = a.offsets[e.read];
-            e.o1 = a.offsets[e.read + 1];
-            ok = e.o0 <= gp && gp < e.o1;
-        }
+        // (the slot's record and the read's two offsets in one round trip: the offsets unconditionally, of read 0 if the count is off)
+        const uint32_t rd = ok ? e.read : 0u;
+        e.sf = a.slot_first[e.slot];
+        e.o0 = a.offsets[rd];
+        e.o1 = a.offsets[rd + 1];
+        ok = ok && e.o0 <= gp && gp < e.o1;
         if (!ok) { // empty reads around here: search from the tile's first read
             e.read = find_read_from(a.offsets, a.n_reads, first_read ? first_read - 1 : 0, gp);
             e.o0 = a.offsets[e.read];
