@@ -484,10 +484,29 @@ __global__ __launch_bounds__(TG_THREADS) void tile_gather_kernel(SketchArgs a, F
     for (uint32_t t = t0 + (uint32_t)wave; t < t1; t += TG_THREADS / 64) {
         const uint32_t n = a.tile_count[t], dst = tile_prefix[t];
         const size_t src = (size_t)t * a.tile_cap;
-        for (uint32_t i = lane; i < n; i += 64) {
-            fw.cand_info[dst + i] = a.tile_info[src + i];
-            fw.cand_pos1[dst + i] = a.tile_pos1[src + i];
-            fw.cand_rec[dst + i] = a.tile_rec[src + i];
+        // (256 records per round, all twelve loads before the first store -- a lane past the end reads record 0 and drops it --: a
+        // slice holds about 150 records, and one load-store round trip per 64 of them left the memory system half idle)
+        for (uint32_t i0 = 0; i0 < n; i0 += 256) {
+            uint64_t ci[4];
+            uint32_t cp[4];
+            uint4 cr[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t i = i0 + 64u * (uint32_t)u + (uint32_t)lane;
+                const size_t at = src + (i < n ? i : 0u);
+                ci[u] = a.tile_info[at];
+                cp[u] = a.tile_pos1[at];
+                cr[u] = a.tile_rec[at];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t i = i0 + 64u * (uint32_t)u + (uint32_t)lane;
+                if (i < n) {
+                    fw.cand_info[dst + i] = ci[u];
+                    fw.cand_pos1[dst + i] = cp[u];
+                    fw.cand_rec[dst + i] = cr[u];
+                }
+            }
         }
     }
     uint32_t hits, nmin, fc, fh;
