@@ -576,8 +576,10 @@ void Mapper::map_device_async(const uint8_t* d_bases, const uint64_t* d_offsets,
     uint32_t* prg_reads, hipStream_t stream)
 {
     if (n_reads == 0) return;
-    if (!use_filter_ || max_lanes_ > 1 || n_bases == 0) { // (no deferred form of the other sequences)
-        map_device(d_bases, d_offsets, n_reads, n_bases, covg, prg_reads, stream);
+    if (!use_filter_ || max_lanes_ > 1 || n_bases == 0) { // (no deferred form of the other sequences: the batch is complete on return,
+        map_device(d_bases, d_offsets, n_reads, n_bases, covg, prg_reads, stream); // including what its tail queued for the leftover reads)
+        HIPCHK(hipSetDevice(device_));
+        wait_stream(stream ? stream : stream_);
         return;
     }
     if (!d_bases || !d_offsets) throw Error(DRPRG_EINVAL, "null device pointer");
@@ -650,7 +652,13 @@ void Mapper::complete_pending()
         sketch_ms_ += ms;
         sketch_launches_ += 1;
     }
+    // a batch that needed the host afterwards (run again with larger buffers, reads left to the generic pipeline) has just had
+    // more work queued for its accumulators: "completed" means that work is done too -- the caller may touch the buffers of a
+    // completed batch from any stream
+    const uint64_t leftover_before = tot_leftover_;
+    const bool overflowed = ((uint32_t)lane.h_scratch[L_OVERFLOW] & 4u) != 0;
     finish_lane(lane, p.d_bases, p.d_offsets, p.n_reads, p.n_bases, p.covg, p.prg_reads, p.stream);
+    if (overflowed || tot_leftover_ != leftover_before) wait_stream(p.stream);
 }
 
 void Mapper::sync()
