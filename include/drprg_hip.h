@@ -91,7 +91,8 @@ int drprg_hip_map_device(drprg_hip_ctx* ctx, const void* d_bases, const void* d_
  * sequence ends with (overflow flags, reads left to the generic pipeline, counters) is looked at while the NEXT batch runs
  * -- by the next call, by drprg_hip_sync, or by anything that reads results -- so back-to-back batches leave no gap on the
  * device.  The buffers of a batch (bases, offsets, accumulators) stay valid and unchanged until the call after the next
- * one returns or drprg_hip_sync does.  An error of a batch is reported by the call that completes it. */
+ * one returns or drprg_hip_sync does; from then on the batch is done on the device as well (its accumulators may be read or
+ * reused from any stream).  An error of a batch is reported by the call that completes it. */
 int drprg_hip_map_device_async(drprg_hip_ctx* ctx, const void* d_bases, const void* d_offsets, uint64_t n_reads,
     uint64_t n_bases, void* d_covg, void* d_prg_reads, void* hip_stream);
 int drprg_hip_sync(drprg_hip_ctx* ctx); /* completes the batch in flight and waits for its stream */
