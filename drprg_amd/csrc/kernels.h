@@ -198,6 +198,7 @@ struct ReadClusterArgs {
     unsigned long long* n_hits_kept;
     unsigned long long* n_complex; // reads left to the generic pipeline (their candidates keep cand_pos1 != 0)
     uint32_t* chunk_counter;       // zeroed device scalar: work distribution of read_cluster_kernel
+    unsigned long long* phase_clock; // DRPRG_RC_DEBUG=1: 12 counters, clock cycles thread 0 of every workgroup spent per phase (else null)
 };
 size_t filter_small_words();
 // the fields of fw that the consumers of a dense candidate list use (candidates.hip, read_cluster.hip)

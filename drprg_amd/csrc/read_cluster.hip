@@ -2,6 +2,8 @@
 // sketch_filter.hip): clusters, size / overlap filters and coverage straight from the ordered candidate list.
 #include "filter_common.h"
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 
 namespace drprg {
 namespace dev {
@@ -75,6 +77,16 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
     int tid = threadIdx.x;
 #define lane (tid & 63)
 #define wave (tid >> 6)
+    // (DRPRG_RC_DEBUG=1: thread 0 of every workgroup adds the clock cycles between two marks to counter `ph`)
+    unsigned long long pc_last = rc.phase_clock ? clock64() : 0;
+#define RC_MARK(ph)                                                  \
+    do {                                                             \
+        if (rc.phase_clock && tid == 0) {                            \
+            const unsigned long long pc_now = clock64();             \
+            atomicAdd(&rc.phase_clock[ph], pc_now - pc_last);        \
+            pc_last = pc_now;                                        \
+        }                                                            \
+    } while (0)
     if (*reinterpret_cast<volatile uint32_t*>(a.overflow) & 4u) return; // a candidate slice overflowed: the host re-runs the batch
     const uint32_t total = *fw.cand_total;
     for (uint32_t i = tid; i < rc.n_prgs; i += RC_THREADS) s_hist[i] = 0;
@@ -86,13 +98,16 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
     // the workgroups idle for the last round); the next chunk number is fetched while the current one is processed
     if (tid == 0) s_chunk = atomicAdd(rc.chunk_counter, 1u);
     for (;;) {
+        RC_MARK(9); // (what ran since mark 8: the wave path of thread 0's wave)
         lds_barrier(tid); // LDS of the previous chunk is free, s_chunk is there
+        RC_MARK(0);
         const uint64_t base64 = (uint64_t)s_chunk * RC_OWN;
         if (base64 >= total) break;
         const uint32_t base = (uint32_t)base64;
         const uint32_t n_loaded = total - base < (uint32_t)RC_SLOTS ? total - base : (uint32_t)RC_SLOTS;
         const uint32_t n_own = total - base < (uint32_t)RC_OWN ? total - base : (uint32_t)RC_OWN;
         lds_barrier(tid); // everybody has read s_chunk
+        RC_MARK(1);
         if (tid == 0) s_chunk = atomicAdd(rc.chunk_counter, 1u);
         // ---- A: stage the candidates: three coalesced loads per slot, nothing depends on them but LDS work ----
         uint4 crec[RC_PER];
@@ -136,6 +151,7 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
             s_n_irr = 0;
         }
         lds_barrier(tid);
+        RC_MARK(2);
         // ---- B: exclusive sum scan of the hit counts and ONE inclusive max scan of (read start << 16 | segment start), in slot
         // order: both starts only grow along the slots and a read start is a segment start, so the packed maximum is the pair ----
         {
@@ -175,6 +191,7 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
             }
             const uint32_t excl_mx_in_wave = __shfl_up(imx, 1);
             lds_barrier(tid);
+            RC_MARK(3);
             uint32_t before = incl - run, mx_before = lane ? excl_mx_in_wave : 0u, sum = 0;
 #pragma unroll
             for (int i = 0; i < RC_WAVES; ++i) {
@@ -196,6 +213,7 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
             if (tid == 0) s_hstart[RC_SLOTS] = sum;
         }
         lds_barrier(tid);
+        RC_MARK(4);
         // ---- C: the hits (one per index record of every minimizer); every segment start closes the segment before it; a
         // minimizer whose group differs from the previous one of its read makes the read irregular; the first minimizer of a
         // segment names the segment's group and threshold ----
@@ -218,13 +236,27 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
             s_grp[h0] = (uint16_t)g;
             s_hpos[h0] = (uint16_t)pos;
             s_cov[h0] = crec[q].w;
-            for (uint32_t r = 1; r < cnt; ++r) { // rare: a k-mer that several k-mer nodes share
-                const uint32_t kn = a.rec_knode[crec[q].x + r], prg = a.rec_prg[crec[q].x + r];
-                const uint32_t rev = ((kn & 1u) == strand) ? 0u : 1u;
-                irregular |= ((prg << 1) | rev) != g;
-                s_grp[h0 + r] = (uint16_t)((prg << 1) | rev);
-                s_hpos[h0 + r] = (uint16_t)pos;
-                s_cov[h0 + r] = (kn >> 1) * 2u + rev;
+            // a k-mer that several k-mer nodes share (a quarter of the minimizers of a PRG index): its further records, four at a
+            // time with their eight loads requested together (one after the other they were up to three round trips that the
+            // whole workgroup waited for at the barrier)
+            for (uint32_t r0 = 1; r0 < cnt; r0 += 4) {
+                uint32_t kn4[4], prg4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t r = r0 + (uint32_t)u < cnt ? r0 + (uint32_t)u : r0;
+                    kn4[u] = a.rec_knode[crec[q].x + r];
+                    prg4[u] = a.rec_prg[crec[q].x + r];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t r = r0 + (uint32_t)u;
+                    if (r >= cnt) break;
+                    const uint32_t rev = ((kn4[u] & 1u) == strand) ? 0u : 1u;
+                    irregular |= ((prg4[u] << 1) | rev) != g;
+                    s_grp[h0 + r] = (uint16_t)((prg4[u] << 1) | rev);
+                    s_hpos[h0 + r] = (uint16_t)pos;
+                    s_cov[h0 + r] = (kn4[u] >> 1) * 2u + rev;
+                }
             }
             if (!mine) continue;
             const uint32_t first = lead - 1, seg = seg1 - 1;
@@ -239,6 +271,7 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
             if (lead && lead <= n_own) s_cplx[lead - 1] = 1;
         }
         lds_barrier(tid);
+        RC_MARK(5);
         // ---- E: the first slot of every segment decides for the segment; reads with several groups queue for the wave path ----
 #pragma unroll
         for (int q = 0; q < RC_PER; ++q) {
@@ -271,6 +304,7 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
             s_dec[i] = (uint8_t)dec;
         }
         lds_barrier(tid);
+        RC_MARK(6);
         // ---- F: the minimizers of the kept segments ----
         {
 #pragma unroll
@@ -288,9 +322,14 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
                 }
             }
         }
+        RC_MARK(8);
         // ---- G: reads with hits in several groups, one wave per read: lane j holds cluster j, the hits are broadcast one by one
         // (clusters per group split at gaps, size threshold, the overlap sweep of cluster_filter_kernel) ----
         const uint32_t n_irr = s_n_irr < (uint32_t)RC_POOL ? s_n_irr : (uint32_t)RC_POOL;
+        if (rc.phase_clock && tid == 0) { // (counters 10, 11 of the debug block: reads that took the wave path, chunks)
+            atomicAdd(&rc.phase_clock[10], (unsigned long long)n_irr);
+            atomicAdd(&rc.phase_clock[11], 1ull);
+        }
         for (uint32_t r = wave; r < n_irr; r += RC_WAVES) {
             const uint32_t i = s_irr[r] & 0xFFFFu, e = s_irr[r] >> 16;
             const uint32_t read = s_read[i], hb = s_hstart[i], he = s_hstart[e];
@@ -306,7 +345,7 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
                     const uint64_t mm = __ballot(lane < nc && cl_g == g);
                     if (mm) {
                         const int f = 63 - __clzll((long long)mm);
-                        const uint32_t last_f = __shfl(cl_last, f);
+                        const uint32_t last_f = (uint32_t)__builtin_amdgcn_readlane((int)cl_last, f); // (f is wave-uniform: a register read, not an LDS round trip)
                         if ((int)(pos - last_f) <= rc.max_diff) {
                             if (lane == f) {
                                 ++cl_n;
@@ -344,7 +383,8 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
                 uint32_t rank = 0;
                 for (uint64_t mm = alive; mm; mm &= mm - 1) {
                     const int o = __ffsll((long long)mm) - 1;
-                    const uint32_t of = __shfl(cl_first, o), on = __shfl(cl_n, o), og = __shfl(cl_g, o);
+                    const uint32_t of = (uint32_t)__builtin_amdgcn_readlane((int)cl_first, o), on = (uint32_t)__builtin_amdgcn_readlane((int)cl_n, o),
+                                   og = (uint32_t)__builtin_amdgcn_readlane((int)cl_g, o);
                     rank += (of < cl_first || (of == cl_first && (on > cl_n || (on == cl_n && og < cl_g)))) ? 1u : 0u;
                 }
                 const int nk = __popcll(alive);
@@ -352,7 +392,8 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
                 uint32_t pg = 0, pn = 0, p_last = 0;
                 for (int o = 0; o < nk; ++o) {
                     const int cur = __ffsll((long long)__ballot(kept && rank == (uint32_t)o)) - 1;
-                    const uint32_t cg = __shfl(cl_g, cur), cn = __shfl(cl_n, cur), c_last = __shfl(cl_last, cur);
+                    const uint32_t cg = (uint32_t)__builtin_amdgcn_readlane((int)cl_g, cur), cn = (uint32_t)__builtin_amdgcn_readlane((int)cl_n, cur),
+                                   c_last = (uint32_t)__builtin_amdgcn_readlane((int)cl_last, cur);
                     if (prev >= 0) {
                         const bool same_prg_other_strand = (pg >> 1) == (cg >> 1) && (pg & 1u) != (cg & 1u);
                         if (same_prg_other_strand || c_last <= p_last) {
@@ -379,7 +420,8 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
                 const uint32_t hg = h < he ? s_grp[h] : 0xFFFFFFFFu, hp = h < he ? s_hpos[h] : 0u;
                 for (uint64_t mm = alive; mm; mm &= mm - 1) {
                     const int o = __ffsll((long long)mm) - 1;
-                    const uint32_t og = __shfl(cl_g, o), of = __shfl(cl_first, o), ol = __shfl(cl_last, o);
+                    const uint32_t og = (uint32_t)__builtin_amdgcn_readlane((int)cl_g, o), of = (uint32_t)__builtin_amdgcn_readlane((int)cl_first, o),
+                                   ol = (uint32_t)__builtin_amdgcn_readlane((int)cl_last, o);
                     if (hg == og && hp >= of && hp <= ol) atomicAdd(&rc.covg[s_cov[h]], 1u);
                 }
             }
@@ -387,6 +429,7 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
                 if (s_pos1[c]) fw.cand_pos1[base + c] = 0; // handled
         }
     }
+    RC_MARK(7);
     // ---- workgroup totals ----
     if (my_kept) atomicAdd(&s_tot[0], (unsigned long long)my_kept);
     if (my_kept_hits) atomicAdd(&s_tot[1], my_kept_hits);
@@ -402,6 +445,7 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
 }
 #undef lane
 #undef wave
+#undef RC_MARK
 
 // DRPRG_FT_DEBUG=8: no read_cluster_kernel; the generic pipeline runs iff there is a hit
 __global__ void flag_complex_kernel(const unsigned long long* n_hits, unsigned long long* n_complex)
@@ -415,10 +459,28 @@ hipError_t launch_read_cluster(const SketchArgs& a, const FilterWork& fw, const 
         hipLaunchKernelGGL(flag_complex_kernel, dim3(1), dim3(1), 0, stream, a.n_hits, rc.n_complex);
         return hipGetLastError();
     }
+    ReadClusterArgs rcd = rc;
+    static unsigned long long* d_phase = nullptr;
+    const bool debug = std::getenv("DRPRG_RC_DEBUG") != nullptr;
+    if (debug) {
+        if (!d_phase) HIP_TRY(hipMalloc(&d_phase, 12 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemsetAsync(d_phase, 0, 12 * sizeof(unsigned long long), stream));
+        rcd.phase_clock = d_phase;
+    }
     const size_t dyn = (size_t)rc.n_prgs * sizeof(uint32_t); // the per-PRG histogram, behind ~70 KB of static LDS
     static size_t configured[MAX_HIP_DEVICES] = {};
     HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&read_cluster_kernel), dyn, configured));
-    hipLaunchKernelGGL(read_cluster_kernel, dim3((uint32_t)n_cus * 2), dim3(RC_THREADS), dyn, stream, a, fw, rc);
+    hipLaunchKernelGGL(read_cluster_kernel, dim3((uint32_t)n_cus * 2), dim3(RC_THREADS), dyn, stream, a, fw, rcd);
+    if (debug) { // cycles of thread 0, summed over the workgroups, per phase (the marks follow the barriers of the chunk loop)
+        unsigned long long h[12];
+        HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(hipMemcpy(h, d_phase, sizeof h, hipMemcpyDeviceToHost));
+        unsigned long long sum = 0;
+        for (int i = 0; i < 10; ++i) sum += h[i];
+        std::fprintf(stderr, "[read_cluster phases, %% of %llu Mcycles]", sum / 1000000);
+        for (int i = 0; i < 10; ++i) std::fprintf(stderr, " %d:%.1f", i, sum ? 100.0 * (double)h[i] / (double)sum : 0.0);
+        std::fprintf(stderr, " | %llu reads on the wave path in %llu chunks\n", h[10], h[11]);
+    }
     return hipGetLastError();
 }
 
