@@ -95,35 +95,62 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
     uint32_t my_kept = 0, my_complex = 0;
 
     // chunks are handed out by a global counter (two or three chunks per workgroup: a static split leaves a third of
-    // the workgroups idle for the last round); the next chunk number is fetched while the current one is processed
+    // the workgroups idle for the last round); the next chunk number is fetched while the current one is processed, and
+    // the next chunk's candidates are requested before the wave path (G) of the current one: that path keeps one or two waves
+    // busy for microseconds while the others wait, which is when the loads travel
+    struct Staged { // the raw loads of one chunk: slot tid + q * RC_THREADS, and the two neighbours of the staged range
+        uint4 rec[RC_PER];
+        uint32_t info[RC_PER], pos1[RC_PER], edge_prev, edge_next;
+    };
+    auto request = [&](uint32_t chunk) {
+        Staged st;
+        const uint64_t b64 = (uint64_t)chunk * RC_OWN;
+        const bool live = b64 < total; // (past the end: nothing is read, the loop ends on this chunk)
+        const uint32_t b = live ? (uint32_t)b64 : 0u;
+        const uint32_t n_in = total - b < (uint32_t)RC_SLOTS ? total - b : (uint32_t)RC_SLOTS;
+#pragma unroll
+        for (int q = 0; q < RC_PER; ++q) { // (all six loads together and without a branch: a slot past the end reads the chunk's first
+                                           // candidate and drops it)
+            const uint32_t i = (uint32_t)tid + (uint32_t)q * RC_THREADS;
+            const uint32_t src = b + (i < n_in ? i : 0u);
+            st.info[q] = live ? (uint32_t)fw.cand_info[src] : 0u;
+            st.pos1[q] = live ? fw.cand_pos1[src] : 0u;
+            st.rec[q] = live ? fw.cand_rec[src] : make_uint4(0, 0, 0, 0);
+        }
+        const bool nxt = n_in == (uint32_t)RC_SLOTS && b + n_in < total;
+        st.edge_prev = live ? (uint32_t)fw.cand_info[b ? b - 1 : 0u] : 0u;
+        st.edge_next = live ? (uint32_t)fw.cand_info[nxt ? b + n_in : b] : 0u;
+        return st;
+    };
     if (tid == 0) s_chunk = atomicAdd(rc.chunk_counter, 1u);
+    lds_barrier(tid);
+    uint32_t cur = s_chunk;
+    Staged nx = request(cur);
     for (;;) {
         RC_MARK(9); // (what ran since mark 8: the wave path of thread 0's wave)
-        lds_barrier(tid); // LDS of the previous chunk is free, s_chunk is there
+        lds_barrier(tid); // LDS of the previous chunk is free, everybody holds the chunk number in a register
         RC_MARK(0);
-        const uint64_t base64 = (uint64_t)s_chunk * RC_OWN;
+        const uint64_t base64 = (uint64_t)cur * RC_OWN;
         if (base64 >= total) break;
         const uint32_t base = (uint32_t)base64;
         const uint32_t n_loaded = total - base < (uint32_t)RC_SLOTS ? total - base : (uint32_t)RC_SLOTS;
         const uint32_t n_own = total - base < (uint32_t)RC_OWN ? total - base : (uint32_t)RC_OWN;
-        lds_barrier(tid); // everybody has read s_chunk
         RC_MARK(1);
-        if (tid == 0) s_chunk = atomicAdd(rc.chunk_counter, 1u);
-        // ---- A: stage the candidates: three coalesced loads per slot, nothing depends on them but LDS work ----
+        // (the ticket of the next chunk: a device-wide atomic that returns a value takes microseconds; it is asked for here and put
+        // into LDS two phases later, so that nobody waits for it at the barrier that closes stage A)
+        uint32_t ticket = 0;
+        if (tid == 0) ticket = atomicAdd(rc.chunk_counter, 1u);
+        // ---- A: stage the candidates (requested one chunk ago) ----
         uint4 crec[RC_PER];
         uint32_t st_read[RC_PER], st_pos1[RC_PER];
 #pragma unroll
-        for (int q = 0; q < RC_PER; ++q) { // (all six loads first and without a branch -- a slot past the end reads the chunk's first
-                                           // candidate and drops it --, then the LDS stores: one round trip instead of one per slot)
-            const uint32_t i = (uint32_t)tid + (uint32_t)q * RC_THREADS;
-            const uint32_t src = base + (i < n_loaded ? i : 0u);
-            st_read[q] = (uint32_t)fw.cand_info[src];
-            st_pos1[q] = fw.cand_pos1[src];
-            crec[q] = fw.cand_rec[src];
+        for (int q = 0; q < RC_PER; ++q) {
+            st_read[q] = nx.info[q];
+            st_pos1[q] = nx.pos1[q];
+            crec[q] = nx.rec[q];
         }
-        // (the two neighbours of the staged range, for thread 0, in the same round trip: uniform addresses)
         const bool has_next = n_loaded == (uint32_t)RC_SLOTS && base + n_loaded < total;
-        const uint32_t edge_prev = (uint32_t)fw.cand_info[base ? base - 1 : 0u], edge_next = (uint32_t)fw.cand_info[has_next ? base + n_loaded : base];
+        const uint32_t edge_prev = nx.edge_prev, edge_next = nx.edge_next;
 #pragma unroll
         for (int q = 0; q < RC_PER; ++q) {
             const uint32_t i = (uint32_t)tid + (uint32_t)q * RC_THREADS;
@@ -212,6 +239,7 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
             }
             if (tid == 0) s_hstart[RC_SLOTS] = sum;
         }
+        if (tid == 0) s_chunk = ticket;
         lds_barrier(tid);
         RC_MARK(4);
         // ---- C: the hits (one per index record of every minimizer); every segment start closes the segment before it; a
@@ -323,6 +351,8 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
             }
         }
         RC_MARK(8);
+        cur = s_chunk; // (written by thread 0 before the barrier that closed phase B)
+        nx = request(cur);
         // ---- G: reads with hits in several groups, one wave per read: lane j holds cluster j, the hits are broadcast one by one
         // (clusters per group split at gaps, size threshold, the overlap sweep of cluster_filter_kernel) ----
         const uint32_t n_irr = s_n_irr < (uint32_t)RC_POOL ? s_n_irr : (uint32_t)RC_POOL;
@@ -333,6 +363,7 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
         for (uint32_t r = wave; r < n_irr; r += RC_WAVES) {
             const uint32_t i = s_irr[r] & 0xFFFFu, e = s_irr[r] >> 16;
             const uint32_t read = s_read[i], hb = s_hstart[i], he = s_hstart[e];
+            const uint64_t len = a.offsets[read + 1] - a.offsets[read]; // (requested here, needed after the loop over the hits)
             uint32_t cl_g = 0, cl_n = 0, cl_first = 0, cl_last = 0;
             int nc = 0;
             bool complex = false;
@@ -367,7 +398,6 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
                 if (lane == 0) ++my_complex;
                 continue;
             }
-            const uint64_t len = a.offsets[read + 1] - a.offsets[read];
             const uint64_t expected = len * 2 / (uint64_t)(a.w + 1);
             bool kept = false;
             if (lane < nc) {
