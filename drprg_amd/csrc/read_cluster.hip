@@ -307,18 +307,25 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
             const uint32_t lead = s_lead[i];
             if (i >= n_loaded || s_seg[i] != i + 1 || lead == 0 || lead > n_own) continue;
             uint32_t flags = (s_cplx[lead - 1] ? RC_COMPLEX : 0u) | (s_irrf[lead - 1] ? RC_IRREGULAR : 0u);
+            // A read with hits in several groups whose hits, all groups together, do not exceed the smallest size threshold a
+            // cluster can have cannot keep any cluster: it is done without the wave path (every segment of the read sees the same
+            // total, so all of them decide alike).  Most such reads are of this kind: a stray hit or two in another group.
+            bool dropped = false;
+            uint32_t e = i; // the first slot after the read: follow its segments
+            if (flags == RC_IRREGULAR) {
+                for (uint32_t sg = i; sg < (uint32_t)RC_SLOTS && s_lead[sg] == lead; sg = s_end[sg]) e = s_end[sg];
+                dropped = s_hstart[e] - s_hstart[lead - 1] <= rc.min_cluster_size;
+            }
             if (lead == i + 1) { // first slot of the read
                 if (flags & RC_COMPLEX) ++my_complex;
-                else if (flags & RC_IRREGULAR) {
-                    uint32_t e = i; // the first slot after the read: follow its segments
-                    for (uint32_t sg = i; sg < (uint32_t)RC_SLOTS && s_lead[sg] == lead; sg = s_end[sg]) e = s_end[sg];
+                else if ((flags & RC_IRREGULAR) && !dropped) {
                     const uint32_t at = atomicAdd(&s_n_irr, 1u);
                     if (at < (uint32_t)RC_POOL) s_irr[at] = i | (e << 16);
                     else ++my_complex;
                 }
             }
             const uint32_t n_hits = s_hstart[s_end[i]] - s_hstart[i];
-            uint32_t dec = 0; // 0 leave alone, 1 handled, 2 handled and every hit counts
+            uint32_t dec = dropped ? 1u : 0u; // 0 leave alone, 1 handled, 2 handled and every hit counts
             if (!flags && n_hits) {
                 const uint32_t g_thr = s_gt[i];
                 dec = 1;
