@@ -377,28 +377,64 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
             for (uint32_t b = hb; b < he && !complex; b += 64) {
                 const uint32_t h = b + lane;
                 const uint32_t hg = h < he ? s_grp[h] : 0u, hp = h < he ? s_hpos[h] : 0u;
-                const int nb = he - b < 64u ? (int)(he - b) : 64;
-                for (int t = 0; t < nb; ++t) {
-                    const uint32_t g = __builtin_amdgcn_readlane(hg, t), pos = __builtin_amdgcn_readlane(hp, t);
-                    const uint64_t mm = __ballot(lane < nc && cl_g == g);
-                    if (mm) {
-                        const int f = 63 - __clzll((long long)mm);
-                        const uint32_t last_f = (uint32_t)__builtin_amdgcn_readlane((int)cl_last, f); // (f is wave-uniform: a register read, not an LDS round trip)
-                        if ((int)(pos - last_f) <= rc.max_diff) {
-                            if (lane == f) {
-                                ++cl_n;
-                                cl_last = pos;
-                            }
-                            continue;
+                // The hits of the batch, in position order, one group after the other (a read has two or three): within a group a
+                // hit starts a new cluster iff the previous hit of its group lies more than max_diff before it -- for the first one:
+                // iff there is no cluster of the group yet, or its last hit lies that far back -- so the starts come out of one
+                // ballot, every new cluster lane picks its span out of the group's mask, and the hits before the first start extend
+                // the group's latest cluster.  (One hit at a time -- find the group's latest cluster, compare, join or create -- was
+                // a chain of two hundred cycles per hit, on one wave, with the rest of the workgroup waiting at the next barrier.)
+                const bool valid = h < he;
+                const uint64_t lt = (1ull << lane) - 1ull;
+                uint64_t todo = __ballot(valid);
+                while (todo) {
+                    const uint32_t G = (uint32_t)__builtin_amdgcn_readlane((int)hg, __ffsll((long long)todo) - 1);
+                    const uint64_t m = __ballot(valid && hg == G);
+                    todo &= ~m;
+                    const uint64_t open = __ballot(lane < nc && cl_g == G); // the group's clusters so far: the highest lane is the latest
+                    const int fo = open ? 63 - __clzll((long long)open) : -1;
+                    const uint32_t open_last = fo >= 0 ? (uint32_t)__builtin_amdgcn_readlane((int)cl_last, fo) : 0u;
+                    const uint64_t below = m & lt;
+                    const int prev = below ? 63 - __clzll((long long)below) : -1;
+                    const uint32_t prev_pos = __shfl(hp, prev < 0 ? lane : prev); // (every lane takes part in the shuffle)
+                    const bool member = ((m >> lane) & 1ull) != 0;
+                    const bool start = member
+                        && (prev >= 0 ? (int)(hp - prev_pos) > rc.max_diff : (fo < 0 || (int)(hp - open_last) > rc.max_diff));
+                    const uint64_t starts = __ballot(start);
+                    const int n_new = __popcll(starts);
+                    if (nc + n_new > 64) {
+                        complex = true;
+                        break;
+                    }
+                    const uint64_t cont = m & (starts ? (1ull << (__ffsll((long long)starts) - 1)) - 1ull : ~0ull); // before the first start
+                    if (cont) { // (then the group has a cluster: otherwise its first hit would be a start)
+                        const uint32_t lp = (uint32_t)__builtin_amdgcn_readlane((int)hp, 63 - __clzll((long long)cont));
+                        if (lane == fo) {
+                            cl_n += (uint32_t)__popcll(cont);
+                            cl_last = lp;
                         }
                     }
-                    if (nc == 64) { complex = true; break; }
-                    if (lane == nc) {
-                        cl_g = g;
-                        cl_n = 1;
-                        cl_first = cl_last = pos;
+                    const int c = lane - nc; // lane nc + c takes the c-th start
+                    const bool mine = c >= 0 && c < n_new;
+                    int first_lane = lane, last_lane = lane;
+                    uint32_t span_n = 0;
+                    if (mine) {
+                        uint64_t mm = starts;
+                        for (int k = 0; k < c; ++k) mm &= mm - 1;
+                        first_lane = __ffsll((long long)mm) - 1;
+                        const uint64_t rest = mm & (mm - 1);
+                        const uint64_t upto = rest ? (1ull << (__ffsll((long long)rest) - 1)) - 1ull : ~0ull; // lanes below the next start
+                        const uint64_t span = m & upto & ~((1ull << first_lane) - 1ull);
+                        last_lane = 63 - __clzll((long long)span);
+                        span_n = (uint32_t)__popcll(span);
                     }
-                    ++nc;
+                    const uint32_t fpos = __shfl(hp, first_lane), lpos = __shfl(hp, last_lane);
+                    if (mine) {
+                        cl_g = G;
+                        cl_n = span_n;
+                        cl_first = fpos;
+                        cl_last = lpos;
+                    }
+                    nc += n_new;
                 }
             }
             if (complex) {
