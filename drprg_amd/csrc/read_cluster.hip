@@ -93,6 +93,7 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
     if (tid < 3) s_tot[tid] = 0;
     unsigned long long my_kept_hits = 0;
     uint32_t my_kept = 0, my_complex = 0;
+    const uint32_t w1_magic = w1_reciprocal(a.w);
 
     // chunks are handed out by a global counter (two or three chunks per workgroup: a static split leaves a third of
     // the workgroups idle for the last round); the next chunk number is fetched while the current one is processed, and
@@ -441,7 +442,7 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
                 if (lane == 0) ++my_complex;
                 continue;
             }
-            const uint64_t expected = len * 2 / (uint64_t)(a.w + 1);
+            const uint64_t expected = expected_minimizers(len, a.w, w1_magic); // (2 len / (w + 1) without a 64-bit division)
             bool kept = false;
             if (lane < nc) {
                 uint64_t m = rc.prg_min_path_len[cl_g >> 1];
