@@ -200,6 +200,9 @@ def test_reads_with_hits_in_several_groups(tmp_path, oracle, illumina):
     lb, lo = _reads_from(rng, seqs, 300, 700)  # several clusters per read with the Illumina gap limit
     bases = np.concatenate([bases, lb])
     offs = np.concatenate([offs, lo[1:] + offs[-1]])
+    nb, no = _reads_from(rng, seqs, 300, 700, sub_rate=0.06)  # errors tear the hit runs: many clusters per group, hundreds of hits
+    bases = np.concatenate([bases, nb])
+    offs = np.concatenate([offs, no[1:] + offs[-1]])
     for kernel in (1, 2, 3):
         ctx = _ctx(tmp_path, panel, 11, 15, illumina, kernel=kernel)
         cnt = _compare(ctx, oracle, bases, offs, 11, 15, illumina, kernel)
