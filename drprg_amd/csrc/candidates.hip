@@ -459,20 +459,26 @@ __global__ __launch_bounds__(EX_THREADS) void recount_kernel(SketchArgs a, Filte
 // candidate form of the direct sequence: tile slices -> dense list
 // ---------------------------------------------------------------------------------------------
 constexpr int TG_THREADS = 1024, TG_TILES = 64; // tiles per workgroup: every wave copies four tile slices
-__global__ __launch_bounds__(TG_THREADS) void tile_gather_kernel(SketchArgs a, FilterWork fw, const uint32_t* __restrict__ tile_prefix,
-    uint32_t n_tiles, uint64_t dense_capacity)
+// (a slice or the dense list too small: the host grows the workspace and runs the batch again; nothing is counted or copied)
+__device__ __forceinline__ bool tile_overflow(const SketchArgs& a, const uint32_t* tile_prefix, uint32_t n_tiles, uint64_t dense_capacity)
+{
+    return (*reinterpret_cast<volatile uint32_t*>(a.overflow) & 4u) != 0 || (uint64_t)tile_prefix[n_tiles] > dense_capacity;
+}
+
+// The batch counters: hits and minimizers of all tiles (and what sketch_wave_kernel clustered itself), summed by a small grid --
+// one atomic per counter and workgroup: as part of the gather (6000 workgroups, four atomics each on the same four addresses) the
+// sums cost 0.3 ms of its 0.8 on the 500-locus index.
+__global__ __launch_bounds__(TG_THREADS) void tile_totals_kernel(SketchArgs a, const uint32_t* __restrict__ tile_prefix, uint32_t n_tiles,
+    uint64_t dense_capacity)
 {
     __shared__ uint32_t s_w[TG_THREADS / 64 + 1];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // (a slice or the dense list too small: the host grows the workspace and runs the batch again; count nothing)
-    const bool overflow = (*reinterpret_cast<volatile uint32_t*>(a.overflow) & 4u) != 0 || (uint64_t)tile_prefix[n_tiles] > dense_capacity;
-    if (overflow) {
+    const int tid = threadIdx.x;
+    if (tile_overflow(a, tile_prefix, n_tiles, dense_capacity)) {
         if (blockIdx.x == 0 && tid == 0) atomicOr(a.overflow, 4u);
         return;
     }
-    const uint32_t t0 = blockIdx.x * TG_TILES, t1 = t0 + TG_TILES < n_tiles ? t0 + TG_TILES : n_tiles;
     uint32_t my_hits = 0, my_nmin = 0, my_fc = 0, my_fh = 0;
-    for (uint32_t t = t0 + (uint32_t)tid; t < t1; t += TG_THREADS) {
+    for (uint32_t t = blockIdx.x * TG_THREADS + (uint32_t)tid; t < n_tiles; t += gridDim.x * TG_THREADS) {
         my_hits += a.tile_hits[t];
         my_nmin += a.tile_nmin[t];
         if (a.fuse > 0) { // what sketch_wave_kernel clustered itself
@@ -481,6 +487,28 @@ __global__ __launch_bounds__(TG_THREADS) void tile_gather_kernel(SketchArgs a, F
             my_fh += f >> 16;
         }
     }
+    // (sums of 32-bit partials per workgroup: a workgroup covers at most n_tiles / gridDim.x + 1024 tiles of <= 2^16 hits each)
+    uint32_t hits, nmin, fc, fh;
+    (void)block_exclusive_scan<TG_THREADS / 64>(my_hits, s_w, &hits);
+    (void)block_exclusive_scan<TG_THREADS / 64>(my_nmin, s_w, &nmin);
+    (void)block_exclusive_scan<TG_THREADS / 64>(my_fc, s_w, &fc);
+    (void)block_exclusive_scan<TG_THREADS / 64>(my_fh, s_w, &fh);
+    if (tid == 0) {
+        if (hits) atomicAdd(a.n_hits, (unsigned long long)hits);
+        if (nmin) atomicAdd(a.n_minimizers, (unsigned long long)nmin);
+        if (fc) atomicAdd(a.n_clusters_kept, (unsigned long long)fc);
+        if (fh) atomicAdd(a.n_hits_kept, (unsigned long long)fh);
+    }
+}
+
+// The slices copied into the dense, ordered candidate list.  mark != 0 (a copy after read_cluster_kernel has read the candidates
+// from the slices): a candidate whose dense cand_pos1 holds the mark was handled there and gets position 0.
+__global__ __launch_bounds__(TG_THREADS) void tile_gather_kernel(SketchArgs a, FilterWork fw, const uint32_t* __restrict__ tile_prefix,
+    uint32_t n_tiles, uint64_t dense_capacity, uint32_t mark)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tile_overflow(a, tile_prefix, n_tiles, dense_capacity)) return;
+    const uint32_t t0 = blockIdx.x * TG_TILES, t1 = t0 + TG_TILES < n_tiles ? t0 + TG_TILES : n_tiles;
     for (uint32_t t = t0 + (uint32_t)wave; t < t1; t += TG_THREADS / 64) {
         const uint32_t n = a.tile_count[t], dst = tile_prefix[t];
         const size_t src = (size_t)t * a.tile_cap;
@@ -503,22 +531,11 @@ __global__ __launch_bounds__(TG_THREADS) void tile_gather_kernel(SketchArgs a, F
                 const uint32_t i = i0 + 64u * (uint32_t)u + (uint32_t)lane;
                 if (i < n) {
                     fw.cand_info[dst + i] = ci[u];
-                    fw.cand_pos1[dst + i] = cp[u];
+                    fw.cand_pos1[dst + i] = (mark && fw.cand_pos1[dst + i] == mark) ? 0u : cp[u];
                     fw.cand_rec[dst + i] = cr[u];
                 }
             }
         }
-    }
-    uint32_t hits, nmin, fc, fh;
-    (void)block_exclusive_scan<TG_THREADS / 64>(my_hits, s_w, &hits);
-    (void)block_exclusive_scan<TG_THREADS / 64>(my_nmin, s_w, &nmin);
-    (void)block_exclusive_scan<TG_THREADS / 64>(my_fc, s_w, &fc);
-    (void)block_exclusive_scan<TG_THREADS / 64>(my_fh, s_w, &fh);
-    if (tid == 0) {
-        if (hits) atomicAdd(a.n_hits, (unsigned long long)hits);
-        if (nmin) atomicAdd(a.n_minimizers, (unsigned long long)nmin);
-        if (fc) atomicAdd(a.n_clusters_kept, (unsigned long long)fc);
-        if (fh) atomicAdd(a.n_hits_kept, (unsigned long long)fh);
     }
 }
 
@@ -558,7 +575,7 @@ uint32_t direct_first_read_tiles(uint64_t n_bases, int halo, int k, int w, bool 
 }
 
 hipError_t launch_direct_candidates(const SketchArgs& a, bool wide_hash, uint32_t* tile_prefix, void* temp, size_t temp_bytes,
-    uint64_t dense_capacity, const ReadClusterArgs& rc, int n_cus, FilterWork& fw, hipStream_t stream, KernelTimer timer)
+    uint64_t dense_capacity, const ReadClusterArgs& rc, int n_cus, FilterWork& fw, hipStream_t stream, KernelTimer timer, uint32_t slices_mark)
 {
     if (a.n_bases == 0 || !a.tile_cap) return hipErrorInvalidValue;
     const uint32_t n_tiles = direct_candidate_tiles(a.n_bases, a.halo, a.k, a.w, wide_hash);
@@ -567,10 +584,30 @@ hipError_t launch_direct_candidates(const SketchArgs& a, bool wide_hash, uint32_
     // tile_count[n_tiles] is a zero the caller keeps there: the exclusive scan of n_tiles + 1 counts ends with the total
     HIP_TRY(exclusive_scan_u32(temp, temp_bytes, a.tile_count, tile_prefix, n_tiles + 1, stream));
     fw.cand_total = tile_prefix + n_tiles;
-    hipLaunchKernelGGL(tile_gather_kernel, dim3((n_tiles + TG_TILES - 1) / TG_TILES), dim3(TG_THREADS), 0, stream, a, fw, tile_prefix, n_tiles,
-        dense_capacity);
+    const dim3 grid((n_tiles + TG_TILES - 1) / TG_TILES);
+    hipLaunchKernelGGL(tile_totals_kernel, dim3(std::min<uint32_t>((n_tiles + TG_THREADS - 1) / TG_THREADS, (uint32_t)n_cus)), dim3(TG_THREADS), 0, stream, a,
+        tile_prefix, n_tiles, dense_capacity);
+    HIP_TRY(hipGetLastError());
+    if (slices_mark) { // read_cluster_kernel takes the candidates from the slices: a dense list only if reads are left over
+        ReadClusterArgs rcs = rc;
+        rcs.slice_prefix = tile_prefix;
+        rcs.n_slices = n_tiles;
+        rcs.mark_epoch = slices_mark;
+        return launch_read_cluster(a, fw, rcs, n_cus, false, stream);
+    }
+    hipLaunchKernelGGL(tile_gather_kernel, grid, dim3(TG_THREADS), 0, stream, a, fw, tile_prefix, n_tiles, dense_capacity, 0u);
     HIP_TRY(hipGetLastError());
     return launch_read_cluster(a, fw, rc, n_cus, false, stream);
+}
+
+// the dense list after all, for the reads read_cluster_kernel<SLICES> left over: the slices copied, handled candidates (dense
+// cand_pos1 == mark) with position 0
+hipError_t launch_tile_gather_marked(const SketchArgs& a, const FilterWork& fw, const uint32_t* tile_prefix, uint32_t n_tiles, uint64_t dense_capacity,
+    uint32_t mark, hipStream_t stream)
+{
+    hipLaunchKernelGGL(tile_gather_kernel, dim3((n_tiles + TG_TILES - 1) / TG_TILES), dim3(TG_THREADS), 0, stream, a, fw, tile_prefix, n_tiles,
+        dense_capacity, mark);
+    return hipGetLastError();
 }
 
 hipError_t launch_filter_recount(const SketchArgs& a, const FilterWork& fw, hipStream_t stream)

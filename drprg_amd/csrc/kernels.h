@@ -198,6 +198,11 @@ struct ReadClusterArgs {
     unsigned long long* n_hits_kept;
     unsigned long long* n_complex; // reads left to the generic pipeline (their candidates keep cand_pos1 != 0)
     uint32_t* chunk_counter;       // zeroed device scalar: work distribution of read_cluster_kernel
+    // candidates still in their tile slices (direct sequence without tile_gather_kernel): slice_prefix != nullptr.  The ordered
+    // list's entry d lives in slice s = the one with slice_prefix[s] <= d < slice_prefix[s + 1], at s * a.tile_cap + (d - slice_prefix[s]);
+    // handled candidates are marked cand_pos1[d] = mark_epoch in the (otherwise unused) dense array
+    const uint32_t* slice_prefix; // [n_slices + 1], exclusive scan of the slice counts
+    uint32_t n_slices, mark_epoch;
     unsigned long long* phase_clock; // DRPRG_RC_DEBUG=1: 12 counters, clock cycles thread 0 of every workgroup spent per phase (else null)
 };
 size_t filter_small_words();
@@ -219,7 +224,11 @@ hipError_t launch_filter_expand(const SketchArgs& a, const FilterWork& fw, hipSt
 // n_tiles + 1 words; temp: scan_temp_bytes(n_tiles + 1) bytes.  a.n_hits receives the hits of the batch; overflow bit 2:
 // a tile slice or the dense list (dense_capacity entries) was too small (nothing was counted then).
 hipError_t launch_direct_candidates(const SketchArgs& a, bool wide_hash, uint32_t* tile_prefix, void* temp, size_t temp_bytes,
-    uint64_t dense_capacity, const ReadClusterArgs& rc, int n_cus, FilterWork& fw, hipStream_t stream, KernelTimer timer = {});
+    uint64_t dense_capacity, const ReadClusterArgs& rc, int n_cus, FilterWork& fw, hipStream_t stream, KernelTimer timer = {},
+    uint32_t slices_mark = 0); // slices_mark != 0: no gathered list, read_cluster_kernel reads the slices and marks handled candidates with it
+// the gathered list after such a batch, for the reads that were left over (handled candidates get position 0)
+hipError_t launch_tile_gather_marked(const SketchArgs& a, const FilterWork& fw, const uint32_t* tile_prefix, uint32_t n_tiles, uint64_t dense_capacity,
+    uint32_t mark, hipStream_t stream);
 hipError_t exclusive_scan_u32(void* temp, size_t temp_bytes, const uint32_t* in, uint32_t* out, uint32_t n, hipStream_t stream);
 // hits ordered by (read, pos) -> ordered by (read, prg, strand, pos), in place; meant for short reads.  scratch: u32
 // words (>= n) for the list of reads that need reordering; count: zeroed device scalar

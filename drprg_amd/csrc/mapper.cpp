@@ -466,6 +466,18 @@ void Mapper::run_batch_direct_candidates(const uint8_t* d_bases, const uint64_t*
     }
     ensure_lanes(1, std::min<uint64_t>(std::max<uint64_t>(1u << 20, n_bases / 16), (1ull << 31) - 1));
     Lane& lane = lanes_[0];
+    // read_cluster_kernel takes the candidates straight from the tile slices (no gathered list unless reads are left over); what it
+    // handled is marked in the dense cand_pos1 array with a value no other batch used (DRPRG_RC_SLICES=0: gather first, as before)
+    static const bool from_slices = [] {
+        const char* e = std::getenv("DRPRG_RC_SLICES");
+        return !(e && std::atoi(e) == 0);
+    }();
+    uint32_t mark = 0;
+    if (from_slices && !fuse_in_kernel_) {
+        if (++slices_epoch_ < 0x80000000u) slices_epoch_ = 0x80000000u; // (never a value a position + 1 can have, never 0)
+        mark = slices_epoch_;
+    }
+    dev::SketchArgs a_done {};
     for (int attempt = 0;; ++attempt) {
         ensure_tile_workspace(n_tiles, tile_slice_cap_);
         if (!lane.scratch_zero) HIPCHK(hipMemsetAsync(lane.d_scratch, 0, L_N * sizeof(unsigned long long), stream));
@@ -520,7 +532,8 @@ void Mapper::run_batch_direct_candidates(const uint8_t* d_bases, const uint64_t*
             timer.end = ev1_;
         }
         HIPCHK(dev::launch_direct_candidates(a, wide_hash_, d_tile_prefix_, d_tile_temp_, tile_temp_bytes_, lane.raw_capacity, rc, n_cus_, lane.fw,
-            stream, timer));
+            stream, timer, mark));
+        a_done = a;
         HIPCHK(hipMemcpyAsync(lane.h_scratch, lane.d_scratch, L_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipMemsetAsync(lane.d_scratch, 0, L_N * sizeof(unsigned long long), stream));
         lane.scratch_zero = true;
@@ -546,6 +559,8 @@ void Mapper::run_batch_direct_candidates(const uint8_t* d_bases, const uint64_t*
     tot_minimizers_ += lane.h_scratch[L_MINIMIZERS];
     tot_hits_ += lane.h_scratch[L_HITS];
     tot_leftover_ += lane.h_scratch[L_COMPLEX];
+    if (mark && lane.h_scratch[L_COMPLEX]) // reads were left over: the generic pipeline wants the gathered list after all
+        HIPCHK(dev::launch_tile_gather_marked(a_done, lane.fw, d_tile_prefix_, n_tiles, lane.raw_capacity, mark, stream));
     leftovers(lane, d_bases, d_offsets, n_reads, n_bases, covg, prg_reads, stream);
 }
 

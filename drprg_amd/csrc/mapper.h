@@ -179,6 +179,7 @@ private:
     void* d_temp_ = nullptr;
     uint32_t* d_tile_first_ = nullptr;
     // candidate form of the direct sequence: one slice of tile_cap_ records per tile
+    uint32_t slices_epoch_ = 0x80000000u; // mark of the last batch whose candidates read_cluster_kernel took from the slices
     uint32_t tile_slice_cap_ = 256, tile_ws_tiles_ = 0, tile_ws_cap_ = 0;
     uint64_t* d_tile_info_ = nullptr;
     uint32_t *d_tile_pos1_ = nullptr, *d_tile_count_ = nullptr, *d_tile_hits_ = nullptr, *d_tile_nmin_ = nullptr, *d_tile_prefix_ = nullptr, *d_tile_fast_ = nullptr;

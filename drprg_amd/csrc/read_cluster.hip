@@ -54,6 +54,8 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // two 1024-thread workgroups per CU -- the kernel spilled twelve of them to scratch memory)
 __device__ __forceinline__ void lds_barrier(int& t) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+v"(t) : : "memory"); }
 
+// SLICES: the candidates are read from the tile slices of the direct sketch kernel (rc.slice_prefix), not from a gathered list
+template <bool SLICES>
 __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs a, FilterWork fw, ReadClusterArgs rc)
 {
     extern __shared__ uint32_t s_hist[]; // clusters kept per PRG
@@ -88,7 +90,8 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
         }                                                            \
     } while (0)
     if (*reinterpret_cast<volatile uint32_t*>(a.overflow) & 4u) return; // a candidate slice overflowed: the host re-runs the batch
-    const uint32_t total = *fw.cand_total;
+    const uint32_t total = SLICES ? rc.slice_prefix[rc.n_slices] : *fw.cand_total;
+    const uint32_t handled_mark = SLICES ? rc.mark_epoch : 0u; // what a handled candidate's cand_pos1 becomes
     for (uint32_t i = tid; i < rc.n_prgs; i += RC_THREADS) s_hist[i] = 0;
     if (tid < 3) s_tot[tid] = 0;
     unsigned long long my_kept_hits = 0;
@@ -109,18 +112,70 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
         const bool live = b64 < total; // (past the end: nothing is read, the loop ends on this chunk)
         const uint32_t b = live ? (uint32_t)b64 : 0u;
         const uint32_t n_in = total - b < (uint32_t)RC_SLOTS ? total - b : (uint32_t)RC_SLOTS;
+        if constexpr (!SLICES) {
 #pragma unroll
-        for (int q = 0; q < RC_PER; ++q) { // (all six loads together and without a branch: a slot past the end reads the chunk's first
-                                           // candidate and drops it)
-            const uint32_t i = (uint32_t)tid + (uint32_t)q * RC_THREADS;
-            const uint32_t src = b + (i < n_in ? i : 0u);
-            st.info[q] = live ? (uint32_t)fw.cand_info[src] : 0u;
-            st.pos1[q] = live ? fw.cand_pos1[src] : 0u;
-            st.rec[q] = live ? fw.cand_rec[src] : make_uint4(0, 0, 0, 0);
+            for (int q = 0; q < RC_PER; ++q) { // (all six loads together and without a branch: a slot past the end reads the chunk's first
+                                               // candidate and drops it)
+                const uint32_t i = (uint32_t)tid + (uint32_t)q * RC_THREADS;
+                const uint32_t src = b + (i < n_in ? i : 0u);
+                st.info[q] = live ? (uint32_t)fw.cand_info[src] : 0u;
+                st.pos1[q] = live ? fw.cand_pos1[src] : 0u;
+                st.rec[q] = live ? fw.cand_rec[src] : make_uint4(0, 0, 0, 0);
+            }
+            const bool nxt = n_in == (uint32_t)RC_SLOTS && b + n_in < total;
+            st.edge_prev = live ? (uint32_t)fw.cand_info[b ? b - 1 : 0u] : 0u;
+            st.edge_next = live ? (uint32_t)fw.cand_info[nxt ? b + n_in : b] : 0u;
+        } else {
+            // A window of the slice prefix around the slice that entry b should be in if the slices were equally full -- RC_SLOTS
+            // entries, a quarter of them before the guess -- goes to LDS (s_gt is free between phase E and the next phase C); every
+            // slot then finds its slice there by bisection.  If the window does not hold the whole staged range (slices very
+            // unevenly filled), every slot bisects the prefix in global memory instead.
+            uint32_t* const s_pref = s_gt;
+            const uint32_t* __restrict__ P = rc.slice_prefix;
+            const uint32_t guess = live ? (uint32_t)((uint64_t)b * rc.n_slices / (total ? total : 1u)) : 0u;
+            uint32_t w0 = guess > (uint32_t)RC_SLOTS / 4 ? guess - (uint32_t)RC_SLOTS / 4 : 0u;
+            if (w0 + (uint32_t)RC_SLOTS > rc.n_slices + 1) w0 = rc.n_slices + 1 > (uint32_t)RC_SLOTS ? rc.n_slices + 1 - (uint32_t)RC_SLOTS : 0u;
+            const uint32_t w_n = rc.n_slices + 1 - w0 < (uint32_t)RC_SLOTS ? rc.n_slices + 1 - w0 : (uint32_t)RC_SLOTS; // entries in the window
+#pragma unroll
+            for (int q = 0; q < RC_PER; ++q) {
+                const uint32_t j = (uint32_t)tid + (uint32_t)q * RC_THREADS;
+                s_pref[j] = live && j < w_n ? P[w0 + j] : 0xFFFFFFFFu;
+            }
+            lds_barrier(tid);
+            const uint32_t d_last = b + n_in; // one past the staged range (the edge after it included)
+            const bool in_window = s_pref[0] <= (b ? b - 1 : 0u) && (w0 + w_n == rc.n_slices + 1 || s_pref[w_n - 1] > d_last);
+            auto locate = [&](uint32_t d) -> size_t { // where entry d of the ordered list lives in the slice arrays
+                uint32_t s;
+                if (in_window) {
+                    uint32_t lo = 0, hi = w_n; // s_pref[lo] <= d < s_pref[hi] (hi == w_n: the end)
+                    while (hi - lo > 1) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (s_pref[mid] <= d) lo = mid;
+                        else hi = mid;
+                    }
+                    s = w0 + lo;
+                    return (size_t)s * a.tile_cap + (d - s_pref[lo]);
+                }
+                uint32_t lo = 0, hi = rc.n_slices; // P[lo] <= d < P[hi]
+                while (hi - lo > 1) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (P[mid] <= d) lo = mid;
+                    else hi = mid;
+                }
+                return (size_t)lo * a.tile_cap + (d - P[lo]);
+            };
+#pragma unroll
+            for (int q = 0; q < RC_PER; ++q) {
+                const uint32_t i = (uint32_t)tid + (uint32_t)q * RC_THREADS;
+                const size_t src = live ? locate(b + (i < n_in ? i : 0u)) : 0;
+                st.info[q] = live ? (uint32_t)a.tile_info[src] : 0u;
+                st.pos1[q] = live ? a.tile_pos1[src] : 0u;
+                st.rec[q] = live ? a.tile_rec[src] : make_uint4(0, 0, 0, 0);
+            }
+            const bool nxt = n_in == (uint32_t)RC_SLOTS && b + n_in < total;
+            st.edge_prev = live && b ? (uint32_t)a.tile_info[locate(b - 1)] : 0u;
+            st.edge_next = live && nxt ? (uint32_t)a.tile_info[locate(b + n_in)] : 0u;
         }
-        const bool nxt = n_in == (uint32_t)RC_SLOTS && b + n_in < total;
-        st.edge_prev = live ? (uint32_t)fw.cand_info[b ? b - 1 : 0u] : 0u;
-        st.edge_next = live ? (uint32_t)fw.cand_info[nxt ? b + n_in : b] : 0u;
         return st;
     };
     if (tid == 0) s_chunk = atomicAdd(rc.chunk_counter, 1u);
@@ -350,7 +405,7 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
                 if (!cnt || lead == 0 || lead > n_own) continue;
                 const uint32_t decision = s_dec[(uint32_t)s_seg[i] - 1];
                 if (!decision) continue;
-                fw.cand_pos1[base + i] = 0; // handled
+                fw.cand_pos1[base + i] = handled_mark; // handled
                 if (decision == 2) {
                     atomicAdd(&rc.covg[crec[q].w], 1u);
                     const uint32_t h0 = s_hstart[i];
@@ -500,7 +555,7 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
                 }
             }
             for (uint32_t c = i + lane; c < e; c += 64)
-                if (s_pos1[c]) fw.cand_pos1[base + c] = 0; // handled
+                if (s_pos1[c]) fw.cand_pos1[base + c] = handled_mark; // handled
         }
     }
     RC_MARK(7);
@@ -543,8 +598,14 @@ hipError_t launch_read_cluster(const SketchArgs& a, const FilterWork& fw, const 
     }
     const size_t dyn = (size_t)rc.n_prgs * sizeof(uint32_t); // the per-PRG histogram, behind ~70 KB of static LDS
     static size_t configured[MAX_HIP_DEVICES] = {};
-    HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&read_cluster_kernel), dyn, configured));
-    hipLaunchKernelGGL(read_cluster_kernel, dim3((uint32_t)n_cus * 2), dim3(RC_THREADS), dyn, stream, a, fw, rcd);
+    if (rcd.slice_prefix) {
+        static size_t configured_slices[MAX_HIP_DEVICES] = {};
+        HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&read_cluster_kernel<true>), dyn, configured_slices));
+        hipLaunchKernelGGL(read_cluster_kernel<true>, dim3((uint32_t)n_cus * 2), dim3(RC_THREADS), dyn, stream, a, fw, rcd);
+    } else {
+        HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&read_cluster_kernel<false>), dyn, configured));
+        hipLaunchKernelGGL(read_cluster_kernel<false>, dim3((uint32_t)n_cus * 2), dim3(RC_THREADS), dyn, stream, a, fw, rcd);
+    }
     if (debug) { // cycles of thread 0, summed over the workgroups, per phase (the marks follow the barriers of the chunk loop)
         unsigned long long h[12];
         HIP_TRY(hipStreamSynchronize(stream));
