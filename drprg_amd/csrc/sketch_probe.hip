@@ -320,7 +320,7 @@ __global__ __launch_bounds__(SK_THREADS) void sketch_probe_kernel(SketchArgs a)
         if (tid == 0) {
             a.tile_count[blockIdx.x] = written < a.tile_cap ? written : a.tile_cap;
             a.tile_hits[blockIdx.x] = tile_hits;
-            a.tile_nmin[blockIdx.x] = nmin; // (summed by tile_gather_kernel: one atomic per tile on one counter would be ~15 ns each, in series)
+            a.tile_nmin[blockIdx.x] = nmin; // (summed by tile_totals_kernel: one atomic per tile on one counter would be ~15 ns each, in series)
             if (written > a.tile_cap) atomicOr(a.overflow, 4u);
         }
         return;
