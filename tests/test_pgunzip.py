@@ -193,3 +193,34 @@ def test_bgzf_file_as_a_plain_multi_member_stream(tmp_path, text):
     for chunk in (20000, 300000):
         n, accepted, redone = _gunzip(p, tmp_path / "o", 4, chunk)
         assert n == 8_000_000 and (tmp_path / "o").read_bytes() == text[:8_000_000]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_member_layouts(tmp_path, seed):
+    """random mixes of text, noise, runs and empty pieces, compressed member by member with random levels, strategies, flush
+    points and header fields, then inflated with a random chunk size and thread count: always the bytes zlib gives"""
+    rng = np.random.default_rng(1000 + seed)
+    pieces, blob = [], b""
+    for m in range(int(rng.integers(1, 7))):
+        kind = int(rng.integers(0, 5))
+        n = int(rng.integers(0, 1_500_000))
+        if kind == 0:
+            data = _fastq_text(n // 330 + 1, seed=seed * 50 + m)
+        elif kind == 1:
+            data = rng.integers(0, 256, size=n, dtype=np.uint8).tobytes()
+        elif kind == 2:
+            data = bytes([int(rng.integers(0, 256))]) * n
+        elif kind == 3:
+            unit = rng.integers(65, 91, size=int(rng.integers(1, 40000)), dtype=np.uint8).tobytes()
+            data = (unit * (n // len(unit) + 1))[:n]
+        else:
+            data = b""
+        strategy = [zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED][int(rng.integers(0, 5))]
+        flush_every = [0, 0, 4096, 100_000][int(rng.integers(0, 4))]
+        blob += _member(data, level=int(rng.integers(0, 10)), strategy=strategy, flush_every=flush_every,
+                        flush_mode=[zlib.Z_SYNC_FLUSH, zlib.Z_FULL_FLUSH][int(rng.integers(0, 2))],
+                        name=b"x.fq" if rng.random() < 0.3 else None, hcrc=bool(rng.random() < 0.3))
+        pieces.append(data)
+    want = b"".join(pieces)
+    chunk = [0, 1500, 20_000, 300_000][int(rng.integers(0, 4))]
+    _check(tmp_path, blob, want, threads=int(rng.integers(1, 9)), chunk=chunk, name=f"rand{seed}.gz")
