@@ -1,9 +1,10 @@
+# (every command under its own timeout: a sluggish box must not run a whole call into gpurun's limit)
 # usage: bash tools/run_big.sh <tag>   -- parity subset + bench of the 500-locus workload + kernel stats
 O=gpurun_out/$1; mkdir -p $O
-python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "config4 or short_reads or long_reads or ragged or randomized or several_groups or full_size or do_not_fit or longer_than" 2>&1 | tail -5 > $O/gputest.txt
-python bench.py --workload big --steps 5 --cpu-sample 0 > $O/bench_big.json 2> $O/bench_big.err
+timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "config4 or short_reads or long_reads or ragged or randomized or several_groups or full_size or do_not_fit or longer_than" 2>&1 | tail -5 > $O/gputest.txt
+timeout 300 python bench.py --workload big --steps 5 --cpu-sample 0 > $O/bench_big.json 2> $O/bench_big.err
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_big -o big -- python3 $GRAFT_REPO_ROOT/bench.py --workload big --steps 5 --warmup 1 --cpu-sample 0 --no-checks > /dev/null 2>&1
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_big -o big -- python3 $GRAFT_REPO_ROOT/bench.py --workload big --steps 5 --warmup 1 --cpu-sample 0 --no-checks > /dev/null 2>&1
 cd $GRAFT_REPO_ROOT
 python tools/kstats.py $O/prof_big/big_kernel_stats.csv > $O/kstats.txt
 cat $O/gputest.txt; python -c "
