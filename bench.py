@@ -318,10 +318,12 @@ def main():
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        from datetime import timedelta
+        limit = timedelta(minutes=5)  # (a rank that never arrives fails the run in minutes, not in torch's default half hour)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)  # nccl == RCCL on ROCm
+            dist.init_process_group("nccl", device_id=device, timeout=limit)  # nccl == RCCL on ROCm
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=limit)
 
     from drprg_amd import Context, synth
 
