@@ -36,6 +36,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+HBM_ACHIEVABLE_GBS = 6290.0  # same guide, line 36: 6.29 TB/s measured (float4 copy)
 
 
 def gpu_sample_reads(torch, hap_pad, hap_lens, n_reads, read_len, seed, device, sub_rate=0.001, chunk=1 << 20):
@@ -134,6 +135,11 @@ WORKLOADS = {
                  "mtb_8d"),
     "big": ("configs[4]", "10M synthetic 150 bp reads vs 500-locus / 50k-variant synthetic PRG index", 10_000_000, True, "big"),
 }
+# the 8d index grown 2-32 fold (drprg_amd.synth.mtb_scaled_panel: 30 k ... 489 k k-mer nodes): how the hot path degrades between the
+# 15 k nodes of the 8d index and the 620 k of the 500-locus one (not BASELINE configurations; profiles/r03 holds a line per size)
+for _s in (2, 4, 8, 16, 32):
+    WORKLOADS[f"mtb-x{_s}"] = ("configs[1] reads, larger index", f"10M synthetic 150 bp Illumina reads vs the 8d mtb-like index grown {_s}-fold "
+                               f"({18 * _s} loci)", 10_000_000, True, f"mtb_x{_s}")
 
 
 def cpu_model():
@@ -147,6 +153,8 @@ def cpu_model():
 
 
 def make_panel(synth, which):
+    if which.startswith("mtb_x"):
+        return synth.mtb_scaled_panel(int(which[5:]))
     return {"mtb_8d": synth.mtb_8d_panel, "mtb_like": synth.mtb_like_panel, "big": synth.big_panel}[which]()
 
 
@@ -283,7 +291,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="mtb", choices=sorted(WORKLOADS),
                     help="mtb = configs[1] (the bench line); mtb-random = the same reads against a random-backbone panel; "
-                         "nanopore = configs[2]; big = configs[4]'s index")
+                         "nanopore = configs[2]; big = configs[4]'s index; mtb-xN = the 8d index grown N-fold")
     ap.add_argument("--reads-per-gpu", type=int, default=0, help="0 = the workload's size")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--cpu-sample", type=int, default=-1, help="reads timed on the CPU oracle (0 = skip, -1 = ~10 s worth)")
@@ -415,12 +423,18 @@ def main():
     for _ in range(args.warmup):
         step()
     ctx.kernel_timing(enable=True, reset=True)
+    # one event per step on the hot path's stream (recorded behind the step's last launch): the differences are the per-step
+    # device times of the timed region (dispersion of the headline; the steps are queued back to back)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record(stream)
+    for i in range(args.steps):
         acc = step()
+        marks[i + 1].record(stream)
     barrier()
     elapsed = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     covg, prg_reads = acc[: 2 * ctx.n_knodes], acc[2 * ctx.n_knodes:]  # the last step's (reduced) result
     k_ms, k_launches = ctx.kernel_timing(enable=False)
     if world > 1:
@@ -477,6 +491,9 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "timed_region_s": elapsed,
+            "step_ms": {"min": step_ms[0], "median": step_ms[len(step_ms) // 2], "max": step_ms[-1],
+                        "how": "HIP events on the hot path's stream behind every step's last launch (device time per step)"},
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -492,12 +509,18 @@ def main():
                 "bases_per_s": n_bases * world * args.steps / elapsed,
                 "hits_per_batch": counters.get("hits", 0) // (args.warmup + args.steps),
                 "clusters_kept_per_batch": counters.get("clusters_kept", 0) // (args.warmup + args.steps),
+                "leftover_reads_per_batch": counters.get("leftover_reads", 0) // (args.warmup + args.steps),
+                "filter_tiers": ctx.table_tier(),
                 "coverage_checksum": checksum, "full_size_shard_invariance": shard_invariant,
                 "full_size_direct_vs_filtered_kernel_identical": kernels_agree,
             },
             "roofline": {
                 "bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
+                "frac": achieved / HBM_PEAK_GBS, "frac_of_achievable": achieved / HBM_ACHIEVABLE_GBS,
+                "achievable": HBM_ACHIEVABLE_GBS, "traffic": traffic,
+                "traffic_source": "profiles/traffic.json (offline rocprofv3 PMC passes of this workload, FETCH_SIZE doubled + WRITE_SIZE)"
+                                  if traffic is not None else None,
+                "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": avg_ms, "launches_timed": k_launches, "launches_per_step": launches_per_step,
             },
         }

@@ -656,7 +656,7 @@ int drprg_hip_prg_nodes(const drprg_hip_ctx* ctx, uint32_t prg, uint32_t* starts
     return DRPRG_OK;
 }
 
-int drprg_hip_device_tables(drprg_hip_ctx* ctx, uint64_t out[4])
+int drprg_hip_device_tables(drprg_hip_ctx* ctx, uint64_t out[6])
 {
     API_BEGIN(ctx)
     need_mapper(ctx).device_tables(out);

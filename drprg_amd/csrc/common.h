@@ -61,6 +61,28 @@ constexpr uint32_t BLOOM_C1 = 0x9E3779u;
 constexpr uint32_t BLOOM_C2 = 0x85EBCA6Bu;
 constexpr uint32_t BLOOM_CR = 0xC2B2AE35u; // second stage of the level-0 form
 constexpr uint32_t BLOOMR_WBITS = 14;      // 64 KB
+// Middle tier of the filter (k = 15, indexes too large for the all-LDS form; sketch_filter.hip): the 12-mers of a group of four
+// positions are keyed CANONICALLY -- min(code, reverse complement of the code), which halves the entries of both tables --,
+// tested against the 128 KB level-0 array in LDS and then against an exact 2^24-bit bitmap (2 MB, L2-resident); the four 15-mer
+// codes of a surviving group against ONE 16-byte block of a split-block Bloom filter in global memory (L2-resident as well): the
+// block is selected by the group's canonical 12-mer (the same hash as level 0), every index code is entered once per alignment
+// (in the block of the 12-mer at its offset 0..3) and sets one bit in each of the block's four words (bits 31:27, 26:22, 21:17,
+// 16:12 of code * BLOOM_CR).  2^midc_wbits blocks.
+constexpr uint32_t MID_BITMAP_WORDS = 1u << 19;
+constexpr uint32_t MID_C_MAX_WBITS = 17; // 2^17 blocks of 16 bytes = 2 MB
+// reverse complement of a 12-mer code (2 bits per base, first base in the lowest bits, alphabet A 0, C 1, T 2, G 3: complement = ^ 2)
+inline uint32_t rc12_code(uint32_t x)
+{
+    uint32_t r = 0;
+    for (int i = 0; i < 12; ++i) r |= (((x >> (2 * i)) & 3u) ^ 2u) << (2 * (11 - i));
+    return r;
+}
+inline uint32_t canon12_code(uint32_t x)
+{
+    x &= 0xFFFFFFu;
+    const uint32_t r = rc12_code(x);
+    return x < r ? x : r;
+}
 
 // canonical hash of a k-mer given as a string of exactly k ACGT characters.
 // strand = true when the forward k-mer hashes <= its reverse complement.

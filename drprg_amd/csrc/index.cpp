@@ -4,6 +4,7 @@
 #include <atomic>
 #include <cerrno>
 #include <cmath>
+#include <cstdlib>
 #include <fstream>
 #include <sstream>
 #include <sys/stat.h>
@@ -107,19 +108,38 @@ void PrgIndex::flatten()
     // Bloom filter of index k-mer codes for the LDS-prefiltered sketch kernel
     constexpr uint32_t MAX_WBITS = 14; // 16384 words = 64 KB of LDS
     const size_t entries = 2 * recs.size();
-    if (k <= 15 && entries > 0 && entries <= 3 * (size_t(1) << MAX_WBITS)) {
+    // every index k-mer as the kernels' code (letter = bits 2:1 of the ASCII base: A 0, C 1, T 2, G 3; complement = letter ^ 2;
+    // first base in the lowest bits), in both orientations
+    auto for_each_code = [&](auto&& fn) {
+        for (size_t p = 0; p < prgs.size(); ++p) {
+            const auto& nodes = kgs[p].nodes;
+            for (size_t i = 1; i + 1 < nodes.size(); ++i) {
+                const std::string s = kpath_sequence(prgs[p], nodes[i].path);
+                uint32_t fw = 0, rc = 0;
+                for (int j = 0; j < k; ++j) {
+                    const uint32_t c = ((uint32_t)(unsigned char)s[(size_t)j] >> 1) & 3u;
+                    fw |= c << (2 * j);
+                    rc |= (c ^ 2u) << (2 * (k - 1 - j));
+                }
+                fn(fw);
+                fn(rc);
+            }
+        }
+    };
+    constexpr uint32_t L0_WBITS = 15;
+    const bool small_tier = k <= 15 && entries > 0 && entries <= 3 * (size_t(1) << MAX_WBITS);
+    const bool level0 = small_tier && k == 15 && 4 * entries * 3 <= (size_t(32) << L0_WBITS) / 2;
+    const bool force_mid = k == 15 && std::getenv("DRPRG_FORCE_MID_TIER") != nullptr; // (tests: small panels through the middle tier)
+    if (small_tier && !force_mid && (level0 || k < 15 || std::getenv("DRPRG_NO_MID_TIER"))) {
         // level 0 (k = 15 and a small index only): a second array of 2^15 words keyed on the 12-mers at offsets 0..3 of
         // every index k-mer, so that the kernel probes one 12-mer per four read positions (the 12-mer at 4g+3 lies
         // inside every 15-mer that starts at 4g..4g+3).  Levels 1+2 then get 32 KB: 160 KB of LDS in all.
-        constexpr uint32_t L0_WBITS = 15;
-        const bool level0 = k == 15 && 4 * entries * 3 <= (size_t(32) << L0_WBITS) / 2;
         const uint32_t max_wbits = level0 ? MAX_WBITS - 1 : MAX_WBITS;
         uint32_t wbits = 8;
         while (wbits < max_wbits && (size_t(1) << wbits) * 5 < entries * 4) ++wbits; // <= 1.25 entries per word
         f.bloom_wbits = wbits;
         f.bloom.assign(size_t(1) << wbits, 0);
-        // layout: see sketch_filter.hip.  The code is the kernel's own packing: letter = bits 2:1 of the ASCII base
-        // (A 0, C 1, T 2, G 3; complement = letter ^ 2), first base in the lowest bits.
+        // layout: see sketch_filter.hip
         const uint32_t wmask = (1u << wbits) - 1;
         const uint32_t kmask = (1u << (2 * k)) - 1; // k <= 15
         if (level0) {
@@ -129,7 +149,7 @@ void PrgIndex::flatten()
             f.bloomr.assign(size_t(1) << BLOOMR_WBITS, 0);
         }
         const uint32_t wmask0 = (1u << L0_WBITS) - 1;
-        auto add = [&](uint32_t code) {
+        for_each_code([&](uint32_t code) {
             const uint32_t x = code & kmask & 0xFFFFFFu; // level 1: the first min(k,12) bases, 24 x 24 bit multiply
             const uint32_t h = (uint32_t)((uint64_t)x * BLOOM_C1);
             f.bloom[(h >> 18) & wmask] |= (1u << (31 - (h & 31))) | (1u << (31 - ((h >> 8) & 31))) | (1u << (31 - ((x >> 16) & 31)));
@@ -152,21 +172,52 @@ void PrgIndex::flatten()
                     f.bloom0[(g >> 17) & wmask0] |= bits0;
                     f.bloom0f[(g >> 17) & wmask0] |= bits0;
                 }
-        };
-        for (size_t p = 0; p < prgs.size(); ++p) {
-            const auto& nodes = kgs[p].nodes;
-            for (size_t i = 1; i + 1 < nodes.size(); ++i) {
-                const std::string s = kpath_sequence(prgs[p], nodes[i].path);
-                uint32_t fw = 0, rc = 0;
-                for (int j = 0; j < k; ++j) {
-                    const uint32_t c = ((uint32_t)(unsigned char)s[(size_t)j] >> 1) & 3u;
-                    fw |= c << (2 * j);
-                    rc |= (c ^ 2u) << (2 * (k - 1 - j));
-                }
-                add(fw);
-                add(rc);
+        });
+    } else if (k == 15 && entries > 0 && !std::getenv("DRPRG_NO_MID_TIER")) {
+        // Middle tier (round 3): too many index k-mers for an LDS-resident filter of the whole codes.  Level 0 stays in LDS but
+        // is keyed on the CANONICAL 12-mer (half the entries); what passes it is looked up in the exact bitmap of the canonical
+        // index 12-mers (2 MB, in the L2: ~267 G four-byte probes per second chip-wide, measured -- tools/mb_l2probe.hip), and
+        // the four 15-mer codes of a group that passes both in a one-word Bloom filter of the codes (>= 32 bits per code, four
+        // set: one false candidate in several thousand tests).  The forms above are all-LDS and faster: they serve the indexes
+        // that fit them.
+        f.mid_bitmap.assign(MID_BITMAP_WORDS, 0);
+        for_each_code([&](uint32_t code) {
+            for (int o = 0; o < 4; ++o) {
+                const uint32_t key = canon12_code(code >> (2 * o));
+                f.mid_bitmap[key >> 5] |= 1u << (key & 31);
             }
-        }
+        });
+        uint64_t distinct = 0;
+        for (uint32_t wd : f.mid_bitmap) distinct += (uint64_t)__builtin_popcount(wd);
+        // level 0: three bits per 12-mer while the array stays under ~70 % full, else one (a fuller array rejects less with three)
+        f.mid0_bits = distinct * 5 <= (size_t(32) << L0_WBITS) * 2 ? 3 : 1;
+        f.mid0.assign(size_t(1) << L0_WBITS, 0);
+        const uint32_t wmask0 = (1u << L0_WBITS) - 1;
+        for (uint32_t wi = 0; wi < MID_BITMAP_WORDS; ++wi)
+            for (uint32_t wd = f.mid_bitmap[wi]; wd; wd &= wd - 1) {
+                const uint32_t key = (wi << 5) | (uint32_t)__builtin_ctz(wd);
+                const uint32_t g = (uint32_t)((uint64_t)key * BLOOM_C0);
+                uint32_t bits0 = 1u << (31 - (g & 31));
+                if (f.mid0_bits == 3) bits0 |= (1u << (31 - ((g >> 8) & 31))) | (1u << (31 - ((key >> 16) & 31)));
+                f.mid0[(g >> 17) & wmask0] |= bits0;
+            }
+        // split-block filter of the codes: <= ~8 entries per 16-byte block while the table stays within 2 MB (entries = codes x 4 alignments)
+        uint32_t cw = 10;
+        while (cw < MID_C_MAX_WBITS && (size_t(8) << cw) < 4 * entries) ++cw;
+        f.midc_wbits = cw;
+        f.midc.assign(size_t(4) << cw, 0);
+        for_each_code([&](uint32_t code) {
+            const uint32_t h = code * BLOOM_CR;
+            for (int o = 0; o < 4; ++o) {
+                const uint32_t key = canon12_code(code >> (2 * o));
+                const uint32_t blk = (uint32_t)((uint64_t)key * BLOOM_C0) >> (32 - cw);
+                uint32_t* b = &f.midc[(size_t)blk * 4];
+                b[0] |= 1u << (h >> 27);
+                b[1] |= 1u << ((h >> 22) & 31);
+                b[2] |= 1u << ((h >> 17) & 31);
+                b[3] |= 1u << ((h >> 12) & 31);
+            }
+        });
     }
 }
 
@@ -174,6 +225,52 @@ void PrgIndex::filter_selfcheck(uint64_t out[8]) const
 {
     for (int i = 0; i < 8; ++i) out[i] = 0;
     const FlatIndex& f = flat;
+    if (f.midc_wbits) { // middle tier: out[1] / out[2] / out[3] = codes that level 0 / the 12-mer bitmap / the code filter would reject
+        const uint32_t wmask0 = (uint32_t)f.mid0.size() - 1;
+        for (size_t p = 0; p < prgs.size(); ++p) {
+            const auto& nodes = kgs[p].nodes;
+            for (size_t i = 1; i + 1 < nodes.size(); ++i) {
+                const std::string s = kpath_sequence(prgs[p], nodes[i].path);
+                uint32_t both[2] = { 0, 0 };
+                for (int j = 0; j < k; ++j) {
+                    const uint32_t c = ((uint32_t)(unsigned char)s[(size_t)j] >> 1) & 3u;
+                    both[0] |= c << (2 * j);
+                    both[1] |= (c ^ 2u) << (2 * (k - 1 - j));
+                }
+                for (uint32_t code : both) {
+                    ++out[0];
+                    bool miss0 = false, missb = false;
+                    for (int o = 0; o < 4; ++o) { // the kernel sees this k-mer at offset o of a group: key = the 12-mer at 3 - o... any of the four
+                        const uint32_t key = canon12_code(code >> (2 * o));
+                        const uint32_t g = (uint32_t)((uint64_t)key * BLOOM_C0), word = f.mid0[(g >> 17) & wmask0];
+                        uint32_t t = word << (g & 31);
+                        if (f.mid0_bits == 3) t &= (word << ((g >> 8) & 31)) & (word << ((key >> 16) & 31));
+                        miss0 |= !(t >> 31);
+                        missb |= !((f.mid_bitmap[key >> 5] >> (key & 31)) & 1u);
+                    }
+                    out[1] += miss0;
+                    out[2] += missb;
+                    const uint32_t h = code * BLOOM_CR;
+                    bool missc = false;
+                    for (int o = 0; o < 4; ++o) { // whatever the alignment, the block of that alignment's 12-mer must hold the code's bits
+                        const uint32_t key = canon12_code(code >> (2 * o));
+                        const uint32_t* b = &f.midc[(size_t)((uint32_t)((uint64_t)key * BLOOM_C0) >> (32 - f.midc_wbits)) * 4];
+                        missc |= !((b[0] >> (h >> 27)) & (b[1] >> ((h >> 22) & 31)) & (b[2] >> ((h >> 17) & 31)) & (b[3] >> ((h >> 12) & 31)) & 1u);
+                    }
+                    out[3] += missc;
+                }
+            }
+        }
+        auto fill = [](const std::vector<uint32_t>& v) -> uint64_t {
+            uint64_t bits = 0;
+            for (uint32_t w : v) bits += (uint64_t)__builtin_popcount(w);
+            return v.empty() ? 0 : bits * 1000 / (32 * (uint64_t)v.size());
+        };
+        out[4] = fill(f.mid0);
+        out[5] = fill(f.mid_bitmap);
+        out[6] = fill(f.midc);
+        return;
+    }
     if (!f.bloom_wbits) return;
     const uint32_t wmask = (1u << f.bloom_wbits) - 1, kmask = (1u << (2 * k)) - 1, wmask0 = f.bloom0_wbits ? (1u << f.bloom0_wbits) - 1 : 0;
     // the tests exactly as sketch_filter.hip states them (bloom_test: bits 31 - shift of the word)

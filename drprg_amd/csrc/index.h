@@ -40,6 +40,11 @@ struct FlatIndex {
     std::vector<uint32_t> bloom0f; // bloom0 plus the second-stage bits of every code (four per code, in the word its BLOOM_CR hash selects)
     // with level 0: the second stage (refine_kernel), 2^14 words keyed on the whole k-mer code, four bits per code
     std::vector<uint32_t> bloomr;
+    // middle tier (k = 15, too many index k-mers for the forms above; common.h MID_*): level 0 keyed on CANONICAL 12-mers (its own
+    // array `mid0`, 2^15 words, `mid0_bits` = 3 or 1 bits per 12-mer), the exact bitmap of those canonical 12-mers, and the
+    // split-block Bloom filter of the whole codes (2^midc_wbits blocks of four words, block chosen by the 12-mer).  midc_wbits == 0: absent.
+    uint32_t midc_wbits = 0, mid0_bits = 0;
+    std::vector<uint32_t> mid0, mid_bitmap, midc;
     uint32_t total_knodes() const { return knode_base.empty() ? 0 : knode_base.back(); }
 };
 

@@ -138,6 +138,11 @@ struct BloomTables {
     uint32_t bloom0_wbits;
     const uint32_t* bloomr; // second stage of the level-0 form (2^BLOOMR_WBITS words)
     const uint32_t* bloom0f; // level 0 and the second-stage bits in one array (the form with the second stage inside the streaming kernel)
+    // middle tier (FlatIndex::mid0 / mid_bitmap / midc; nullptr: absent)
+    const uint32_t* mid0 = nullptr;
+    const uint32_t* mid_bitmap = nullptr;
+    const uint32_t* midc = nullptr;
+    uint32_t midc_wbits = 0, mid0_bits = 0;
 };
 // Scratch of the filtered launch sequence.  raw_pos: raw_capacity candidate positions (one slice per filter wave);
 // cand_info / cand_pos1: raw_capacity entries each; small: filter_small_words() u32; max_len: device scalar that
@@ -152,6 +157,7 @@ struct FilterBuffers {
     uint64_t raw_capacity;
     uint32_t* small;
     unsigned long long* max_len;
+    unsigned long long* stat = nullptr; // middle tier, DRPRG_FT_STATS=1: four device counters (FilterWork::stat)
 };
 // device view of the workspace of one filtered launch sequence (filled by launch_sketch_filter)
 struct FilterWork {
@@ -160,6 +166,10 @@ struct FilterWork {
     const uint32_t* bloom0;  // level 0 (nullptr / 0: absent)
     uint32_t bloom0_wbits;
     const uint32_t* bloomr;  // second stage of the level-0 form
+    const uint32_t* mid_bitmap; // middle tier: exact bitmap of the canonical index 12-mers (2^24 bits, global memory)
+    const uint32_t* midc;       // middle tier: split-block Bloom filter of the index k-mer codes (2^midc_wbits blocks of 16 bytes, global memory)
+    uint32_t midc_wbits;
+    unsigned long long* stat;   // DRPRG_FT_STATS=1 (middle tier): groups tested, past level 0, past the bitmap, candidate positions
     uint32_t read_begin, read_end; // this launch sequence maps reads [read_begin, read_end) of the batch: the filter kernel
                              // streams the wave tiles (FT_WPOS positions each) that cover their bases, candidates
                              // outside [offsets[read_begin], offsets[read_end]) are dropped by verify_count_kernel

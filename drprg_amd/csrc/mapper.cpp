@@ -1,6 +1,9 @@
 // mapper.cpp -- device context and per-batch launch sequence.  See mapper.h.
 #include "mapper.h"
 #include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <hip/hip_runtime.h>
 
@@ -122,6 +125,26 @@ Mapper::Mapper(const FlatIndex& idx, const MapParams& p, int device) : device_(d
         dmalloc(d_bloomr_, idx.bloomr.size());
         HIPCHK(hipMemcpy(d_bloomr_, idx.bloomr.data(), idx.bloomr.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
+    if (idx.midc_wbits) {
+        // the middle tier pays while the L2 probes it adds cost less than hashing every k-mer (sketch_wave_kernel): measured up to
+        // DRPRG_MID_MAX_RECORDS index records (profiles/r03)
+        size_t max_records = 400000;
+        if (const char* e = std::getenv("DRPRG_MID_MAX_RECORDS")) max_records = std::strtoull(e, nullptr, 10);
+        if (idx.rec_prg.size() <= max_records) {
+            midc_wbits_ = idx.midc_wbits;
+            mid0_bits_ = idx.mid0_bits;
+            dmalloc(d_mid0_, idx.mid0.size());
+            HIPCHK(hipMemcpy(d_mid0_, idx.mid0.data(), idx.mid0.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            dmalloc(d_mid_bitmap_, idx.mid_bitmap.size());
+            HIPCHK(hipMemcpy(d_mid_bitmap_, idx.mid_bitmap.data(), idx.mid_bitmap.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            dmalloc(d_midc_, idx.midc.size());
+            HIPCHK(hipMemcpy(d_midc_, idx.midc.data(), idx.midc.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            if (const char* e = std::getenv("DRPRG_FT_STATS"); e && std::atoi(e)) {
+                dmalloc(d_ft_stat_, (size_t)4);
+                HIPCHK(hipMemset(d_ft_stat_, 0, 4 * sizeof(unsigned long long)));
+            }
+        }
+    }
     HIPCHK(hipDeviceGetAttribute(&n_cus_, hipDeviceAttributeMultiprocessorCount, device_));
     set_params(p); // again: the kernel choice depends on the filter being available
     {
@@ -162,7 +185,7 @@ Mapper::~Mapper()
     if (d_temp_) (void)hipFree(d_temp_);
     dfree(d_tile_info_); dfree(d_tile_pos1_); dfree(d_tile_count_); dfree(d_tile_hits_); dfree(d_tile_nmin_); dfree(d_tile_prefix_); dfree(d_tile_fast_); dfree(d_tile_rec_);
     if (d_tile_temp_) (void)hipFree(d_tile_temp_);
-    dfree(d_bases_); dfree(d_offsets_); dfree(d_tile_first_); dfree(d_bloom_); dfree(d_bloom0_); dfree(d_bloom0f_); dfree(d_bloomr_); dfree(d_pbloom_);
+    dfree(d_bases_); dfree(d_offsets_); dfree(d_tile_first_); dfree(d_bloom_); dfree(d_bloom0_); dfree(d_bloom0f_); dfree(d_bloomr_); dfree(d_pbloom_); dfree(d_mid0_); dfree(d_mid_bitmap_); dfree(d_midc_); dfree(d_ft_stat_);
     for (Lane& lane : lanes_) free_lane(lane);
     if (ev_begin_) (void)hipEventDestroy(ev_begin_);
     if (h_counters_) (void)hipHostFree(h_counters_);
@@ -193,10 +216,10 @@ void Mapper::set_params(const MapParams& p)
     // validate everything before any state changes: a refused call leaves the previous parameters in force
     if (p.k < 1 || p.k > 31) throw Error(DRPRG_EINVAL, "k must be in [1,31]");
     if (p.w < 1 || p.w > 1024) throw Error(DRPRG_EINVAL, "w must be in [1,1024]");
-    const bool filter_ok = bloom_wbits_ != 0 && p.k <= 15 && p.w <= 16;
+    const bool filter_ok = (bloom_wbits_ != 0 || midc_wbits_ != 0) && p.k <= 15 && p.w <= 16;
     if (p.kernel_mode < 0 || p.kernel_mode > 3) throw Error(DRPRG_EINVAL, "kernel must be 0 (auto), 1, 2 or 3");
     if (p.kernel_mode == 2 && !filter_ok)
-        throw Error(DRPRG_EINVAL, "the Bloom-prefiltered kernel needs k <= 15, w <= 16 and an index small enough for an LDS filter");
+        throw Error(DRPRG_EINVAL, "the Bloom-prefiltered kernel needs k <= 15, w <= 16 and an index small enough for its filter tiers");
     params_ = p;
     wide_hash_ = p.k > 15;
     halo_ = std::max(16, ((p.w - 1 + 15) / 16) * 16);
@@ -208,6 +231,7 @@ void Mapper::set_params(const MapParams& p)
         HIPCHK(hipMemcpy(d_prg_thr_, thr.data(), n_prgs_ * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
     use_filter_ = p.kernel_mode == 2 || (p.kernel_mode == 0 && filter_ok);
+    use_mid_ = use_filter_ && bloom_wbits_ == 0;
     use_direct_cands_ = p.kernel_mode == 3 || (p.kernel_mode == 0 && !filter_ok);
 }
 
@@ -258,6 +282,9 @@ void Mapper::grow_lane(Lane& lane, uint64_t cap)
     lane.raw_capacity = cap;
     if (bloom0_wbits_) dmalloc(lane.raw_grp, cap);
     dmalloc(lane.raw_pos, cap); dmalloc(lane.cand_info, cap); dmalloc(lane.cand_pos1, cap); dmalloc(lane.cand_rec, cap);
+    // the slices form of the direct sequence uses cand_pos1 as an array of "handled" marks (mark = a batch's epoch): fresh device
+    // memory may hold anything, including a value some later epoch of this or an earlier Mapper takes
+    HIPCHK(hipMemset(lane.cand_pos1, 0, cap * sizeof(uint32_t)));
 }
 
 void Mapper::ensure_lanes(int n, uint64_t cap)
@@ -293,7 +320,15 @@ void Mapper::launch_lane(Lane& lane, hipStream_t stream, const uint8_t* d_bases,
     a.overflow = reinterpret_cast<uint32_t*>(&lane.d_scratch[L_OVERFLOW]);
     dev::FilterBuffers fb { lane.raw_pos, lane.raw_grp, lane.cand_info, lane.cand_pos1, lane.cand_rec, lane.raw_capacity, lane.small,
         &lane.d_scratch[L_MAXLEN] };
+    fb.stat = d_ft_stat_;
     dev::BloomTables bt { d_bloom_, bloom_wbits_, d_bloom0_, bloom0_wbits_, d_bloomr_, d_bloom0f_ };
+    if (use_mid_) {
+        bt.mid0 = d_mid0_;
+        bt.mid_bitmap = d_mid_bitmap_;
+        bt.midc = d_midc_;
+        bt.midc_wbits = midc_wbits_;
+        bt.mid0_bits = mid0_bits_;
+    }
     dev::ReadClusterArgs rc {};
     rc.prg_min_path_len = d_min_path_len_;
     rc.fraction = params_.cluster_fraction();
@@ -474,7 +509,15 @@ void Mapper::run_batch_direct_candidates(const uint8_t* d_bases, const uint64_t*
     }();
     uint32_t mark = 0;
     if (from_slices && !fuse_in_kernel_) {
-        if (++slices_epoch_ < 0x80000000u) slices_epoch_ = 0x80000000u; // (never a value a position + 1 can have, never 0)
+        // (never a value a position + 1 can have, never 0; one sequence of epochs per process, so that no two Mappers that follow
+        // each other in recycled device memory ever use the same mark)
+        static std::atomic<uint32_t> process_epoch { 0x80000000u };
+        slices_epoch_ = process_epoch.fetch_add(1) + 1;
+        if (slices_epoch_ < 0x80000000u) { // wrapped after 2^31 batches: marks of old batches may still be around, clear them
+            HIPCHK(hipMemsetAsync(lane.cand_pos1, 0, lane.raw_capacity * sizeof(uint32_t), stream));
+            process_epoch.store(0x80000001u);
+            slices_epoch_ = 0x80000001u;
+        }
         mark = slices_epoch_;
     }
     dev::SketchArgs a_done {};
@@ -813,11 +856,14 @@ void Mapper::upload(const std::vector<uint32_t>& covg, const std::vector<uint32_
     HIPCHK(hipMemcpy(d_prg_reads_, prg_reads.data(), prg_reads.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 }
 
-void Mapper::device_tables(uint64_t out[4]) const
+void Mapper::device_tables(uint64_t out[6]) const
 {
+    out[4] = use_mid_ ? (uint64_t)MID_BITMAP_WORDS * 4 + ((uint64_t)16 << midc_wbits_) : 0; // global-memory (L2) tiers of the filter
+    out[5] = 0;
     out[0] = d_pbloom_ ? (uint64_t)1 << pbloom_wbits_ : 0;
     out[1] = ((uint64_t)1 << table_bits_) * (wide_hash_ ? 16 : 12);
     out[2] = bloom_wbits_ ? ((uint64_t)4 << bloom_wbits_) + (bloom0_wbits_ ? ((uint64_t)4 << bloom0_wbits_) + ((uint64_t)4 << BLOOMR_WBITS) : 0) : 0;
+    if (use_mid_) out[2] = (uint64_t)4 << 15;
     out[3] = use_filter_ ? 2 : (use_direct_cands_ ? 3 : 1);
 }
 
@@ -831,6 +877,12 @@ MapCounters Mapper::counters()
     if (std::getenv("DRPRG_WAVE_DEBUG"))
         std::fprintf(stderr, "[sketch_wave] entries %llu: several records out of group %llu, other group than the read's first %llu, read not inside the tile %llu, "
                              "more than 64 entries %llu; entries left to the records path %llu\n", c[C_CHUNK], c[C_CHUNK + 1], c[C_CHUNK + 2], c[C_CHUNK + 3], c[C_CHUNK + 4], c[C_CHUNK + 5]);
+    if (d_ft_stat_) {
+        unsigned long long st[4];
+        HIPCHK(hipMemcpy(st, d_ft_stat_, sizeof(st), hipMemcpyDeviceToHost));
+        std::fprintf(stderr, "[sketch_filter middle tier] groups %llu, past level 0 %llu (%.2f %%), past the bitmap %llu (%.2f %%), candidate positions %llu\n", st[0],
+            st[1], st[0] ? 100.0 * (double)st[1] / (double)st[0] : 0.0, st[2], st[0] ? 100.0 * (double)st[2] / (double)st[0] : 0.0, st[3]);
+    }
     MapCounters m;
     m.reads = tot_reads_;
     m.bases = tot_bases_;

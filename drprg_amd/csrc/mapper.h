@@ -63,7 +63,7 @@ public:
     MapCounters counters(); // synchronises
     // out[0] = words of the L2-resident Bloom tier in front of the probe table (0: none), out[1] = bytes of the probe table
     // (keys + slot records), out[2] = bytes of the LDS-resident filter arrays (0: none), out[3] = sequence in use (1/2/3)
-    void device_tables(uint64_t out[4]) const;
+    void device_tables(uint64_t out[6]) const;
 
     // timing of the dominant kernel (HIP events on the launch stream), for bench.py
     void enable_kernel_timing(bool on) { timing_ = on; }
@@ -149,6 +149,11 @@ private:
     uint32_t* d_bloom0f_ = nullptr; // level 0 + second-stage bits in one array
     uint32_t bloom0_wbits_ = 0;
     uint32_t* d_bloomr_ = nullptr; // second stage of the level-0 form
+    // middle tier of the filter (FlatIndex::mid0 / mid_bitmap / midc): level 0 in LDS, the other two in global memory (L2-resident)
+    uint32_t *d_mid0_ = nullptr, *d_mid_bitmap_ = nullptr, *d_midc_ = nullptr;
+    uint32_t midc_wbits_ = 0, mid0_bits_ = 0;
+    bool use_mid_ = false;                   // the filtered sequence runs in its middle-tier form
+    unsigned long long* d_ft_stat_ = nullptr; // DRPRG_FT_STATS=1: groups tested / past level 0 / past the bitmap, candidate positions
     int n_cus_ = 256;
     bool use_filter_ = false;
     bool fuse_in_kernel_ = false; // sketch_wave_kernel clusters the reads inside one tile itself (DRPRG_WAVE_FUSE=1)

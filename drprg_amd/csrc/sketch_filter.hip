@@ -80,6 +80,17 @@ __device__ __forceinline__ uint32_t bloom_test(uint32_t word, uint32_t h, uint32
     return (word << (h & 31)) & t2 & (word << ((x >> 16) & 0xFF));
 }
 
+// Middle tier: canonical code of a 12-mer = min(code, code of its reverse complement).  v_bfrev reverses the order of the twelve
+// 2-bit letters and swaps the two bits of each; the letter's low bit goes back down (>> 9), its high bit back up (>> 7) and is
+// complemented there (complement of a letter = letter ^ 2).  Bits 24..31 of x are ignored.  (common.h rc12_code is the host's.)
+__device__ __forceinline__ uint32_t canon12_dev(uint32_t x)
+{
+    const uint32_t m = x & 0xFFFFFFu;
+    const uint32_t r = __builtin_bitreverse32(x);
+    const uint32_t rc = ((r >> 9) & 0x555555u) | (~(r >> 7) & 0xAAAAAAu);
+    return m < rc ? m : rc;
+}
+
 // SHORT_K: k < 12, the level-1 key must be masked to 2k bits.  LEVEL0: the level-0 array is present (k = 15).
 // FUSED (with LEVEL0): the second stage runs in this kernel as well.  The groups that pass level 0 are staged in the wave's own
 // 2 KB of LDS and, 64 at a time, put through the second-stage filter one lane per group -- dense lanes, as in refine_kernel --
@@ -90,10 +101,15 @@ __device__ __forceinline__ uint32_t bloom_test(uint32_t word, uint32_t h, uint32
 // not fit, and read from global memory (26 M four-byte loads per batch) it made this form slower than the two kernels, whether
 // the words were waited for at once or a tile later; so the second-stage bits share the level-0 array (FlatIndex::bloom0f): both
 // tests see a fuller array and let more through, which costs less than the records did.
-template <bool SHORT_K, bool LEVEL0, bool FUSED = false>
+// MID (with LEVEL0 and FUSED; 3 or 1 = bits per 12-mer in the level-0 array): the middle tier for indexes whose k-mers do not fit an
+// LDS-resident filter.  Level 0 is keyed on the canonical 12-mer; a group that passes it is looked up in the exact bitmap of the
+// canonical index 12-mers in global memory (2 MB: L2-resident; one exec-masked four-byte load per surviving group, all of a tile's
+// loads in flight together), and the second stage tests the four codes of a group against a one-word Bloom filter in global memory.
+template <bool SHORT_K, bool LEVEL0, bool FUSED = false, int MID = 0>
 __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a, FilterWork fw)
 {
     static_assert(!FUSED || LEVEL0, "the fused second stage belongs to the level-0 form");
+    static_assert(MID == 0 || (LEVEL0 && FUSED), "the middle tier is a variant of the level-0 form with the second stage inside");
     extern __shared__ uint32_t s_dyn[]; // [level 0: FT_L0_WORDS] then [levels 1+2: 2^bloom_wbits words] or, FUSED, [stage: 2 KB per wave]
     constexpr uint32_t L12_BASE = LEVEL0 ? FT_L0_WORDS * 4u : 0u;
     constexpr uint32_t STAGE_RECORDS = 128, STAGE_BASE_WORDS = FT_L0_WORDS;
@@ -107,6 +123,10 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
     const uint32_t kmask = (k < 16) ? ((1u << (2 * k)) - 1) : 0xFFFFFFFFu;
     const uint32_t kmask24 = kmask & 0xFFFFFFu;
     const int sh_w = 32 - (int)fw.bloom_wbits;
+    const uint32_t sh_c = 32u - fw.midc_wbits; // (middle tier)
+    (void)sh_c;
+    uint32_t st_a = 0, st_b = 0, st_c = 0; // DRPRG_FT_STATS (middle tier): groups past level 0 / past the bitmap, candidate positions, per lane
+    (void)st_a; (void)st_b; (void)st_c;
 
     if (LEVEL0) // (FUSED: fw.bloom0 is the array that also holds the second-stage bits)
         for (uint32_t i = tid; i < (1u << fw.bloom0_wbits); i += FT_THREADS) s_dyn[i] = fw.bloom0[i];
@@ -171,37 +191,76 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
     (void)stage;
     auto mb_below = [](uint64_t m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); };
     (void)mb_below;
+    // one round of the second stage: `cand2` = which of the four positions of lane's group (record r) pass, then the ordered append
+#define DRPRG_STAGE2_APPEND(r, cand2_in)                                                                                              \
+    do {                                                                                                                              \
+        uint32_t cand2 = (cand2_in);                                                                                                  \
+        /* ordered append: exclusive prefix of the per-lane counts (0..4) from three ballots */                                       \
+        const uint32_t c2 = (uint32_t)__popc(cand2);                                                                                  \
+        if constexpr (MID != 0) st_c += c2;                                                                                           \
+        const uint64_t e0 = __ballot(c2 & 1u), e1 = __ballot(c2 & 2u), e2 = __ballot(c2 & 4u);                                        \
+        if (e0 | e1 | e2) {                                                                                                           \
+            uint32_t at2 = wcur + mb_below(e0) + 2u * mb_below(e1) + 4u * mb_below(e2);                                               \
+            const uint64_t pos2 = ((uint64_t)(r).y << 32) | (r).x;                                                                    \
+            while (cand2) {                                                                                                           \
+                const int q2 = __ffs(cand2) - 1;                                                                                      \
+                cand2 &= cand2 - 1;                                                                                                   \
+                if (at2 < fw.raw_slice) out[at2] = pos2 + (uint64_t)q2;                                                               \
+                ++at2;                                                                                                                \
+            }                                                                                                                         \
+            wcur += (uint32_t)(__popcll(e0) + 2 * __popcll(e1) + 4 * __popcll(e2));                                                   \
+        }                                                                                                                             \
+    } while (0)
+    // middle tier: the four codes of record r against the 16-byte block `b` its 12-mer selects (one bit in each of the four words)
+#define DRPRG_BLOCK_TEST(r, b, dst)                                                                                                   \
+    do {                                                                                                                              \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                               \
+            const uint32_t f = (q ? __funnelshift_r((r).z, (r).w, 2 * q) : (r).z) & kmask;                                            \
+            const uint32_t h = f * BLOOM_CR;                                                                                          \
+            dst |= (((b).x >> (h >> 27)) & ((b).y >> ((h >> 22) & 31)) & ((b).z >> ((h >> 17) & 31)) & ((b).w >> ((h >> 12) & 31)) & 1u) << q; \
+        }                                                                                                                             \
+    } while (0)
 #define DRPRG_SECOND_STAGE()                                                                                                          \
     do {                                                                                                                              \
         if (lcnt) {                                                                                                                   \
             __builtin_amdgcn_wave_barrier(); /* the wave's own LDS writes come before these reads in program order */                 \
-            for (uint32_t c0 = 0; c0 < lcnt; c0 += 64) {                                                                              \
-                const uint32_t ri = c0 + (uint32_t)lane;                                                                              \
-                uint32_t cand2 = 0;                                                                                                   \
-                uint4 r = make_uint4(0, 0, 0, 0);                                                                                     \
-                if (ri < lcnt) {                                                                                                      \
-                    r = stage[ri];                                                                                                    \
-                    _Pragma("unroll") for (int q = 0; q < 4; ++q) { /* four bits of one word, keyed on the whole code at position q */ \
-                        const uint32_t f = (q ? __funnelshift_r(r.z, r.w, 2 * q) : r.z) & kmask;                                      \
-                        const uint32_t h = f * BLOOM_CR, h2 = f * BLOOM_C2;                                                           \
-                        const uint32_t word = lds_at((h >> 17) << 2);                                                                 \
-                        cand2 |= ((word >> (h & 31)) & (word >> ((h >> 5) & 31)) & (word >> ((h >> 10) & 31)) & (word >> (h2 >> 27))      \
-                                     & (word >> ((h2 >> 22) & 31)) & (word >> ((h2 >> 17) & 31)) & 1u) << q;                           \
+            if constexpr (MID != 0) {                                                                                                 \
+                /* two rounds of 64 groups at a time, both block loads in flight before the first test */                             \
+                for (uint32_t c0 = 0; c0 < lcnt; c0 += 128) {                                                                         \
+                    const uint32_t ia = c0 + (uint32_t)lane, ib = ia + 64;                                                            \
+                    uint4 ra = make_uint4(0, 0, 0, 0), rb = ra, ba = ra, bb = ra;                                                     \
+                    if (ia < lcnt) {                                                                                                  \
+                        ra = stage[ia];                                                                                               \
+                        ba = reinterpret_cast<const uint4*>(fw.midc)[(uint32_t)__umul24(canon12_dev(__funnelshift_r(ra.z, ra.w, 6)), BLOOM_C0) >> sh_c]; /* (__umul24 returns int) */ \
+                    }                                                                                                                 \
+                    if (ib < lcnt) {                                                                                                  \
+                        rb = stage[ib];                                                                                               \
+                        bb = reinterpret_cast<const uint4*>(fw.midc)[(uint32_t)__umul24(canon12_dev(__funnelshift_r(rb.z, rb.w, 6)), BLOOM_C0) >> sh_c]; \
+                    }                                                                                                                 \
+                    uint32_t ca = 0, cb = 0;                                                                                          \
+                    DRPRG_BLOCK_TEST(ra, ba, ca); /* (an all-zero block rejects: lanes without a record) */                           \
+                    DRPRG_STAGE2_APPEND(ra, ca);                                                                                      \
+                    if (c0 + 64 < lcnt) { /* wave-uniform */                                                                          \
+                        DRPRG_BLOCK_TEST(rb, bb, cb);                                                                                 \
+                        DRPRG_STAGE2_APPEND(rb, cb);                                                                                  \
                     }                                                                                                                 \
                 }                                                                                                                     \
-                /* ordered append: exclusive prefix of the per-lane counts (0..4) from three ballots */                               \
-                const uint32_t c2 = (uint32_t)__popc(cand2);                                                                          \
-                const uint64_t e0 = __ballot(c2 & 1u), e1 = __ballot(c2 & 2u), e2 = __ballot(c2 & 4u);                                \
-                if (e0 | e1 | e2) {                                                                                                   \
-                    uint32_t at2 = wcur + mb_below(e0) + 2u * mb_below(e1) + 4u * mb_below(e2);                                       \
-                    const uint64_t pos2 = ((uint64_t)r.y << 32) | r.x;                                                                \
-                    while (cand2) {                                                                                                   \
-                        const int q2 = __ffs(cand2) - 1;                                                                              \
-                        cand2 &= cand2 - 1;                                                                                           \
-                        if (at2 < fw.raw_slice) out[at2] = pos2 + (uint64_t)q2;                                                       \
-                        ++at2;                                                                                                        \
+            } else {                                                                                                                  \
+                for (uint32_t c0 = 0; c0 < lcnt; c0 += 64) {                                                                          \
+                    const uint32_t ri = c0 + (uint32_t)lane;                                                                          \
+                    uint32_t cs = 0;                                                                                                  \
+                    uint4 r = make_uint4(0, 0, 0, 0);                                                                                 \
+                    if (ri < lcnt) {                                                                                                  \
+                        r = stage[ri];                                                                                                \
+                        _Pragma("unroll") for (int q = 0; q < 4; ++q) { /* six bits of one word, keyed on the whole code at position q */ \
+                            const uint32_t f = (q ? __funnelshift_r(r.z, r.w, 2 * q) : r.z) & kmask;                                  \
+                            const uint32_t h = f * BLOOM_CR, h2 = f * BLOOM_C2;                                                       \
+                            const uint32_t word = lds_at((h >> 17) << 2);                                                             \
+                            cs |= ((word >> (h & 31)) & (word >> ((h >> 5) & 31)) & (word >> ((h >> 10) & 31)) & (word >> (h2 >> 27))  \
+                                      & (word >> ((h2 >> 22) & 31)) & (word >> ((h2 >> 17) & 31)) & 1u) << q;                         \
+                        }                                                                                                             \
                     }                                                                                                                 \
-                    wcur += (uint32_t)(__popcll(e0) + 2 * __popcll(e1) + 4 * __popcll(e2));                                           \
+                    DRPRG_STAGE2_APPEND(r, cs);                                                                                       \
                 }                                                                                                                     \
             }                                                                                                                         \
             __builtin_amdgcn_wave_barrier();                                                                                          \
@@ -239,12 +298,31 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
                 const int j = 4 * g + 3;
                 const uint32_t lo = j < 16 ? wa : wb, hi = j < 16 ? wb : wc;
                 xs[g] = __builtin_amdgcn_alignbit(hi, lo, 2 * (j & 15));
+                if constexpr (MID != 0) xs[g] = canon12_dev(xs[g]);
                 hs[g] = __umul24(xs[g], BLOOM_C0);
                 ws[g] = lds_at((hs[g] >> 15) & amask0);
             }
 #pragma unroll
-            for (int g = FT_G / 4 - 1; g >= 0; --g) grp = __builtin_amdgcn_alignbit(grp, bloom_test(ws[g], hs[g], xs[g]), 31);
+            for (int g = FT_G / 4 - 1; g >= 0; --g)
+                grp = __builtin_amdgcn_alignbit(grp, MID == 1 ? ws[g] << (hs[g] & 31) : bloom_test(ws[g], hs[g], xs[g]), 31);
             if (lane == 63 || (fw.debug & 1u)) grp = 0;
+            if constexpr (MID != 0) {
+                // ---- the exact bitmap of the canonical index 12-mers, only for the groups that passed level 0: one exec-masked load
+                // each, all in flight before the first test (the L2 serves ~267 G such probes per second chip-wide whatever their
+                // width, so every group level 0 rejects is 3.7 ps saved) ----
+                st_a += (uint32_t)__popc(grp);
+                uint32_t bw[FT_G / 4];
+#pragma unroll
+                for (int g = 0; g < FT_G / 4; ++g) {
+                    bw[g] = 0;
+                    if (grp & (1u << g)) bw[g] = fw.mid_bitmap[xs[g] >> 5];
+                }
+                uint32_t keep = 0;
+#pragma unroll
+                for (int g = 0; g < FT_G / 4; ++g) keep |= ((bw[g] >> (xs[g] & 31)) & 1u) << g;
+                grp &= keep;
+                st_b += (uint32_t)__popc(grp);
+            }
             // ---- append in (lane, group) = position order: exclusive prefix of the per-lane counts (0..8) from four ballots ----
             const uint32_t cnt = (uint32_t)__popc(grp);
             const uint64_t b0 = __ballot(cnt & 1u), b1 = __ballot(cnt & 2u), b2 = __ballot(cnt & 4u), b3 = __ballot(cnt & 8u);
@@ -375,8 +453,17 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
     close_slice();
     for (++slice; slice < (gw + 1) * FT_SUB; ++slice) // slices this wave never reached (the last waves of a short batch)
         if (lane == 0) (LEVEL0 && !FUSED ? fw.grp_count : fw.slice_count)[slice] = 0;
+    if constexpr (MID != 0)
+        if (fw.stat) {
+            atomicAdd(&fw.stat[1], (unsigned long long)st_a);
+            atomicAdd(&fw.stat[2], (unsigned long long)st_b);
+            atomicAdd(&fw.stat[3], (unsigned long long)st_c);
+            if (lane == 0) atomicAdd(&fw.stat[0], (unsigned long long)(tile_end > t_lo + gw * tiles_per_wave ? tile_end - (t_lo + gw * tiles_per_wave) : 0u) * 63ull * (FT_G / 4));
+        }
 }
 #undef DRPRG_SECOND_STAGE
+#undef DRPRG_BLOCK_TEST
+#undef DRPRG_STAGE2_APPEND
 
 // Second stage of the filter for the groups that passed level 0 (level-0 form of sketch_filter_kernel): one lane per
 // group tests its four k-mer codes against a 64 KB LDS-resident filter (four bits per code, < 15 % full); every wave
@@ -472,21 +559,28 @@ hipError_t launch_sketch_filter(const SketchArgs& a, uint32_t read_begin, uint32
     fw.read_begin = read_begin;
     fw.read_end = read_end;
     if (a.n_bases == 0) return hipSuccess;
-    if ((1u << bt.bloom_wbits) > (uint32_t)FT_BLOOM_WORDS) return hipErrorInvalidValue;
-    if (bt.bloom0 && (1u << bt.bloom0_wbits) != (uint32_t)FT_L0_WORDS) return hipErrorInvalidValue;
-    if (bt.bloom0 && (!b.raw_grp || !bt.bloomr || !bt.bloom0f)) return hipErrorInvalidValue;
+    const bool mid = bt.mid_bitmap != nullptr; // middle tier: level 0 (canonical 12-mers) in LDS, bitmap + code filter in global memory
+    if (mid && (a.k != 15 || !bt.mid0 || !bt.midc || bt.midc_wbits < 1 || bt.midc_wbits > MID_C_MAX_WBITS || (bt.mid0_bits != 1 && bt.mid0_bits != 3)))
+        return hipErrorInvalidValue;
+    if (!mid && (1u << bt.bloom_wbits) > (uint32_t)FT_BLOOM_WORDS) return hipErrorInvalidValue;
+    if (!mid && bt.bloom0 && (1u << bt.bloom0_wbits) != (uint32_t)FT_L0_WORDS) return hipErrorInvalidValue;
+    if (!mid && bt.bloom0 && (!b.raw_grp || !bt.bloomr || !bt.bloom0f)) return hipErrorInvalidValue;
     if (const char* dbg = std::getenv("DRPRG_FT_DEBUG")) fw.debug = (uint32_t)std::atoi(dbg); // 1 no filter test, 4 no level 0, 8 no read_cluster_kernel
-    const bool level0 = bt.bloom0 != nullptr && a.k == 15 && ((size_t)4 << bt.bloom_wbits) + (size_t)FT_L0_WORDS * 4 <= 160 * 1024
-        && !(fw.debug & 4u);
+    const bool level0 = mid || (bt.bloom0 != nullptr && a.k == 15 && ((size_t)4 << bt.bloom_wbits) + (size_t)FT_L0_WORDS * 4 <= 160 * 1024
+        && !(fw.debug & 4u));
     // the second stage inside the streaming kernel (default; its bits share the level-0 array) or as refine_kernel behind it
     // (DRPRG_FILTER_FORM=refine): 0.64 against 0.69 ms per 10 M reads, DESIGN.md section 6
     const char* form = std::getenv("DRPRG_FILTER_FORM");
-    const bool fused = level0 && !(form && std::string(form) == "refine");
+    const bool fused = mid || (level0 && !(form && std::string(form) == "refine"));
     fw.bloom = bt.bloom;
     fw.bloom_wbits = bt.bloom_wbits;
     fw.bloomr = bt.bloomr;
-    fw.bloom0 = level0 ? (fused ? bt.bloom0f : bt.bloom0) : nullptr;
-    fw.bloom0_wbits = level0 ? bt.bloom0_wbits : 0;
+    fw.bloom0 = mid ? bt.mid0 : (level0 ? (fused ? bt.bloom0f : bt.bloom0) : nullptr);
+    fw.bloom0_wbits = mid ? 15 : (level0 ? bt.bloom0_wbits : 0);
+    fw.mid_bitmap = bt.mid_bitmap;
+    fw.midc = bt.midc;
+    fw.midc_wbits = bt.midc_wbits;
+    fw.stat = mid ? b.stat : nullptr;
     const uint32_t grid = filter_grid(level0, n_cus, filter_n_tiles(a.n_bases));
     fw.n_slices = grid * FT_WAVES * FT_SUB;
     fw.raw_slice = (uint32_t)std::min<uint64_t>(b.raw_capacity / fw.n_slices, 0x7FFFFFFFull / fw.n_slices);
@@ -503,13 +597,15 @@ hipError_t launch_sketch_filter(const SketchArgs& a, uint32_t read_begin, uint32
     if (timer.begin) HIP_TRY(hipEventRecord(timer.begin, stream));
     {
         using Kernel = void (*)(SketchArgs, FilterWork);
-        const int which = level0 ? (fused ? 3 : 2) : (a.k < 12 ? 1 : 0);
-        const Kernel kernel = which == 3 ? &sketch_filter_kernel<false, true, true>
+        const int which = mid ? (bt.mid0_bits == 3 ? 4 : 5) : level0 ? (fused ? 3 : 2) : (a.k < 12 ? 1 : 0);
+        const Kernel kernel = which == 5 ? &sketch_filter_kernel<false, true, true, 1>
+            : which == 4                 ? &sketch_filter_kernel<false, true, true, 3>
+            : which == 3                 ? &sketch_filter_kernel<false, true, true>
             : which == 2                 ? &sketch_filter_kernel<false, true>
             : which == 1                 ? &sketch_filter_kernel<true, false>
                                          : &sketch_filter_kernel<false, false>;
         const size_t dyn = level0 ? (size_t)FT_L0_WORDS * 4 + (fused ? (size_t)FT_WAVES * 2048 : 0) : ((size_t)4 << bt.bloom_wbits);
-        static size_t configured[4][MAX_HIP_DEVICES] = {};
+        static size_t configured[6][MAX_HIP_DEVICES] = {};
         HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), dyn, configured[which]));
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(FT_THREADS), dyn, stream, a, fw);
     }

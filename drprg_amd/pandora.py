@@ -201,9 +201,10 @@ class Context:
         return dict(zip(names, (int(x) for x in out)))
 
     def table_tier(self):
-        out = (C.c_uint64 * 4)()
+        out = (C.c_uint64 * 6)()
         _check(lib.drprg_hip_device_tables(self._h, out), self._h)
-        return dict(pbloom_words=int(out[0]), table_bytes=int(out[1]), lds_filter_bytes=int(out[2]), kernel=int(out[3]))
+        return dict(pbloom_words=int(out[0]), table_bytes=int(out[1]), lds_filter_bytes=int(out[2]), kernel=int(out[3]),
+                    l2_filter_bytes=int(out[4]))
 
     def export_index(self):
         """Flat index (sorted keys + CSR records) in the layout oracle/oracle.c consumes."""

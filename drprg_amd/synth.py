@@ -374,6 +374,22 @@ def mtb_8d_panel(index_dir=None):
     return panel_from_index_dir(index_dir, fill_every=60)[0]
 
 
+def mtb_scaled_panel(scale, index_dir=None, seed=20230308, site_every=24):
+    """The 8d index grown `scale`-fold (round 3: how does the hot path behave between the 15 k k-mer nodes of the 8d index and
+    the 620 k of the 500-locus one?): the 18 genes of mtb_8d_panel() plus (scale - 1) x 18 further loci `<gene>_x<j>` of the same
+    padded lengths on seeded random backbones (65.6 % GC) with a site about every 24 bases (<= 4 alts, 10 % nested, 5 % indels),
+    which gives them the k-mer node density of the 8d genes (~0.49 nodes per base: ~14.9 k nodes per 18 loci).  Reads sampled from
+    HaplotypeGenomes of this panel hit it `scale` times as often as the 8d one (the loci cover scale x 0.7 % of the genome)."""
+    base = mtb_8d_panel(index_dir)
+    rng = np.random.default_rng(seed + 1000 * int(scale))
+    names, trees = list(base.names), list(base.trees)
+    for j in range(1, int(scale)):
+        for n, L in MTB_LOCI:
+            names.append(f"{n}_x{j}")
+            trees.append(make_locus(rng, L, site_every=site_every, indel_frac=0.05))
+    return Panel(names, trees)
+
+
 def haplotype_with(segs, choose):
     """sequence of a locus where site number i (in order) takes allele choose(i) (0 = reference allele)"""
     s, i = "", 0

@@ -458,8 +458,7 @@ def test_config4_500_locus_index(tmp_path, oracle, kernel):
     panel, genomes = _baseline_panel("big")
     ctx = _ctx(tmp_path, panel, 11, 15, True, genome_size=synth.MTB_GENOME_SIZE, kernel=kernel)
     assert ctx.n_keys > 500_000 and ctx.n_prgs == 500
-    sc = ctx.filter_selfcheck()
-    assert sc["codes"] == 0  # no LDS-resident filter for this index ...
+    assert ctx.table_tier()["lds_filter_bytes"] == 0 and ctx.table_tier()["l2_filter_bytes"] == 0  # no filter tier serves this index ...
     with pytest.raises(DependencyError):
         ctx.set_opts(illumina=True, genome_size=synth.MTB_GENOME_SIZE, kernel=2)  # ... so the filtered sequence is refused
     ctx.set_opts(illumina=True, genome_size=synth.MTB_GENOME_SIZE, kernel=kernel)
@@ -706,3 +705,88 @@ def test_second_stage_inside_the_streaming_kernel(tmp_path, oracle, monkeypatch)
     monkeypatch.setenv("DRPRG_FILTER_FORM", "refine")
     ctx = _ctx(tmp_path, panel, 11, 15, True, kernel=2)
     _compare(ctx, oracle, sparse[0], sparse[1], 11, 15, True, 2)
+
+
+# ---- middle tier of the filter (round 3): level 0 on canonical 12-mers in LDS, exact 12-mer bitmap + code filter in the L2 ----------
+_SCALED = {}
+
+
+def _scaled(scale):
+    from drprg_amd import synth
+    if scale not in _SCALED:
+        panel = synth.mtb_scaled_panel(scale, GOLDEN_INDEX_DIR)
+        _SCALED[scale] = (panel, synth.HaplotypeGenomes(panel, n_hap=8))
+    return _SCALED[scale]
+
+
+@pytest.mark.parametrize("scale", [2, 4, 8, 16])
+def test_scaled_mtb_indexes_take_the_middle_tier(tmp_path, oracle, scale):
+    """The 8d index grown 2-16 fold (30 k - 244 k k-mer nodes): too many k-mers for the all-LDS filter, so `auto` is the filtered
+    sequence in its middle-tier form; coverage and counters equal the oracle's, and the direct kernel's candidate form agrees."""
+    from drprg_amd import synth
+    panel, genomes = _scaled(scale)
+    n = 600_000 if scale <= 4 else 300_000
+    bases, offs = synth.sample_short_reads(genomes, n, seed=20 + scale)
+    ctx = _ctx(tmp_path, panel, 11, 15, True, genome_size=synth.MTB_GENOME_SIZE, kernel=0)
+    tier = ctx.table_tier()
+    assert tier["kernel"] == 2 and tier["l2_filter_bytes"] >= 2 << 20 and tier["lds_filter_bytes"] == 128 << 10
+    sc = ctx.filter_selfcheck()
+    assert sc["codes"] == 2 * ctx.n_records and sc["level0_false_negatives"] == sc["level12_false_negatives"] == sc["stage2_false_negatives"] == 0
+    cnt = _compare(ctx, oracle, bases, offs, 11, 15, True, 2, threads=ORACLE_THREADS)
+    assert cnt["clusters_kept"] > 2000 * scale
+    if not FORCED_GENERIC:
+        assert ctx.counters()["leftover_reads"] == 0
+    if scale in (2, 16):
+        ctx3 = _ctx(tmp_path, panel, 11, 15, True, genome_size=synth.MTB_GENOME_SIZE, kernel=3)
+        _compare(ctx3, oracle, bases, offs, 11, 15, True, 3, threads=ORACLE_THREADS)
+
+
+def test_scaled_mtb_index_long_reads_middle_tier(tmp_path, oracle):
+    from drprg_amd import synth
+    panel, genomes = _scaled(4)
+    bases, offs = synth.sample_long_reads(genomes, 12_000, seed=31)
+    ctx = _ctx(tmp_path, panel, 11, 15, False, genome_size=synth.MTB_GENOME_SIZE, kernel=0)
+    assert ctx.table_tier()["l2_filter_bytes"] > 0
+    cnt = _compare(ctx, oracle, bases, offs, 11, 15, False, 2, threads=ORACLE_THREADS)
+    assert cnt["clusters_kept"] > 300
+
+
+@pytest.mark.parametrize("w", [11, 14, 1])
+def test_middle_tier_on_small_panels(tmp_path, oracle, monkeypatch, w):
+    """DRPRG_FORCE_MID_TIER=1 builds the middle-tier tables for an index the all-LDS filter would serve, so the edge cases of the
+    small panels run through it: ragged / empty / N-containing / lower-case reads, tiles dense with index k-mers (more groups than
+    the stage holds), long noisy reads."""
+    from drprg_amd import synth
+    monkeypatch.setenv("DRPRG_FORCE_MID_TIER", "1")
+    panel = synth.small_panel(seed=2)
+    ctx = _ctx(tmp_path, panel, w, 15, True, kernel=2)
+    assert ctx.table_tier()["l2_filter_bytes"] > 0
+    rng = np.random.default_rng(0)
+    gen = synth.HaplotypeGenomes(panel, genome_size=20000, n_hap=2, seed=3)
+    g = gen.haps[0]
+    reads = []
+    for i in range(12000):
+        L = int(rng.choice([0, 1, 14, 15, 24, 25, 26, 40, 150, 151, 300, 4064, 4096, 5000, 8160, 8192]))
+        s = int(rng.integers(0, len(g) - L))
+        r = g[s:s + L].copy()
+        if L and rng.random() < 0.3:
+            r[rng.integers(0, L, size=max(1, L // 50))] = ord("N")
+        if L and rng.random() < 0.2:
+            r = np.frombuffer(r.tobytes().lower(), dtype=np.uint8)
+        reads.append(r)
+    offs = np.zeros(len(reads) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(r) for r in reads])
+    _compare(ctx, oracle, np.concatenate(reads), offs, w, 15, True, 2)
+    # amplicon-like: every read inside the panel
+    dense_panel = synth.small_panel(seed=6, n_loci=3, length=900)
+    haps = [synth.sample_haplotype(rng, t).encode() for t in dense_panel.trees]
+    bases, offs = _reads_from(rng, haps, 6000, 150)
+    ctx = _ctx(tmp_path, dense_panel, w, 15, True, kernel=2)
+    cnt = _compare(ctx, oracle, bases, offs, w, 15, True, 2)
+    assert cnt["clusters_kept"] > 3000
+    # long noisy reads
+    lp = synth.small_panel(seed=11, n_loci=6, length=1500)
+    ctx = _ctx(tmp_path, lp, w, 15, False, kernel=2)
+    gen = synth.HaplotypeGenomes(lp, genome_size=60000, n_hap=4, seed=3)
+    bases, offs = synth.sample_long_reads(gen, 1500, seed=3)
+    _compare(ctx, oracle, bases, offs, w, 15, False, 2)
