@@ -137,6 +137,9 @@ WORKLOADS = {
 }
 # the 8d index grown 2-32 fold (drprg_amd.synth.mtb_scaled_panel: 30 k ... 489 k k-mer nodes): how the hot path degrades between the
 # 15 k nodes of the 8d index and the 620 k of the 500-locus one (not BASELINE configurations; profiles/r03 holds a line per size)
+WORKLOADS["mtb-dense"] = ("configs[1] reads, denser index", "10M synthetic 150 bp Illumina reads vs the 8d genes with a seeded SNP bubble about every 8 "
+                          "bases between the panel sites (36 k k-mer nodes on the same 30 kb: the index grows, the hits do not)", 10_000_000, True,
+                          "mtb_dense")
 for _s in (2, 4, 8, 16, 32):
     WORKLOADS[f"mtb-x{_s}"] = ("configs[1] reads, larger index", f"10M synthetic 150 bp Illumina reads vs the 8d mtb-like index grown {_s}-fold "
                                f"({18 * _s} loci)", 10_000_000, True, f"mtb_x{_s}")
@@ -155,6 +158,8 @@ def cpu_model():
 def make_panel(synth, which):
     if which.startswith("mtb_x"):
         return synth.mtb_scaled_panel(int(which[5:]))
+    if which == "mtb_dense":
+        return synth.panel_from_index_dir(os.path.join(ROOT, "tests", "golden", "downstream"), fill_every=8)[0]
     return {"mtb_8d": synth.mtb_8d_panel, "mtb_like": synth.mtb_like_panel, "big": synth.big_panel}[which]()
 
 
@@ -213,7 +218,7 @@ def full_size_checks(torch, ctx, opts, bases, offsets, n_reads, covg, prg_reads,
         direct = torch.zeros_like(covg)
         map_range(ctx, bases, offsets, 0, n_reads, direct, sp, stream, torch)
         kernels_agree = bool(torch.equal(full, direct))
-        ctx.set_opts(kernel=0, **opts)
+        ctx.set_opts(kernel=int(os.environ.get("DRPRG_BENCH_KERNEL", "0")), **opts)
     return shard_invariant, kernels_agree
 
 
@@ -343,7 +348,8 @@ def main():
     panel.write(prg, os.path.join(tmp, "genes.fa"))
     ctx = Context(prg, W, K, device=local_rank, from_files=False, threads=8)
     opts = dict(illumina=illumina, min_cluster_size=10, genome_size=synth.MTB_GENOME_SIZE)
-    ctx.set_opts(**opts)
+    forced_kernel = int(os.environ.get("DRPRG_BENCH_KERNEL", "0"))  # experiments: 3 = the direct sequence where auto picks the filtered one
+    ctx.set_opts(kernel=forced_kernel, **opts)
 
     # synthetic reads, generated on the device; every rank samples a different shard (seed + rank)
     genomes = synth.HaplotypeGenomes(panel, n_hap=8)

@@ -720,11 +720,18 @@ def _scaled(scale):
 
 
 @pytest.mark.parametrize("scale", [2, 4, 8, 16])
-def test_scaled_mtb_indexes_take_the_middle_tier(tmp_path, oracle, scale):
+def test_scaled_mtb_indexes_take_the_middle_tier(tmp_path, oracle, monkeypatch, scale):
     """The 8d index grown 2-16 fold (30 k - 244 k k-mer nodes): too many k-mers for the all-LDS filter, so `auto` is the filtered
-    sequence in its middle-tier form; coverage and counters equal the oracle's, and the direct kernel's candidate form agrees."""
+    sequence in its middle-tier form (up to 180 k index records; beyond that the direct sequence is faster and `auto` takes it:
+    the 16-fold index is pushed through the middle tier here all the same); coverage and counters equal the oracle's, and the
+    direct kernel's candidate form agrees."""
     from drprg_amd import synth
     panel, genomes = _scaled(scale)
+    if scale == 16:
+        ctx = _ctx(tmp_path, panel, 11, 15, True, genome_size=synth.MTB_GENOME_SIZE, kernel=0)
+        assert ctx.table_tier()["kernel"] == 3 and ctx.table_tier()["l2_filter_bytes"] == 0
+        ctx.close()
+        monkeypatch.setenv("DRPRG_MID_MAX_RECORDS", "1000000")
     n = 600_000 if scale <= 4 else 300_000
     bases, offs = synth.sample_short_reads(genomes, n, seed=20 + scale)
     ctx = _ctx(tmp_path, panel, 11, 15, True, genome_size=synth.MTB_GENOME_SIZE, kernel=0)
