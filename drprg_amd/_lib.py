@@ -48,6 +48,12 @@ SIGNATURES = {
     "drprg_hip_open": (C.c_void_p, [C.c_char_p, C.c_int, C.c_int, C.c_int]),
     "drprg_hip_open_prg": (C.c_void_p, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "drprg_hip_open_multi": (C.c_void_p, [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int]),
+    "drprg_hip_reduce": (C.c_int, [C.c_void_p]),
+    "drprg_hip_reduce_info": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
+    "drprg_hip_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "drprg_hip_comm_init_rank": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int, C.c_int]),
+    "drprg_hip_comm_destroy": (C.c_int, [C.c_void_p]),
+    "drprg_hip_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "drprg_hip_close": (None, [C.c_void_p]),
     "drprg_hip_last_error": (C.c_char_p, [C.c_void_p]),
     "drprg_hip_set_opts": (C.c_int, [C.c_void_p, C.POINTER(MapOpts)]),

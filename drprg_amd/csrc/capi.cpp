@@ -11,6 +11,7 @@
 #include "pgunzip.h"
 #include "denovo.h"
 #include "mapper.h"
+#include "rccl_dyn.h"
 #include <cstdlib>
 #include <cstring>
 #include <fcntl.h>
@@ -43,8 +44,15 @@ struct drprg_hip_ctx {
     // page-locked ingest blocks of drprg_hip_map_fastx, recycled between calls
     std::mutex pin_mu;
     std::vector<std::pair<void*, size_t>> pin_free, pin_busy;
+    // multi-device context: RCCL communicators of its devices (created on first use; empty when RCCL is not used)
+    std::vector<Rccl::Comm> comms;
+    std::string reduce_how; // how the last drprg_hip_reduce summed the vectors (drprg_hip_reduce_info)
     ~drprg_hip_ctx()
     {
+        if (!comms.empty())
+            if (const Rccl* r = Rccl::get())
+                for (Rccl::Comm c : comms)
+                    if (c) (void)r->CommDestroy(c);
         for (auto& b : pin_free) Mapper::pinned_free(b.first);
         for (auto& b : pin_busy) Mapper::pinned_free(b.first);
     }
@@ -80,6 +88,63 @@ static void apply_defaults(MapParams& p, const drprg_hip_map_opts* o)
     p.genome_size = (o && o->genome_size) ? o->genome_size : 5000000;
     p.genotyping_error_rate = (o && o->genotyping_error_rate > 0) ? o->genotyping_error_rate : 0.01;
     p.kernel_mode = o ? o->kernel : 0;
+}
+
+// Sum of the per-device coverage vectors of a multi-device context into its first device, on the devices (SURVEY.md section 8e:
+// "one ncclReduce(sum, u32) after the last batch").  All devices distinct and RCCL present: one communicator over them
+// (ncclCommInitAll, kept by the context) and two ncclReduce calls (coverage, reads per PRG) per device inside one group.  A
+// device listed twice (what the one-GPU tests do), no RCCL, or DRPRG_HIP_NO_RCCL=1: peer copy into device 0 + an add kernel,
+// device after device.  Then the other devices' vectors are cleared and their counters folded into the context.
+static void reduce_devices(drprg_hip_ctx* ctx)
+{
+    if (ctx->extra.empty() || !ctx->mapper) return;
+    Mapper& m = *ctx->mapper;
+    std::vector<Mapper*> all { &m };
+    for (auto& e : ctx->extra) all.push_back(e.get());
+    for (Mapper* x : all) x->sync();
+    bool distinct = true;
+    for (size_t i = 0; i < all.size(); ++i)
+        for (size_t j = i + 1; j < all.size(); ++j) distinct &= all[i]->device() != all[j]->device();
+    const char* no = std::getenv("DRPRG_HIP_NO_RCCL");
+    std::string why;
+    const Rccl* r = (distinct && !(no && *no && *no != '0')) ? Rccl::get(&why) : nullptr;
+    bool done = false;
+    if (r) {
+        auto chk = [&](int rc, const char* what) {
+            if (rc != Rccl::Success) throw Error(DRPRG_EIO, std::string("RCCL ") + what + ": " + (r->GetErrorString ? r->GetErrorString(rc) : "error"));
+        };
+        if (ctx->comms.empty()) {
+            std::vector<int> devs;
+            for (Mapper* x : all) devs.push_back(x->device());
+            ctx->comms.assign(all.size(), nullptr);
+            chk(r->CommInitAll(ctx->comms.data(), (int)all.size(), devs.data()), "ncclCommInitAll");
+        }
+        const size_t nc = 2 * (size_t)m.n_knodes(), np = m.n_prgs();
+        chk(r->GroupStart(), "ncclGroupStart");
+        for (size_t d = 0; d < all.size(); ++d) {
+            if (hipSetDevice(all[d]->device()) != hipSuccess) throw Error(DRPRG_EIO, "hipSetDevice failed");
+            chk(r->Reduce(all[d]->d_covg(), all[d]->d_covg(), nc, Rccl::Uint32, Rccl::Sum, 0, ctx->comms[d], all[d]->stream()), "ncclReduce");
+            chk(r->Reduce(all[d]->d_prg_reads(), all[d]->d_prg_reads(), np, Rccl::Uint32, Rccl::Sum, 0, ctx->comms[d], all[d]->stream()), "ncclReduce");
+        }
+        chk(r->GroupEnd(), "ncclGroupEnd");
+        for (Mapper* x : all) {
+            if (hipSetDevice(x->device()) != hipSuccess || hipStreamSynchronize(x->stream()) != hipSuccess) throw Error(DRPRG_EIO, "stream synchronisation after ncclReduce failed");
+        }
+        ctx->reduce_how = "rccl: ncclReduce(sum, u32) over " + std::to_string(all.size()) + " devices";
+        done = true;
+    }
+    if (!done) {
+        for (auto& e : ctx->extra) m.add_vectors_from(*e);
+        ctx->reduce_how = std::string("device add: peer copy + add kernel per device (") + (distinct ? (why.empty() ? "RCCL switched off" : why) : "a device is listed twice") + ")";
+    }
+    for (auto& e : ctx->extra) {
+        const MapCounters k = e->counters();
+        ctx->extra_counts.reads += k.reads; ctx->extra_counts.bases += k.bases; ctx->extra_counts.minimizers += k.minimizers;
+        ctx->extra_counts.hits += k.hits; ctx->extra_counts.clusters_kept += k.clusters_kept;
+        ctx->extra_counts.hits_kept += k.hits_kept; ctx->extra_counts.leftover_reads += k.leftover_reads;
+        e->reset_coverage();
+    }
+    ctx->host_coverage_valid = false;
 }
 
 extern "C" {
@@ -224,7 +289,8 @@ int drprg_hip_map_fastx(drprg_hip_ctx* ctx, const char* reads_path)
     std::atomic<size_t> next_dev { 0 };
     auto mapper_of = [&](size_t d) -> Mapper& { return d == 0 ? m : *ctx->extra[d - 1]; };
     if (ndev == 1) {
-        hooks.submit = [&](const PinnedBatch& b) { m.map_host(b.bases, b.offsets, b.n_reads); };
+        // (the copy of a block overlaps the kernels of the block before it: Mapper::map_host_async)
+        hooks.submit = [&](const PinnedBatch& b) { m.map_host_async(b.bases, b.offsets, b.n_reads); };
     } else {
         hooks.concurrent_submit = true;
         hooks.submit = [&](const PinnedBatch& b) {
@@ -233,30 +299,20 @@ int drprg_hip_map_fastx(drprg_hip_ctx* ctx, const char* reads_path)
                 const size_t d = (first + i) % ndev;
                 std::unique_lock<std::mutex> l(dev_mu[d], std::try_to_lock);
                 if (!l.owns_lock()) continue;
-                mapper_of(d).map_host(b.bases, b.offsets, b.n_reads);
+                mapper_of(d).map_host_async(b.bases, b.offsets, b.n_reads);
                 return;
             }
             std::lock_guard<std::mutex> l(dev_mu[first]); // all busy: wait for the round-robin choice
-            mapper_of(first).map_host(b.bases, b.offsets, b.n_reads);
+            mapper_of(first).map_host_async(b.bases, b.offsets, b.n_reads);
         };
     }
-    // the coverage vectors of the other devices are summed into device 0 (unsigned sums commute: the result does not
-    // depend on which device mapped which block), their counters folded into the context
+    // the coverage vectors of the other devices are summed into device 0 ON THE DEVICE (drprg_hip_reduce: one RCCL reduce over
+    // the devices of the context, or a peer copy + add kernel per device); unsigned sums commute, so the result does not depend
+    // on which device mapped which block
     auto fold = [&]() {
-        if (ctx->extra.empty()) return;
-        std::vector<uint32_t> total, prg_total, c, p;
-        m.download(total, prg_total);
-        for (auto& e : ctx->extra) {
-            e->download(c, p);
-            for (size_t i = 0; i < total.size(); ++i) total[i] += c[i];
-            for (size_t i = 0; i < prg_total.size(); ++i) prg_total[i] += p[i];
-            const MapCounters k = e->counters();
-            ctx->extra_counts.reads += k.reads; ctx->extra_counts.bases += k.bases; ctx->extra_counts.minimizers += k.minimizers;
-            ctx->extra_counts.hits += k.hits; ctx->extra_counts.clusters_kept += k.clusters_kept;
-            ctx->extra_counts.hits_kept += k.hits_kept; ctx->extra_counts.leftover_reads += k.leftover_reads;
-            e->reset_coverage();
-        }
-        m.upload(total, prg_total);
+        m.sync();
+        for (auto& e : ctx->extra) e->sync();
+        reduce_devices(ctx);
     };
     try {
         IngestStats st = ingest_fastx(reads_path, ctx->threads, hooks);
@@ -322,6 +378,97 @@ int drprg_hip_sync(drprg_hip_ctx* ctx)
 {
     API_BEGIN(ctx)
     if (ctx->mapper) ctx->mapper->sync();
+    API_END(ctx)
+}
+
+int drprg_hip_reduce(drprg_hip_ctx* ctx)
+{
+    API_BEGIN(ctx)
+    need_mapper(ctx);
+    reduce_devices(ctx);
+    API_END(ctx)
+}
+
+int drprg_hip_reduce_info(const drprg_hip_ctx* ctx, char* out, size_t cap)
+{
+    if (!ctx || !out || cap == 0) return DRPRG_EINVAL;
+    std::snprintf(out, cap, "%s", ctx->reduce_how.c_str());
+    return DRPRG_OK;
+}
+
+int drprg_hip_comm_unique_id(uint8_t id[128])
+{
+    if (!id) return DRPRG_EINVAL;
+    std::string why;
+    const Rccl* r = Rccl::get(&why);
+    if (!r) {
+        g_last_error = why;
+        return DRPRG_ENODEV;
+    }
+    Rccl::UniqueId u;
+    const int rc = r->GetUniqueId(&u);
+    if (rc != Rccl::Success) {
+        g_last_error = std::string("ncclGetUniqueId: ") + r->GetErrorString(rc);
+        return DRPRG_EIO;
+    }
+    std::memcpy(id, u.internal, sizeof u.internal);
+    return DRPRG_OK;
+}
+
+int drprg_hip_comm_init_rank(void** comm, int nranks, const uint8_t id[128], int rank, int device)
+{
+    if (!comm || !id || nranks < 1 || rank < 0 || rank >= nranks || device < 0) return DRPRG_EINVAL;
+    std::string why;
+    const Rccl* r = Rccl::get(&why);
+    if (!r) {
+        g_last_error = why;
+        return DRPRG_ENODEV;
+    }
+    if (hipSetDevice(device) != hipSuccess) {
+        g_last_error = "hipSetDevice failed";
+        return DRPRG_ENODEV;
+    }
+    Rccl::UniqueId u;
+    std::memcpy(u.internal, id, sizeof u.internal);
+    Rccl::Comm c = nullptr;
+    const int rc = r->CommInitRank(&c, nranks, u, rank);
+    if (rc != Rccl::Success) {
+        g_last_error = std::string("ncclCommInitRank: ") + r->GetErrorString(rc);
+        return DRPRG_EIO;
+    }
+    *comm = c;
+    return DRPRG_OK;
+}
+
+int drprg_hip_comm_destroy(void* comm)
+{
+    if (!comm) return DRPRG_OK;
+    const Rccl* r = Rccl::get();
+    if (!r) return DRPRG_ENODEV;
+    return r->CommDestroy(comm) == Rccl::Success ? DRPRG_OK : DRPRG_EIO;
+}
+
+int drprg_hip_allreduce(drprg_hip_ctx* ctx, void* comm, void* d_covg, void* d_prg_reads, void* hip_stream)
+{
+    API_BEGIN(ctx)
+    Mapper& m = need_mapper(ctx);
+    if (!comm) throw Error(DRPRG_EINVAL, "null communicator");
+    std::string why;
+    const Rccl* r = Rccl::get(&why);
+    if (!r) throw Error(DRPRG_ENODEV, why);
+    m.sync(); // a batch queued by map_device_async may still need the host (leftover reads) before its vector is final
+    if (hipSetDevice(m.device()) != hipSuccess) throw Error(DRPRG_EIO, "hipSetDevice failed");
+    uint32_t* c = d_covg ? (uint32_t*)d_covg : m.d_covg();
+    uint32_t* p = d_prg_reads ? (uint32_t*)d_prg_reads : m.d_prg_reads();
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : m.stream();
+    auto chk = [&](int rc, const char* what) {
+        if (rc != Rccl::Success) throw Error(DRPRG_EIO, std::string("RCCL ") + what + ": " + r->GetErrorString(rc));
+    };
+    chk(r->GroupStart(), "ncclGroupStart");
+    chk(r->AllReduce(c, c, 2 * (size_t)m.n_knodes(), Rccl::Uint32, Rccl::Sum, comm, st), "ncclAllReduce");
+    chk(r->AllReduce(p, p, (size_t)m.n_prgs(), Rccl::Uint32, Rccl::Sum, comm, st), "ncclAllReduce");
+    chk(r->GroupEnd(), "ncclGroupEnd");
+    ctx->host_coverage_valid = false; // (asynchronous on the stream: the caller synchronises it, or reads through this context, which does)
     API_END(ctx)
 }
 

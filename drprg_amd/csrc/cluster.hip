@@ -1,6 +1,7 @@
 // cluster.hip -- K3: per-read hit clustering, size / overlap filters and atomic coverage accumulation on the
 // sorted hit list (pandora define_clusters / filter_clusters / add_hits_to_kmergraphs).
 #include "device_common.h"
+#include <algorithm>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -204,6 +205,20 @@ hipError_t launch_cluster_pipeline(const ClusterArgs& a, uint32_t n_hits, uint32
     hipLaunchKernelGGL(cluster_count_kernel, dim3(256), dim3(256), 0, stream, a, n_prgs);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(accumulate_kernel, dim3((n_hits + 255) / 256), dim3(256), 0, stream, a, n_hits);
+    return hipGetLastError();
+}
+
+// dst[i] += src[i]: the device-side sum of two coverage vectors (several devices in one process: capi.cpp drprg_hip_reduce)
+__global__ __launch_bounds__(256) void vector_add_u32_kernel(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, uint64_t n)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) dst[i] += src[i];
+}
+
+hipError_t launch_vector_add_u32(uint32_t* dst, const uint32_t* src, uint64_t n, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(vector_add_u32_kernel, dim3(grid), dim3(256), 0, stream, dst, src, n);
     return hipGetLastError();
 }
 

@@ -252,6 +252,7 @@ hipError_t launch_cluster_flags(const uint64_t* key, uint32_t n, int max_diff, u
     size_t temp_bytes, hipStream_t stream);
 hipError_t launch_cluster_starts(const uint32_t* head, const uint32_t* scan, uint32_t n, uint32_t* cstart, hipStream_t stream);
 hipError_t launch_cluster_pipeline(const ClusterArgs& a, uint32_t n_hits, uint32_t n_prgs, hipStream_t stream);
+hipError_t launch_vector_add_u32(uint32_t* dst, const uint32_t* src, uint64_t n, hipStream_t stream); // dst[i] += src[i]
 
 } // namespace dev
 } // namespace drprg

@@ -188,6 +188,12 @@ Mapper::~Mapper()
     if (d_tile_temp_) (void)hipFree(d_tile_temp_);
     dfree(d_bases_); dfree(d_offsets_); dfree(d_tile_first_); dfree(d_bloom_); dfree(d_bloom0_); dfree(d_bloom0f_); dfree(d_bloomr_); dfree(d_pbloom_); dfree(d_mid0_); dfree(d_mid_bitmap_); dfree(d_midc_); dfree(d_ft_stat_);
     for (Lane& lane : lanes_) free_lane(lane);
+    for (Stage& st : stage_) {
+        dfree(st.d_bases); dfree(st.d_offsets);
+        if (st.copied) (void)hipEventDestroy(st.copied);
+    }
+    dfree(d_peer_tmp_);
+    if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
     if (ev_begin_) (void)hipEventDestroy(ev_begin_);
     if (h_counters_) (void)hipHostFree(h_counters_);
     if (h_bases_) (void)hipHostFree(h_bases_);
@@ -680,11 +686,14 @@ void Mapper::map_device_async(const uint8_t* d_bases, const uint64_t* d_offsets,
     cur.covg = covg;
     cur.prg_reads = prg_reads;
     cur.stream = stream;
-    complete_pending(); // the batch before this one, while this one runs
+    // the batch just queued is registered before the previous one is completed: if completing that one throws (a read too long,
+    // an overflow that does not go away, a HIP error) the queued batch is still known to sync() and to the next call
+    const Pending prev = pending_;
     pending_ = cur;
     pipe_next_ ^= 1;
     tot_reads_ += n_reads;
     tot_bases_ += n_bases;
+    if (prev.active) complete_batch(prev); // the batch before this one, while this one runs
 }
 
 void Mapper::complete_pending()
@@ -692,6 +701,11 @@ void Mapper::complete_pending()
     if (!pending_.active) return;
     const Pending p = pending_;
     pending_.active = false;
+    complete_batch(p);
+}
+
+void Mapper::complete_batch(const Pending& p)
+{
     HIPCHK(hipSetDevice(device_));
     Lane& lane = pipe_lanes_[(size_t)p.lane];
     static const bool spin = [] {
@@ -835,6 +849,68 @@ void Mapper::map_host(const uint8_t* bases, const uint64_t* offsets, uint64_t n_
     HIPCHK(hipMemcpyAsync(d_offsets_, offsets, (n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream_));
     map_device(d_bases_, d_offsets_, n_reads, n_bases, nullptr, nullptr, stream_);
     HIPCHK(hipStreamSynchronize(stream_)); // the staging buffers are reused by the next call
+}
+
+void Mapper::map_host_async(const uint8_t* bases, const uint64_t* offsets, uint64_t n_reads)
+{
+    if (n_reads == 0) return;
+    if (!use_filter_ || max_lanes_ > 1) { // no deferred form of this sequence
+        map_host(bases, offsets, n_reads);
+        return;
+    }
+    HIPCHK(hipSetDevice(device_));
+    if (offsets[0] != 0) throw Error(DRPRG_EINVAL, "offsets[0] must be 0");
+    const uint64_t n_bases = offsets[n_reads];
+    if (n_bases == 0) { // only empty reads: nothing to copy, nothing to map (the counters still see them)
+        tot_reads_ += n_reads;
+        return;
+    }
+    if (!copy_stream_) HIPCHK(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
+    // the batch that used this staging set two calls ago was completed by the previous call (map_device_async completes the batch
+    // before the one it queues), so the set is free
+    Stage& st = stage_[stage_next_];
+    stage_next_ ^= 1;
+    if (!st.copied) HIPCHK(hipEventCreateWithFlags(&st.copied, hipEventDisableTiming));
+    if (n_bases + 64 > st.bases_cap) {
+        sync(); // (freeing device memory waits for the device; be explicit about the batch in flight)
+        dfree(st.d_bases);
+        st.bases_cap = n_bases + n_bases / 4 + 64;
+        dmalloc(st.d_bases, st.bases_cap);
+    }
+    if (n_reads + 1 > st.reads_cap) {
+        sync();
+        dfree(st.d_offsets);
+        st.reads_cap = n_reads + n_reads / 4 + 1;
+        dmalloc(st.d_offsets, st.reads_cap);
+    }
+    HIPCHK(hipMemcpyAsync(st.d_bases, bases, n_bases, hipMemcpyHostToDevice, copy_stream_));
+    HIPCHK(hipMemcpyAsync(st.d_offsets, offsets, (n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, copy_stream_));
+    HIPCHK(hipEventRecord(st.copied, copy_stream_));
+    HIPCHK(hipStreamWaitEvent(stream_, st.copied, 0));
+    map_device_async(st.d_bases, st.d_offsets, n_reads, n_bases, nullptr, nullptr, stream_);
+    HIPCHK(hipEventSynchronize(st.copied)); // the caller's block is free again; the kernels run on
+}
+
+void Mapper::add_vectors_from(Mapper& other)
+{
+    if (other.n_knodes_ != n_knodes_ || other.n_prgs_ != n_prgs_) throw Error(DRPRG_EINVAL, "coverage size mismatch");
+    other.sync();
+    HIPCHK(hipSetDevice(other.device_));
+    HIPCHK(hipStreamSynchronize(other.stream_));
+    sync();
+    HIPCHK(hipSetDevice(device_));
+    const size_t nc = 2 * (size_t)n_knodes_, np = n_prgs_;
+    const uint32_t *src_c = other.d_covg_, *src_p = other.d_prg_reads_;
+    if (other.device_ != device_) {
+        if (!d_peer_tmp_) dmalloc(d_peer_tmp_, nc + np);
+        HIPCHK(hipMemcpyPeerAsync(d_peer_tmp_, device_, other.d_covg_, other.device_, nc * sizeof(uint32_t), stream_));
+        HIPCHK(hipMemcpyPeerAsync(d_peer_tmp_ + nc, device_, other.d_prg_reads_, other.device_, np * sizeof(uint32_t), stream_));
+        src_c = d_peer_tmp_;
+        src_p = d_peer_tmp_ + nc;
+    }
+    HIPCHK(dev::launch_vector_add_u32(d_covg_, src_c, nc, stream_));
+    HIPCHK(dev::launch_vector_add_u32(d_prg_reads_, src_p, np, stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
 }
 
 void Mapper::download(std::vector<uint32_t>& covg, std::vector<uint32_t>& prg_reads)

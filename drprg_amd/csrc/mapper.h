@@ -49,6 +49,14 @@ public:
 
     // Map a host batch (copies through pinned staging buffers, then map_device on the own accumulators).
     void map_host(const uint8_t* bases, const uint64_t* offsets, uint64_t n_reads);
+    // The same without waiting for the kernels: the copy to the device runs on a copy stream into one of two staging sets, the
+    // launch sequence is queued behind it (map_device_async) and the call returns as soon as the COPY is done -- the host block
+    // may be reused then -- so that the next block's copy overlaps this block's kernels.  sync() (or anything that reads
+    // results) completes what is in flight.  Sequences without a deferred form fall back to map_host.
+    void map_host_async(const uint8_t* bases, const uint64_t* offsets, uint64_t n_reads);
+    // this += other, on the device (the other Mapper's vectors are left as they are): peer copy into a scratch buffer + one
+    // add kernel, or the add kernel alone when both live on the same device.  Both are synchronised first.
+    void add_vectors_from(Mapper& other);
 
     // page-locked host memory for ingest blocks (H2D copies from it run at DMA speed)
     static void* pinned_alloc(size_t bytes);
@@ -120,6 +128,7 @@ private:
         hipStream_t stream = nullptr;
     };
     void complete_pending();
+    void complete_batch(const Pending& p);
     void finish_lane(Lane& lane, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads, uint64_t n_bases, uint32_t* covg,
         uint32_t* prg_reads, hipStream_t stream);
     Pending pending_;
@@ -199,6 +208,17 @@ private:
     uint8_t* d_bases_ = nullptr;
     uint64_t* d_offsets_ = nullptr;
     uint64_t stage_bases_cap_ = 0, stage_reads_cap_ = 0;
+    // map_host_async: two staging sets taken in turn, their copies on a stream of their own
+    struct Stage {
+        uint8_t* d_bases = nullptr;
+        uint64_t* d_offsets = nullptr;
+        uint64_t bases_cap = 0, reads_cap = 0;
+        hipEvent_t copied = nullptr;
+    };
+    Stage stage_[2];
+    int stage_next_ = 0;
+    hipStream_t copy_stream_ = nullptr;
+    uint32_t* d_peer_tmp_ = nullptr; // add_vectors_from: the other device's vectors on this device
     // timing
     bool timing_ = false;
     double sketch_ms_ = 0;

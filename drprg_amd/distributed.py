@@ -35,16 +35,52 @@ def reduce_coverage(covg, prg_reads, total_bases, group=None):
         return int(total_bases)
     # ONE collective: coverage, per-PRG cluster counts and the base count travel in one int32 buffer --
     # the message is a few hundred KB at most, so the exchange is latency-bound and every extra collective costs a round trip
+    if not (covg.is_contiguous() and prg_reads.is_contiguous()) or covg.dtype != torch.int32 or prg_reads.dtype != torch.int32:
+        raise ValueError("reduce_coverage works in place: covg / prg_reads must be contiguous int32 tensors")
     tb = int(total_bases)
     n_c, n_p = covg.numel(), prg_reads.numel()
     buf = torch.empty(n_c + n_p + 4, dtype=torch.int32, device=covg.device)
-    buf[:n_c] = covg.reshape(-1)
-    buf[n_c:n_c + n_p] = prg_reads.reshape(-1)
+    buf[:n_c] = covg.view(-1)
+    buf[n_c:n_c + n_p] = prg_reads.view(-1)
     # the 64-bit base count as four 16-bit pieces (int32 lanes do not carry into each other)
     pieces = torch.tensor([tb & 0xFFFF, (tb >> 16) & 0xFFFF, (tb >> 32) & 0xFFFF, tb >> 48], dtype=torch.int32, device=covg.device)
     buf[n_c + n_p:] = pieces
     dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
-    covg.reshape(-1).copy_(buf[:n_c])
-    prg_reads.reshape(-1).copy_(buf[n_c:n_c + n_p])
+    covg.view(-1).copy_(buf[:n_c])
+    prg_reads.view(-1).copy_(buf[n_c:n_c + n_p])
     p = [int(x) for x in buf[n_c + n_p:].tolist()]  # each piece summed over <= 2^15 ranks stays below 2^31
     return p[0] + (p[1] << 16) + (p[2] << 32) + (p[3] << 48)
+
+
+class NativeComm:
+    """RCCL communicator made through the C ABI (drprg_hip_comm_*), one rank per process / GPU: what a host without PyTorch
+    would use.  `exchange(id_bytes_or_None) -> id_bytes` is whatever channel the host has for handing rank 0's 128-byte id to
+    the other ranks (bench.py: a torch.distributed broadcast; a Rust host: its own launcher)."""
+
+    def __init__(self, rank, world, device, exchange):
+        import ctypes as C
+        from ._lib import lib
+        self._lib = lib
+        ident = (C.c_uint8 * 128)()
+        if rank == 0:
+            rc = lib.drprg_hip_comm_unique_id(ident)
+            if rc != 0:
+                raise RuntimeError(f"drprg_hip_comm_unique_id: {lib.drprg_hip_last_error(None).decode()} ({rc})")
+        raw = exchange(bytes(ident) if rank == 0 else None)
+        ident = (C.c_uint8 * 128).from_buffer_copy(raw)
+        comm = C.c_void_p()
+        rc = lib.drprg_hip_comm_init_rank(C.byref(comm), world, ident, rank, device)
+        if rc != 0:
+            raise RuntimeError(f"drprg_hip_comm_init_rank: {lib.drprg_hip_last_error(None).decode()} ({rc})")
+        self.handle = comm
+
+    def allreduce(self, ctx, d_covg=None, d_prg_reads=None, stream=None):
+        """in-place sum of the context's (or the given) device vectors over the ranks; asynchronous on the stream"""
+        rc = self._lib.drprg_hip_allreduce(ctx._h, self.handle, d_covg, d_prg_reads, stream)
+        if rc != 0:
+            raise RuntimeError(f"drprg_hip_allreduce: {self._lib.drprg_hip_last_error(ctx._h).decode()} ({rc})")
+
+    def close(self):
+        if self.handle:
+            self._lib.drprg_hip_comm_destroy(self.handle)
+            self.handle = None

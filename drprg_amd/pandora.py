@@ -103,6 +103,13 @@ class Context:
     def sync(self):
         _check(lib.drprg_hip_sync(self._h), self._h)
 
+    def reduce(self):
+        """multi-device context: the devices' vectors summed into the first device, on the devices (drprg_hip_reduce)"""
+        _check(lib.drprg_hip_reduce(self._h), self._h)
+        buf = C.create_string_buffer(256)
+        lib.drprg_hip_reduce_info(self._h, buf, len(buf))
+        return buf.value.decode()
+
     # ---- coverage ------------------------------------------------------------------------------
     def coverage(self):
         covg = np.zeros(2 * self.n_knodes, dtype=np.uint32)

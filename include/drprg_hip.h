@@ -60,6 +60,28 @@ drprg_hip_ctx* drprg_hip_open_prg(const char* prg_file, int w, int k, int device
  * (two concurrent launch sequences on one GPU: what the single-GPU test uses). */
 drprg_hip_ctx* drprg_hip_open_multi(const char* prg_file, int w, int k, const int* devices, int ndev, int from_files);
 
+/* ---- the one collective of the path: the sum of the per-GPU coverage vectors (BASELINE north_star "a single
+ * RCCL reduce over xGMI").  The reference is single-process and has no counterpart; what these calls feed is the genotyping
+ * that follows `pandora map`'s read loop (/root/reference/src/lib.rs:580-642).  RCCL is bound at run time (librccl.so.1):
+ * a host that never reduces across GPUs does not need the library.
+ *
+ * Layout A, one process over several GPUs (drprg_hip_open_multi): drprg_hip_reduce sums the devices' vectors into devices[0]
+ * on the devices -- one ncclReduce(sum, u32) over a communicator of the context's devices, or, when a device is listed twice
+ * / RCCL is absent / DRPRG_HIP_NO_RCCL=1, a peer copy + add kernel per device -- clears the other devices and folds their
+ * counters.  drprg_hip_map_fastx calls it before it returns.  drprg_hip_reduce_info: which of the two ran last. */
+int drprg_hip_reduce(drprg_hip_ctx* ctx);
+int drprg_hip_reduce_info(const drprg_hip_ctx* ctx, char* out, size_t cap);
+/* Layout B, one process per GPU (what `north_star` describes and bench.py --gpus N runs): rank 0 makes an id
+ * (drprg_hip_comm_unique_id, 128 bytes) and hands it to the other ranks by whatever channel the host has; every rank calls
+ * drprg_hip_comm_init_rank(&comm, nranks, id, rank, device) and, after its last batch, drprg_hip_allreduce(ctx, comm, ...):
+ * an in-place ncclAllReduce(sum, u32) of the coverage vector and of the reads-per-PRG vector (NULL: the context's own
+ * accumulators) on `hip_stream` (NULL: the context's stream), asynchronous on that stream -- every rank then holds the sample's
+ * vectors and rank 0 genotypes.  `comm` is an ncclComm_t: a host that already has one (its own RCCL binding) may pass it. */
+int drprg_hip_comm_unique_id(uint8_t id[128]);
+int drprg_hip_comm_init_rank(void** comm, int nranks, const uint8_t id[128], int rank, int device);
+int drprg_hip_comm_destroy(void* comm);
+int drprg_hip_allreduce(drprg_hip_ctx* ctx, void* comm, void* d_covg, void* d_prg_reads, void* hip_stream);
+
 void drprg_hip_close(drprg_hip_ctx* ctx);
 const char* drprg_hip_last_error(const drprg_hip_ctx* ctx);
 

@@ -533,6 +533,9 @@ def test_multi_device_context_equals_single(tmp_path, oracle):
     multi.map_fastx(fq)
     got, got_prg = multi.coverage()
     assert np.array_equal(got, want) and np.array_equal(got_prg, want_prg)
+    # the vectors were summed on the device (one GPU listed three times cannot form an RCCL communicator: peer copy + add kernel)
+    assert multi.reduce().startswith("device add") or multi.reduce().startswith("rccl")
+    assert np.array_equal(multi.coverage()[0], want)  # (a second reduce finds the other devices empty)
     cs, cm = single.counters(), multi.counters()
     for key in ("reads", "bases", "hits", "clusters_kept", "hits_kept"):
         assert cs[key] == cm[key], key
@@ -797,3 +800,55 @@ def test_middle_tier_on_small_panels(tmp_path, oracle, monkeypatch, w):
     gen = synth.HaplotypeGenomes(lp, genome_size=60000, n_hap=4, seed=3)
     bases, offs = synth.sample_long_reads(gen, 1500, seed=3)
     _compare(ctx, oracle, bases, offs, w, 15, False, 2)
+
+
+def test_native_rccl_communicator_single_rank(tmp_path, oracle):
+    """The C-ABI collective of the one-process-per-GPU layout (drprg_hip_comm_unique_id / comm_init_rank / allreduce): a
+    communicator of ONE rank on the GPU box (more ranks need more GPUs) -- the id, the init, the grouped in-place
+    ncclAllReduce(sum, u32) of both vectors on the context's stream and the teardown all run; the sum over one rank is the
+    rank's own vector, which must still equal the oracle's."""
+    from drprg_amd import synth
+    from drprg_amd.distributed import NativeComm
+    panel = synth.small_panel(seed=42)
+    ctx = _ctx(tmp_path, panel, 11, 15, True, kernel=0)
+    gen = synth.HaplotypeGenomes(panel, genome_size=20000, n_hap=4, seed=3)
+    bases, offs = synth.sample_short_reads(gen, 20000, seed=7)
+    idx = _oracle_index(oracle, ctx.prg_strings, 11, 15)
+    ocov, oprg, _ = _oracle_map(oracle, idx, bases, offs, 11, 15, True)
+    ctx.map_host(bases, offs)
+    comm = NativeComm(0, 1, 0, exchange=lambda ident: ident)
+    comm.allreduce(ctx)
+    ctx.sync()
+    got, got_prg = ctx.coverage()
+    assert np.array_equal(got, ocov) and np.array_equal(got_prg, oprg) and got.sum() > 0
+    comm.allreduce(ctx)  # twice: still the same vector with one rank
+    assert np.array_equal(ctx.coverage()[0], ocov)
+    comm.close()
+
+
+def test_reopened_direct_context_with_leftover_reads(tmp_path, oracle):
+    """A kernel = 3 context whose batches leave reads to the generic pipeline (read_cluster_kernel reads the candidates from the
+    tile slices and marks the handled ones in a dense array): open, map, close, open again -- device memory is recycled, the marks
+    of the first context must not be taken for marks of the second (the array is cleared when it is allocated and every batch of
+    the process uses a mark of its own)."""
+    from drprg_amd import synth
+    panel = synth.small_panel(seed=5, n_loci=2, length=16000, site_every=50)
+    gen = synth.HaplotypeGenomes(panel, genome_size=60000, n_hap=2, seed=3)
+    rng = np.random.default_rng(3)
+    # 9 kb reads inside a 16 kb locus: more staged hits than the per-read kernel holds -> left over
+    reads = []
+    for i in range(300):
+        h = gen.haps[i % 2]
+        s = int(rng.integers(0, len(h) - 9000))
+        reads.append(h[s:s + 9000])
+    short = synth.sample_short_reads(gen, 4000, seed=11)
+    offs = np.zeros(len(reads) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(r) for r in reads])
+    bases = np.concatenate(reads + [short[0]])
+    offs = np.concatenate([offs, offs[-1] + short[1][1:]])
+    for attempt in range(3):
+        ctx = _ctx(tmp_path, panel, 11, 15, False, genome_size=60000, kernel=3)
+        _compare(ctx, oracle, bases, offs, 11, 15, False, 3)
+        if not FORCED_GENERIC:
+            assert ctx.counters()["leftover_reads"] > 0
+        ctx.close()
