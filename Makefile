@@ -9,7 +9,7 @@ HIPFLAGS := $(CXXFLAGS) --offload-arch=$(ARCH)
 
 SRC  := drprg_amd/csrc
 OBJD := build/obj
-HOST_SRCS := prg.cpp kmergraph.cpp index.cpp fastx.cpp genotype.cpp denovo.cpp mapper.cpp capi.cpp vcfio.cpp bcfout.cpp annotate.cpp report_json.cpp ingest.cpp pgunzip.cpp rccl_dyn.cpp
+HOST_SRCS := prg.cpp kmergraph.cpp index.cpp fastx.cpp genotype.cpp params.cpp denovo.cpp mapper.cpp capi.cpp vcfio.cpp bcfout.cpp annotate.cpp report_json.cpp ingest.cpp pgunzip.cpp rccl_dyn.cpp
 HIP_SRCS := sketch_probe.hip sketch_wave.hip sketch_filter.hip candidates.hip read_cluster.hip cluster.hip
 OBJS := $(addprefix $(OBJD)/,$(HOST_SRCS:.cpp=.o)) $(addprefix $(OBJD)/,$(HIP_SRCS:.hip=.o))
 LIB  := drprg_amd/lib/libdrprg_hip.so
@@ -40,8 +40,8 @@ $(BIN): $(SRC)/pandora_main.cpp $(LIB)
 	@mkdir -p $(dir $@)
 	$(HIPCC) $(CXXFLAGS) -x c++ $< -o $@ -Ldrprg_amd/lib -ldrprg_hip -Wl,-rpath,'$$ORIGIN/../lib'
 
-$(ORACLE): oracle/oracle.c oracle/oracle_index.c
-	$(CC) -O2 -fPIC -shared -Wall -o $@ oracle/oracle.c oracle/oracle_index.c -lm
+$(ORACLE): oracle/oracle.c oracle/oracle_index.c oracle/oracle_params.c
+	$(CC) -O2 -fPIC -shared -Wall -o $@ oracle/oracle.c oracle/oracle_index.c oracle/oracle_params.c -lm
 
 clean:
 	rm -rf build $(LIB) $(BIN) $(ORACLE)

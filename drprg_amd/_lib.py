@@ -22,6 +22,7 @@ class MapOpts(C.Structure):
         ("genome_size", C.c_uint64),
         ("genotyping_error_rate", C.c_double),
         ("kernel", C.c_int32),
+        ("binomial", C.c_int32),
     ]
 
 
@@ -84,6 +85,15 @@ SIGNATURES = {
     "drprg_hip_genotype_site": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_double, C.c_double, C.c_void_p,
                                           C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
     "drprg_hip_genotype_alleles": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "drprg_hip_estimate_parameters": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int, C.c_double, C.c_int,
+                                               C.POINTER(C.c_double)]),
+    "drprg_hip_kmer_log_prob": (C.c_int, [C.c_int, C.c_double, C.c_double, C.c_double, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]),
+    "drprg_hip_prob_threshold": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_int)]),
+    "drprg_hip_max_path": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "drprg_hip_path_base_coverage": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64,
+                                              C.POINTER(C.c_uint64)]),
+    "drprg_hip_path_coverage_too_low": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32]),
+    "drprg_hip_coverage_model": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "drprg_hip_index_sizes": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "drprg_hip_filter_selfcheck": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "drprg_hip_device_tables": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),

@@ -38,6 +38,8 @@ struct drprg_hip_ctx {
     int threads = 4; // parser threads of drprg_hip_map_fastx
     uint32_t ginfo[4] = { 0, 0, 0, 0 };
     std::vector<VcfRecord> last_records; // of the last drprg_hip_genotype (drprg_hip_genotype_alleles)
+    CoverageModel last_model;            // of the last drprg_hip_genotype (drprg_hip_coverage_model)
+    size_t last_dropped = 0;             // loci it dropped for a bare best path
     // the last drprg_hip_discover_reads: what drprg_hip_update_prg applies
     GenotypeResult last_discover;
     std::vector<NovelVariant> last_variants;
@@ -88,6 +90,7 @@ static void apply_defaults(MapParams& p, const drprg_hip_map_opts* o)
     p.genome_size = (o && o->genome_size) ? o->genome_size : 5000000;
     p.genotyping_error_rate = (o && o->genotyping_error_rate > 0) ? o->genotyping_error_rate : 0.01;
     p.kernel_mode = o ? o->kernel : 0;
+    p.binomial = o && o->binomial;
 }
 
 // Sum of the per-device coverage vectors of a multi-device context into its first device, on the devices (SURVEY.md section 8e:
@@ -564,6 +567,8 @@ int drprg_hip_genotype(drprg_hip_ctx* ctx, const char* vcf_refs, const char* out
     ctx->ginfo[1] = r.min_kmer_covg;
     ctx->ginfo[2] = (uint32_t)r.present.size();
     ctx->ginfo[3] = (uint32_t)r.records.size();
+    ctx->last_model = r.model;
+    ctx->last_dropped = r.dropped_low_coverage.size();
     ctx->last_records = std::move(r.records);
     API_END(ctx)
 }
@@ -720,6 +725,74 @@ int drprg_hip_genotype_alleles(drprg_hip_ctx* ctx, const char* out_tsv)
         }
     if (!o) throw Error(DRPRG_EIO, std::string("short write to ") + out_tsv);
     API_END(ctx)
+}
+
+int drprg_hip_estimate_parameters(const uint32_t* kmer_covg, uint64_t n, uint64_t clusters, uint64_t loci, uint32_t global_covg, int k, double e_rate,
+    int bin, double out[10])
+{
+    if ((n && !kmer_covg) || !out) return DRPRG_EINVAL;
+    const CoverageModel m = estimate_parameters(std::vector<uint32_t>(kmer_covg, kmer_covg + n), clusters, loci, global_covg, k, e_rate, bin != 0);
+    out[0] = m.exp_depth_covg; out[1] = m.bin ? 1 : 0; out[2] = m.e_rate; out[3] = m.nb_p; out[4] = m.nb_r; out[5] = m.branch;
+    out[6] = m.mean; out[7] = m.var; out[8] = m.num_reads; out[9] = m.bin_p;
+    return DRPRG_OK;
+}
+
+int drprg_hip_kmer_log_prob(int use_bin, double nb_p, double nb_r, double bin_p, uint32_t fwd, uint32_t rev, uint32_t locus_reads, float* out)
+{
+    if (!out) return DRPRG_EINVAL;
+    CoverageModel m;
+    m.bin = use_bin != 0;
+    m.nb_p = (float)nb_p;
+    m.nb_r = (float)nb_r;
+    m.bin_p = bin_p;
+    *out = kmer_log_prob(m, fwd, rev, locus_reads);
+    return DRPRG_OK;
+}
+
+int drprg_hip_prob_threshold(const float* logp, uint64_t n, int* out)
+{
+    if ((n && !logp) || !out) return DRPRG_EINVAL;
+    *out = prob_threshold(std::vector<float>(logp, logp + n));
+    return DRPRG_OK;
+}
+
+int drprg_hip_max_path(const drprg_hip_ctx* ctx, uint32_t prg, const float* logp, int thresh, uint32_t max_kmers_to_average, uint32_t* path,
+    uint64_t cap, uint64_t* n_path)
+{
+    if (!ctx || !logp || !n_path || prg >= ctx->index.kgs.size()) return DRPRG_EINVAL;
+    const KmerGraph& kg = ctx->index.kgs[prg];
+    const std::vector<uint32_t> p = find_max_path(kg, std::vector<float>(logp, logp + kg.nodes.size()), thresh, max_kmers_to_average);
+    *n_path = p.size();
+    for (size_t i = 0; i < p.size() && i < cap; ++i) path[i] = p[i];
+    return DRPRG_OK;
+}
+
+int drprg_hip_path_base_coverage(const drprg_hip_ctx* ctx, uint32_t prg, const uint32_t* path, uint64_t n_path, const uint32_t* covg2, uint32_t* out,
+    uint64_t cap, uint64_t* n_out)
+{
+    if (!ctx || (n_path && !path) || !covg2 || !n_out || prg >= ctx->index.kgs.size()) return DRPRG_EINVAL;
+    const KmerGraph& kg = ctx->index.kgs[prg];
+    for (uint64_t i = 0; i < n_path; ++i)
+        if (path[i] >= kg.nodes.size()) return DRPRG_EINVAL;
+    const std::vector<uint32_t> b = base_coverage_along_path(ctx->index.prgs[prg], kg, std::vector<uint32_t>(path, path + n_path), covg2);
+    *n_out = b.size();
+    for (size_t i = 0; i < b.size() && i < cap; ++i) out[i] = b[i];
+    return DRPRG_OK;
+}
+
+int drprg_hip_path_coverage_too_low(const uint32_t* base_covg, uint64_t n, uint32_t global_covg)
+{
+    if (n && !base_covg) return DRPRG_EINVAL;
+    return path_coverage_too_low(std::vector<uint32_t>(base_covg, base_covg + n), global_covg) ? 1 : 0;
+}
+
+int drprg_hip_coverage_model(const drprg_hip_ctx* ctx, double out[12])
+{
+    if (!ctx || !out) return DRPRG_EINVAL;
+    const CoverageModel& m = ctx->last_model;
+    out[0] = m.exp_depth_covg; out[1] = m.bin ? 1 : 0; out[2] = m.e_rate; out[3] = m.nb_p; out[4] = m.nb_r; out[5] = m.branch;
+    out[6] = m.mean; out[7] = m.var; out[8] = m.num_reads; out[9] = m.bin_p; out[10] = m.thresh; out[11] = (double)ctx->last_dropped;
+    return DRPRG_OK;
 }
 
 int drprg_hip_allele_stats(const uint32_t* fwd, const uint32_t* rev, uint32_t n, uint32_t min_kmer_covg, uint32_t out[6], double* gaps)

@@ -113,6 +113,7 @@ struct MapParams {
     bool illumina = false;          // -I
     uint64_t genome_size = 5000000; // -g
     double genotyping_error_rate = 0.01;
+    bool binomial = false;          // --bin: binomial model of the k-mer coverages (default: negative binomial)
     int kernel_mode = 0; // 0 auto, 1 direct sketch (sketch_probe_kernel) + generic cluster pipeline, 2 Bloom-prefiltered
                          // (sketch_filter_kernel), 3 direct sketch in its candidate form + read_cluster_kernel
     double cluster_fraction() const; // 0.5 / exp(error_rate * k)

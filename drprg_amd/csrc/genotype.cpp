@@ -1,5 +1,6 @@
 // genotype.cpp -- see genotype.h and DESIGN.md "Semantics".
 #include "genotype.h"
+#include "params.h"
 #include "fastx.h"
 #include <algorithm>
 #include <cmath>
@@ -391,26 +392,52 @@ GenotypeResult genotype(const PrgIndex& idx, const std::vector<uint32_t>& covg, 
     if (!vcf_refs.empty())
         for (auto& kv : read_fasta(vcf_refs)) refs[kv.first] = kv.second;
 
-    // presence + exp_depth_covg over the k-mers of present loci (pandora estimate_parameters)
+    // ---- the coverage model of the sample over the loci that have clusters (pandora estimate_parameters; params.cpp) ----
     std::vector<bool> present(idx.prgs.size(), false);
     std::vector<uint32_t> kcov;
+    uint64_t clusters = 0, loci = 0;
+    auto sat = [](uint32_t c) { return std::min<uint32_t>(c, 65535u); }; // pandora keeps u16 saturating counters
     for (size_t pi = 0; pi < idx.prgs.size(); ++pi) {
         if (prg_reads[pi] == 0) continue;
+        clusters += prg_reads[pi];
+        ++loci;
         const uint32_t base = f.knode_base[pi], n = (uint32_t)idx.kgs[pi].nodes.size();
-        bool any = false;
-        for (uint32_t i = 1; i + 1 < n; ++i)
-            if (covg[2 * (size_t)(base + i)] + covg[2 * (size_t)(base + i) + 1] > 0) { any = true; break; }
-        if (!any) continue;
-        present[pi] = true;
-        for (uint32_t i = 1; i + 1 < n; ++i) {
-            uint32_t fw = std::min<uint32_t>(covg[2 * (size_t)(base + i)], 65535u); // pandora keeps u16 saturating counters
-            uint32_t rv = std::min<uint32_t>(covg[2 * (size_t)(base + i) + 1], 65535u);
-            kcov.push_back(fw + rv);
-        }
+        for (uint32_t i = 1; i + 1 < n; ++i) kcov.push_back(sat(covg[2 * (size_t)(base + i)]) + sat(covg[2 * (size_t)(base + i) + 1]));
     }
     const uint32_t global_covg = (uint32_t)std::min<uint64_t>(total_bases / std::max<uint64_t>(p.genome_size, 1), 0xFFFFFFFFull);
-    res.exp_depth_covg = estimate_exp_depth_covg(kcov, global_covg / 10);
+    CoverageModel model = estimate_parameters(kcov, clusters, loci, global_covg, p.k, p.error_rate, p.binomial);
+    {
+        std::vector<float> lp;
+        lp.reserve(kcov.size());
+        for (size_t pi = 0; pi < idx.prgs.size(); ++pi) {
+            if (prg_reads[pi] == 0) continue;
+            const uint32_t base = f.knode_base[pi], n = (uint32_t)idx.kgs[pi].nodes.size();
+            for (uint32_t i = 1; i + 1 < n; ++i)
+                lp.push_back(kmer_log_prob(model, sat(covg[2 * (size_t)(base + i)]), sat(covg[2 * (size_t)(base + i) + 1]), prg_reads[pi]));
+        }
+        model.thresh = prob_threshold(lp);
+    }
+    res.exp_depth_covg = model.exp_depth_covg;
     res.min_kmer_covg = res.exp_depth_covg / 10;
+    res.model = model;
+    // ---- which loci stay: one with clusters whose maximum-likelihood path is not almost bare in a deep sample
+    // (LocalPRG::add_consensus_path_to_fastaq clears the path, pandora map then removes the node: no ##contig line) ----
+    for (size_t pi = 0; pi < idx.prgs.size(); ++pi) {
+        if (prg_reads[pi] == 0) continue;
+        const KmerGraph& kg = idx.kgs[pi];
+        const uint32_t base = f.knode_base[pi], n = (uint32_t)kg.nodes.size();
+        std::vector<uint32_t> local(2 * (size_t)n);
+        for (size_t i = 0; i < local.size(); ++i) local[i] = sat(covg[2 * (size_t)base + i]);
+        std::vector<float> lp(n, 0.0f);
+        for (uint32_t i = 1; i + 1 < n; ++i) lp[i] = kmer_log_prob(model, local[2 * (size_t)i], local[2 * (size_t)i + 1], prg_reads[pi]);
+        const std::vector<uint32_t> mlp = find_max_path(kg, lp, model.thresh);
+        if (mlp.empty()) continue; // no path: nothing to call on
+        if (path_coverage_too_low(base_coverage_along_path(idx.prgs[pi], kg, mlp, local.data()), global_covg)) {
+            res.dropped_low_coverage.push_back(idx.prgs[pi].name);
+            continue;
+        }
+        present[pi] = true;
+    }
 
     for (size_t pi = 0; pi < idx.prgs.size(); ++pi) {
         const LocalGraph& g = idx.prgs[pi];

@@ -6,6 +6,7 @@
 // /root/reference/src/lib.rs:935-1181, src/filter.rs:50-55, src/minor.rs:85-97.
 #pragma once
 #include "index.h"
+#include "params.h"
 
 namespace drprg {
 
@@ -65,8 +66,10 @@ struct DiscoverParams {
 struct GenotypeResult {
     uint32_t exp_depth_covg = 1;
     uint32_t min_kmer_covg = 0;
+    CoverageModel model;              // what estimate_parameters made of the k-mer coverages (params.h)
     std::vector<std::string> present; // loci with a ##contig line, sorted
     std::vector<std::string> absent;
+    std::vector<std::string> dropped_low_coverage; // loci with clusters whose best path is almost bare in a deep sample (among `absent`)
     std::vector<VcfRecord> records;   // sorted by (chrom, pos, ref, alts)
     std::vector<CandidateRegion> candidates; // low-coverage regions of the called consensus of every present locus
     std::vector<LocusConsensus> consensus;   // of the loci that have candidate regions

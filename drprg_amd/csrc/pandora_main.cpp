@@ -27,7 +27,7 @@ struct Args {
     std::string cmd;
     int threads = 1, w = 14, k = 15;
     uint32_t min_cluster_size = 10;
-    bool illumina = false, genotype = false, local = false, verbose = false, clean = false;
+    bool illumina = false, genotype = false, local = false, verbose = false, clean = false, binomial = false;
     double error_rate = -1, gt_conf = 1;
     int max_diff = -1;
     uint64_t genome_size = 5000000;
@@ -80,6 +80,7 @@ Args parse(int argc, char** argv)
         else if (s == "-e" || s == "--error-rate") a.error_rate = std::atof(need(i));
         else if (s == "-m" || s == "--max-diff") a.max_diff = std::atoi(need(i));
         else if (s == "-I" || s == "--illumina") a.illumina = true;
+        else if (s == "--bin") a.binomial = true;
         else if (s == "-K" || s == "--debugging-files") a.clean = false;
         else if (s == "--genotype") a.genotype = true;
         else if (s == "--local") a.local = true;
@@ -127,6 +128,7 @@ drprg_hip_ctx* open_ctx(const Args& a)
     if (!ctx) die(std::string("cannot open index for ") + a.positional[0] + ": " + drprg_hip_last_error(nullptr));
     drprg_hip_map_opts o {};
     o.illumina = a.illumina;
+    o.binomial = a.binomial;
     o.error_rate = a.error_rate;
     o.max_diff = a.max_diff;
     o.min_cluster_size = a.min_cluster_size;

@@ -72,10 +72,11 @@ class Context:
 
     # ---- options -------------------------------------------------------------------------------
     def set_opts(self, illumina=False, min_cluster_size=10, genome_size=MTB_GENOME_SIZE, max_diff=0, error_rate=0.0,
-                 genotyping_error_rate=0.0, kernel=0):
+                 genotyping_error_rate=0.0, kernel=0, binomial=False):
         """kernel: 0 auto, 1 direct sketch kernel + generic cluster pipeline, 2 Bloom-prefiltered kernel, 3 direct sketch
         kernel in its candidate form (read_cluster_kernel)"""
-        o = MapOpts(max_diff, error_rate, min_cluster_size, 1 if illumina else 0, genome_size, genotyping_error_rate, kernel)
+        o = MapOpts(max_diff, error_rate, min_cluster_size, 1 if illumina else 0, genome_size, genotyping_error_rate, kernel,
+                    1 if binomial else 0)
         _check(lib.drprg_hip_set_opts(self._h, C.byref(o)), self._h)
 
     # ---- mapping -------------------------------------------------------------------------------
@@ -143,6 +144,17 @@ class Context:
         gi = (C.c_uint32 * 4)()
         lib.drprg_hip_genotype_info(self._h, gi)
         return dict(exp_depth_covg=int(gi[0]), min_kmer_covg=int(gi[1]), loci_present=int(gi[2]), records=int(gi[3]))
+
+    def coverage_model(self):
+        """what estimate_parameters made of the coverage of the last genotype() (drprg_hip_coverage_model)"""
+        out = (C.c_double * 12)()
+        _check(lib.drprg_hip_coverage_model(self._h, out), self._h)
+        names = ("exp_depth_covg", "binomial", "e_rate", "nb_p", "nb_r", "branch", "mean", "var", "reads_per_locus", "bin_p", "thresh",
+                 "dropped_low_coverage")
+        d = dict(zip(names, (float(x) for x in out)))
+        for key in ("exp_depth_covg", "binomial", "branch", "reads_per_locus", "thresh", "dropped_low_coverage"):
+            d[key] = int(d[key])
+        return d
 
     def discover(self, vcf_refs, out_dir, sample="sample"):
         """candidate_regions.tsv + denovo_paths.txt ("0 loci": no local assembly) under out_dir; returns the regions"""

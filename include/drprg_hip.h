@@ -36,6 +36,8 @@ typedef struct drprg_hip_map_opts {
     double genotyping_error_rate; /* <=0: 0.01 */
     int32_t kernel;            /* 0 auto (2 when it applies, else 3); 1 direct sketch kernel + generic cluster pipeline (radix sort);
                                 * 2 Bloom-prefiltered kernel (k<=15, w<=16, small index); 3 direct sketch kernel, candidate form */
+    int32_t binomial;          /* --bin: binomial model of the k-mer coverages (pandora's default, and what drprg runs, is the negative
+                                * binomial: the argv of /root/reference/src/lib.rs:594-618 has no --bin) */
 } drprg_hip_map_opts;
 
 /* Replaces Pandora::index_with (`pandora index -t T -w W -k K <prg>`, /root/reference/src/lib.rs:479-510):
@@ -182,6 +184,29 @@ int drprg_hip_genotype_alleles(drprg_hip_ctx* ctx, const char* out_tsv);
  * negatives: must be 0), out[4..6] = bits set per thousand in those three arrays, out[7] = codes that the array holding level 0
  * and the second-stage bits together (second stage inside the streaming kernel) would wrongly reject.  All zero: no filter. */
 int drprg_hip_filter_selfcheck(const drprg_hip_ctx* ctx, uint64_t out[8]);
+/* ---- between the read loop and the VCF: the coverage model of the sample, the best path of a locus, the presence rule ----
+ * (csrc/params.h; what `pandora map` computes in estimate_parameters / find_max_path / add_consensus_path_to_fastaq behind
+ * /root/reference/src/lib.rs:580-642.  The reference consumes e = exp_depth_covg through every LIKELIHOOD / GT_CONF --
+ * /root/reference/src/filter.rs:12-16, :149 -- and the presence of a locus through the ##contig lines,
+ * /root/reference/src/predict.rs:757-765.)  drprg_hip_genotype runs all of it; these entries expose the pieces so that the test
+ * suite can hold each against the oracle's separate statement (oracle/oracle_params.c).
+ * estimate_parameters: kmer_covg = fwd + rev coverage of every k-mer of every locus with a cluster; out[0] exp_depth_covg,
+ * [1] binomial model in force, [2] e_rate, [3] nb_p, [4] nb_r, [5] branch (1 binomial, 2 negative binomial, 3 insufficient
+ * coverage, 0 no locus), [6] mean, [7] variance, [8] clusters per locus, [9] binomial p.  coverage_model: the same of the last
+ * drprg_hip_genotype, then [10] thresh, [11] loci dropped because their best path was almost bare. */
+int drprg_hip_estimate_parameters(const uint32_t* kmer_covg, uint64_t n, uint64_t clusters, uint64_t loci, uint32_t global_covg, int k,
+    double e_rate, int bin, double out[10]);
+int drprg_hip_kmer_log_prob(int use_bin, double nb_p, double nb_r, double bin_p, uint32_t fwd, uint32_t rev, uint32_t locus_reads, float* out);
+int drprg_hip_prob_threshold(const float* logp, uint64_t n, int* out);
+/* best path of locus `prg` for per-node log probabilities logp[n_nodes of that locus]: node ids, source and sink excluded */
+int drprg_hip_max_path(const drprg_hip_ctx* ctx, uint32_t prg, const float* logp, int thresh, uint32_t max_kmers_to_average, uint32_t* path,
+    uint64_t cap, uint64_t* n_path);
+/* per-base coverage of the local nodes along `path`; covg2 = (fwd, rev) per k-mer node of the locus */
+int drprg_hip_path_base_coverage(const drprg_hip_ctx* ctx, uint32_t prg, const uint32_t* path, uint64_t n_path, const uint32_t* covg2,
+    uint32_t* out, uint64_t cap, uint64_t* n_out);
+int drprg_hip_path_coverage_too_low(const uint32_t* base_covg, uint64_t n, uint32_t global_covg); /* 1: the locus is dropped */
+int drprg_hip_coverage_model(const drprg_hip_ctx* ctx, double out[12]);
+
 /* Index introspection for harnesses: sizes[0..4] = keys, records, prgs, k-mer nodes, table slots. */
 int drprg_hip_index_sizes(const drprg_hip_ctx* ctx, uint64_t sizes[5]);
 int drprg_hip_index_export(const drprg_hip_ctx* ctx, uint64_t* keys, uint32_t* rec_off, uint32_t* rec_prg,

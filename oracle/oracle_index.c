@@ -695,6 +695,43 @@ ORC_API uint32_t orc_kg_path(const orc_kgraph* g, uint32_t id, uint32_t* iv, uin
     return kn->n_iv;
 }
 
+/* per-base coverage of the local nodes that the k-mers path[0..n_path) (node ids 1..n) run through, in the order the path first
+ * reaches them: base = the largest covg_total[id] among the path's k-mers that cover it, 0 if none does (pandora
+ * get_covgs_along_localnode_path [UPSTREAM-MEMORY]).  covg_total is indexed by node id (n_nodes entries).  Returns the number of
+ * bases, the first `cap` of them in out[]. */
+ORC_API int64_t orc_kg_base_coverage(const orc_kgraph* g, const uint32_t* path, int64_t n_path, const uint32_t* covg_total, uint32_t* out, int64_t cap)
+{
+    int64_t* first_base = (int64_t*)malloc(sizeof(int64_t) * (g->n_ln ? g->n_ln : 1)); /* position of a local node's first base in out[], -1 = not reached yet */
+    for (uint32_t i = 0; i < g->n_ln; ++i) first_base[i] = -1;
+    int64_t n_out = 0;
+    for (int64_t pi = 0; pi < n_path; ++pi) {
+        const uint32_t id = path[pi];
+        if (id < 1 || id > g->n_kn) continue;
+        const knode* kn = &g->kn[g->order[id - 1]];
+        for (uint32_t j = 0; j < kn->n_iv; ++j) {
+            const uint32_t a = kn->iv[2 * j], b = kn->iv[2 * j + 1];
+            uint32_t ln = g->n_ln;
+            for (uint32_t q = 0; q < g->n_ln; ++q) /* the local node this interval lies in (an empty node for an empty interval) */
+                if (g->ln[q].start <= a && b <= g->ln[q].end && (a < b || g->ln[q].start == g->ln[q].end)) {
+                    ln = q;
+                    break;
+                }
+            if (ln == g->n_ln) continue;
+            if (first_base[ln] < 0) {
+                first_base[ln] = n_out;
+                for (uint32_t x = g->ln[ln].start; x < g->ln[ln].end; ++x, ++n_out)
+                    if (n_out < cap) out[n_out] = 0;
+            }
+            for (uint32_t x = a; x < b; ++x) {
+                const int64_t at = first_base[ln] + (int64_t)(x - g->ln[ln].start);
+                if (at < cap && out[at] < covg_total[id]) out[at] = covg_total[id];
+            }
+        }
+    }
+    free(first_base);
+    return n_out;
+}
+
 /* ------------------------------------------------------------------------------------------------------------------
  * the read-side definition over every walk fragment: all minima of every window of w consecutive k-mers (and, for a
  * complete walk that holds fewer than w k-mers, of the whole walk)
