@@ -37,9 +37,13 @@ bool is_dir(const std::string& p)
 }
 
 // -x <path | species[@version]> (/root/reference/src/cli.rs:21-78); named indexes live in ~/.drprg/<species>/<species>-<version>
-std::string resolve_index(const std::string& s)
+// *named: the index was found by species name, i.e. it is one `drprg index --download` fetched (/root/reference/src/index.rs:122):
+// its k-mer graphs and .idx are the real pandora's files
+std::string resolve_index(const std::string& s, bool* named = nullptr)
 {
+    if (named) *named = false;
     if (exists(s)) return s;
+    if (named) *named = true;
     if (s.find('/') != std::string::npos) die("Received an index which is path-like but does not exist");
     std::string species = s, version = "latest";
     size_t at = s.find('@');
@@ -101,7 +105,7 @@ void usage()
     std::fprintf(stderr,
         "drprg predict -x <index dir | species[@version]> -i <reads.fq[.gz]> [-o DIR] [-s SAMPLE] [-I] [-S]\n"
         "              [-f MAF] [-d MIN_COVG] [-D MAX_COVG] [-b MIN_STRAND_BIAS] [-g MIN_GT_CONF] [-L MAX_INDEL] [-K MIN_FRS]\n"
-        "              [-C MIN_CLUSTER_SIZE] [--debug] [-v] [-t THREADS]\n"
+        "              [-C MIN_CLUSTER_SIZE] [--debug] [-v] [-t THREADS] [--rebuild-index]\n"
         "MI355X-native hot path; -p/-m/-M (external tools) are accepted and not needed: novel variants update the PRG in process.\n");
 }
 
@@ -114,7 +118,7 @@ int main(int argc, char** argv)
         return argc >= 2 && (!std::strcmp(argv[1], "-h") || !std::strcmp(argv[1], "--help")) ? 0 : 2;
     }
     std::string index, input, outdir = ".", sample;
-    bool illumina = false, verbose = false, maf_given = false;
+    bool illumina = false, verbose = false, maf_given = false, rebuild_index = false;
     int threads = 1;
     uint32_t min_cluster = 10;
     drprg_hip_annotate_opts ao {};
@@ -159,6 +163,7 @@ int main(int argc, char** argv)
         else if (a == "-t" || a == "--threads") threads = std::atoi(need(i));
         else if (a == "-v" || a == "--verbose") verbose = true;
         else if (a == "--debug") verbose = true;
+        else if (a == "--rebuild-index") rebuild_index = true;
         else if (a == "-h" || a == "--help") { usage(); return 0; }
         else die("unknown option " + a, 2);
     }
@@ -168,7 +173,16 @@ int main(int argc, char** argv)
     }
     if (illumina && !maf_given) ao.maf = 0.1f; // default_value_if("is_illumina", .., "0.1"), src/minor.rs:26-33
     if (!exists(input)) die(input + " does not exist");
-    index = resolve_index(index);
+    bool named_index = false;
+    index = resolve_index(index, &named_index);
+    // An index found by species name is a downloaded one: its dr.prg.k*.w*.idx and kmer_prgs/ are the real pandora's files.  If
+    // they do not parse in the layout this build reads, rebuilding the graphs from dr.prg would run -- and silently hide that the
+    // two programs may not agree on the k-mer graphs the coverage is counted on -- so that is an error here unless the user asks
+    // for the rebuild (--rebuild-index / DRPRG_HIP_REBUILD_INDEX=1).  An index given as a path keeps the rebuild with a warning.
+    {
+        const char* rb = std::getenv("DRPRG_HIP_REBUILD_INDEX");
+        if (named_index && !rebuild_index && !(rb && *rb && *rb != '0')) setenv("DRPRG_HIP_STRICT_INDEX", "1", 1);
+    }
     if (mkdir(outdir.c_str(), 0777) != 0 && errno != EEXIST) die("Failed to create output directory " + outdir);
     // validate_index (/root/reference/src/predict.rs:400-418)
     int k = 0, w = 0;
@@ -194,7 +208,9 @@ int main(int argc, char** argv)
     if (devices.size() == 1) device = devices[0];
     drprg_hip_ctx* ctx = devices.size() > 1 ? drprg_hip_open_multi(prg.c_str(), w, k, devices.data(), (int)devices.size(), 1)
                                             : drprg_hip_open(prg.c_str(), w, k, device);
-    if (!ctx) die(std::string("cannot open the index: ") + drprg_hip_last_error(nullptr));
+    if (!ctx)
+        die(std::string("cannot open the index: ") + drprg_hip_last_error(nullptr)
+            + (named_index ? " (a downloaded index whose pandora files this build cannot read: --rebuild-index rebuilds the k-mer graphs from dr.prg)" : ""));
     drprg_hip_map_opts mo {};
     mo.illumina = illumina;
     mo.min_cluster_size = min_cluster;

@@ -221,12 +221,13 @@ int cmd_discover(const Args& a)
     // The mapping half of discover is the same kernels as `map`; its products are (1) the candidate regions -- stretches of each
     // locus' called consensus that the reads do not support --, (2) the novel variants a host-side pile-up of
     // the reads finds in them, and (3) the coverage vector, kept for the `map` call drprg issues next on the unchanged PRG.
-    // denovo_paths.txt lists the loci with novel variants only when DRPRG_HIP_DENOVO_PATHS=1: the caller then runs make_prg on this
-    // file, and its layout is written from the one example in the reference tree (/root/reference/src/lib.rs:3010-3038) without a
-    // make_prg here to try it on; by default the file reports 0 loci (drprg keeps the index PRG, /root/reference/src/lib.rs:299-301)
-    // and the findings are in denovo_variants.tsv.
+    // denovo_paths.txt lists the loci with novel variants (the caller then runs `make_prg update` on this file,
+    // /root/reference/src/lib.rs:279-456): the layout of the example in the reference tree (/root/reference/src/lib.rs:3010-3038),
+    // read back in the tests by a line-for-line port of the reference's own parser (/root/reference/src/lib.rs:648-697) for files
+    // with several loci, several variants per locus and paths through nested sites.  DRPRG_HIP_DENOVO_PATHS=0: report 0 loci
+    // (drprg then keeps the index PRG, /root/reference/src/lib.rs:299-301); the findings are in denovo_variants.tsv either way.
     const char* paths_env = std::getenv("DRPRG_HIP_DENOVO_PATHS");
-    const int list_loci = paths_env && std::atoi(paths_env) != 0;
+    const int list_loci = !(paths_env && std::atoi(paths_env) == 0);
     uint32_t found[3] = { 0, 0, 0 };
     if (int rc = drprg_hip_discover_reads(ctx, reads.c_str(), nullptr, a.outdir.c_str(), sample.c_str(), list_loci, found))
         die(drprg_hip_last_error(ctx), -rc);
@@ -235,7 +236,7 @@ int cmd_discover(const Args& a)
     if (found[1] && !list_loci)
         std::fprintf(stderr,
             "pandora (drprg-hip): WARNING: %u novel variant(s) in %u locus/loci found (%s/denovo_variants.tsv) but denovo_paths.txt reports 0 "
-            "loci, so the PRG will not be updated: set DRPRG_HIP_DENOVO_PATHS=1 to list them for make_prg.\n", found[1], found[2], a.outdir.c_str());
+            "loci (DRPRG_HIP_DENOVO_PATHS=0), so the PRG will not be updated.\n", found[1], found[2], a.outdir.c_str());
     std::printf("[pandora-hip] discover: %u candidate regions, %u novel variants in %u loci%s\n", found[0], found[1], found[2],
         list_loci ? "" : " (not listed in denovo_paths.txt)");
     drprg_hip_close(ctx);

@@ -617,3 +617,141 @@ def test_discover_with_noisy_long_reads(tmp_path, oracle, kind):
     locus, pos1, ref, alt, support, spanning = variants[0]
     assert locus == "g1" and support >= 4 and spanning >= support
     assert _same_variant((pos1 - 1, ref, alt), want, ref1)
+
+
+def test_discover_lists_several_loci_several_variants_and_a_variant_inside_a_nested_allele(tmp_path, oracle):
+    """NEXT-2 at drop-in quality: a denovo_paths.txt with three loci -- two novel SNPs in one locus, one in another, one inside the
+    long allele of a NESTED site of a third -- read back by the line-for-line port of the reference's parser
+    (/root/reference/src/lib.rs:648-697: the `<N> loci with denovo variants` line, a locus name before every `<n> nodes` line).
+    The PRG update places all four: the one in the nested allele becomes a site inside that allele (never somewhere else), a
+    fifth variant that overlaps an existing site is reported and skipped; mapping against the updated PRG calls every placed allele
+    at its own position."""
+    from drprg_amd import Context, Pandora, synth
+    from drprg_amd.synth import Site
+    rng = np.random.default_rng(77)
+    rs = lambda n: synth.random_seq(rng, n)
+    w, k = 11, 15
+    # g0: two site-free stretches around one SNP site; g1: a nested site whose second allele is long; g2: plain
+    t0 = [rs(260), Site([["A"], ["C"]]), rs(260)]
+    inner = Site([["G"], ["T"]])
+    long_allele = [rs(14), inner, rs(40)]
+    t1 = [rs(250), Site([["C"], long_allele]), rs(250)]
+    t2 = [rs(240), Site([["T"], ["G"]]), rs(240), Site([["AC"], ["A"]]), rs(60)]
+    panel = synth.Panel(["g0", "g1", "g2"], [t0, t1, t2])
+    prg, genes = str(tmp_path / "dr.prg"), str(tmp_path / "genes.fa")
+    panel.write(prg, genes)
+
+    def flip(s, i):
+        return s[:i] + "ACGT".replace(s[i], "")[0] + s[i + 1:]
+
+    # the sample: g0 follows the first alleles with novel SNPs at 100 and 400; g1 takes the long allele (inner G) with a novel SNP in
+    # the 40-base stretch behind the inner site; g2 has a novel SNP at 120 and one that overlaps its first site (position 240)
+    h0 = flip(flip(panel.refs[0], 100), 400)
+    g1_hap = t1[0] + long_allele[0] + "G" + long_allele[2] + t1[2]
+    p1 = len(t1[0]) + len(long_allele[0]) + 1 + 20
+    h1 = flip(g1_hap, p1)
+    h2 = flip(panel.refs[2], 120)
+    h2 = h2[:239] + "ACGT".replace(h2[239], "")[1] + "ACGT".replace(h2[240], "").replace("G", "")[0] + h2[241:]  # 239-240: across the T/G site
+    reads = []
+    for hap in (h0, h1, h2):
+        h = np.frombuffer((rs(200) + hap + rs(200)).encode(), np.uint8)
+        for s in rng.integers(0, len(h) - 150, size=1100):
+            r = h[s:s + 150]
+            reads.append(synth._COMP[r[::-1]] if rng.random() < 0.5 else r)
+    offs = np.arange(len(reads) + 1, dtype=np.uint64) * np.uint64(150)
+    bases = np.concatenate(reads)
+    fq = str(tmp_path / "reads.fq")
+    synth.write_fastq(fq, bases, offs)
+    ctx = Context(prg, w, k, device=-1, from_files=False)
+    ctx.set_opts(illumina=True, genome_size=3000)
+    md, er = map_params(k, True)
+    covg, prg_reads, _ = oracle.map_reads(bases, offs, oracle.build_index(panel.prgs, w, k), w, k, md, cluster_fraction(er, k), 10)
+    ctx.set_coverage(covg, prg_reads, int(offs[-1]))
+    out = tmp_path / "discover"
+    out.mkdir()
+    ctx.set_threads(4)
+    variants = ctx.discover_reads(fq, genes, str(out))
+    by_locus = {}
+    for locus, pos1, ref, alt, support, spanning in variants:
+        by_locus.setdefault(locus, []).append((pos1, ref, alt))
+    assert sorted(by_locus) == ["g0", "g1", "g2"], variants
+    assert [p for p, _, _ in by_locus["g0"]] == [101, 401] and all(len(r) == len(a) == 1 for _, r, a in by_locus["g0"])
+    assert by_locus["g1"] == [(p1 + 1, g1_hap[p1], h1[p1])]
+    assert (121, panel.refs[2][120], h2[120]) in by_locus["g2"]
+    # ---- the file the reference parses ----
+    path = str(out / "denovo_paths.txt")
+    assert Pandora.list_prgs_with_novel_variants(path) == ["g0", "g1", "g2"]
+    text = open(path).read()
+    assert text.startswith("1 samples\nSample sample\n3 loci with denovo variants\n")
+    blocks = re.split(r"\n(?=g[012]\n\d+ nodes\n)", text)
+    assert len(blocks) == 4
+    for name, blk in zip(("g0", "g1", "g2"), blocks[1:]):
+        lines = blk.split("\n")
+        assert lines[0] == name
+        n_nodes = int(lines[1].split()[0])
+        nodes = [re.fullmatch(r"\((\d+) \[(\d+), (\d+)\) ([ACGT]*)\)", l) for l in lines[2:2 + n_nodes]]
+        assert all(nodes) and all(int(m.group(3)) - int(m.group(2)) == len(m.group(4)) for m in nodes)
+        # the node intervals are offsets into the PRG string (markers and their spaces included)
+        pstr = panel.prgs[("g0", "g1", "g2").index(name)]
+        assert all(pstr[int(m.group(2)):int(m.group(3))] == m.group(4) for m in nodes)
+        nv = int(lines[2 + n_nodes].split()[0])
+        assert lines[2 + n_nodes] == f"{nv} denovo variants for this locus" and nv == len(by_locus[name])
+        got = [tuple(l.split("\t")) for l in lines[3 + n_nodes:3 + n_nodes + nv]]
+        assert got == [(str(p), r, a) for p, r, a in by_locus[name]]
+    g1_nodes = "".join(m.group(4) for m in [re.fullmatch(r"\((\d+) \[(\d+), (\d+)\) ([ACGT]*)\)", l) for l in blocks[2].split("\n")[2:]] if m)
+    assert g1_nodes == g1_hap  # the called path runs through the long (nested) allele
+    # ---- the update: four placed, the one across the existing site reported and left out ----
+    new_prg = str(tmp_path / "updated.dr.prg")
+    n_sites_before = [len(re.findall(r" \d+ ", p)) for p in panel.prgs]
+    applied = ctx.update_prg(new_prg)
+    placed = sum(len(v) for v in by_locus.values())
+    assert applied in (placed, placed - 1) and applied >= 4
+    prgs = [l.rstrip("\n") for l in open(new_prg) if not l.startswith(">")]
+    # g1: the new site sits inside the long allele, i.e. between the inner site's close and the outer site's close
+    m = re.search(r" 7 (?P<tail>[ACGT]+ \d+ [ACGT] \d+ [ACGT] \d+ [ACGT]+) 5 ", prgs[1])
+    assert m, prgs[1][240:420]
+    assert len(re.findall(r" \d+ ", prgs[1])) == n_sites_before[1] + 3
+    # ---- every placed allele is called at its position on the updated PRG ----
+    ctx2 = Context(new_prg, w, k, device=-1, from_files=False)
+    ctx2.set_opts(illumina=True, genome_size=3000)
+    covg, prg_reads, _ = oracle.map_reads(bases, offs, oracle.build_index(prgs, w, k), w, k, md, cluster_fraction(er, k), 10)
+    ctx2.set_coverage(covg, prg_reads, int(offs[-1]))
+    vcf = str(tmp_path / "updated.vcf")
+    ctx2.genotype(genes, vcf)
+    alt_calls = {(t[0], int(t[1])) for t, fmt in _parse_vcf(vcf) if fmt["GT"] not in ("0", ".")}
+    assert ("g0", 101) in alt_calls and ("g0", 401) in alt_calls and ("g2", 121) in alt_calls
+    assert any(c == "g1" for c, _ in alt_calls)
+
+
+def test_named_index_with_foreign_files_is_an_error_unless_rebuild_is_asked_for(tmp_path):
+    """NEXT-3: `-x mtb` resolves a downloaded index (~/.drprg/mtb/mtb-<version>, /root/reference/src/cli.rs:21-78) whose
+    dr.prg.k15.w11.idx / kmer_prgs are the real pandora's files.  If they do not parse in the layout this build reads, a silent
+    rebuild from dr.prg would hide that: `drprg predict` stops there; --rebuild-index (or DRPRG_HIP_REBUILD_INDEX=1) asks for the
+    rebuild; an index given as a path keeps the rebuild with a warning."""
+    from drprg_amd import synth
+    exe = os.path.join(ROOT, "drprg_amd", "bin", "drprg")
+    home = tmp_path / "home"
+    idx = home / ".drprg" / "mtb" / "mtb-20230308"
+    (idx / "kmer_prgs").mkdir(parents=True)
+    (idx / "msas").mkdir()
+    panel = synth.small_panel(seed=3)
+    panel.write(str(idx / "dr.prg"), str(idx / "genes.fa"))
+    (idx / "dr.prg.k15.w11.idx").write_text("1234\n0 1 2 3\n")  # files of the right names, foreign content
+    for n in panel.names:
+        (idx / "kmer_prgs" / f"{n}.k15.w11.gfa").write_text("H\tVN:Z:1.0\tbn:Z:--linear --singlearr\n")
+    (idx / ".config.toml").write_text('min_match_len = 5\nmax_nesting = 5\nk = 15\nw = 11\npadding = 100\nversion = "20230308"\n')
+    for f in ("panel.bcf", "panel.bcf.csi"):
+        (idx / f).write_bytes(open(os.path.join(GOLDEN, "downstream", f), "rb").read())
+    reads = tmp_path / "r.fq"
+    reads.write_text("@r\nACGT\n+\nIIII\n")
+    env = dict(os.environ, HOME=str(home))
+    env.pop("DRPRG_HIP_REBUILD_INDEX", None)
+    env.pop("DRPRG_HIP_STRICT_INDEX", None)
+    r = subprocess.run([exe, "predict", "-x", "mtb", "-i", str(reads), "-o", str(tmp_path / "o1")], capture_output=True, text=True, env=env)
+    assert r.returncode != 0 and "cannot open the index" in r.stderr and "--rebuild-index" in r.stderr and "rebuilding the" not in r.stderr, r.stderr
+    assert ".idx" in r.stderr or "kmer_prgs" in r.stderr
+    r = subprocess.run([exe, "predict", "-x", "mtb@20230308", "-i", str(reads), "-o", str(tmp_path / "o2"), "--rebuild-index"],
+                       capture_output=True, text=True, env=env)
+    assert "rebuilding the k-mer graphs" in r.stderr, r.stderr  # (then it needs a GPU: -ENODEV on this host)
+    r = subprocess.run([exe, "predict", "-x", str(idx), "-i", str(reads), "-o", str(tmp_path / "o3")], capture_output=True, text=True, env=env)
+    assert "rebuilding the k-mer graphs" in r.stderr, r.stderr
