@@ -2,6 +2,8 @@
 #include "ingest.h"
 #include "pgunzip.h"
 #include <atomic>
+#include <chrono>
+#include <cstdio>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
@@ -16,6 +18,9 @@
 #include <thread>
 #include <unistd.h>
 #include <zlib.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 namespace drprg {
 
@@ -31,12 +36,22 @@ struct Block {
     uint8_t* bases = nullptr;
     uint64_t* offsets = nullptr;
     uint64_t n_reads = 0, n_bases = 0;
+    // the block is handed over once it holds this many bases: BLOCK_BASES, except for a worker's first hand-over, which comes
+    // early and at a different fill for every worker -- otherwise all workers fill their first block at the same moment, the
+    // copy engine idles until then and works through a burst afterwards (measured: 10 M x 150 bp, first copies at 67 of 95 ms)
+    size_t flush_at = 0;
 };
 
 struct Shared {
     const IngestHooks& hooks;
     std::mutex submit_mu, err_mu;
     std::atomic<uint64_t> reads { 0 }, bases { 0 }, batches { 0 };
+    std::atomic<uint32_t> first_flush { 0 };
+    // DRPRG_INGEST_DEBUG=1: where the wall time of a call goes (nanoseconds)
+    const bool debug = std::getenv("DRPRG_INGEST_DEBUG") != nullptr;
+    std::chrono::steady_clock::time_point t_start = std::chrono::steady_clock::now();
+    std::atomic<int64_t> ns_first_submit { -1 }, ns_submit_wait { 0 }, ns_submit_run { 0 }, ns_parse { 0 }, ns_alloc { 0 }, ns_read { 0 };
+    int64_t now_ns() const { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_start).count(); }
     std::atomic<bool> failed { false };
     std::string error;
     int error_code = DRPRG_EFORMAT;
@@ -54,16 +69,27 @@ struct Shared {
     {
         if (b.n_reads == 0) return;
         PinnedBatch pb { b.bases, b.offsets, b.n_reads, b.n_bases };
+        const int64_t t0 = debug ? now_ns() : 0;
+        if (debug) {
+            int64_t none = -1;
+            ns_first_submit.compare_exchange_strong(none, t0);
+        }
         if (hooks.concurrent_submit) hooks.submit(pb);
         else {
             std::lock_guard<std::mutex> g(submit_mu);
+            const int64_t t1 = debug ? now_ns() : 0;
             hooks.submit(pb);
+            if (debug) {
+                ns_submit_wait += t1 - t0;
+                ns_submit_run += now_ns() - t1;
+            }
         }
         reads += b.n_reads;
         bases += b.n_bases;
         batches += 1;
         b.n_reads = 0;
         b.n_bases = 0;
+        b.flush_at = BLOCK_BASES;
     }
     Block new_block()
     {
@@ -73,6 +99,8 @@ struct Shared {
         b.offsets = (uint64_t*)(hooks.alloc ? hooks.alloc(bytes_o) : std::malloc(bytes_o));
         if (!b.bases || !b.offsets) throw Error(DRPRG_ENOMEM, "cannot allocate an ingest block");
         b.offsets[0] = 0;
+        // first hand-over: between 1/16 and 16/16 of a block, a different sixteenth for consecutive workers
+        b.flush_at = BLOCK_BASES / 16 * (1 + (size_t)(first_flush.fetch_add(1) % 16));
         return b;
     }
     void free_block(Block& b)
@@ -125,9 +153,64 @@ inline void strip_cr(const char* s, const char*& e)
     if (e > s && e[-1] == '\r') --e;
 }
 
+// The records of a 4-line FASTQ slice, AVX2: the newline search is inline (32 bytes per compare; four glibc memchr calls per
+// record cost more than the scanning they do: ~100 ns per 150-base record, i.e. 1 GB/s of text per thread, which made the parse
+// -- not PCIe -- the limit of the end-to-end path).  Stops in front of the last 64 bytes of the slice (the vector loads must not
+// run past a mapping's end) or at anything that is not the plain case; the caller's general loop continues from the returned
+// position.
+#if defined(__x86_64__)
+// first newline at or after q, nullptr if none before `safe`
+__attribute__((target("avx2"))) inline const char* find_nl_avx2(const char* q, const char* safe)
+{
+    const __m256i nl = _mm256_set1_epi8('\n');
+    while (q < safe) {
+        const unsigned m = (unsigned)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i*)q), nl));
+        if (m) {
+            q += __builtin_ctz(m);
+            return q < safe ? q : nullptr;
+        }
+        q += 32;
+    }
+    return nullptr;
+}
+
+__attribute__((target("avx2"))) const char* parse_fastq_avx2(const char* p, const char* e, Block& blk, Shared& sh)
+{
+    if (e - p < 128) return p;
+    const char* const safe = e - 64;
+    auto find = [&](const char* q) __attribute__((target("avx2"))) { return find_nl_avx2(q, safe); };
+    while (p < safe) {
+        if (*p != '@') return p; // blank line, CR, or malformed: the general loop decides
+        const char* h_end = find(p);
+        if (!h_end) return p;
+        const char* seq = h_end + 1;
+        const char* s_end = find(seq);
+        if (!s_end || s_end + 1 >= safe || s_end[1] != '+') return p;
+        const char* plus_end = find(s_end + 1);
+        if (!plus_end) return p;
+        const char* q_end = find(plus_end + 1);
+        if (!q_end) return p;
+        const char* s_stop = s_end;
+        if (s_stop > seq && s_stop[-1] == '\r') --s_stop;
+        const size_t len = (size_t)(s_stop - seq);
+        if (len > BLOCK_BASES) return p;
+        if (blk.n_bases + len > blk.flush_at || blk.n_reads + 1 > BLOCK_READS) sh.submit(blk);
+        std::memcpy(blk.bases + blk.n_bases, seq, len);
+        blk.n_bases += len;
+        blk.offsets[++blk.n_reads] = blk.n_bases;
+        p = q_end + 1;
+    }
+    return p;
+}
+#endif
+
 // parse the records of [p, e) (whole records only) into the block, submitting whenever it fills up
 void parse_slice(const char* p, const char* e, bool fastq, Block& blk, Shared& sh)
 {
+#if defined(__x86_64__)
+    static const bool have_avx2 = __builtin_cpu_supports("avx2") && !std::getenv("DRPRG_PARSE_NO_SIMD");
+    if (fastq && have_avx2) p = parse_fastq_avx2(p, e, blk, sh);
+#endif
     while (p < e) {
         if (*p == '\n' || *p == '\r') {
             ++p;
@@ -149,7 +232,7 @@ void parse_slice(const char* p, const char* e, bool fastq, Block& blk, Shared& s
             strip_cr(cursor, s_stop);
             const size_t len = (size_t)(s_stop - cursor);
             if (len > BLOCK_BASES) throw Error(DRPRG_EOVERFLOW, "a read is longer than the ingest block");
-            if (blk.n_bases + len > BLOCK_BASES || blk.n_reads + 1 > BLOCK_READS) sh.submit(blk);
+            if (blk.n_bases + len > blk.flush_at || blk.n_reads + 1 > BLOCK_READS) sh.submit(blk);
             std::memcpy(blk.bases + blk.n_bases, cursor, len);
             blk.n_bases += len;
             blk.offsets[++blk.n_reads] = blk.n_bases;
@@ -164,7 +247,7 @@ void parse_slice(const char* p, const char* e, bool fastq, Block& blk, Shared& s
             }
             const size_t bound = (size_t)(rec_end - cursor);
             if (bound > BLOCK_BASES) throw Error(DRPRG_EOVERFLOW, "a read is longer than the ingest block");
-            if (blk.n_bases + bound > BLOCK_BASES || blk.n_reads + 1 > BLOCK_READS) sh.submit(blk);
+            if (blk.n_bases + bound > blk.flush_at || blk.n_reads + 1 > BLOCK_READS) sh.submit(blk);
             while (cursor < rec_end) {
                 const char* nl = find_nl(cursor, rec_end);
                 const char* stop = nl ? nl : rec_end;
@@ -185,6 +268,8 @@ struct Slice {
     const char* begin = nullptr;
     const char* end = nullptr;
     std::shared_ptr<TextBuffer> owner; // inflated gzip text; null for a memory-mapped file
+    std::shared_ptr<void> mapping;     // plain file: the slice's own mapping, unmapped by the parser thread when it is done with it
+    uint64_t file_off = 0, file_len = 0; // plain file, begin == nullptr: the parser thread reads these bytes into a buffer of its own
 };
 
 class SliceQueue {
@@ -260,8 +345,9 @@ public:
         if (!v || v->size() < size) v.reset(new TextBuffer(size));
         TextBuffer* raw = v.release();
         return std::shared_ptr<TextBuffer>(raw, [this](TextBuffer* p) {
+            std::unique_ptr<TextBuffer> own(p);
             std::lock_guard<std::mutex> g(mu_);
-            free_.emplace_back(p);
+            if (free_.size() < 64) free_.push_back(std::move(own)); // (else freed here)
         });
     }
 
@@ -351,6 +437,13 @@ void inflate_member(void* dec, const unsigned char* in, size_t in_len, char* out
     if (rc != 0 || got != out_len) throw Error(DRPRG_EIO, "corrupt gzip block in " + path);
 }
 
+// text buffers of the plain-file parser threads, kept between calls (a buffer is ~40 MB of huge pages; at most 64 are kept)
+BufferPool& plain_pool()
+{
+    static BufferPool pool;
+    return pool;
+}
+
 bool detect_format(const char* p, const char* e, bool& fastq)
 {
     while (p < e && (*p == '\n' || *p == '\r' || *p == ' ')) ++p;
@@ -385,12 +478,30 @@ IngestStats ingest_fastx(const std::string& path, int threads, const IngestHooks
 
     auto worker = [&]() {
         Block blk;
+        std::shared_ptr<TextBuffer> own_text;
         try {
             Slice s;
             while (queue.pop(s)) {
                 if (sh.failed) continue; // drain
-                if (!blk.bases) blk = sh.new_block();
-                parse_slice(s.begin, s.end, fastq, blk, sh);
+                if (!blk.bases) {
+                    const int64_t t0 = sh.debug ? sh.now_ns() : 0;
+                    blk = sh.new_block();
+                    if (sh.debug) sh.ns_alloc += sh.now_ns() - t0;
+                }
+                const int64_t t0 = sh.debug ? sh.now_ns() : 0;
+                if (!s.begin && s.file_len) { // plain file: this thread reads the slice into its own (recycled, huge-page) buffer
+                    if (!own_text || own_text->size() < s.file_len + 64) own_text = plain_pool().acquire(std::max<size_t>(s.file_len + 64, SLICE_BYTES + (SLICE_BYTES >> 1)));
+                    size_t have = 0;
+                    while (have < s.file_len) {
+                        const ssize_t r = pread(fd, own_text->data() + have, s.file_len - have, (off_t)(s.file_off + have));
+                        if (r <= 0) throw Error(DRPRG_EIO, "cannot read " + path);
+                        have += (size_t)r;
+                    }
+                    if (sh.debug) sh.ns_read += sh.now_ns() - t0;
+                    parse_slice(own_text->data(), own_text->data() + s.file_len, fastq, blk, sh);
+                } else parse_slice(s.begin, s.end, fastq, blk, sh);
+                s = Slice(); // (a mapped slice: its mapping goes now, on this thread)
+                if (sh.debug) sh.ns_parse += sh.now_ns() - t0;
             }
             if (!sh.failed) sh.submit(blk);
         } catch (const Error& e) {
@@ -413,27 +524,106 @@ IngestStats ingest_fastx(const std::string& path, int threads, const IngestHooks
                 close(fd);
                 return st;
             }
-            map = mmap(nullptr, map_len, PROT_READ, MAP_PRIVATE, fd, 0);
-            if (map == MAP_FAILED) throw Error(DRPRG_EIO, "cannot mmap " + path);
-            madvise(map, map_len, MADV_SEQUENTIAL);
-            const char* text = (const char*)map;
-            const char* end = text + map_len;
-            if (!detect_format(text, end, fastq)) {
-                munmap(map, map_len);
-                close(fd);
-                return st;
+            // The file is mapped slice by slice, and every slice's mapping is torn down by the parser thread that read it: one
+            // mapping of the whole file costs ~25 ns per 4 KB page to unmap -- 10 M x 150 bp of FASTQ text are 3.2 GB, 770 k
+            // pages, 40-75 ms of munmap on the calling thread after the last read was parsed (measured: the parser threads were
+            // busy for 25 of a call's 90 ms).  A slice's mapping starts at the page that holds the slice's first byte and reaches
+            // a quarter slice past its nominal end, where the next record start is looked for.
+            const size_t page = (size_t)sysconf(_SC_PAGESIZE);
+            {
+                // format and layout from the head of the file (8 MB at a time until something other than blank lines shows up)
+                bool known = false;
+                for (size_t at = 0; at < map_len && !known; at += (size_t)8 << 20) {
+                    const size_t n = std::min(map_len - at, (size_t)8 << 20);
+                    void* m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, (off_t)at);
+                    if (m == MAP_FAILED) throw Error(DRPRG_EIO, "cannot mmap " + path);
+                    struct Unmap {
+                        void* p;
+                        size_t n;
+                        ~Unmap() { munmap(p, n); }
+                    } unmap { m, n };
+                    const char* text = (const char*)m;
+                    if (detect_format(text, text + n, fastq)) {
+                        known = true;
+                        if (fastq) require_four_line_fastq(text, text + n);
+                    }
+                }
+                if (!known) {
+                    close(fd);
+                    return st;
+                }
             }
-            if (fastq) require_four_line_fastq(text, end);
             // (a worker pins its own block -- a few milliseconds of driver time, serialised -- so every worker should have several
             // slices to fill it with: measured on 4 M reads, 8 workers 50 ms, 32 workers 139 ms)
             const int n_workers = (int)std::min<size_t>((size_t)threads, map_len / (3 * SLICE_BYTES) + 1);
             for (int t = 0; t < n_workers; ++t) pool.emplace_back(worker);
-            const char* cur = text;
-            while (cur < end && !sh.failed) {
-                const char* cut = end;
-                if ((size_t)(end - cur) > SLICE_BYTES + (SLICE_BYTES >> 2)) cut = next_record(cur + SLICE_BYTES, end, fastq);
-                queue.push(Slice { cur, cut, nullptr });
+            size_t cur = 0; // file offset of the next slice's first byte (a record start)
+            // Default: no mapping at all -- the parser thread reads its slice with pread into a buffer it keeps (no page-table
+            // set-up and tear-down per 4 KB page of the file, which is what a mapping costs however it is cut: 40-50 ms per thread
+            // with 32 threads under one address-space lock against ~15 ms for the copy); the cut points come from small reads
+            // around the nominal slice ends.  DRPRG_INGEST_MMAP=1: the per-slice mappings below.
+            static const bool use_mmap = [] {
+                const char* e = std::getenv("DRPRG_INGEST_MMAP");
+                return e && std::atoi(e) != 0;
+            }();
+            std::vector<char> win;
+            while (!use_mmap && cur < map_len && !sh.failed) {
+                size_t cut = map_len;
+                if (map_len - cur > SLICE_BYTES + (SLICE_BYTES >> 2)) {
+                    for (size_t look = (size_t)1 << 18;; look *= 4) { // the next record start at or after cur + SLICE_BYTES
+                        const size_t at = cur + SLICE_BYTES, n = std::min(look, map_len - at);
+                        win.resize(n);
+                        size_t have = 0;
+                        while (have < n) {
+                            const ssize_t r = pread(fd, win.data() + have, n - have, (off_t)(at + have));
+                            if (r <= 0) throw Error(DRPRG_EIO, "cannot read " + path);
+                            have += (size_t)r;
+                        }
+                        const char* c = next_record(win.data(), win.data() + n, fastq);
+                        if (c < win.data() + n) {
+                            cut = at + (size_t)(c - win.data());
+                            break;
+                        }
+                        if (at + n >= map_len) { // the rest of the file holds no further record start
+                            cut = map_len;
+                            break;
+                        }
+                        if (look > ((size_t)1 << 30)) throw Error(DRPRG_EFORMAT, "no record boundary in 1 GB of " + path);
+                    }
+                }
+                Slice sl;
+                sl.file_off = cur;
+                sl.file_len = cut - cur;
                 cur = cut;
+                queue.push(std::move(sl));
+            }
+            while (cur < map_len && !sh.failed) {
+                size_t want = SLICE_BYTES + (SLICE_BYTES >> 2);
+                for (;;) {
+                    const size_t lo = cur / page * page;
+                    const size_t hi = std::min(map_len, cur + want);
+                    void* m = mmap(nullptr, hi - lo, PROT_READ, MAP_PRIVATE, fd, (off_t)lo);
+                    if (m == MAP_FAILED) throw Error(DRPRG_EIO, "cannot mmap " + path);
+                    const size_t m_len = hi - lo;
+                    std::shared_ptr<void> owner(m, [m_len](void* q) { munmap(q, m_len); });
+                    const char* b = (const char*)m + (cur - lo);
+                    const char* e = (const char*)m + m_len;
+                    const char* cut = e;
+                    if (hi < map_len) {
+                        cut = next_record(b + std::min(SLICE_BYTES, (size_t)(e - b) - 1), e, fastq);
+                        if (cut >= e) { // no record start in the last quarter (a very long read): map more and look again
+                            want *= 2;
+                            continue;
+                        }
+                    }
+                    Slice sl;
+                    sl.begin = b;
+                    sl.end = cut;
+                    sl.mapping = std::move(owner);
+                    cur += (size_t)(cut - b);
+                    queue.push(std::move(sl));
+                    break;
+                }
             }
         } else {
             // Four ways to inflate: (1) BGZF: the members are located from their headers and inflated in parallel, a window
@@ -597,6 +787,11 @@ IngestStats ingest_fastx(const std::string& path, int threads, const IngestHooks
     st.bases = sh.bases;
     st.batches = sh.batches;
     st.parallel = threads > 1;
+    if (sh.debug)
+        std::fprintf(stderr, "[ingest] wall %.1f ms, %llu batches, first hand-over at %.1f ms; summed over the %zu parser threads: parse (hand-overs included) %.1f ms, "
+                             "waiting for the submitter %.1f ms, inside the submitter %.1f ms, block allocation %.1f ms, reading the file %.1f ms\n", sh.now_ns() / 1e6,
+            (unsigned long long)st.batches, sh.ns_first_submit.load() / 1e6, pool.size(), sh.ns_parse.load() / 1e6, sh.ns_submit_wait.load() / 1e6,
+            sh.ns_submit_run.load() / 1e6, sh.ns_alloc.load() / 1e6, sh.ns_read.load() / 1e6);
     return st;
 }
 
