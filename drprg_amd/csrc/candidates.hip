@@ -100,161 +100,192 @@ template <int KC> __device__ __forceinline__ uint32_t verify_mix(uint32_t x, uin
     else return HashTraits<uint32_t>::mix(x, kmask);
 }
 
+// what the kernels below derive once from their arguments
+struct VerifyConsts {
+    const uint32_t* __restrict__ slot_key;
+    uint32_t tmask, kmask, w1_magic;
+    int k, w, sh_k;
+    int64_t n_bases, win_lo, win_hi;
+    double reads_per_base;
+    __device__ VerifyConsts(const SketchArgs& a, const FilterWork& fw)
+        : slot_key(reinterpret_cast<const uint32_t*>(a.slot_key)), tmask((1u << a.table_bits) - 1), kmask((1u << (2 * a.k)) - 1), w1_magic(w1_reciprocal(a.w)),
+          k(a.k), w(a.w), sh_k(32 - 2 * a.k), n_bases((int64_t)a.n_bases), win_lo((int64_t)a.offsets[fw.read_begin]), win_hi((int64_t)a.offsets[fw.read_end]),
+          reads_per_base((double)a.n_reads / (double)(a.n_bases ? a.n_bases : 1))
+    {
+    }
+};
+// everything one candidate leaves behind
+struct VerifyOut {
+    uint32_t pos1 = 0, slot = 0, read = READ_NONE, strand = 0;
+    uint4 crec = make_uint4(0, 0, 0, 0);
+};
+
+// the record of a candidate that is a minimizer of its read: what read_cluster_kernel needs of it (and the lane's totals)
+__device__ __forceinline__ void verify_emit(const SketchArgs& a, const ReadClusterArgs& rc, const VerifyConsts& c, int64_t gp, int64_t r0, int64_t r1, uint32_t strand,
+    const uint4& sf, VerifyOut& o, uint32_t& my_hits, uint32_t& my_nmin, uint32_t& my_maxlen)
+{
+    const uint64_t pos = (uint64_t)(gp - r0);
+    if (pos >= (1ull << HIT_POS_BITS)) {
+        atomicOr(a.overflow, 2u);
+        return;
+    }
+    o.pos1 = (uint32_t)pos + 1;
+    my_hits += sf.y;
+    my_nmin += 1;
+    const uint32_t len = (uint32_t)((r1 - r0) > 0xFFFFFFFFll ? 0xFFFFFFFFll : (r1 - r0));
+    my_maxlen = len > my_maxlen ? len : my_maxlen;
+    // for read_cluster_kernel: the first hit of this minimizer and the size threshold of a cluster of this read on that hit's PRG
+    // (cluster_eval_kernel)
+    const uint32_t kn = sf.z, prg = sf.w & 0xFFFu;
+    const uint32_t rev = ((kn & 1u) == strand) ? 0u : 1u;
+    const uint64_t expected = expected_minimizers((uint64_t)(r1 - r0), c.w, c.w1_magic);
+    uint64_t m = sf.w >> 12;
+    if (expected < m) m = expected;
+    const uint32_t length_based = (uint32_t)((double)m * rc.fraction);
+    uint32_t thr = length_based > rc.min_cluster_size ? length_based : rc.min_cluster_size;
+    if (thr > 0xFFFFu) thr = 0xFFFFu; // read_cluster_kernel stages at most RC_HCAP hits: no difference
+    o.crec = make_uint4(sf.x, sf.y, (strand << 31) | (((prg << 1) | rev) << 16) | thr, (kn >> 1) * 2u + rev);
+}
+
+// One candidate, start to finish, by one lane (the whole algorithm described above verify_count_kernel)
+template <int KC>
+__device__ __forceinline__ void verify_one_lane(const SketchArgs& a, const FilterWork& fw, const ReadClusterArgs& rc, const VerifyConsts& c, int64_t gp, VerifyOut& o,
+    uint32_t& my_hits, uint32_t& my_nmin, uint32_t& my_maxlen)
+{
+    using Tr = HashTraits<uint32_t>;
+    const uint32_t* __restrict__ slot_key = c.slot_key;
+    const uint32_t tmask = c.tmask, kmask = c.kmask;
+    const int k = c.k, w = c.w, sh_k = c.sh_k;
+    const int64_t n_bases = c.n_bases, win_lo = c.win_lo, win_hi = c.win_hi;
+    const double reads_per_base = c.reads_per_base;
+    uint32_t &pos1 = o.pos1, &slot = o.slot, &read = o.read, &strand = o.strand;
+    (void)pos1;
+    if (gp >= win_lo && gp < win_hi && gp + k <= n_bases) { // (the boundary tiles of a read range reach past it)
+        // Everything the candidate needs from memory that does not depend on other loads is requested before anything is
+        // waited for: the two read offsets around the interpolated read index and the four 16-byte words of the 64 bases
+        // [a0, a0+64) that hold the candidate and all its neighbours (w <= 16, k <= 15).  (One guarded load after the other,
+        // each behind its own branch, was four round trips in a row, and the read lookup two more.)
+        uint32_t guess = (uint32_t)((double)gp * reads_per_base);
+        if (guess >= a.n_reads) guess = a.n_reads - 1;
+        const uint64_t o0 = a.offsets[guess], o1 = a.offsets[guess + 1];
+        const int64_t a0 = (gp > 15 ? gp - 15 : 0) & ~(int64_t)15;
+        uint4 b0, b1, b2, b3;
+        if (a0 + 64 <= n_bases) {
+            const uint4* __restrict__ bp = reinterpret_cast<const uint4*>(a.bases + a0);
+            b0 = bp[0];
+            b1 = bp[1];
+            b2 = bp[2];
+            b3 = bp[3];
+        } else { // the last bytes of the buffer
+            b0 = load16_guarded(a.bases, n_bases, a0);
+            b1 = load16_guarded(a.bases, n_bases, a0 + 16);
+            b2 = load16_guarded(a.bases, n_bases, a0 + 32);
+            b3 = load16_guarded(a.bases, n_bases, a0 + 48);
+        }
+        // the read of every candidate, index k-mer or not: read_cluster_kernel finds the first candidate of a read by
+        // comparing neighbours (the interpolated index is exact for fixed-length reads; a short gallop otherwise)
+        int64_t r0 = (int64_t)o0, r1 = (int64_t)o1;
+        if (o0 <= (uint64_t)gp && (uint64_t)gp < o1) read = guess;
+        else {
+            read = find_read_near(a.offsets, a.n_reads, guess, (uint64_t)gp);
+            r0 = (int64_t)a.offsets[read];
+            r1 = (int64_t)a.offsets[read + 1];
+        }
+        uint32_t r0w, r1w, r2w, r3w, n0, n1, n2, n3;
+        pack16n(b0, r0w, n0);
+        pack16n(b1, r1w, n1);
+        pack16n(b2, r2w, n2);
+        pack16n(b3, r3w, n3);
+        uint64_t bad = (uint64_t)(n0 | (n1 << 16)) | ((uint64_t)(n2 | (n3 << 16)) << 32); // bit i: base a0+i is not ACGT
+        if (bad) { // -> bit i: the k-mer starting at a0+i holds such a base
+            uint64_t m = bad;
+            for (int i = 1; i < k; ++i) m |= bad >> i;
+            bad = m;
+        }
+        // ---- the candidate's own canonical hash, exact lookup ----
+        const int oc = (int)(gp - a0); // 0..30
+        uint32_t g = 0;
+        if (!((bad >> oc) & 1u)) {
+            const uint32_t h0 = (oc & 16) ? r1w : r0w, h1 = (oc & 16) ? r2w : r1w;
+            const uint32_t f = __funnelshift_l(h1, h0, 2 * (oc & 15)) >> sh_k;
+            const uint32_t hf = verify_mix<KC>(f, kmask), hr = verify_mix<KC>(revcomp_code(f, k), kmask);
+            strand = hf <= hr ? 1u : 0u;
+            g = (hf < hr ? hf : hr) + 1;
+        }
+        bool found = false;
+        if (g && !(fw.debug & 32u)) { // (DRPRG_FT_DEBUG=32: timing only, no table probe and nothing after it)
+            const uint32_t h = g - 1;
+            uint32_t sl = table_slot_dev(h, a.table_bits);
+            while (true) {
+                const uint32_t key = slot_key[sl];
+                if (key == h) { found = true; break; }
+                if (key == Tr::EMPTY) break;
+                sl = (sl + 1) & tmask;
+            }
+            slot = sl;
+        }
+        if (found) {
+            if (gp + k <= r1) { // the k-mer lies inside one read
+                // (requested before the window scan that decides whether it is needed: the scan hides the round trip)
+                const uint4 sf = a.slot_first[slot]; // record offset, count, first record's node, its prg and that prg's shortest path
+                // ---- scan q = q_first .. q_first + 2w-2; steps outside [gp-(w-1), gp+(w-1)] or the read are invalid ----
+                const int64_t q_lo = gp - (w - 1);
+                const int64_t q_first = q_lo > a0 ? q_lo : a0; // a0 <= max(q_lo, 0)
+                const int of = (int)(q_first - a0);            // 0..30
+                const int64_t v_lo = r0 > q_first ? r0 : q_first;
+                const int64_t v_hi = (r1 - k) < (gp + w - 1) ? (r1 - k) : (gp + w - 1);
+                const int i_lo = (int)(v_lo - q_first), i_hi = (int)(v_hi - q_first), ic = (int)(gp - q_first);
+                // align the shift register on q_first: 48 bases in three words cover 2w-1 + k-1 <= 45
+                if (of & 16) { r0w = r1w; r1w = r2w; r2w = r3w; r3w = 0; }
+                const int s2 = 2 * (of & 15);
+                r0w = __funnelshift_l(r1w, r0w, s2);
+                r1w = __funnelshift_l(r2w, r1w, s2);
+                r2w = __funnelshift_l(r3w, r2w, s2);
+                // steps that can count at all: inside the read and the window, no N in the k-mer (bit i = step i)
+                const uint32_t valid = ((2u << i_hi) - 1u) & ~((1u << i_lo) - 1u) & ~(uint32_t)(bad >> of);
+                uint32_t streak = 0, right = 0, alive = 1;
+                uint32_t rcw = revcomp_code(r0w >> sh_k, k) << 2; // the reverse complement rolls along: one base in, one out
+                const int n_steps = (fw.debug & 16u) ? 0 : 2 * w - 1; // (DRPRG_FT_DEBUG=16: measurement only, no window test)
+                for (int i = 0; i < n_steps; ++i) {
+                    const uint32_t f = r0w >> sh_k;
+                    rcw = (rcw >> 2) | ((~f & 3u) << (2 * k - 2));
+                    r0w = __funnelshift_l(r1w, r0w, 2);
+                    r1w = __funnelshift_l(r2w, r1w, 2);
+                    r2w <<= 2;
+                    const uint32_t hf = verify_mix<KC>(f, kmask), hr = verify_mix<KC>(rcw, kmask);
+                    const uint32_t x = (hf < hr ? hf : hr) + 1;
+                    const bool ok = ((valid >> i) & 1u) && x >= g;
+                    if (i < ic) streak = ok ? streak + 1 : 0;
+                    else if (i > ic) {
+                        alive = ok ? alive : 0u;
+                        right += alive;
+                    }
+                }
+                if ((int)(streak + right) >= w - 1) verify_emit(a, rc, c, gp, r0, r1, strand, sf, o, my_hits, my_nmin, my_maxlen);
+            }
+        }
+    }
+}
+
 template <int KC>
 __global__ __launch_bounds__(EX_THREADS) void verify_count_kernel(SketchArgs a, FilterWork fw, ReadClusterArgs rc)
 {
-    using Tr = HashTraits<uint32_t>;
     __shared__ uint32_t s_red[3][EX_THREADS / 64];
     const int tid = threadIdx.x;
     uint32_t t_begin, t_end;
     candidate_range(fw, blockIdx.x, gridDim.x, t_begin, t_end);
-    const uint32_t* __restrict__ slot_key = reinterpret_cast<const uint32_t*>(a.slot_key);
-    const uint32_t tmask = (1u << a.table_bits) - 1;
-    const int k = a.k, w = a.w;
-    const int sh_k = 32 - 2 * k;
-    const uint32_t kmask = (1u << (2 * k)) - 1;
-    const int64_t n_bases = (int64_t)a.n_bases;
-    const double reads_per_base = (double)a.n_reads / (double)(a.n_bases ? a.n_bases : 1);
-    const uint32_t w1_magic = w1_reciprocal(w);
-    const int64_t win_lo = (int64_t)a.offsets[fw.read_begin], win_hi = (int64_t)a.offsets[fw.read_end];
+    const VerifyConsts c(a, fw);
     uint32_t my_hits = 0, my_nmin = 0, my_maxlen = 0;
     // (the position of this thread's next candidate is requested one round early: one round trip less in the chain of each)
     int64_t gp_next = t_begin + tid < t_end ? (int64_t)fw.cand_info[t_begin + tid] : 0;
     for (uint32_t t = t_begin + tid; t < t_end; t += EX_THREADS) {
         const int64_t gp = gp_next; // position now, (slot, strand, read) when this lane is done
         if (t + EX_THREADS < t_end) gp_next = (int64_t)fw.cand_info[t + EX_THREADS];
-        uint32_t pos1 = 0, slot = 0, read = READ_NONE, strand = 0;
-        uint4 crec = make_uint4(0, 0, 0, 0);
-        if (gp >= win_lo && gp < win_hi && gp + k <= n_bases) { // (the boundary tiles of a read range reach past it)
-            // Everything the candidate needs from memory that does not depend on other loads is requested before anything is
-            // waited for: the two read offsets around the interpolated read index and the four 16-byte words of the 64 bases
-            // [a0, a0+64) that hold the candidate and all its neighbours (w <= 16, k <= 15).  (One guarded load after the other,
-            // each behind its own branch, was four round trips in a row, and the read lookup two more.)
-            uint32_t guess = (uint32_t)((double)gp * reads_per_base);
-            if (guess >= a.n_reads) guess = a.n_reads - 1;
-            const uint64_t o0 = a.offsets[guess], o1 = a.offsets[guess + 1];
-            const int64_t a0 = (gp > 15 ? gp - 15 : 0) & ~(int64_t)15;
-            uint4 b0, b1, b2, b3;
-            if (a0 + 64 <= n_bases) {
-                const uint4* __restrict__ bp = reinterpret_cast<const uint4*>(a.bases + a0);
-                b0 = bp[0];
-                b1 = bp[1];
-                b2 = bp[2];
-                b3 = bp[3];
-            } else { // the last bytes of the buffer
-                b0 = load16_guarded(a.bases, n_bases, a0);
-                b1 = load16_guarded(a.bases, n_bases, a0 + 16);
-                b2 = load16_guarded(a.bases, n_bases, a0 + 32);
-                b3 = load16_guarded(a.bases, n_bases, a0 + 48);
-            }
-            // the read of every candidate, index k-mer or not: read_cluster_kernel finds the first candidate of a read by
-            // comparing neighbours (the interpolated index is exact for fixed-length reads; a short gallop otherwise)
-            int64_t r0 = (int64_t)o0, r1 = (int64_t)o1;
-            if (o0 <= (uint64_t)gp && (uint64_t)gp < o1) read = guess;
-            else {
-                read = find_read_near(a.offsets, a.n_reads, guess, (uint64_t)gp);
-                r0 = (int64_t)a.offsets[read];
-                r1 = (int64_t)a.offsets[read + 1];
-            }
-            uint32_t r0w, r1w, r2w, r3w, n0, n1, n2, n3;
-            pack16n(b0, r0w, n0);
-            pack16n(b1, r1w, n1);
-            pack16n(b2, r2w, n2);
-            pack16n(b3, r3w, n3);
-            uint64_t bad = (uint64_t)(n0 | (n1 << 16)) | ((uint64_t)(n2 | (n3 << 16)) << 32); // bit i: base a0+i is not ACGT
-            if (bad) { // -> bit i: the k-mer starting at a0+i holds such a base
-                uint64_t m = bad;
-                for (int i = 1; i < k; ++i) m |= bad >> i;
-                bad = m;
-            }
-            // ---- the candidate's own canonical hash, exact lookup ----
-            const int oc = (int)(gp - a0); // 0..30
-            uint32_t g = 0;
-            if (!((bad >> oc) & 1u)) {
-                const uint32_t h0 = (oc & 16) ? r1w : r0w, h1 = (oc & 16) ? r2w : r1w;
-                const uint32_t f = __funnelshift_l(h1, h0, 2 * (oc & 15)) >> sh_k;
-                const uint32_t hf = verify_mix<KC>(f, kmask), hr = verify_mix<KC>(revcomp_code(f, k), kmask);
-                strand = hf <= hr ? 1u : 0u;
-                g = (hf < hr ? hf : hr) + 1;
-            }
-            bool found = false;
-            if (g && !(fw.debug & 32u)) { // (DRPRG_FT_DEBUG=32: timing only, no table probe and nothing after it)
-                const uint32_t h = g - 1;
-                uint32_t sl = table_slot_dev(h, a.table_bits);
-                while (true) {
-                    const uint32_t key = slot_key[sl];
-                    if (key == h) { found = true; break; }
-                    if (key == Tr::EMPTY) break;
-                    sl = (sl + 1) & tmask;
-                }
-                slot = sl;
-            }
-            if (found) {
-                if (gp + k <= r1) { // the k-mer lies inside one read
-                    // (requested before the window scan that decides whether it is needed: the scan hides the round trip)
-                    const uint4 sf = a.slot_first[slot]; // record offset, count, first record's node, its prg and that prg's shortest path
-                    // ---- scan q = q_first .. q_first + 2w-2; steps outside [gp-(w-1), gp+(w-1)] or the read are invalid ----
-                    const int64_t q_lo = gp - (w - 1);
-                    const int64_t q_first = q_lo > a0 ? q_lo : a0; // a0 <= max(q_lo, 0)
-                    const int of = (int)(q_first - a0);            // 0..30
-                    const int64_t v_lo = r0 > q_first ? r0 : q_first;
-                    const int64_t v_hi = (r1 - k) < (gp + w - 1) ? (r1 - k) : (gp + w - 1);
-                    const int i_lo = (int)(v_lo - q_first), i_hi = (int)(v_hi - q_first), ic = (int)(gp - q_first);
-                    // align the shift register on q_first: 48 bases in three words cover 2w-1 + k-1 <= 45
-                    if (of & 16) { r0w = r1w; r1w = r2w; r2w = r3w; r3w = 0; }
-                    const int s2 = 2 * (of & 15);
-                    r0w = __funnelshift_l(r1w, r0w, s2);
-                    r1w = __funnelshift_l(r2w, r1w, s2);
-                    r2w = __funnelshift_l(r3w, r2w, s2);
-                    // steps that can count at all: inside the read and the window, no N in the k-mer (bit i = step i)
-                    const uint32_t valid = ((2u << i_hi) - 1u) & ~((1u << i_lo) - 1u) & ~(uint32_t)(bad >> of);
-                    uint32_t streak = 0, right = 0, alive = 1;
-                    uint32_t rcw = revcomp_code(r0w >> sh_k, k) << 2; // the reverse complement rolls along: one base in, one out
-                    const int n_steps = (fw.debug & 16u) ? 0 : 2 * w - 1; // (DRPRG_FT_DEBUG=16: measurement only, no window test)
-                    for (int i = 0; i < n_steps; ++i) {
-                        const uint32_t f = r0w >> sh_k;
-                        rcw = (rcw >> 2) | ((~f & 3u) << (2 * k - 2));
-                        r0w = __funnelshift_l(r1w, r0w, 2);
-                        r1w = __funnelshift_l(r2w, r1w, 2);
-                        r2w <<= 2;
-                        const uint32_t hf = verify_mix<KC>(f, kmask), hr = verify_mix<KC>(rcw, kmask);
-                        const uint32_t x = (hf < hr ? hf : hr) + 1;
-                        const bool ok = ((valid >> i) & 1u) && x >= g;
-                        if (i < ic) streak = ok ? streak + 1 : 0;
-                        else if (i > ic) {
-                            alive = ok ? alive : 0u;
-                            right += alive;
-                        }
-                    }
-                    if ((int)(streak + right) >= w - 1) {
-                        const uint64_t pos = (uint64_t)(gp - r0);
-                        if (pos >= (1ull << HIT_POS_BITS)) atomicOr(a.overflow, 2u);
-                        else {
-                            pos1 = (uint32_t)pos + 1;
-                            const uint2 rec = make_uint2(sf.x, sf.y);
-                            my_hits += rec.y;
-                            my_nmin += 1;
-                            const uint32_t len = (uint32_t)((r1 - r0) > 0xFFFFFFFFll ? 0xFFFFFFFFll : (r1 - r0));
-                            my_maxlen = len > my_maxlen ? len : my_maxlen;
-                            // for read_cluster_kernel: the first hit of this minimizer and the size threshold of a cluster
-                            // of this read on that hit's PRG (cluster_eval_kernel)
-                            const uint32_t kn = sf.z, prg = sf.w & 0xFFFu;
-                            const uint32_t rev = ((kn & 1u) == strand) ? 0u : 1u;
-                            const uint64_t expected = expected_minimizers((uint64_t)(r1 - r0), w, w1_magic);
-                            uint64_t m = sf.w >> 12;
-                            if (expected < m) m = expected;
-                            const uint32_t length_based = (uint32_t)((double)m * rc.fraction);
-                            uint32_t thr = length_based > rc.min_cluster_size ? length_based : rc.min_cluster_size;
-                            if (thr > 0xFFFFu) thr = 0xFFFFu; // read_cluster_kernel stages at most RC_HCAP hits: no difference
-                            crec = make_uint4(rec.x, rec.y, (strand << 31) | (((prg << 1) | rev) << 16) | thr, (kn >> 1) * 2u + rev);
-                        }
-                    }
-                }
-            }
-        }
-        fw.cand_pos1[t] = pos1;
-        fw.cand_info[t] = ((uint64_t)slot << 32) | ((uint64_t)strand << 31) | (uint64_t)read;
-        fw.cand_rec[t] = crec;
+        VerifyOut o;
+        verify_one_lane<KC>(a, fw, rc, c, gp, o, my_hits, my_nmin, my_maxlen);
+        fw.cand_pos1[t] = o.pos1;
+        fw.cand_info[t] = ((uint64_t)o.slot << 32) | ((uint64_t)o.strand << 31) | (uint64_t)o.read;
+        fw.cand_rec[t] = o.crec;
     }
     // ---- per-workgroup totals (the only barrier of the kernel) ----
     const uint32_t wh = wave_inclusive_scan(my_hits), wn = wave_inclusive_scan(my_nmin), wm = wave_max(my_maxlen);
@@ -276,6 +307,13 @@ __global__ __launch_bounds__(EX_THREADS) void verify_count_kernel(SketchArgs a, 
         fw.wg_maxlen[blockIdx.x] = mx;
     }
 }
+
+// (Round 3 built a wave-cooperative form of this kernel -- the 64 consecutive candidates of a wave work out which k-mer positions
+// their windows need, hash each ONCE, four per lane, into LDS, and read their neighbours from there -- and measured it slower than
+// one lane per candidate on every index size: 151 against 118-132 us on the 8d index, 1.06 against 0.82 ms on the 8-fold one.  The
+// SQ counters say why: 51.6 M VALU wave-instructions against 54.3 M.  Stray candidates and read ends keep the shared windows short
+// (19 hashes per candidate instead of 42), hashing is under half of the lane form's instructions, and the bookkeeping -- segments,
+// quad origins, 64-bit positions, LDS round trips -- costs what the sharing saves.  DESIGN.md section 6.)
 
 // one workgroup: wg_base = exclusive scan of wg_hits; batch totals
 __global__ __launch_bounds__(SCAN_THREADS) void hit_scan_kernel(SketchArgs a, FilterWork fw, int recount)
