@@ -489,6 +489,19 @@ def main():
             traffic = json.load(open(tfile)).get(args.workload, {}).get(kernel_name, {}).get("hbm_bytes_per_launch")
             if traffic is not None:
                 traffic = traffic / launches_per_step  # (measured per batch)
+        # secondary bound (SURVEY 8d "report honestly"): the dominant kernel's VALU issue slots.  Wave instructions per launch come
+        # from offline rocprofv3 SQ-counter passes of this workload (profiles/valu.json, SQ_INSTS_VALU); the duration is the live one.
+        # One wave64 VALU instruction occupies its SIMD for 4 cycles (measured: tools/microbench.hip), 1024 SIMDs at 2.4 GHz.
+        secondary = None
+        vfile = os.path.join(ROOT, "profiles", "valu.json")
+        if n_reads == default_reads and os.path.exists(vfile) and avg_ms > 0:
+            v = json.load(open(vfile)).get(args.workload, {}).get(kernel_name, {}).get("valu_wave_insts_per_launch")
+            if v:
+                v = v / launches_per_step
+                peak = 1024 * 2.4e9 / 4
+                secondary = {"bound": "valu_issue", "wave_insts": v, "achieved": v / (avg_ms * 1e-3), "peak": peak, "unit": "wave-instructions/s",
+                             "frac": v / (avg_ms * 1e-3) / peak,
+                             "source": "profiles/valu.json (offline rocprofv3 --pmc SQ_INSTS_VALU of this workload) over the live kernel duration"}
         out = {
             "metric": "reads/sec (+ achieved HBM GB/s) predicting on mtb index, 1/2/4/8 GPUs",
             "value": value,
@@ -528,6 +541,7 @@ def main():
                                   if traffic is not None else None,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": avg_ms, "launches_timed": k_launches, "launches_per_step": launches_per_step,
+                "secondary": secondary,
             },
         }
         # CPU baseline: the oracle (a scalar port of the same path, oracle/oracle.c) on a bounded sample of rank 0's shard,

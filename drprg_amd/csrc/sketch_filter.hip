@@ -430,17 +430,24 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
         fetch(tile + step, r1);
     }
     __syncthreads(); // Bloom filter in place; the only barrier
+    // (middle tier: a tile's bitmap probes are waited for inside process(), and the wait is for every load the wave has issued --
+    // so the tile after next is requested BEHIND process(), not in front of it: the wait then covers L2 probes and a tile that was
+    // requested a whole tile ago, not a fresh HBM round trip in every tile)
+    constexpr bool FETCH_LATE = MID != 0;
     while (tile < full_end) {
-        fetch(tile + 2 * step, r2);
+        if (!FETCH_LATE) fetch(tile + 2 * step, r2);
         process(tile, r0);
+        if (FETCH_LATE) fetch(tile + 2 * step, r2);
         tile += step;
         if (tile >= full_end) break;
-        fetch(tile + 2 * step, r0);
+        if (!FETCH_LATE) fetch(tile + 2 * step, r0);
         process(tile, r1);
+        if (FETCH_LATE) fetch(tile + 2 * step, r0);
         tile += step;
         if (tile >= full_end) break;
-        fetch(tile + 2 * step, r1);
+        if (!FETCH_LATE) fetch(tile + 2 * step, r1);
         process(tile, r2);
+        if (FETCH_LATE) fetch(tile + 2 * step, r1);
         tile += step;
     }
     for (; tile < tile_end; tile += step) { // the end of the buffer, guarded loads

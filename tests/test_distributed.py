@@ -39,6 +39,11 @@ WORKER = textwrap.dedent("""
     covg, prg_reads, _ = orc.map_reads(b, o, orc.build_index(panel.prgs, w, k), w, k, md, cluster_fraction(er, k), 10)
     tc = torch.from_numpy(covg.view(np.int32).copy())
     tp = torch.from_numpy(prg_reads.view(np.int32).copy())
+    try:  # (refused before any collective: every rank takes the same path)
+        reduce_coverage(tc[::2], tp, 0)
+        raise SystemExit("reduce_coverage accepted a non-contiguous tensor it cannot update in place")
+    except ValueError:
+        pass
     total = reduce_coverage(tc, tp, int(o[-1]))
     if rank == 0:
         ctx.set_coverage(tc.numpy().view(np.uint32), tp.numpy().view(np.uint32), total)
@@ -89,3 +94,23 @@ def test_two_rank_reduce_equals_single_rank(tmp_path, oracle):
     ctx.genotype(genes, str(tmp_path / "single.vcf"))
     strip = lambda p: [l for l in open(p) if not l.startswith("##fileDate")]
     assert strip(tmp_path / "multi.vcf") == strip(tmp_path / "single.vcf")
+
+
+def test_reduce_coverage_refuses_tensors_it_cannot_update_in_place():
+    """reduce_coverage writes the reduced values back into its arguments: a non-contiguous view or a tensor of another dtype would
+    silently keep the unreduced values, so both are refused (single rank: nothing to reduce, nothing to check)."""
+    import torch
+    import torch.distributed as dist
+    from drprg_amd.distributed import reduce_coverage
+    a = torch.zeros(8, dtype=torch.int32)
+    assert reduce_coverage(a, a[:2], 5) == 5  # no process group: a no-op
+    if dist.is_available() and not dist.is_initialized():
+        import socket
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+        try:
+            assert reduce_coverage(a, a[:2], 7) == 7  # world size 1: still a no-op
+        finally:
+            dist.destroy_process_group()
