@@ -252,13 +252,19 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
                     uint4 r = make_uint4(0, 0, 0, 0);                                                                                 \
                     if (ri < lcnt) {                                                                                                  \
                         r = stage[ri];                                                                                                \
-                        _Pragma("unroll") for (int q = 0; q < 4; ++q) { /* six bits of one word, keyed on the whole code at position q */ \
+                        /* six bits of one word, keyed on the whole code at position q; the four words requested before the first test  \
+                           (one after the other they were four LDS round trips in a row) */                                             \
+                        uint32_t hq[4], h2q[4], wq[4];                                                                                \
+                        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                               \
                             const uint32_t f = (q ? __funnelshift_r(r.z, r.w, 2 * q) : r.z) & kmask;                                  \
-                            const uint32_t h = f * BLOOM_CR, h2 = f * BLOOM_C2;                                                       \
-                            const uint32_t word = lds_at((h >> 17) << 2);                                                             \
-                            cs |= ((word >> (h & 31)) & (word >> ((h >> 5) & 31)) & (word >> ((h >> 10) & 31)) & (word >> (h2 >> 27))  \
-                                      & (word >> ((h2 >> 22) & 31)) & (word >> ((h2 >> 17) & 31)) & 1u) << q;                         \
+                            hq[q] = f * BLOOM_CR;                                                                                     \
+                            h2q[q] = f * BLOOM_C2;                                                                                    \
+                            wq[q] = lds_at((hq[q] >> 17) << 2);                                                                       \
                         }                                                                                                             \
+                        __builtin_amdgcn_sched_barrier(0); /* (the scheduler otherwise pulls the tests back between the reads) */     \
+                        _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                                 \
+                            cs |= ((wq[q] >> (hq[q] & 31)) & (wq[q] >> ((hq[q] >> 5) & 31)) & (wq[q] >> ((hq[q] >> 10) & 31)) & (wq[q] >> (h2q[q] >> 27)) \
+                                      & (wq[q] >> ((h2q[q] >> 22) & 31)) & (wq[q] >> ((h2q[q] >> 17) & 31)) & 1u) << q;               \
                     }                                                                                                                 \
                     DRPRG_STAGE2_APPEND(r, cs);                                                                                       \
                 }                                                                                                                     \
