@@ -159,7 +159,7 @@ def make_panel(synth, which):
     if which.startswith("mtb_x"):
         return synth.mtb_scaled_panel(int(which[5:]))
     if which == "mtb_dense":
-        return synth.panel_from_index_dir(os.path.join(ROOT, "tests", "golden", "downstream"), fill_every=8)[0]
+        return synth.panel_from_index_dir(synth.MTB_8D_DIR, fill_every=8)[0]
     return {"mtb_8d": synth.mtb_8d_panel, "mtb_like": synth.mtb_like_panel, "big": synth.big_panel}[which]()
 
 

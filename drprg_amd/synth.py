@@ -13,6 +13,8 @@ MTB_LOCI = [("embA", 3485), ("fabG1", 944), ("rpsL", 575), ("gid", 875), ("rplC"
             ("rpoB", 3719), ("ethA", 1670), ("ahpC", 788), ("ddn", 656), ("gyrB", 2228), ("tlyA", 1007), ("embB", 3497),
             ("gyrA", 2717), ("pncA", 761), ("katG", 2423), ("inhA", 1010)]
 MTB_GENOME_SIZE = 4411532
+import os as _os
+MTB_8D_DIR = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "data", "mtb_8d")  # genes.fa + panel.bcf of the reference's test index
 _ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
 _COMP = np.zeros(256, dtype=np.uint8)
 _COMP[list(b"ACGTNacgtn")] = list(b"TGCANtgcan")
@@ -367,10 +369,10 @@ def mtb_8d_panel(index_dir=None):
     """The "mtb-like" index of SURVEY.md section 8d: backbone = the reference's test genes.fa (18 genes, 30,355 bp with
     padding 100), sites = the panel.bcf records that fit without overlapping + seeded random SNP bubbles at 1 per 60 bp
     elsewhere, <= 4 alts, 10 % nested; k = 15, w = 11, seed 20230308.  The index files are the committed copies under
-    tests/golden/downstream/ (data fixtures of /root/reference/tests/cases/predict/)."""
-    import os
+    drprg_amd/data/mtb_8d/ (genes.fa and panel.bcf: data files of /root/reference/tests/cases/predict/, the same bytes as under
+    tests/golden/downstream/ -- the package carries its own copy so that bench.py and smoke() do not depend on tests/)."""
     if index_dir is None:
-        index_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "downstream")
+        index_dir = MTB_8D_DIR
     return panel_from_index_dir(index_dir, fill_every=60)[0]
 
 

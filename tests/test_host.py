@@ -755,3 +755,13 @@ def test_named_index_with_foreign_files_is_an_error_unless_rebuild_is_asked_for(
     assert "rebuilding the k-mer graphs" in r.stderr, r.stderr  # (then it needs a GPU: -ENODEV on this host)
     r = subprocess.run([exe, "predict", "-x", str(idx), "-i", str(reads), "-o", str(tmp_path / "o3")], capture_output=True, text=True, env=env)
     assert "rebuilding the k-mer graphs" in r.stderr, r.stderr
+
+
+def test_package_workload_data_equals_the_golden_fixtures():
+    """drprg_amd/data/mtb_8d holds the two data files the SURVEY-8d workload is built from (so that bench.py does not depend on
+    tests/): the same bytes as the fixtures tools/make_golden.py copied from /root/reference/tests/cases/predict"""
+    import filecmp
+    from drprg_amd import synth
+    for f in ("genes.fa", "panel.bcf"):
+        assert filecmp.cmp(os.path.join(synth.MTB_8D_DIR, f), os.path.join(GOLDEN, "downstream", f), shallow=False), f
+    assert len(synth.mtb_8d_panel().names) == 18
