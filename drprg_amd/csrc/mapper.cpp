@@ -184,9 +184,8 @@ Mapper::~Mapper()
     dfree(d_key_a_); dfree(d_key_b_); dfree(d_val_a_); dfree(d_val_b_);
     dfree(d_head_); dfree(d_scan_); dfree(d_cstart_); dfree(d_order_); dfree(d_clusters_);
     if (d_temp_) (void)hipFree(d_temp_);
-    dfree(d_tile_info_); dfree(d_tile_pos1_); dfree(d_tile_count_); dfree(d_tile_hits_); dfree(d_tile_nmin_); dfree(d_tile_prefix_); dfree(d_tile_fast_); dfree(d_tile_rec_);
-    if (d_tile_temp_) (void)hipFree(d_tile_temp_);
-    dfree(d_bases_); dfree(d_offsets_); dfree(d_tile_first_); dfree(d_bloom_); dfree(d_bloom0_); dfree(d_bloom0f_); dfree(d_bloomr_); dfree(d_pbloom_); dfree(d_mid0_); dfree(d_mid_bitmap_); dfree(d_midc_); dfree(d_ft_stat_);
+    for (TileSet& t : tsets_) free_tile_set(t);
+    dfree(d_bases_); dfree(d_offsets_); dfree(d_bloom_); dfree(d_bloom0_); dfree(d_bloom0f_); dfree(d_bloomr_); dfree(d_pbloom_); dfree(d_mid0_); dfree(d_mid_bitmap_); dfree(d_midc_); dfree(d_ft_stat_);
     for (Lane& lane : lanes_) free_lane(lane);
     for (Stage& st : stage_) {
         dfree(st.d_bases); dfree(st.d_offsets);
@@ -428,7 +427,7 @@ dev::SketchArgs Mapper::sketch_args(const uint8_t* d_bases, const uint64_t* d_of
     a.table_bits = table_bits_;
     a.rec_knode = d_rec_knode_;
     a.rec_prg = d_rec_prg_;
-    a.tile_first_read = d_tile_first_;
+    a.tile_first_read = ts_->d_tile_first;
     a.pbloom = d_pbloom_;
     a.pbloom_wbits = pbloom_wbits_;
     a.hit_key = d_key_a_;
@@ -478,36 +477,51 @@ void Mapper::leftovers(Lane& lane, const uint8_t* d_bases, const uint64_t* d_off
     cluster_hits(d_offsets, (uint32_t)n_left, lane.h_scratch[L_MAXLEN] <= READ_SORT_MAX_LEN, &lane.d_scratch[L_UNSORTED], covg, prg_reads, stream);
 }
 
-void Mapper::ensure_tile_workspace(uint32_t n_tiles, uint32_t tile_cap)
+void Mapper::free_tile_set(TileSet& t)
 {
-    if (n_tiles <= tile_ws_tiles_ && tile_cap <= tile_ws_cap_) return;
-    dfree(d_tile_info_); dfree(d_tile_pos1_); dfree(d_tile_count_); dfree(d_tile_hits_); dfree(d_tile_nmin_); dfree(d_tile_prefix_); dfree(d_tile_fast_); dfree(d_tile_rec_);
-    if (d_tile_temp_) (void)hipFree(d_tile_temp_);
-    d_tile_temp_ = nullptr;
-    tile_ws_tiles_ = std::max(tile_ws_tiles_, n_tiles + n_tiles / 8 + 32);
-    tile_ws_cap_ = std::max(tile_ws_cap_, tile_cap);
-    const size_t n = (size_t)tile_ws_tiles_ * tile_ws_cap_;
-    dmalloc(d_tile_info_, n); dmalloc(d_tile_pos1_, n); dmalloc(d_tile_rec_, n);
-    dmalloc(d_tile_count_, (size_t)tile_ws_tiles_ + 1); dmalloc(d_tile_hits_, (size_t)tile_ws_tiles_ + 1); dmalloc(d_tile_nmin_, (size_t)tile_ws_tiles_ + 1); dmalloc(d_tile_prefix_, (size_t)tile_ws_tiles_ + 1); dmalloc(d_tile_fast_, (size_t)tile_ws_tiles_ + 1);
-    tile_temp_bytes_ = dev::scan_temp_bytes(tile_ws_tiles_ + 1);
-    HIPCHK(hipMalloc(&d_tile_temp_, tile_temp_bytes_ ? tile_temp_bytes_ : 1));
+    dfree(t.d_tile_info); dfree(t.d_tile_pos1); dfree(t.d_tile_count); dfree(t.d_tile_hits); dfree(t.d_tile_nmin); dfree(t.d_tile_prefix); dfree(t.d_tile_fast);
+    dfree(t.d_tile_rec); dfree(t.d_tile_first);
+    if (t.d_tile_temp) (void)hipFree(t.d_tile_temp);
+    t.d_tile_temp = nullptr;
+    for (hipEvent_t* e : { &t.done, &t.t0, &t.t1 })
+        if (*e) (void)hipEventDestroy(*e);
+    t = TileSet();
+}
+
+void Mapper::ensure_tile_workspace(TileSet& t, uint32_t n_tiles, uint32_t tile_cap)
+{
+    if (n_tiles <= t.ws_tiles && tile_cap <= t.ws_cap) return;
+    dfree(t.d_tile_info); dfree(t.d_tile_pos1); dfree(t.d_tile_count); dfree(t.d_tile_hits); dfree(t.d_tile_nmin); dfree(t.d_tile_prefix); dfree(t.d_tile_fast); dfree(t.d_tile_rec);
+    if (t.d_tile_temp) (void)hipFree(t.d_tile_temp);
+    t.d_tile_temp = nullptr;
+    t.ws_tiles = std::max(t.ws_tiles, n_tiles + n_tiles / 8 + 32);
+    t.ws_cap = std::max(t.ws_cap, tile_cap);
+    const size_t n = (size_t)t.ws_tiles * t.ws_cap;
+    dmalloc(t.d_tile_info, n); dmalloc(t.d_tile_pos1, n); dmalloc(t.d_tile_rec, n);
+    dmalloc(t.d_tile_count, (size_t)t.ws_tiles + 1); dmalloc(t.d_tile_hits, (size_t)t.ws_tiles + 1); dmalloc(t.d_tile_nmin, (size_t)t.ws_tiles + 1); dmalloc(t.d_tile_prefix, (size_t)t.ws_tiles + 1); dmalloc(t.d_tile_fast, (size_t)t.ws_tiles + 1);
+    t.tile_temp_bytes = dev::scan_temp_bytes(t.ws_tiles + 1);
+    HIPCHK(hipMalloc(&t.d_tile_temp, t.tile_temp_bytes ? t.tile_temp_bytes : 1));
 }
 
 // Direct sequence, candidate form: every k-mer hashed (any k, any w, any index size); each tile leaves its index minimizers
 // as candidate records in position order, a scan + gather makes the dense ordered list and read_cluster_kernel takes it from
 // there -- no hit list, no radix sort, no cluster kernels for the reads that fit it.
-void Mapper::run_batch_direct_candidates(const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads, uint64_t n_bases,
-    uint32_t* covg, uint32_t* prg_reads, hipStream_t stream)
+// One attempt, asynchronous on `stream`: the launches, the lane's counters to their pinned mirror, the counters cleared behind the copy.
+void Mapper::direct_launch(int set, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads, uint64_t n_bases, uint32_t* covg,
+    uint32_t* prg_reads, hipStream_t stream, bool timed_by_set_events)
 {
+    TileSet& t = tsets_[set];
+    ts_ = &t;
     const uint32_t n_tiles = dev::direct_candidate_tiles(n_bases, halo_, params_.k, params_.w, wide_hash_); // = slices
     const uint32_t n_first = dev::direct_first_read_tiles(n_bases, halo_, params_.k, params_.w, wide_hash_);
-    if (n_first > tile_cap_) { // first read of every tile
-        dfree(d_tile_first_);
-        tile_cap_ = n_first + n_first / 4 + 16;
-        dmalloc(d_tile_first_, (size_t)tile_cap_);
+    if (n_first > t.first_cap) { // first read of every tile
+        dfree(t.d_tile_first);
+        t.first_cap = n_first + n_first / 4 + 16;
+        dmalloc(t.d_tile_first, (size_t)t.first_cap);
     }
-    ensure_lanes(1, std::min<uint64_t>(std::max<uint64_t>(1u << 20, n_bases / 16), (1ull << 31) - 1));
-    Lane& lane = lanes_[0];
+    ensure_lanes(set + 1, 0); // (the lanes exist; only this set's lane may grow: the other one may belong to a batch in flight)
+    Lane& lane = lanes_[(size_t)set];
+    grow_lane(lane, std::min<uint64_t>(std::max<uint64_t>(1u << 20, n_bases / 16), (1ull << 31) - 1));
     // read_cluster_kernel takes the candidates straight from the tile slices (no gathered list unless reads are left over); what it
     // handled is marked in the dense cand_pos1 array with a value no other batch used (DRPRG_RC_SLICES=0: gather first, as before)
     static const bool from_slices = [] {
@@ -527,91 +541,119 @@ void Mapper::run_batch_direct_candidates(const uint8_t* d_bases, const uint64_t*
         }
         mark = slices_epoch_;
     }
-    dev::SketchArgs a_done {};
-    for (int attempt = 0;; ++attempt) {
-        ensure_tile_workspace(n_tiles, tile_slice_cap_);
-        if (!lane.scratch_zero) HIPCHK(hipMemsetAsync(lane.d_scratch, 0, L_N * sizeof(unsigned long long), stream));
-        lane.scratch_zero = false;
-        HIPCHK(hipMemsetAsync(d_tile_count_ + n_tiles, 0, sizeof(uint32_t), stream)); // the scan's closing zero
-        dev::SketchArgs a = sketch_args(d_bases, d_offsets, n_reads, n_bases);
-        a.n_hits = &lane.d_scratch[L_HITS];
-        a.n_minimizers = &lane.d_scratch[L_MINIMIZERS];
-        a.overflow = reinterpret_cast<uint32_t*>(&lane.d_scratch[L_OVERFLOW]);
-        a.tile_cap = tile_ws_cap_;
-        a.tile_info = d_tile_info_;
-        a.tile_pos1 = d_tile_pos1_;
-        a.tile_rec = d_tile_rec_;
-        a.tile_count = d_tile_count_;
-        a.tile_hits = d_tile_hits_;
-        a.tile_nmin = d_tile_nmin_;
-        a.tile_fast = d_tile_fast_;
-        a.prg_min_path_len = d_min_path_len_;
-        a.prg_thr = d_prg_thr_;
-        // sketch_wave_kernel can cluster the reads that lie inside one tile itself and add their coverage on the spot
-        // (opt-in: DRPRG_WAVE_FUSE=1; never with DRPRG_FT_DEBUG=8, "every read through the generic pipeline")
-        a.fuse = fuse_in_kernel_ && dev::direct_uses_wave_form(params_.k, params_.w, wide_hash_) ? fuse_mode_ : 0;
-        a.max_diff = params_.max_diff;
-        a.covg = covg;
-        a.prg_reads = prg_reads;
-        a.n_clusters_kept = &d_counters_[C_CLUSTERS_KEPT];
-        a.n_hits_kept = &d_counters_[C_HITS_KEPT];
-        a.dbg = std::getenv("DRPRG_WAVE_DEBUG") ? &d_counters_[C_CHUNK] : nullptr; // (words C_CHUNK.. are unused by this sequence)
-        a.fraction = params_.cluster_fraction();
-        a.min_cluster_size = params_.min_cluster_size;
-        dev::FilterBuffers fb { lane.raw_pos, lane.raw_grp, lane.cand_info, lane.cand_pos1, lane.cand_rec, lane.raw_capacity, lane.small,
-            &lane.d_scratch[L_MAXLEN] };
-        dev::ReadClusterArgs rc {};
-        rc.prg_min_path_len = d_min_path_len_;
-        rc.fraction = params_.cluster_fraction();
-        rc.min_cluster_size = params_.min_cluster_size;
-        rc.max_diff = params_.max_diff;
-        rc.n_prgs = n_prgs_;
-        rc.covg = covg;
-        rc.prg_reads = prg_reads;
-        rc.n_clusters_kept = &d_counters_[C_CLUSTERS_KEPT];
-        rc.n_hits_kept = &d_counters_[C_HITS_KEPT];
-        rc.n_complex = &lane.d_scratch[L_COMPLEX];
-        rc.chunk_counter = reinterpret_cast<uint32_t*>(&lane.d_scratch[L_CHUNK]);
-        lane.fw = dev::FilterWork {};
-        lane.fw.read_begin = 0;
-        lane.fw.read_end = n_reads;
-        dev::init_candidate_work(lane.fw, fb, n_cus_);
-        dev::KernelTimer timer;
-        if (timing_) {
+    ensure_tile_workspace(t, n_tiles, t.slice_cap);
+    if (!lane.scratch_zero) HIPCHK(hipMemsetAsync(lane.d_scratch, 0, L_N * sizeof(unsigned long long), stream));
+    lane.scratch_zero = false;
+    HIPCHK(hipMemsetAsync(t.d_tile_count + n_tiles, 0, sizeof(uint32_t), stream)); // the scan's closing zero
+    dev::SketchArgs a = sketch_args(d_bases, d_offsets, n_reads, n_bases);
+    a.n_hits = &lane.d_scratch[L_HITS];
+    a.n_minimizers = &lane.d_scratch[L_MINIMIZERS];
+    a.overflow = reinterpret_cast<uint32_t*>(&lane.d_scratch[L_OVERFLOW]);
+    a.tile_cap = t.ws_cap;
+    a.tile_info = t.d_tile_info;
+    a.tile_pos1 = t.d_tile_pos1;
+    a.tile_rec = t.d_tile_rec;
+    a.tile_count = t.d_tile_count;
+    a.tile_hits = t.d_tile_hits;
+    a.tile_nmin = t.d_tile_nmin;
+    a.tile_fast = t.d_tile_fast;
+    a.prg_min_path_len = d_min_path_len_;
+    a.prg_thr = d_prg_thr_;
+    // sketch_wave_kernel can cluster the reads that lie inside one tile itself and add their coverage on the spot
+    // (opt-in: DRPRG_WAVE_FUSE=1; never with DRPRG_FT_DEBUG=8, "every read through the generic pipeline")
+    a.fuse = fuse_in_kernel_ && dev::direct_uses_wave_form(params_.k, params_.w, wide_hash_) ? fuse_mode_ : 0;
+    a.max_diff = params_.max_diff;
+    a.covg = covg;
+    a.prg_reads = prg_reads;
+    a.n_clusters_kept = &d_counters_[C_CLUSTERS_KEPT];
+    a.n_hits_kept = &d_counters_[C_HITS_KEPT];
+    a.dbg = std::getenv("DRPRG_WAVE_DEBUG") ? &d_counters_[C_CHUNK] : nullptr; // (words C_CHUNK.. are unused by this sequence)
+    a.fraction = params_.cluster_fraction();
+    a.min_cluster_size = params_.min_cluster_size;
+    dev::FilterBuffers fb { lane.raw_pos, lane.raw_grp, lane.cand_info, lane.cand_pos1, lane.cand_rec, lane.raw_capacity, lane.small,
+        &lane.d_scratch[L_MAXLEN] };
+    dev::ReadClusterArgs rc {};
+    rc.prg_min_path_len = d_min_path_len_;
+    rc.fraction = params_.cluster_fraction();
+    rc.min_cluster_size = params_.min_cluster_size;
+    rc.max_diff = params_.max_diff;
+    rc.n_prgs = n_prgs_;
+    rc.covg = covg;
+    rc.prg_reads = prg_reads;
+    rc.n_clusters_kept = &d_counters_[C_CLUSTERS_KEPT];
+    rc.n_hits_kept = &d_counters_[C_HITS_KEPT];
+    rc.n_complex = &lane.d_scratch[L_COMPLEX];
+    rc.chunk_counter = reinterpret_cast<uint32_t*>(&lane.d_scratch[L_CHUNK]);
+    lane.fw = dev::FilterWork {};
+    lane.fw.read_begin = 0;
+    lane.fw.read_end = n_reads;
+    dev::init_candidate_work(lane.fw, fb, n_cus_);
+    dev::KernelTimer timer;
+    if (timing_) {
+        if (timed_by_set_events) {
+            if (!t.t0) HIPCHK(hipEventCreate(&t.t0));
+            if (!t.t1) HIPCHK(hipEventCreate(&t.t1));
+            timer.begin = t.t0;
+            timer.end = t.t1;
+        } else {
             timer.begin = ev0_;
             timer.end = ev1_;
         }
-        HIPCHK(dev::launch_direct_candidates(a, wide_hash_, d_tile_prefix_, d_tile_temp_, tile_temp_bytes_, lane.raw_capacity, rc, n_cus_, lane.fw,
-            stream, timer, mark));
-        a_done = a;
-        HIPCHK(hipMemcpyAsync(lane.h_scratch, lane.d_scratch, L_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-        HIPCHK(hipMemsetAsync(lane.d_scratch, 0, L_N * sizeof(unsigned long long), stream));
-        lane.scratch_zero = true;
-        wait_stream(stream);
-        note_kernel_time();
-        const uint32_t ovf = (uint32_t)lane.h_scratch[L_OVERFLOW];
-        if (ovf & 2u) throw Error(DRPRG_EOVERFLOW, "a read is longer than 2^" + std::to_string(dev::HIT_POS_BITS) + " bases");
-        if (!(ovf & 4u)) break;
-        // a tile slice or the dense list was too small: nothing was counted except the minimizers, and those only in this
-        // attempt's scratch block; grow both and run again.  What sketch_wave_kernel already added to the coverage vector for the
-        // reads it clusters itself is taken back first: the same launch with fuse = -1 repeats exactly those additions as
-        // subtractions (same input, same slice capacity, so the same reads take that path).
+    }
+    HIPCHK(dev::launch_direct_candidates(a, wide_hash_, t.d_tile_prefix, t.d_tile_temp, t.tile_temp_bytes, lane.raw_capacity, rc, n_cus_, lane.fw,
+        stream, timer, mark));
+    t.a_done = a;
+    t.mark = mark;
+    t.n_tiles = n_tiles;
+    HIPCHK(hipMemcpyAsync(lane.h_scratch, lane.d_scratch, L_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipMemsetAsync(lane.d_scratch, 0, L_N * sizeof(unsigned long long), stream));
+    lane.scratch_zero = true;
+}
+
+// The read-back of such an attempt has arrived.  false: a tile slice or the dense list was too small -- nothing was counted except the
+// minimizers, and those only in this attempt's scratch block --, the buffers have been grown and the caller runs the batch again.
+// What sketch_wave_kernel already added to the coverage vector for the reads it clusters itself is taken back first: the same launch
+// with fuse = -1 repeats exactly those additions as subtractions (same input, same slice capacity, so the same reads take that path).
+// true: totals taken, reads left to the generic pipeline queued on `stream`.
+bool Mapper::direct_finish(int set, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads, uint64_t n_bases, uint32_t* covg,
+    uint32_t* prg_reads, hipStream_t stream, int attempt)
+{
+    TileSet& t = tsets_[set];
+    ts_ = &t;
+    Lane& lane = lanes_[(size_t)set];
+    const uint32_t ovf = (uint32_t)lane.h_scratch[L_OVERFLOW];
+    if (ovf & 2u) throw Error(DRPRG_EOVERFLOW, "a read is longer than 2^" + std::to_string(dev::HIT_POS_BITS) + " bases");
+    if (ovf & 4u) {
         if (attempt > 6) throw Error(DRPRG_EOVERFLOW, "candidate buffer overflow after regrow");
-        if (a.fuse > 0) {
-            dev::SketchArgs undo = a;
-            undo.fuse = -a.fuse;
+        if (t.a_done.fuse > 0) {
+            dev::SketchArgs undo = t.a_done;
+            undo.fuse = -t.a_done.fuse;
             HIPCHK(dev::launch_sketch_wave(undo, stream));
             HIPCHK(hipStreamSynchronize(stream));
         }
-        tile_slice_cap_ = std::min<uint32_t>(tile_slice_cap_ * 2, 4096);
+        HIPCHK(hipStreamSynchronize(stream)); // (the buffers are about to be freed)
+        t.slice_cap = std::min<uint32_t>(t.slice_cap * 2, 4096);
         grow_lane(lane, std::min<uint64_t>(lane.raw_capacity * 2, (1ull << 31) - 1));
+        return false;
     }
     tot_minimizers_ += lane.h_scratch[L_MINIMIZERS];
     tot_hits_ += lane.h_scratch[L_HITS];
     tot_leftover_ += lane.h_scratch[L_COMPLEX];
-    if (mark && lane.h_scratch[L_COMPLEX]) // reads were left over: the generic pipeline wants the gathered list after all
-        HIPCHK(dev::launch_tile_gather_marked(a_done, lane.fw, d_tile_prefix_, n_tiles, lane.raw_capacity, mark, stream));
+    if (t.mark && lane.h_scratch[L_COMPLEX]) // reads were left over: the generic pipeline wants the gathered list after all
+        HIPCHK(dev::launch_tile_gather_marked(t.a_done, lane.fw, t.d_tile_prefix, t.n_tiles, lane.raw_capacity, t.mark, stream));
     leftovers(lane, d_bases, d_offsets, n_reads, n_bases, covg, prg_reads, stream);
+    return true;
+}
+
+void Mapper::run_batch_direct_candidates(const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads, uint64_t n_bases,
+    uint32_t* covg, uint32_t* prg_reads, hipStream_t stream)
+{
+    for (int attempt = 0;; ++attempt) {
+        direct_launch(0, d_bases, d_offsets, n_reads, n_bases, covg, prg_reads, stream, false);
+        wait_stream(stream);
+        note_kernel_time();
+        if (direct_finish(0, d_bases, d_offsets, n_reads, n_bases, covg, prg_reads, stream, attempt)) break;
+    }
 }
 
 // What the host does with a lane's read-back once its sequence has finished: a candidate slice that was too small -> the range
@@ -641,7 +683,9 @@ void Mapper::map_device_async(const uint8_t* d_bases, const uint64_t* d_offsets,
     uint32_t* prg_reads, hipStream_t stream)
 {
     if (n_reads == 0) return;
-    if (!use_filter_ || max_lanes_ > 1 || n_bases == 0) { // (no deferred form of the other sequences: the batch is complete on return,
+    const bool deferred_filter = use_filter_ && max_lanes_ == 1;
+    const bool deferred_direct = !use_filter_ && use_direct_cands_ && !fuse_in_kernel_;
+    if ((!deferred_filter && !deferred_direct) || n_bases == 0) { // (no deferred form of the other sequences: the batch is complete on return,
         map_device(d_bases, d_offsets, n_reads, n_bases, covg, prg_reads, stream); // including what its tail queued for the leftover reads)
         HIPCHK(hipSetDevice(device_));
         wait_stream(stream ? stream : stream_);
@@ -655,6 +699,34 @@ void Mapper::map_device_async(const uint8_t* d_bases, const uint64_t* d_offsets,
     if (!stream) stream = stream_;
     if (!covg) covg = d_covg_;
     if (!prg_reads) prg_reads = d_prg_reads_;
+    if (deferred_direct) {
+        // the direct sequence in its candidate form, deferred the same way: two sets of the tile workspace taken in turn, the batch's
+        // read-back looked at while the next batch runs (a batch whose slices overflowed, or that left reads to the generic pipeline,
+        // is finished then -- from its own set, which the batch in flight does not touch)
+        const int set = pipe_next_;
+        direct_launch(set, d_bases, d_offsets, (uint32_t)n_reads, n_bases, covg, prg_reads, stream, true);
+        TileSet& t = tsets_[set];
+        if (!t.done) HIPCHK(hipEventCreateWithFlags(&t.done, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(t.done, stream));
+        Pending cur;
+        cur.active = true;
+        cur.direct = true;
+        cur.lane = set;
+        cur.d_bases = d_bases;
+        cur.d_offsets = d_offsets;
+        cur.n_reads = (uint32_t)n_reads;
+        cur.n_bases = n_bases;
+        cur.covg = covg;
+        cur.prg_reads = prg_reads;
+        cur.stream = stream;
+        const Pending prev = pending_;
+        pending_ = cur;
+        pipe_next_ ^= 1;
+        tot_reads_ += n_reads;
+        tot_bases_ += n_bases;
+        if (prev.active) complete_batch(prev);
+        return;
+    }
     if (pipe_lanes_.empty()) {
         for (int j = 0; j < 2; ++j) {
             pipe_lanes_.emplace_back();
@@ -707,6 +779,37 @@ void Mapper::complete_pending()
 void Mapper::complete_batch(const Pending& p)
 {
     HIPCHK(hipSetDevice(device_));
+    if (p.direct) {
+        TileSet& t = tsets_[p.lane];
+        static const bool spin_d = [] {
+            const char* e = std::getenv("DRPRG_HIP_SPIN");
+            return !(e && std::atoi(e) == 0);
+        }();
+        bool ready = false;
+        for (int spins = 0; spin_d && spins < 2048 && !ready; ++spins) {
+            const hipError_t e = hipEventQuery(t.done);
+            if (e == hipSuccess) ready = true;
+            else if (e != hipErrorNotReady) HIPCHK(e);
+        }
+        if (!ready) HIPCHK(hipEventSynchronize(t.done));
+        if (timing_ && t.t0 && t.t1) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, t.t0, t.t1) == hipSuccess) {
+                sketch_ms_ += ms;
+                sketch_launches_ += 1;
+            }
+        }
+        const uint64_t leftover_before = tot_leftover_;
+        bool reran = false;
+        for (int attempt = 0; !direct_finish(p.lane, p.d_bases, p.d_offsets, p.n_reads, p.n_bases, p.covg, p.prg_reads, p.stream, attempt); ++attempt) {
+            // its slices were too small: nothing of it was counted; again, alone, behind whatever is queued on its stream
+            direct_launch(p.lane, p.d_bases, p.d_offsets, p.n_reads, p.n_bases, p.covg, p.prg_reads, p.stream, false);
+            wait_stream(p.stream);
+            reran = true;
+        }
+        if (reran || tot_leftover_ != leftover_before) wait_stream(p.stream);
+        return;
+    }
     Lane& lane = pipe_lanes_[(size_t)p.lane];
     static const bool spin = [] {
         const char* e = std::getenv("DRPRG_HIP_SPIN");
@@ -786,10 +889,11 @@ void Mapper::run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32
     // ---- direct sequence, generic form: every k-mer hashed, hits in tile order, global radix sort ----
     ensure_workspace(std::max<uint64_t>(1u << 20, n_bases / 64));
     const uint32_t n_tiles = dev::sketch_n_tiles(n_bases, halo_);
-    if (n_tiles > tile_cap_) { // first read of every tile
-        dfree(d_tile_first_);
-        tile_cap_ = n_tiles + n_tiles / 4 + 16;
-        dmalloc(d_tile_first_, (size_t)tile_cap_);
+    ts_ = &tsets_[0];
+    if (n_tiles > ts_->first_cap) { // first read of every tile
+        dfree(ts_->d_tile_first);
+        ts_->first_cap = n_tiles + n_tiles / 4 + 16;
+        dmalloc(ts_->d_tile_first, (size_t)ts_->first_cap);
     }
     for (int attempt = 0;; ++attempt) {
         HIPCHK(hipMemsetAsync(&d_counters_[C_HITS], 0, 2 * sizeof(unsigned long long), stream)); // hits + minimizers of this attempt

@@ -42,7 +42,8 @@ public:
     // back-to-back batches leave no gap on the device (measured on 10 M x 150 bp: ~50 us of host round trip per 0.7 ms
     // batch).  The caller keeps d_bases / d_offsets / the accumulators of a batch valid and unchanged until the call after
     // the next one returns, or sync() does (a batch whose candidate buffers overflowed is run again from them).
-    // Filtered sequence with one lane only; everything else falls back to map_device.
+    // Filtered sequence with one lane, and the direct sequence in its candidate form (two tile workspaces in turn); everything else
+    // falls back to map_device.
     void map_device_async(const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n_reads, uint64_t n_bases,
         uint32_t* d_covg, uint32_t* d_prg_reads, hipStream_t stream);
     void sync(); // completes the batch map_device_async left in flight and waits for its stream
@@ -108,7 +109,6 @@ private:
         uint32_t* prg_reads, hipStream_t stream);
     void run_batch_direct_candidates(const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads, uint64_t n_bases,
         uint32_t* covg, uint32_t* prg_reads, hipStream_t stream);
-    void ensure_tile_workspace(uint32_t n_tiles, uint32_t tile_cap);
     void run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads, uint64_t n_bases,
         uint32_t* d_covg, uint32_t* d_prg_reads, hipStream_t stream);
     void cluster_hits(const uint64_t* d_offsets, uint32_t n_hits, bool ordered, unsigned long long* d_unsorted, uint32_t* d_covg,
@@ -126,6 +126,7 @@ private:
         uint64_t n_bases = 0;
         uint32_t *covg = nullptr, *prg_reads = nullptr;
         hipStream_t stream = nullptr;
+        bool direct = false; // a batch of the direct sequence's candidate form (lane = its tile set)
     };
     void complete_pending();
     void complete_batch(const Pending& p);
@@ -191,16 +192,30 @@ private:
     uint64_t lanes_min_bases_ = 64ull << 20; // smaller batches always take one lane
     hipEvent_t ev_begin_ = nullptr; // recorded on the caller's stream: the other lanes start behind it
     void* d_temp_ = nullptr;
-    uint32_t* d_tile_first_ = nullptr;
-    // candidate form of the direct sequence: one slice of tile_cap_ records per tile
+    // candidate form of the direct sequence: one slice of `cap` records per tile.  Two sets of the workspace: the synchronous calls use
+    // the first; map_device_async takes them in turn (a batch's slices must survive until its read-back has been looked at: reads left
+    // to the generic pipeline are gathered from them)
+    struct TileSet {
+        uint32_t slice_cap = 256, ws_tiles = 0, ws_cap = 0, first_cap = 0;
+        uint64_t* d_tile_info = nullptr;
+        uint32_t *d_tile_pos1 = nullptr, *d_tile_count = nullptr, *d_tile_hits = nullptr, *d_tile_nmin = nullptr, *d_tile_prefix = nullptr, *d_tile_fast = nullptr;
+        uint4* d_tile_rec = nullptr;
+        void* d_tile_temp = nullptr;
+        size_t tile_temp_bytes = 0;
+        uint32_t* d_tile_first = nullptr; // first read of every tile
+        hipEvent_t done = nullptr, t0 = nullptr, t1 = nullptr;
+        uint32_t mark = 0, n_tiles = 0;   // of the batch in flight
+        dev::SketchArgs a_done {};
+    };
+    TileSet tsets_[2];
+    TileSet* ts_ = &tsets_[0];
     uint32_t slices_epoch_ = 0x80000000u; // mark of the last batch whose candidates read_cluster_kernel took from the slices
-    uint32_t tile_slice_cap_ = 256, tile_ws_tiles_ = 0, tile_ws_cap_ = 0;
-    uint64_t* d_tile_info_ = nullptr;
-    uint32_t *d_tile_pos1_ = nullptr, *d_tile_count_ = nullptr, *d_tile_hits_ = nullptr, *d_tile_nmin_ = nullptr, *d_tile_prefix_ = nullptr, *d_tile_fast_ = nullptr;
-    uint4* d_tile_rec_ = nullptr;
-    void* d_tile_temp_ = nullptr;
-    size_t tile_temp_bytes_ = 0;
-    uint32_t tile_cap_ = 0;
+    void free_tile_set(TileSet& t);
+    void ensure_tile_workspace(TileSet& t, uint32_t n_tiles, uint32_t tile_cap);
+    void direct_launch(int set, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads, uint64_t n_bases, uint32_t* covg, uint32_t* prg_reads,
+        hipStream_t stream, bool timed_by_set_events);
+    bool direct_finish(int set, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads, uint64_t n_bases, uint32_t* covg, uint32_t* prg_reads,
+        hipStream_t stream, int attempt);
     size_t temp_bytes_ = 0;
     // host staging
     uint8_t* h_bases_ = nullptr;

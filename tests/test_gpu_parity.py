@@ -626,7 +626,7 @@ def test_wave_tile_geometry_edges(tmp_path, oracle, monkeypatch, fuse):
     _compare(ctx, oracle, bases, offs, 14, 15, True, 3)
 
 
-@pytest.mark.parametrize("kernel", [0, 1])
+@pytest.mark.parametrize("kernel", [0, 1, 3])
 def test_deferred_batches_equal_synchronous_ones(tmp_path, oracle, kernel):
     """drprg_hip_map_device_async: a batch is queued and its read-back is looked at while the next one runs.  Batches that need the
     host afterwards -- dense reads that overflow the candidate slices (run again with larger buffers), reads of a 70-copy locus
