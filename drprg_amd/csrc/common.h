@@ -3,6 +3,7 @@
 // The hash and base encoding follow pandora's KmerHash / inthash (external program invoked at
 // /root/reference/src/lib.rs:580-642); see DESIGN.md "Semantics".
 #pragma once
+#include <cstdlib>
 #include <cstdint>
 #include <cstdio>
 #include <stdexcept>
@@ -69,6 +70,13 @@ constexpr uint32_t BLOOMR_WBITS = 14;      // 64 KB
 // (in the block of the 12-mer at its offset 0..3) and sets one bit in each of the block's four words (bits 31:27, 26:22, 21:17,
 // 16:12 of code * BLOOM_CR).  2^midc_wbits blocks.
 constexpr uint32_t MID_BITMAP_WORDS = 1u << 19;
+// largest index (records) the middle tier serves: beyond it hashing every k-mer (sketch_wave_kernel) is faster -- measured crossover
+// between 121 k records (2.5 against 3.7 ms per 10 M reads) and 244 k (5.4 against 4.2 ms); DRPRG_MID_MAX_RECORDS moves it
+inline size_t mid_tier_max_records()
+{
+    if (const char* e = std::getenv("DRPRG_MID_MAX_RECORDS")) return (size_t)std::strtoull(e, nullptr, 10);
+    return 180000;
+}
 constexpr uint32_t MID_C_MAX_WBITS = 17; // 2^17 blocks of 16 bytes = 2 MB
 // reverse complement of a 12-mer code (2 bits per base, first base in the lowest bits, alphabet A 0, C 1, T 2, G 3: complement = ^ 2)
 inline uint32_t rc12_code(uint32_t x)

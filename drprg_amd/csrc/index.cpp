@@ -173,7 +173,7 @@ void PrgIndex::flatten()
                     f.bloom0f[(g >> 17) & wmask0] |= bits0;
                 }
         });
-    } else if (k == 15 && entries > 0 && !std::getenv("DRPRG_NO_MID_TIER")) {
+    } else if (k == 15 && entries > 0 && !std::getenv("DRPRG_NO_MID_TIER") && recs.size() <= mid_tier_max_records()) {
         // Middle tier (round 3): too many index k-mers for an LDS-resident filter of the whole codes.  Level 0 stays in LDS but
         // is keyed on the CANONICAL 12-mer (half the entries); what passes it is looked up in the exact bitmap of the canonical
         // index 12-mers (2 MB, in the L2: ~267 G four-byte probes per second chip-wide, measured -- tools/mb_l2probe.hip), and

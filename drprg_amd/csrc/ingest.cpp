@@ -347,7 +347,7 @@ public:
         return std::shared_ptr<TextBuffer>(raw, [this](TextBuffer* p) {
             std::unique_ptr<TextBuffer> own(p);
             std::lock_guard<std::mutex> g(mu_);
-            if (free_.size() < 64) free_.push_back(std::move(own)); // (else freed here)
+            if (free_.size() < 24) free_.push_back(std::move(own)); // (else freed here: at most ~1 GB of text buffers stays with the process)
         });
     }
 
@@ -437,7 +437,7 @@ void inflate_member(void* dec, const unsigned char* in, size_t in_len, char* out
     if (rc != 0 || got != out_len) throw Error(DRPRG_EIO, "corrupt gzip block in " + path);
 }
 
-// text buffers of the plain-file parser threads, kept between calls (a buffer is ~40 MB of huge pages; at most 64 are kept)
+// text buffers of the plain-file parser threads, kept between calls (a buffer is ~48 MB of huge pages; at most 24 are kept)
 BufferPool& plain_pool()
 {
     static BufferPool pool;

@@ -126,11 +126,7 @@ Mapper::Mapper(const FlatIndex& idx, const MapParams& p, int device) : device_(d
         HIPCHK(hipMemcpy(d_bloomr_, idx.bloomr.data(), idx.bloomr.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
     if (idx.midc_wbits) {
-        // the middle tier pays while its L2 probes and the per-candidate verification behind it cost less than hashing every k-mer
-        // (sketch_wave_kernel): 10 M x 150 bp against the 8d index grown 8-fold (121 k records) 2.5 against 3.7 ms, grown 16-fold
-        // (244 k records) 5.4 against 4.2 ms (profiles/r03); DRPRG_MID_MAX_RECORDS moves the switch
-        size_t max_records = 180000;
-        if (const char* e = std::getenv("DRPRG_MID_MAX_RECORDS")) max_records = std::strtoull(e, nullptr, 10);
+        const size_t max_records = mid_tier_max_records(); // (common.h: where the direct sequence takes over)
         if (idx.rec_prg.size() <= max_records) {
             midc_wbits_ = idx.midc_wbits;
             mid0_bits_ = idx.mid0_bits;
