@@ -112,16 +112,24 @@ static void reduce_devices(drprg_hip_ctx* ctx)
     std::string why;
     const Rccl* r = (distinct && !(no && *no && *no != '0')) ? Rccl::get(&why) : nullptr;
     bool done = false;
+    auto chk = [&](int rc, const char* what) {
+        if (rc != Rccl::Success) throw Error(DRPRG_EIO, std::string("RCCL ") + what + ": " + (r && r->GetErrorString ? r->GetErrorString(rc) : "error"));
+    };
     if (r) {
-        auto chk = [&](int rc, const char* what) {
-            if (rc != Rccl::Success) throw Error(DRPRG_EIO, std::string("RCCL ") + what + ": " + (r->GetErrorString ? r->GetErrorString(rc) : "error"));
-        };
         if (ctx->comms.empty()) {
             std::vector<int> devs;
             for (Mapper* x : all) devs.push_back(x->device());
-            ctx->comms.assign(all.size(), nullptr);
-            chk(r->CommInitAll(ctx->comms.data(), (int)all.size(), devs.data()), "ncclCommInitAll");
+            std::vector<Rccl::Comm> comms(all.size(), nullptr);
+            const int rc = r->CommInitAll(comms.data(), (int)all.size(), devs.data());
+            if (rc == Rccl::Success) ctx->comms = comms;
+            else { // no communicator (nothing has been touched yet): the device add path below
+                why = std::string("ncclCommInitAll: ") + (r->GetErrorString ? r->GetErrorString(rc) : "error");
+                std::fprintf(stderr, "drprg-hip: warning: %s; summing the devices' vectors by peer copies\n", why.c_str());
+                r = nullptr;
+            }
         }
+    }
+    if (r) {
         const size_t nc = 2 * (size_t)m.n_knodes(), np = m.n_prgs();
         chk(r->GroupStart(), "ncclGroupStart");
         for (size_t d = 0; d < all.size(); ++d) {
