@@ -263,6 +263,9 @@ def e2e_leg(torch, ctx, synth, bases, n_reads, read_len, covg):
         run(fq, n_reads)  # (first pass: pinned blocks and workspaces are allocated)
         res["plain"], got = run(fq, n_reads)
         res["plain"]["coverage_equals_hbm_resident_run"] = bool(np.array_equal(got, want))
+        # what the link alone would take for the bases + offsets of this batch (PCIe Gen5 x16: 63 GB/s spec, MI355X_MICROARCH.md):
+        # the gap to `seconds` is host work (file reads, parse, hand-over) that the copies do not hide
+        res["plain"]["pcie_floor_s"] = (int(host.size) + 8 * (n_reads + 1)) / 63e9
         n_gz = min(n_reads, 2_000_000)
         rec = os.path.getsize(fq) // n_reads
         text = open(fq, "rb").read(rec * n_gz)

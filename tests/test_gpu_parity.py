@@ -294,6 +294,14 @@ def test_randomized_configurations(tmp_path, oracle, seed):
     for kernel in (1, 2, 3):
         ctx = _ctx(tmp_path, panel, w, k, illumina, kernel=kernel, min_cluster_size=mcs)
         _compare(ctx, oracle, bases, offs, w, k, illumina, kernel, min_cluster_size=mcs)
+    if k == 15:  # the same batch through the middle tier of the filter (tables built for this small index on request)
+        os.environ["DRPRG_FORCE_MID_TIER"] = "1"
+        try:
+            ctx = _ctx(tmp_path, panel, w, k, illumina, kernel=2, min_cluster_size=mcs)
+            assert ctx.table_tier()["l2_filter_bytes"] > 0
+            _compare(ctx, oracle, bases, offs, w, k, illumina, 2, min_cluster_size=mcs)
+        finally:
+            del os.environ["DRPRG_FORCE_MID_TIER"]
 
 
 def test_batches_accumulate(tmp_path, oracle):
