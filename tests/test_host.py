@@ -515,6 +515,23 @@ def _same_variant(got, want, ref):
     return apply(got) == apply(want) and len(got[1]) - len(got[2]) == len(want[1]) - len(want[2])
 
 
+def _oracle_pile_up(discover_dir, consensus, bases, offs):
+    """the oracle's separate statement of the accurate-read pile-up (oracle/oracle_denovo.py) on the candidate regions the product
+    wrote and the consensus the test knows the sample to have"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("oracle_denovo", os.path.join(ROOT, "oracle", "oracle_denovo.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    regions = []
+    for line in open(os.path.join(str(discover_dir), "candidate_regions.tsv")):
+        if not line.startswith("#"):
+            f = line.split("\t")
+            regions.append((f[0], int(f[1]), int(f[2])))
+    text = bases.tobytes().decode()
+    reads = [text[int(offs[i]):int(offs[i + 1])] for i in range(len(offs) - 1)]
+    return mod.pile_up(consensus, regions, reads)
+
+
 @pytest.mark.parametrize("kind", ["snp", "del", "ins"])
 def test_discover_finds_the_novel_variant_and_the_updated_prg_calls_it(tmp_path, oracle, kind):
     """/root/reference/src/predict.rs:247-302 in one piece: discover -> (update PRG) -> index -> map -> genotype.  The reads carry a
@@ -532,6 +549,7 @@ def test_discover_finds_the_novel_variant_and_the_updated_prg_calls_it(tmp_path,
     assert locus == "g1" and support >= 10 and support >= 0.8 * spanning
     assert _same_variant((pos1 - 1, ref, alt), want, panel.refs[1])
     assert Pandora.list_prgs_with_novel_variants(str(out / "denovo_paths.txt")) == ["g1"]
+    assert _oracle_pile_up(out, dict(zip(panel.names, panel.refs)), bases, offs) == [(l, p - 1, r, a, s, n) for l, p, r, a, s, n in variants]
     text = (out / "denovo_paths.txt").read_text()
     assert "\n1 denovo variants for this locus\n" in text and f"\n{pos1}\t{ref}\t{alt}\n" in text
     nodes = re.findall(r"\((\d+) \[(\d+), (\d+)\) ([ACGT]*)\)", text)
@@ -678,6 +696,9 @@ def test_discover_lists_several_loci_several_variants_and_a_variant_inside_a_nes
     assert [p for p, _, _ in by_locus["g0"]] == [101, 401] and all(len(r) == len(a) == 1 for _, r, a in by_locus["g0"])
     assert by_locus["g1"] == [(p1 + 1, g1_hap[p1], h1[p1])]
     assert (121, panel.refs[2][120], h2[120]) in by_locus["g2"]
+    # the oracle's own pile-up over the same regions agrees variant for variant, support for support
+    want = _oracle_pile_up(out, {"g0": panel.refs[0], "g1": g1_hap, "g2": panel.refs[2]}, bases, offs)
+    assert want == [(l, p - 1, r, a, s, n) for l, p, r, a, s, n in variants]
     # ---- the file the reference parses ----
     path = str(out / "denovo_paths.txt")
     assert Pandora.list_prgs_with_novel_variants(path) == ["g0", "g1", "g2"]
