@@ -1,6 +1,7 @@
 #include <set>
 #include <atomic>
 #include <mutex>
+#include <thread>
 #include <fstream>
 #include <cstdio>
 // capi.cpp -- the C ABI declared in include/drprg_hip.h.
@@ -23,6 +24,66 @@
 
 using namespace drprg;
 
+// Page-locked ingest blocks, kept between calls AND between contexts of the process: page-locking costs driver time, in series
+// over the threads that ask -- a `drprg predict` that finds a novel variant opens a second context on the updated PRG and maps
+// the reads again, and paid for pinning the same blocks a second time while they were kept per context.  (Portable allocations: valid for every
+// device.)  The blocks go back to the driver when the last context of the process closes.
+struct PinPool {
+    std::mutex mu;
+    std::vector<std::pair<void*, size_t>> free_, busy_;
+    int contexts = 0;
+    static PinPool& get()
+    {
+        static PinPool* p = new PinPool; // (never destroyed: contexts may outlive static destruction order)
+        return *p;
+    }
+    void context_opened()
+    {
+        std::lock_guard<std::mutex> g(mu);
+        ++contexts;
+    }
+    void context_closed()
+    {
+        std::vector<std::pair<void*, size_t>> drop;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            if (--contexts > 0) return;
+            drop.swap(free_);
+        }
+        for (auto& b : drop) Mapper::pinned_free(b.first);
+    }
+    void* take(size_t n)
+    {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            for (size_t i = 0; i < free_.size(); ++i)
+                if (free_[i].second == n) {
+                    void* p = free_[i].first;
+                    free_.erase(free_.begin() + (long)i);
+                    busy_.emplace_back(p, n);
+                    return p;
+                }
+        }
+        void* p = Mapper::pinned_alloc(n);
+        if (p) {
+            std::lock_guard<std::mutex> g(mu);
+            busy_.emplace_back(p, n);
+        }
+        return p;
+    }
+    void give_back(void* p)
+    {
+        std::lock_guard<std::mutex> g(mu);
+        for (size_t i = 0; i < busy_.size(); ++i)
+            if (busy_[i].first == p) {
+                free_.push_back(busy_[i]);
+                busy_.erase(busy_.begin() + (long)i);
+                return;
+            }
+        Mapper::pinned_free(p);
+    }
+};
+
 struct drprg_hip_ctx {
     PrgIndex index;
     std::unique_ptr<Mapper> mapper; // null for a host-only context; device 0 of a multi-device context
@@ -43,9 +104,7 @@ struct drprg_hip_ctx {
     // the last drprg_hip_discover_reads: what drprg_hip_update_prg applies
     GenotypeResult last_discover;
     std::vector<NovelVariant> last_variants;
-    // page-locked ingest blocks of drprg_hip_map_fastx, recycled between calls
-    std::mutex pin_mu;
-    std::vector<std::pair<void*, size_t>> pin_free, pin_busy;
+    // (the page-locked ingest blocks of drprg_hip_map_fastx are recycled process-wide: PinPool above)
     // multi-device context: RCCL communicators of its devices (created on first use; empty when RCCL is not used)
     std::vector<Rccl::Comm> comms;
     std::string reduce_how; // how the last drprg_hip_reduce summed the vectors (drprg_hip_reduce_info)
@@ -55,9 +114,9 @@ struct drprg_hip_ctx {
             if (const Rccl* r = Rccl::get())
                 for (Rccl::Comm c : comms)
                     if (c) (void)r->CommDestroy(c);
-        for (auto& b : pin_free) Mapper::pinned_free(b.first);
-        for (auto& b : pin_busy) Mapper::pinned_free(b.first);
+        PinPool::get().context_closed();
     }
+    drprg_hip_ctx() { PinPool::get().context_opened(); }
 };
 
 static thread_local std::string g_last_error;
@@ -184,6 +243,16 @@ static drprg_hip_ctx* open_impl(const char* prg_file, int w, int k, int device, 
     }
     std::unique_ptr<drprg_hip_ctx> ctx(new (std::nothrow) drprg_hip_ctx);
     if (!ctx) return nullptr;
+    // the HIP runtime starts (first call of the process: 50-250 ms) while the index files are read
+    std::thread warm;
+    if (device >= 0) warm = std::thread(Mapper::warm_device, device);
+    struct Join {
+        std::thread& t;
+        ~Join()
+        {
+            if (t.joinable()) t.join();
+        }
+    } join_warm { warm };
     try {
         ctx->prg_file = prg_file;
         if (from_files) {
@@ -203,6 +272,7 @@ static drprg_hip_ctx* open_impl(const char* prg_file, int w, int k, int device, 
         ctx->params.w = w;
         ctx->params.k = k;
         apply_defaults(ctx->params, nullptr);
+        if (warm.joinable()) warm.join();
         if (device >= 0) ctx->mapper.reset(new Mapper(ctx->index.flat, ctx->params, device));
         for (int i = 0; i < n_more; ++i) ctx->extra.emplace_back(new Mapper(ctx->index.flat, ctx->params, more_devices[i]));
     } catch (const std::exception& e) {
@@ -264,34 +334,8 @@ int drprg_hip_map_fastx(drprg_hip_ctx* ctx, const char* reads_path)
     // multi-threaded ingest into pinned blocks (ingest.cpp); multi-line FASTQ falls back to the serial reader
     IngestHooks hooks;
     // pinned ingest blocks are kept by the context between calls (pinning 32 MB costs milliseconds of driver time)
-    hooks.alloc = [ctx](size_t n) -> void* {
-        {
-            std::lock_guard<std::mutex> g(ctx->pin_mu);
-            for (size_t i = 0; i < ctx->pin_free.size(); ++i)
-                if (ctx->pin_free[i].second == n) {
-                    void* p = ctx->pin_free[i].first;
-                    ctx->pin_free.erase(ctx->pin_free.begin() + (long)i);
-                    ctx->pin_busy.emplace_back(p, n);
-                    return p;
-                }
-        }
-        void* p = Mapper::pinned_alloc(n);
-        if (p) {
-            std::lock_guard<std::mutex> g(ctx->pin_mu);
-            ctx->pin_busy.emplace_back(p, n);
-        }
-        return p;
-    };
-    hooks.release = [ctx](void* p) {
-        std::lock_guard<std::mutex> g(ctx->pin_mu);
-        for (size_t i = 0; i < ctx->pin_busy.size(); ++i)
-            if (ctx->pin_busy[i].first == p) {
-                ctx->pin_free.push_back(ctx->pin_busy[i]);
-                ctx->pin_busy.erase(ctx->pin_busy.begin() + (long)i);
-                return;
-            }
-        Mapper::pinned_free(p);
-    };
+    hooks.alloc = [](size_t n) -> void* { return PinPool::get().take(n); };
+    hooks.release = [](void* p) { PinPool::get().give_back(p); };
     // One device: one submitter at a time (the ingest serialises the calls).  Several devices (drprg_hip_open_multi): the
     // reads shard by block -- a block goes to the first idle device, round robin from the one after the last choice --
     // and the parser threads that carry the blocks are the submitters, one per device at a time.

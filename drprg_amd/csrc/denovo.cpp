@@ -208,8 +208,11 @@ std::vector<NovelVariant> assemble_candidate_regions(const GenotypeResult& gr, c
             }
     }
     if (anchors.empty()) return out;
-    std::vector<uint8_t> prefilter(1u << 16, 0); // low 16 bits of the packed k-mer: most read k-mers stop here
-    for (auto& kv : anchors) prefilter[kv.first & 0xFFFF] = 1;
+    // low 16 bits of the packed k-mer, one BIT each (8 KB: stays in the L1 of every parser thread): most read k-mers stop here
+    std::vector<uint64_t> prefilter(1u << 10, 0);
+    for (auto& kv : anchors) prefilter[(kv.first & 0xFFFF) >> 6] |= 1ull << (kv.first & 63);
+    uint8_t code_of[256]; // the scan below is the whole cost of this pass (every base of every read): table, no branches per base
+    for (int ch = 0; ch < 256; ++ch) code_of[ch] = (uint8_t)nt4((unsigned char)ch);
     std::vector<RegionVotes> votes(gr.candidates.size());
     const uint64_t mask = A == 32 ? ~0ull : ((1ull << (2 * A)) - 1);
 
@@ -232,13 +235,10 @@ std::vector<NovelVariant> assemble_candidate_regions(const GenotypeResult& gr, c
             uint64_t v = 0;
             uint32_t run = 0;
             for (uint64_t p = 0; p < len; ++p) {
-                const int c = nt4((unsigned char)s[p]);
-                if (c > 3) {
-                    run = 0;
-                    continue;
-                }
-                v = ((v << 2) | (uint64_t)c) & mask;
-                if (++run < A || !prefilter[v & 0xFFFF]) continue;
+                const uint32_t c = code_of[(unsigned char)s[p]];
+                v = ((v << 2) | (uint64_t)(c & 3)) & mask;
+                run = c > 3 ? 0 : run + 1; // (a k-mer over a non-ACGT base never counts: the run restarts after it)
+                if (!((prefilter[(v & 0xFFFF) >> 6] >> (v & 63)) & 1) || run < A) continue;
                 auto range = anchors.equal_range(v);
                 for (auto it = range.first; it != range.second; ++it)
                     hits.push_back(Hit { it->second.region, (uint32_t)(p + 1 - A), it->second.right, it->second.reverse, it->second.j });

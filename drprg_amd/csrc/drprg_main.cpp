@@ -8,6 +8,7 @@
 // the image has no Rust toolchain; a Rust drprg binds the same ABI.
 #include "../../include/drprg_hip.h"
 #include <cerrno>
+#include <chrono>
 #include <climits>
 #include <cstdio>
 #include <cstdlib>
@@ -16,6 +17,7 @@
 #include <fstream>
 #include <string>
 #include <sys/stat.h>
+#include <unistd.h>
 #include <vector>
 
 namespace {
@@ -111,8 +113,22 @@ void usage()
 
 } // namespace
 
+// seconds since main() was entered, for the -v lines (where the wall time of a prediction goes); since the moment the parent
+// process names in DRPRG_HIP_T0 (seconds since the epoch, e.g. `DRPRG_HIP_T0=$(date +%s.%N)`), when it does -- that adds the
+// time the loader takes before main()
+static double since_start()
+{
+    static const double t0 = [] {
+        const char* e = std::getenv("DRPRG_HIP_T0");
+        const double given = e ? std::atof(e) : 0;
+        return given > 0 ? given : std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count();
+    }();
+    return std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count() - t0;
+}
+
 int main(int argc, char** argv)
 {
+    const double at_main = since_start();
     if (argc < 2 || std::strcmp(argv[1], "predict") != 0) {
         usage();
         return argc >= 2 && (!std::strcmp(argv[1], "-h") || !std::strcmp(argv[1], "--help")) ? 0 : 2;
@@ -217,9 +233,11 @@ int main(int argc, char** argv)
     mo.genome_size = 4411532; // MTB_GENOME_SIZE, /root/reference/src/lib.rs:36
     if (int rc = drprg_hip_set_opts(ctx, &mo)) die(drprg_hip_last_error(ctx), -rc);
     drprg_hip_set_threads(ctx, threads);
-    if (verbose) std::fprintf(stderr, "[drprg-hip] mapping %s against %s (k=%d w=%d) on device %d\n", input.c_str(), index.c_str(), k, w, device);
+    if (verbose && std::getenv("DRPRG_HIP_T0")) std::fprintf(stderr, "[drprg-hip +%.3fs] main() entered\n", at_main);
+    if (verbose) std::fprintf(stderr, "[drprg-hip +%.3fs] mapping %s against %s (k=%d w=%d) on device %d\n", since_start(), input.c_str(), index.c_str(), k, w, device);
     // discover + map share ONE pass over the reads (the reference runs two, /root/reference/src/predict.rs:248-302)
     if (int rc = drprg_hip_map_fastx(ctx, input.c_str())) die(drprg_hip_last_error(ctx), -rc);
+    if (verbose) std::fprintf(stderr, "[drprg-hip +%.3fs] reads mapped\n", since_start());
     {
         // discover (/root/reference/src/predict.rs:247-256): candidate regions of every locus' called consensus, then a host-side
         // pile-up of the reads over them (whole strings with -I, column-wise majority of aligned strings without).  Novel variants update the PRG (what MakePrg::update does with
@@ -231,21 +249,24 @@ int main(int argc, char** argv)
         if (int rc = drprg_hip_discover_reads(ctx, input.c_str(), (index + "/genes.fa").c_str(), ddir.c_str(), sample.c_str(), 1, found))
             die(drprg_hip_last_error(ctx), -rc);
         if (verbose || found[1])
-            std::fprintf(stderr, "[drprg-hip] discover: %u candidate region(s), %u novel variant(s) in %u locus/loci\n", found[0], found[1], found[2]);
+            std::fprintf(stderr, "[drprg-hip +%.3fs] discover: %u candidate region(s), %u novel variant(s) in %u locus/loci\n", since_start(), found[0], found[1], found[2]);
         if (found[1]) {
             const std::string updated = outdir + "/updated.dr.prg";
             uint32_t applied = 0;
             if (int rc = drprg_hip_update_prg(ctx, updated.c_str(), &applied)) die(drprg_hip_last_error(ctx), -rc);
             if (applied) {
                 if (int rc = drprg_hip_index(updated.c_str(), w, k, threads)) die(drprg_hip_last_error(nullptr), -rc);
+                // (the new context opens BEFORE the old one closes: the page-locked ingest blocks of the process go back to the
+                // driver with its last context, and pinning them again costs more than the second index does in HBM)
+                drprg_hip_ctx* next = devices.size() > 1 ? drprg_hip_open_multi(updated.c_str(), w, k, devices.data(), (int)devices.size(), 1)
+                                                         : drprg_hip_open(updated.c_str(), w, k, device);
+                if (!next) die(std::string("cannot open the updated PRG: ") + drprg_hip_last_error(nullptr));
                 drprg_hip_close(ctx);
-                ctx = devices.size() > 1 ? drprg_hip_open_multi(updated.c_str(), w, k, devices.data(), (int)devices.size(), 1)
-                                         : drprg_hip_open(updated.c_str(), w, k, device);
-                if (!ctx) die(std::string("cannot open the updated PRG: ") + drprg_hip_last_error(nullptr));
+                ctx = next;
                 if (int rc = drprg_hip_set_opts(ctx, &mo)) die(drprg_hip_last_error(ctx), -rc);
                 drprg_hip_set_threads(ctx, threads);
                 if (int rc = drprg_hip_map_fastx(ctx, input.c_str())) die(drprg_hip_last_error(ctx), -rc);
-                if (verbose) std::fprintf(stderr, "[drprg-hip] %u novel site(s) added to %s; reads mapped again\n", applied, updated.c_str());
+                if (verbose) std::fprintf(stderr, "[drprg-hip +%.3fs] %u novel site(s) added to %s; reads mapped again\n", since_start(), applied, updated.c_str());
             }
         }
     }
@@ -256,16 +277,21 @@ int main(int argc, char** argv)
         uint32_t gi[4];
         drprg_hip_counters(ctx, c);
         drprg_hip_genotype_info(ctx, gi);
-        std::fprintf(stderr, "[drprg-hip] reads=%llu hits=%llu clusters=%llu exp_depth_covg=%u loci_present=%u records=%u\n",
-            (unsigned long long)c[0], (unsigned long long)c[3], (unsigned long long)c[4], gi[0], gi[2], gi[3]);
+        std::fprintf(stderr, "[drprg-hip +%.3fs] reads=%llu hits=%llu clusters=%llu exp_depth_covg=%u loci_present=%u records=%u\n",
+            since_start(), (unsigned long long)c[0], (unsigned long long)c[3], (unsigned long long)c[4], gi[0], gi[2], gi[3]);
     }
     drprg_hip_close(ctx);
+    if (verbose) std::fprintf(stderr, "[drprg-hip +%.3fs] device context closed\n", since_start());
     char err[1024] = { 0 };
     const std::string out_vcf = outdir + "/" + sample + ".drprg.vcf", out_json = outdir + "/" + sample + ".drprg.json";
     if (int rc = drprg_hip_annotate(index.c_str(), pandora_vcf.c_str(), out_vcf.c_str(), &ao, err, sizeof err)) die(err, -rc);
+    if (verbose) std::fprintf(stderr, "[drprg-hip +%.3fs] panel annotated: %s\n", since_start(), out_vcf.c_str());
     // <sample>.drprg.bcf: the file the reference leaves (/root/reference/src/predict.rs:429-431); the text VCF stays beside it
     if (int rc = drprg_hip_vcf_to_bcf(out_vcf.c_str(), (outdir + "/" + sample + ".drprg.bcf").c_str(), err, sizeof err)) die(err, -rc);
     if (int rc = drprg_hip_report_json(index.c_str(), out_vcf.c_str(), out_json.c_str(), sample.c_str(), -1, nullptr, err, sizeof err)) die(err, -rc);
-    if (verbose) std::fprintf(stderr, "[drprg-hip] wrote %s\n", out_json.c_str());
-    return 0;
+    if (verbose) std::fprintf(stderr, "[drprg-hip +%.3fs] wrote %s\n", since_start(), out_json.c_str());
+    // Every output file is closed.  Leave without the static destructors of the HIP runtime and without handing gigabytes of
+    // read buffers back page by page: measured 0.11-0.18 s between the line above and the parent seeing the exit otherwise.
+    std::fflush(nullptr);
+    _exit(0);
 }

@@ -30,7 +30,7 @@ namespace {
 // sequence per slice).  Pinning memory is slow (~10 GB/s), hence small blocks, allocated only by workers that get work.
 constexpr size_t SLICE_BYTES = 32u << 20; // text handed to one parser task
 constexpr size_t BLOCK_BASES = 24u << 20; // pinned block: bases capacity ...
-constexpr size_t BLOCK_READS = 1u << 20;  // ... and read capacity (flushed early when either fills up)
+constexpr size_t BLOCK_READS = 1u << 18;  // ... and read capacity (flushed early when either fills up: reads under 96 bases)
 
 struct Block {
     uint8_t* bases = nullptr;

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <hip/hip_runtime.h>
+#include <sys/mman.h>
 
 namespace drprg {
 
@@ -198,18 +199,39 @@ Mapper::~Mapper()
     if (stream_) (void)hipStreamDestroy(stream_);
 }
 
-// Portable: the ingest's parser threads call this with whatever device is current on their thread; a portable
-// allocation is page-locked for every device, so the copy engine of the mapper's device takes it at DMA speed.
+// Page-locked memory for the ingest's parser threads.  Portable: they call this with whatever device is current on their
+// thread, and a portable registration is page-locked for every device, so the copy engine of the mapper's device takes it at
+// DMA speed.  Ordinary memory (2 MB aligned, transparent huge pages asked for), touched by the calling thread and THEN
+// registered: measured on the MI355X box for 32 threads x 32 MB, hipHostMalloc pins at 6.7 GB/s (161 ms), touch +
+// hipHostRegister takes 5 + 13 ms, and host -> device copies run at the same 56 GB/s from both (tools/mb_pin.cpp,
+// profiles/r03/mb_pin.txt).
 void* Mapper::pinned_alloc(size_t bytes)
 {
-    void* p = nullptr;
-    if (hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) return nullptr;
+    constexpr size_t HUGE = 2u << 20;
+    const size_t n = (bytes + HUGE - 1) / HUGE * HUGE;
+    void* p = std::aligned_alloc(HUGE, n);
+    if (!p) return nullptr;
+    (void)madvise(p, n, MADV_HUGEPAGE);
+    for (size_t i = 0; i < n; i += 4096) static_cast<volatile char*>(p)[i] = 0;
+    if (hipHostRegister(p, n, hipHostRegisterPortable) != hipSuccess) {
+        std::free(p);
+        return nullptr;
+    }
     return p;
 }
 
 void Mapper::pinned_free(void* p)
 {
-    if (p) (void)hipHostFree(p);
+    if (!p) return;
+    (void)hipHostUnregister(p);
+    std::free(p);
+}
+
+// First HIP call of a process: tens to hundreds of milliseconds of runtime start-up.  drprg_hip_open runs this on a thread of
+// its own while the index files are read; errors are left to the Mapper constructor, which reports them.
+void Mapper::warm_device(int device)
+{
+    if (hipSetDevice(device) == hipSuccess) (void)hipFree(nullptr);
 }
 
 void Mapper::set_params(const MapParams& p)

@@ -62,6 +62,7 @@ public:
     // page-locked host memory for ingest blocks (H2D copies from it run at DMA speed)
     static void* pinned_alloc(size_t bytes);
     static void pinned_free(void* p);
+    static void warm_device(int device);
 
     void reset_coverage();
     // own accumulators

@@ -40,13 +40,16 @@ for label in ("wild_type", "off_panel_snp"):
     synth.write_fastq_fixed(fq, bases, 150)
     out = os.path.join(tmp, "out_" + label)
     t = time.time()
-    r = subprocess.run([os.path.join(exe, "drprg"), "predict", "-x", idx, "-i", fq, "-o", out, "-s", label, "-I", "-t", threads, "-v"], capture_output=True, text=True)
+    r = subprocess.run([os.path.join(exe, "drprg"), "predict", "-x", idx, "-i", fq, "-o", out, "-s", label, "-I", "-t", threads, "-v"], capture_output=True, text=True,
+                       env=dict(os.environ, DRPRG_HIP_T0=repr(t)))
     dt = time.time() - t
     assert r.returncode == 0, r.stderr
     res = json.load(open(os.path.join(out, label + ".drprg.json")))
     calls = {d: v["predict"] for d, v in res["susceptibility"].items() if v["predict"] != "S"}
     print(f"{label}: {n} reads ({os.path.getsize(fq) / 1e9:.2f} GB FASTQ), process start -> JSON {dt:.2f}s = {n / dt / 1e6:.1f} M reads/s; non-S: {calls}", flush=True)
     print("   " + " | ".join(l for l in r.stderr.splitlines() if "discover" in l or "novel" in l), flush=True)
+    if os.environ.get("E2E_STDERR"):
+        print(r.stderr, flush=True)
     if label == "wild_type" and os.environ.get("E2E_GZ", "1") != "0":
         # the same sample as one plain gzip stream (what `gzip` writes; inflated by all -t threads, csrc/pgunzip.cpp)
         gz = fq + ".gz"
