@@ -73,6 +73,9 @@ SIGNATURES = {
     "drprg_hip_set_coverage": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64]),
     "drprg_hip_device_coverage": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "drprg_hip_reset": (C.c_int, [C.c_void_p]),
+    "drprg_hip_keep_reads": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "drprg_hip_map_resident": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "drprg_hip_resident_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "drprg_hip_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "drprg_hip_genotype": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p]),
     "drprg_hip_genotype_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),

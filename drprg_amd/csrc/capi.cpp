@@ -104,6 +104,10 @@ struct drprg_hip_ctx {
     // the last drprg_hip_discover_reads: what drprg_hip_update_prg applies
     GenotypeResult last_discover;
     std::vector<NovelVariant> last_variants;
+    // drprg_hip_keep_reads: the files drprg_hip_map_fastx has mapped since the last reset (the resident reads stand for a file
+    // only if they are that file's and nothing else's); whether the last drprg_hip_discover_reads took its reads from HBM
+    std::vector<std::string> mapped_paths;
+    bool last_discover_resident = false;
     // (the page-locked ingest blocks of drprg_hip_map_fastx are recycled process-wide: PinPool above)
     // multi-device context: RCCL communicators of its devices (created on first use; empty when RCCL is not used)
     std::vector<Rccl::Comm> comms;
@@ -212,7 +216,7 @@ static void reduce_devices(drprg_hip_ctx* ctx)
         ctx->extra_counts.reads += k.reads; ctx->extra_counts.bases += k.bases; ctx->extra_counts.minimizers += k.minimizers;
         ctx->extra_counts.hits += k.hits; ctx->extra_counts.clusters_kept += k.clusters_kept;
         ctx->extra_counts.hits_kept += k.hits_kept; ctx->extra_counts.leftover_reads += k.leftover_reads;
-        e->reset_coverage();
+        e->reset_coverage(false); // (its vectors are in the sum now; the reads it keeps in HBM stay)
     }
     ctx->host_coverage_valid = false;
 }
@@ -331,6 +335,7 @@ int drprg_hip_map_fastx(drprg_hip_ctx* ctx, const char* reads_path)
     if (!reads_path) throw Error(DRPRG_EINVAL, "null reads path");
     Mapper& m = need_mapper(ctx);
     ctx->host_coverage_valid = false;
+    ctx->mapped_paths.push_back(reads_path);
     // multi-threaded ingest into pinned blocks (ingest.cpp); multi-line FASTQ falls back to the serial reader
     IngestHooks hooks;
     // pinned ingest blocks are kept by the context between calls (pinning 32 MB costs milliseconds of driver time)
@@ -591,6 +596,68 @@ int drprg_hip_reset(drprg_hip_ctx* ctx)
     ctx->prg_reads.clear();
     ctx->host_coverage_valid = false;
     ctx->total_bases = 0;
+    ctx->mapped_paths.clear();
+    API_END(ctx)
+}
+
+static std::vector<Mapper*> mappers_of(drprg_hip_ctx* ctx)
+{
+    std::vector<Mapper*> all;
+    if (ctx->mapper) all.push_back(ctx->mapper.get());
+    for (auto& e : ctx->extra) all.push_back(e.get());
+    return all;
+}
+
+// do the reads in HBM stand for the file `path` (null: for whatever was mapped)?
+static bool reads_resident(drprg_hip_ctx* ctx, const char* path)
+{
+    const std::vector<Mapper*> all = mappers_of(ctx);
+    if (all.empty()) return false;
+    for (Mapper* m : all)
+        if (!m->kept_complete()) return false;
+    if (path && (ctx->mapped_paths.size() != 1 || ctx->mapped_paths[0] != path)) return false;
+    return true;
+}
+
+int drprg_hip_keep_reads(drprg_hip_ctx* ctx, uint64_t max_bytes)
+{
+    API_BEGIN(ctx)
+    need_mapper(ctx);
+    for (Mapper* m : mappers_of(ctx)) m->keep_reads(max_bytes);
+    // (reads mapped before this call are not resident: only a context that has mapped nothing yet can stand for a file)
+    if (ctx->total_bases != 0) ctx->mapped_paths.assign(2, std::string());
+    API_END(ctx)
+}
+
+int drprg_hip_map_resident(drprg_hip_ctx* ctx, drprg_hip_ctx* from)
+{
+    API_BEGIN(ctx)
+    if (!from || from == ctx) throw Error(DRPRG_EINVAL, "drprg_hip_map_resident needs another open context");
+    need_mapper(ctx);
+    const std::vector<Mapper*> dst = mappers_of(ctx), src = mappers_of(from);
+    if (!reads_resident(from, nullptr)) throw Error(DRPRG_ENODATA, "the other context does not hold all of its reads in device memory");
+    if (dst.size() != src.size()) throw Error(DRPRG_EINVAL, "the two contexts span different numbers of devices");
+    for (size_t i = 0; i < dst.size(); ++i)
+        if (dst[i]->device() != src[i]->device()) throw Error(DRPRG_EINVAL, "the two contexts list different devices");
+    ctx->host_coverage_valid = false;
+    for (size_t i = 0; i < dst.size(); ++i) dst[i]->map_kept_from(*src[i]);
+    ctx->total_bases += from->total_bases;
+    ctx->mapped_paths.insert(ctx->mapped_paths.end(), from->mapped_paths.begin(), from->mapped_paths.end());
+    reduce_devices(ctx);
+    API_END(ctx)
+}
+
+int drprg_hip_resident_info(drprg_hip_ctx* ctx, uint64_t out[4])
+{
+    API_BEGIN(ctx)
+    if (!out) throw Error(DRPRG_EINVAL, "null output");
+    out[0] = reads_resident(ctx, nullptr) ? 1 : 0;
+    out[1] = out[2] = 0;
+    for (Mapper* m : mappers_of(ctx)) {
+        out[1] += m->kept_bytes();
+        out[2] += m->kept().size();
+    }
+    out[3] = ctx->last_discover_resident ? 1 : 0;
     API_END(ctx)
 }
 
@@ -675,7 +742,14 @@ int drprg_hip_discover_reads(drprg_hip_ctx* ctx, const char* reads_path, const c
         adp.min_support = 4;
         adp.min_fraction = 0.6;
     }
-    std::vector<NovelVariant> variants = assemble_candidate_regions(r, reads_path, ctx->threads, adp, ctx->params.illumina);
+    // the reads of this very file are in HBM (drprg_hip_keep_reads): the device picks the few that hold an anchor k-mer
+    ResidentReads resident;
+    ctx->last_discover_resident = reads_resident(ctx, reads_path);
+    if (ctx->last_discover_resident)
+        resident = [ctx](const std::vector<uint64_t>& anchors, uint32_t A, std::vector<uint8_t>& bases, std::vector<uint64_t>& offsets) {
+            for (Mapper* m : mappers_of(ctx)) m->select_reads_with_anchors(anchors, A, bases, offsets);
+        };
+    std::vector<NovelVariant> variants = assemble_candidate_regions(r, reads_path, ctx->threads, adp, ctx->params.illumina, resident);
     write_denovo_paths(dir, smp, r, variants, list_loci != 0);
     if (out) {
         out[0] = (uint32_t)r.candidates.size();

@@ -27,6 +27,7 @@ enum : int {
     DRPRG_ENODEV = -19,
     DRPRG_EOVERFLOW = -75,
     DRPRG_EFORMAT = -84,
+    DRPRG_ENODATA = -61, // the reads of the sample are not (all) resident in HBM: the caller reads the file instead
     DRPRG_EAGAIN_SERIAL = -11, // internal: the parallel ingest hands the file to the serial reader (nothing was mapped yet)
 };
 

@@ -183,7 +183,7 @@ std::string column_consensus(const CandidateRegion& cr, const std::string& core,
 } // namespace
 
 std::vector<NovelVariant> assemble_candidate_regions(const GenotypeResult& gr, const std::string& reads_path, int threads, const DiscoverParams& dp,
-    bool accurate_reads)
+    bool accurate_reads, const ResidentReads& resident)
 {
     std::vector<NovelVariant> out;
     const uint32_t A = dp.anchor_len;
@@ -275,14 +275,28 @@ std::vector<NovelVariant> assemble_candidate_regions(const GenotypeResult& gr, c
             }
         }
     };
-    IngestHooks hooks;
-    hooks.concurrent_submit = true;
-    hooks.submit = scan_batch;
-    try {
-        ingest_fastx(reads_path, threads, hooks);
-    } catch (const Error& e) {
-        if (e.code != DRPRG_EAGAIN_SERIAL) throw;
-        throw Error(DRPRG_EFORMAT, "discover: multi-line FASTQ is not supported by the region pile-up");
+    if (resident) {
+        // the reads are in HBM: the device picks those that hold an anchor, the scan above runs on them alone
+        std::vector<uint64_t> kmers;
+        for (auto& kv : anchors) kmers.push_back(kv.first);
+        std::vector<uint8_t> sel_bases;
+        std::vector<uint64_t> sel_offsets;
+        resident(kmers, A, sel_bases, sel_offsets);
+        if (sel_offsets.size() > 1) {
+            sel_bases.resize(sel_bases.size() + 64); // (what an ingest block has after its last base)
+            PinnedBatch b { sel_bases.data(), sel_offsets.data(), sel_offsets.size() - 1, sel_offsets.back() };
+            scan_batch(b);
+        }
+    } else {
+        IngestHooks hooks;
+        hooks.concurrent_submit = true;
+        hooks.submit = scan_batch;
+        try {
+            ingest_fastx(reads_path, threads, hooks);
+        } catch (const Error& e) {
+            if (e.code != DRPRG_EAGAIN_SERIAL) throw;
+            throw Error(DRPRG_EFORMAT, "discover: multi-line FASTQ is not supported by the region pile-up");
+        }
     }
     for (uint32_t r = 0; r < gr.candidates.size(); ++r) {
         const CandidateRegion& c = gr.candidates[r];

@@ -1,6 +1,7 @@
 // denovo.h -- novel variants inside the candidate regions of `discover`, and the PRG update they lead to.  See denovo.cpp.
 #pragma once
 #include "genotype.h"
+#include <functional>
 
 namespace drprg {
 
@@ -14,8 +15,11 @@ struct NovelVariant {
 
 // second pass over the reads file (host threads): exact-anchor pile-up over every candidate region of `gr`; accurate_reads:
 // whole strings are counted (Illumina), otherwise the strings are aligned to the consensus and counted column by column
+// resident (may be empty): called with the packed anchor k-mers and their length instead of reading the file; it appends every
+// read that holds one of them (more reads do no harm) to bases / offsets -- Mapper::select_reads_with_anchors.
+using ResidentReads = std::function<void(const std::vector<uint64_t>& anchors, uint32_t anchor_len, std::vector<uint8_t>& bases, std::vector<uint64_t>& offsets)>;
 std::vector<NovelVariant> assemble_candidate_regions(const GenotypeResult& gr, const std::string& reads_path, int threads, const DiscoverParams& dp,
-    bool accurate_reads);
+    bool accurate_reads, const ResidentReads& resident = ResidentReads());
 
 // <dir>/denovo_paths.txt (+ denovo_sequences.fa, denovo_variants.tsv).  list_loci = false keeps the "0 loci" line: the
 // variants are then reported in denovo_variants.tsv only and the caller's make_prg step is not triggered.

@@ -233,6 +233,12 @@ int main(int argc, char** argv)
     mo.genome_size = 4411532; // MTB_GENOME_SIZE, /root/reference/src/lib.rs:36
     if (int rc = drprg_hip_set_opts(ctx, &mo)) die(drprg_hip_last_error(ctx), -rc);
     drprg_hip_set_threads(ctx, threads);
+    // The reads stay in HBM after the mapping pass (up to DRPRG_HIP_KEEP_READS_GB per device, default 32, 0 = off): discover takes
+    // the few reads it needs from there and a novel variant maps them again from there -- the file is read once.
+    double keep_gb = 32;
+    if (const char* e = std::getenv("DRPRG_HIP_KEEP_READS_GB")) keep_gb = std::atof(e);
+    if (keep_gb > 0)
+        if (int rc = drprg_hip_keep_reads(ctx, (uint64_t)(keep_gb * 1e9))) die(drprg_hip_last_error(ctx), -rc);
     if (verbose && std::getenv("DRPRG_HIP_T0")) std::fprintf(stderr, "[drprg-hip +%.3fs] main() entered\n", at_main);
     if (verbose) std::fprintf(stderr, "[drprg-hip +%.3fs] mapping %s against %s (k=%d w=%d) on device %d\n", since_start(), input.c_str(), index.c_str(), k, w, device);
     // discover + map share ONE pass over the reads (the reference runs two, /root/reference/src/predict.rs:248-302)
@@ -248,8 +254,12 @@ int main(int argc, char** argv)
         uint32_t found[3] = { 0, 0, 0 };
         if (int rc = drprg_hip_discover_reads(ctx, input.c_str(), (index + "/genes.fa").c_str(), ddir.c_str(), sample.c_str(), 1, found))
             die(drprg_hip_last_error(ctx), -rc);
-        if (verbose || found[1])
-            std::fprintf(stderr, "[drprg-hip +%.3fs] discover: %u candidate region(s), %u novel variant(s) in %u locus/loci\n", since_start(), found[0], found[1], found[2]);
+        if (verbose || found[1]) {
+            uint64_t ri[4] = { 0, 0, 0, 0 };
+            drprg_hip_resident_info(ctx, ri);
+            std::fprintf(stderr, "[drprg-hip +%.3fs] discover: %u candidate region(s), %u novel variant(s) in %u locus/loci (reads %s)\n", since_start(), found[0],
+                found[1], found[2], ri[3] ? "resident in device memory" : "from the file");
+        }
         if (found[1]) {
             const std::string updated = outdir + "/updated.dr.prg";
             uint32_t applied = 0;
@@ -261,12 +271,18 @@ int main(int argc, char** argv)
                 drprg_hip_ctx* next = devices.size() > 1 ? drprg_hip_open_multi(updated.c_str(), w, k, devices.data(), (int)devices.size(), 1)
                                                          : drprg_hip_open(updated.c_str(), w, k, device);
                 if (!next) die(std::string("cannot open the updated PRG: ") + drprg_hip_last_error(nullptr));
+                if (int rc = drprg_hip_set_opts(next, &mo)) die(drprg_hip_last_error(next), -rc);
+                drprg_hip_set_threads(next, threads);
+                // the reads again, against the updated index: from HBM if the first context kept them all, else from the file
+                const int from_hbm = drprg_hip_map_resident(next, ctx);
+                if (from_hbm != 0 && from_hbm != -61 /* ENODATA */) die(drprg_hip_last_error(next), -from_hbm);
                 drprg_hip_close(ctx);
                 ctx = next;
-                if (int rc = drprg_hip_set_opts(ctx, &mo)) die(drprg_hip_last_error(ctx), -rc);
-                drprg_hip_set_threads(ctx, threads);
-                if (int rc = drprg_hip_map_fastx(ctx, input.c_str())) die(drprg_hip_last_error(ctx), -rc);
-                if (verbose) std::fprintf(stderr, "[drprg-hip +%.3fs] %u novel site(s) added to %s; reads mapped again\n", since_start(), applied, updated.c_str());
+                if (from_hbm != 0)
+                    if (int rc = drprg_hip_map_fastx(ctx, input.c_str())) die(drprg_hip_last_error(ctx), -rc);
+                if (verbose)
+                    std::fprintf(stderr, "[drprg-hip +%.3fs] %u novel site(s) added to %s; reads mapped again (%s)\n", since_start(), applied, updated.c_str(),
+                        from_hbm == 0 ? "resident in device memory" : "from the file");
             }
         }
     }
@@ -290,8 +306,9 @@ int main(int argc, char** argv)
     if (int rc = drprg_hip_vcf_to_bcf(out_vcf.c_str(), (outdir + "/" + sample + ".drprg.bcf").c_str(), err, sizeof err)) die(err, -rc);
     if (int rc = drprg_hip_report_json(index.c_str(), out_vcf.c_str(), out_json.c_str(), sample.c_str(), -1, nullptr, err, sizeof err)) die(err, -rc);
     if (verbose) std::fprintf(stderr, "[drprg-hip +%.3fs] wrote %s\n", since_start(), out_json.c_str());
-    // Every output file is closed.  Leave without the static destructors of the HIP runtime and without handing gigabytes of
-    // read buffers back page by page: measured 0.11-0.18 s between the line above and the parent seeing the exit otherwise.
+    // Every output file is closed.  Leave without the static destructors of the HIP runtime: measured (9 runs each, one box)
+    // 0.15 s between the line above and the parent seeing the exit with `return 0`, 0.001 s this way for a sample without a
+    // novel variant (with one, the kernel still takes ~0.13 s to take the process apart; hipDeviceReset first changes nothing).
     std::fflush(nullptr);
     _exit(0);
 }

@@ -26,11 +26,34 @@ namespace drprg {
 
 namespace {
 
-// A slice of FASTQ text is about half bases, so one slice normally fills one block (one H2D copy + one launch
-// sequence per slice).  Pinning memory is slow (~10 GB/s), hence small blocks, allocated only by workers that get work.
-constexpr size_t SLICE_BYTES = 32u << 20; // text handed to one parser task
-constexpr size_t BLOCK_BASES = 24u << 20; // pinned block: bases capacity ...
-constexpr size_t BLOCK_READS = 1u << 18;  // ... and read capacity (flushed early when either fills up: reads under 96 bases)
+// The text is cut into slices, one parser task each; a parser thread copies the bases of its slices into its page-locked block
+// and hands the block over when it is full (one H2D copy + one launch sequence per block).  Page-locking costs time per byte
+// (Mapper::pinned_alloc), hence small blocks, allocated only by workers that get work.
+constexpr size_t SLICE_BYTES = 32u << 20; // text handed to one parser task (compressed input: a window of inflated text)
+// ... of a plain-text file read with pread: smaller (8 MB), because the parser thread keeps a buffer of 1.5 slices, every page of
+// which is faulted in once and torn down at exit (DRPRG_INGEST_SLICE_MB; `drprg predict` on 10 M reads, medians of 7 runs on one
+// box: 0.41 s with 32 MB slices and 24 MB blocks, 0.25 s with 8 and 12 -- profiles/r03/e2e_cli.txt)
+inline size_t plain_slice_bytes()
+{
+    static const size_t n = [] {
+        const char* e = std::getenv("DRPRG_INGEST_SLICE_MB");
+        const long mb = e ? std::atol(e) : 0;
+        return (size_t)(mb >= 1 && mb <= 1024 ? mb : 8) << 20;
+    }();
+    return n;
+}
+// pinned block: bases capacity (12 MB; DRPRG_INGEST_BLOCK_MB; also the longest read the parallel ingest takes) ...
+inline size_t block_bases_now()
+{
+    static const size_t n = [] {
+        const char* e = std::getenv("DRPRG_INGEST_BLOCK_MB");
+        const long mb = e ? std::atol(e) : 0;
+        return (size_t)(mb >= 1 && mb <= 1024 ? mb : 12) << 20;
+    }();
+    return n;
+}
+#define BLOCK_BASES (block_bases_now())
+#define BLOCK_READS (BLOCK_BASES / 96) // ... and read capacity (flushed early when either fills up: reads under 96 bases)
 
 struct Block {
     uint8_t* bases = nullptr;
@@ -490,7 +513,7 @@ IngestStats ingest_fastx(const std::string& path, int threads, const IngestHooks
                 }
                 const int64_t t0 = sh.debug ? sh.now_ns() : 0;
                 if (!s.begin && s.file_len) { // plain file: this thread reads the slice into its own (recycled, huge-page) buffer
-                    if (!own_text || own_text->size() < s.file_len + 64) own_text = plain_pool().acquire(std::max<size_t>(s.file_len + 64, SLICE_BYTES + (SLICE_BYTES >> 1)));
+                    if (!own_text || own_text->size() < s.file_len + 64) own_text = plain_pool().acquire(std::max<size_t>(s.file_len + 64, plain_slice_bytes() + (plain_slice_bytes() >> 1)));
                     size_t have = 0;
                     while (have < s.file_len) {
                         const ssize_t r = pread(fd, own_text->data() + have, s.file_len - have, (off_t)(s.file_off + have));
@@ -569,9 +592,10 @@ IngestStats ingest_fastx(const std::string& path, int threads, const IngestHooks
             std::vector<char> win;
             while (!use_mmap && cur < map_len && !sh.failed) {
                 size_t cut = map_len;
-                if (map_len - cur > SLICE_BYTES + (SLICE_BYTES >> 2)) {
-                    for (size_t look = (size_t)1 << 18;; look *= 4) { // the next record start at or after cur + SLICE_BYTES
-                        const size_t at = cur + SLICE_BYTES, n = std::min(look, map_len - at);
+                const size_t slice = plain_slice_bytes();
+                if (map_len - cur > slice + (slice >> 2)) {
+                    for (size_t look = (size_t)1 << 18;; look *= 4) { // the next record start at or after cur + slice
+                        const size_t at = cur + slice, n = std::min(look, map_len - at);
                         win.resize(n);
                         size_t have = 0;
                         while (have < n) {

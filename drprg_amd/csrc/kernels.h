@@ -254,5 +254,22 @@ hipError_t launch_cluster_starts(const uint32_t* head, const uint32_t* scan, uin
 hipError_t launch_cluster_pipeline(const ClusterArgs& a, uint32_t n_hits, uint32_t n_prgs, hipStream_t stream);
 hipError_t launch_vector_add_u32(uint32_t* dst, const uint32_t* src, uint64_t n, hipStream_t stream); // dst[i] += src[i]
 
+// anchor_scan.hip: reads of a resident batch that hold one of the (sorted) anchor k-mers of length A -- every such read once,
+// in any order, appended to `list` (count keeps counting past list_cap).  prefilter: 2^16 bits, bit (kmer & 0xFFFF) set for every
+// anchor; flags: n_reads words, zero before the launch.
+struct SelectedRead {
+    uint64_t offset;       // of its first base in the batch's base array
+    uint32_t len, read, batch, pad;
+};
+hipError_t launch_anchor_scan(const uint8_t* bases, const uint64_t* offsets, uint32_t n_reads, uint64_t n_bases, const uint64_t* anchors,
+    uint32_t n_anchors, uint32_t A, const uint32_t* prefilter, uint32_t batch, uint32_t* flags, unsigned long long* count, SelectedRead* list,
+    uint64_t list_cap, int n_cus, hipStream_t stream);
+struct GatherEntry {
+    const uint8_t* src;
+    uint64_t dst;
+    uint32_t len, pad;
+};
+hipError_t launch_gather_reads(const GatherEntry* table, uint32_t n, uint8_t* out, hipStream_t stream); // out[dst .. dst+len) = src[0 .. len)
+
 } // namespace dev
 } // namespace drprg

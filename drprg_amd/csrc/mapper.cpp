@@ -189,6 +189,8 @@ Mapper::~Mapper()
         if (st.copied) (void)hipEventDestroy(st.copied);
     }
     dfree(d_peer_tmp_);
+    for (auto& a : kept_arenas_) (void)hipFree(a.first);
+    if (kept_copied_) (void)hipEventDestroy(kept_copied_);
     if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
     if (ev_begin_) (void)hipEventDestroy(ev_begin_);
     if (h_counters_) (void)hipHostFree(h_counters_);
@@ -259,7 +261,7 @@ void Mapper::set_params(const MapParams& p)
     use_direct_cands_ = p.kernel_mode == 3 || (p.kernel_mode == 0 && !filter_ok);
 }
 
-void Mapper::reset_coverage()
+void Mapper::reset_coverage(bool new_sample)
 {
     sync();
     HIPCHK(hipSetDevice(device_));
@@ -268,6 +270,7 @@ void Mapper::reset_coverage()
     HIPCHK(hipMemsetAsync(d_counters_, 0, C_N * sizeof(unsigned long long), stream_));
     HIPCHK(hipStreamSynchronize(stream_));
     tot_reads_ = tot_bases_ = tot_hits_ = tot_leftover_ = tot_minimizers_ = 0;
+    if (new_sample) drop_kept();
 }
 
 void Mapper::ensure_workspace(uint64_t cap)
@@ -714,6 +717,7 @@ void Mapper::map_device_async(const uint8_t* d_bases, const uint64_t* d_offsets,
     if (n_reads > dev::MAX_BATCH_READS)
         throw Error(DRPRG_EOVERFLOW, "at most " + std::to_string(dev::MAX_BATCH_READS) + " reads per batch");
     HIPCHK(hipSetDevice(device_));
+    if (kept_cap_ && !in_keep_call_) kept_broken_ = true;
     if (!stream) stream = stream_;
     if (!covg) covg = d_covg_;
     if (!prg_reads) prg_reads = d_prg_reads_;
@@ -943,6 +947,7 @@ void Mapper::map_device(const uint8_t* d_bases, const uint64_t* d_offsets, uint6
     if (n_reads > dev::MAX_BATCH_READS)
         throw Error(DRPRG_EOVERFLOW, "at most " + std::to_string(dev::MAX_BATCH_READS) + " reads per batch");
     HIPCHK(hipSetDevice(device_));
+    if (kept_cap_ && !in_keep_call_) kept_broken_ = true; // reads of the caller's own buffers: not among the kept ones
     complete_pending();
     run_batch(d_bases, d_offsets, (uint32_t)n_reads, n_bases, covg ? covg : d_covg_, prg_reads ? prg_reads : d_prg_reads_,
         stream ? stream : stream_);
@@ -973,9 +978,178 @@ void Mapper::map_host(const uint8_t* bases, const uint64_t* offsets, uint64_t n_
     HIPCHK(hipStreamSynchronize(stream_)); // the staging buffers are reused by the next call
 }
 
+void* Mapper::arena_take(size_t bytes)
+{
+    bytes = (bytes + 255) / 256 * 256;
+    if (kept_bytes_ + bytes > kept_cap_) return nullptr;
+    if (bytes > arena_left_) {
+        // (what is left of the current piece is not used: pieces are 256 MB, blocks ~25 MB)
+        const size_t piece = std::max<size_t>(bytes, std::min<uint64_t>(256ull << 20, kept_cap_ - kept_bytes_));
+        void* p = nullptr;
+        if (hipMalloc(&p, piece) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        kept_arenas_.emplace_back(p, piece);
+        arena_at_ = static_cast<uint8_t*>(p);
+        arena_left_ = piece;
+    }
+    void* r = arena_at_;
+    arena_at_ += bytes;
+    arena_left_ -= bytes;
+    kept_bytes_ += bytes;
+    return r;
+}
+
+void Mapper::keep_reads(uint64_t max_bytes)
+{
+    drop_kept();
+    kept_cap_ = max_bytes;
+}
+
+void Mapper::drop_kept()
+{
+    if (!kept_arenas_.empty()) {
+        sync();
+        HIPCHK(hipSetDevice(device_));
+        HIPCHK(hipStreamSynchronize(stream_));
+        for (auto& a : kept_arenas_) (void)hipFree(a.first);
+    }
+    kept_arenas_.clear();
+    kept_.clear();
+    arena_at_ = nullptr;
+    arena_left_ = 0;
+    kept_bytes_ = 0;
+    kept_broken_ = false;
+}
+
+uint64_t Mapper::map_kept_from(const Mapper& other)
+{
+    if (other.device_ != device_) throw Error(DRPRG_EINVAL, "the kept reads live on another device");
+    if (!other.kept_complete()) throw Error(DRPRG_ENODATA, "the other context does not hold all of its reads");
+    uint64_t n = 0;
+    for (const KeptBatch& b : other.kept_) {
+        map_device_async(b.d_bases, b.d_offsets, b.n_reads, b.n_bases, nullptr, nullptr, stream_);
+        n += b.n_reads;
+    }
+    sync();
+    HIPCHK(hipStreamSynchronize(stream_));
+    return n;
+}
+
+void Mapper::select_reads_with_anchors(std::vector<uint64_t> anchors, uint32_t A, std::vector<uint8_t>& bases, std::vector<uint64_t>& offsets)
+{
+    if (!kept_complete()) throw Error(DRPRG_ENODATA, "not every read of the sample is resident");
+    if (A == 0 || A > 31) throw Error(DRPRG_EINVAL, "anchor length must be 1..31");
+    if (offsets.empty()) offsets.push_back(0);
+    std::sort(anchors.begin(), anchors.end());
+    anchors.erase(std::unique(anchors.begin(), anchors.end()), anchors.end());
+    if (anchors.empty() || kept_.empty()) return;
+    sync();
+    HIPCHK(hipSetDevice(device_));
+    std::vector<uint32_t> pf(2048, 0);
+    for (uint64_t a : anchors) pf[(a & 0xFFFF) >> 5] |= 1u << (a & 31);
+    uint64_t total_reads = 0, max_reads = 0;
+    for (const KeptBatch& b : kept_) {
+        total_reads += b.n_reads;
+        max_reads = std::max(max_reads, b.n_reads);
+    }
+    // device scratch of this call (freed on every way out)
+    struct Scratch {
+        std::vector<void*> p;
+        ~Scratch()
+        {
+            for (void* q : p) (void)hipFree(q);
+        }
+        void* get(size_t bytes)
+        {
+            void* q = nullptr;
+            if (hipMalloc(&q, bytes ? bytes : 16) != hipSuccess) throw Error(DRPRG_ENOMEM, "out of device memory (read selection)");
+            p.push_back(q);
+            return q;
+        }
+    } scratch;
+    uint64_t* d_anchors = static_cast<uint64_t*>(scratch.get(anchors.size() * sizeof(uint64_t)));
+    uint32_t* d_pf = static_cast<uint32_t*>(scratch.get(pf.size() * sizeof(uint32_t)));
+    uint32_t* d_flags = static_cast<uint32_t*>(scratch.get(max_reads * sizeof(uint32_t)));
+    unsigned long long* d_count = static_cast<unsigned long long*>(scratch.get(sizeof(unsigned long long)));
+    dev::SelectedRead* d_list = static_cast<dev::SelectedRead*>(scratch.get(total_reads * sizeof(dev::SelectedRead)));
+    HIPCHK(hipMemcpyAsync(d_anchors, anchors.data(), anchors.size() * sizeof(uint64_t), hipMemcpyHostToDevice, stream_));
+    HIPCHK(hipMemcpyAsync(d_pf, pf.data(), pf.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
+    HIPCHK(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), stream_));
+    for (size_t b = 0; b < kept_.size(); ++b) {
+        const KeptBatch& kb = kept_[b];
+        HIPCHK(hipMemsetAsync(d_flags, 0, kb.n_reads * sizeof(uint32_t), stream_));
+        HIPCHK(dev::launch_anchor_scan(kb.d_bases, kb.d_offsets, (uint32_t)kb.n_reads, kb.n_bases, d_anchors, (uint32_t)anchors.size(), A, d_pf, (uint32_t)b,
+            d_flags, d_count, d_list, total_reads, n_cus_, stream_));
+    }
+    unsigned long long count = 0;
+    HIPCHK(hipMemcpyAsync(&count, d_count, sizeof count, hipMemcpyDeviceToHost, stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    if (count > total_reads) throw Error(DRPRG_EIO, "read selection: more reads than the batches hold"); // (each read is appended once)
+    if (count == 0) return;
+    std::vector<dev::SelectedRead> list(count);
+    HIPCHK(hipMemcpy(list.data(), d_list, count * sizeof(dev::SelectedRead), hipMemcpyDeviceToHost));
+    std::sort(list.begin(), list.end(), [](const dev::SelectedRead& x, const dev::SelectedRead& y) { return x.batch != y.batch ? x.batch < y.batch : x.read < y.read; });
+    std::vector<dev::GatherEntry> table(count);
+    uint64_t at = 0;
+    for (size_t i = 0; i < count; ++i) {
+        table[i].src = kept_[list[i].batch].d_bases + list[i].offset;
+        table[i].dst = at;
+        table[i].len = list[i].len;
+        table[i].pad = 0;
+        at += list[i].len;
+    }
+    dev::GatherEntry* d_table = static_cast<dev::GatherEntry*>(scratch.get(count * sizeof(dev::GatherEntry)));
+    uint8_t* d_out = static_cast<uint8_t*>(scratch.get(at));
+    HIPCHK(hipMemcpyAsync(d_table, table.data(), count * sizeof(dev::GatherEntry), hipMemcpyHostToDevice, stream_));
+    HIPCHK(dev::launch_gather_reads(d_table, (uint32_t)count, d_out, stream_));
+    const size_t base0 = bases.size();
+    bases.resize(base0 + at);
+    if (at) HIPCHK(hipMemcpyAsync(bases.data() + base0, d_out, at, hipMemcpyDeviceToHost, stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    for (size_t i = 0; i < count; ++i) offsets.push_back(offsets.back() + list[i].len);
+}
+
 void Mapper::map_host_async(const uint8_t* bases, const uint64_t* offsets, uint64_t n_reads)
 {
     if (n_reads == 0) return;
+    if (kept_cap_ && !kept_broken_) {
+        // the block goes into device memory of its own and stays there
+        HIPCHK(hipSetDevice(device_));
+        if (offsets[0] != 0) throw Error(DRPRG_EINVAL, "offsets[0] must be 0");
+        const uint64_t n_bases = offsets[n_reads];
+        uint8_t* db = n_bases ? static_cast<uint8_t*>(arena_take(n_bases + 64)) : nullptr;
+        uint64_t* doff = n_bases && db ? static_cast<uint64_t*>(arena_take((n_reads + 1) * sizeof(uint64_t))) : nullptr;
+        if (n_bases == 0) {
+            tot_reads_ += n_reads; // (only empty reads: nothing to keep)
+            return;
+        }
+        if (db && doff) {
+            if (!copy_stream_) HIPCHK(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
+            if (!kept_copied_) HIPCHK(hipEventCreateWithFlags(&kept_copied_, hipEventDisableTiming));
+            HIPCHK(hipMemcpyAsync(db, bases, n_bases, hipMemcpyHostToDevice, copy_stream_));
+            HIPCHK(hipMemcpyAsync(doff, offsets, (n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, copy_stream_));
+            HIPCHK(hipEventRecord(kept_copied_, copy_stream_));
+            HIPCHK(hipStreamWaitEvent(stream_, kept_copied_, 0));
+            kept_.push_back(KeptBatch { db, doff, n_reads, n_bases });
+            in_keep_call_ = true;
+            try {
+                map_device_async(db, doff, n_reads, n_bases, nullptr, nullptr, stream_);
+            } catch (...) {
+                in_keep_call_ = false;
+                throw;
+            }
+            in_keep_call_ = false;
+            HIPCHK(hipEventSynchronize(kept_copied_)); // the caller's block is free again
+            return;
+        }
+        // over the limit (or the device is full): nothing is kept from here on, and what was kept is of no use without the rest
+        const uint64_t cap = kept_cap_;
+        drop_kept();
+        kept_cap_ = cap;
+        kept_broken_ = true;
+    }
     if (!use_filter_ || max_lanes_ > 1) { // no deferred form of this sequence
         map_host(bases, offsets, n_reads);
         return;
@@ -1048,6 +1222,8 @@ void Mapper::download(std::vector<uint32_t>& covg, std::vector<uint32_t>& prg_re
 
 void Mapper::upload(const std::vector<uint32_t>& covg, const std::vector<uint32_t>& prg_reads)
 {
+    if (kept_cap_) kept_broken_ = true; // coverage that came without its reads
+
     if (covg.size() != 2 * (size_t)n_knodes_ || prg_reads.size() != n_prgs_) throw Error(DRPRG_EINVAL, "coverage size mismatch");
     sync();
     HIPCHK(hipSetDevice(device_));

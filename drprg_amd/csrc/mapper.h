@@ -55,6 +55,28 @@ public:
     // may be reused then -- so that the next block's copy overlaps this block's kernels.  sync() (or anything that reads
     // results) completes what is in flight.  Sequences without a deferred form fall back to map_host.
     void map_host_async(const uint8_t* bases, const uint64_t* offsets, uint64_t n_reads);
+    // Reads that stay in HBM (off by default).  keep_reads(max_bytes > 0): from now on map_host_async copies every block into
+    // device memory of its own instead of a staging set and leaves it there -- at most max_bytes of it; one byte more and
+    // everything kept is dropped and the staging sets are back.  kept_complete(): every read mapped since keep_reads() /
+    // reset_coverage() is among kept().  What they are for: select_reads_with_anchors below (the pile-up of `discover` without a
+    // second pass over the file) and mapping the same reads again against another index (map_kept_from).
+    struct KeptBatch {
+        const uint8_t* d_bases;
+        const uint64_t* d_offsets;
+        uint64_t n_reads, n_bases;
+    };
+    void keep_reads(uint64_t max_bytes);
+    bool kept_complete() const { return kept_cap_ > 0 && !kept_broken_; }
+    const std::vector<KeptBatch>& kept() const { return kept_; }
+    uint64_t kept_bytes() const { return kept_bytes_; }
+    void drop_kept();
+    // Every kept read that holds one of `anchors` (k-mers of length A <= 31 packed 2 bits per base, A=0 .. T=3, first base in the
+    // high bits) -- and possibly a few that do not -- appended to bases / offsets (offsets[0] = 0 is written when offsets is
+    // empty), in batch and read order.  anchor_scan.hip.
+    void select_reads_with_anchors(std::vector<uint64_t> anchors, uint32_t A, std::vector<uint8_t>& bases, std::vector<uint64_t>& offsets);
+    // maps the batches another Mapper of the same device keeps (it must outlive the call); returns the reads mapped
+    uint64_t map_kept_from(const Mapper& other);
+
     // this += other, on the device (the other Mapper's vectors are left as they are): peer copy into a scratch buffer + one
     // add kernel, or the add kernel alone when both live on the same device.  Both are synchronised first.
     void add_vectors_from(Mapper& other);
@@ -64,7 +86,7 @@ public:
     static void pinned_free(void* p);
     static void warm_device(int device);
 
-    void reset_coverage();
+    void reset_coverage(bool new_sample = true); // new_sample: the reads kept in HBM (keep_reads) go as well
     // own accumulators
     uint32_t* d_covg() const { return d_covg_; }
     uint32_t* d_prg_reads() const { return d_prg_reads_; }
@@ -234,6 +256,15 @@ private:
     Stage stage_[2];
     int stage_next_ = 0;
     hipStream_t copy_stream_ = nullptr;
+    // keep_reads: device memory in large pieces, handed out front to back
+    std::vector<std::pair<void*, size_t>> kept_arenas_;
+    uint8_t* arena_at_ = nullptr;
+    size_t arena_left_ = 0;
+    std::vector<KeptBatch> kept_;
+    uint64_t kept_cap_ = 0, kept_bytes_ = 0;
+    bool kept_broken_ = false, in_keep_call_ = false;
+    hipEvent_t kept_copied_ = nullptr;
+    void* arena_take(size_t bytes);
     uint32_t* d_peer_tmp_ = nullptr; // add_vectors_from: the other device's vectors on this device
     // timing
     bool timing_ = false;

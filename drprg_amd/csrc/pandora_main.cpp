@@ -215,6 +215,14 @@ int cmd_discover(const Args& a)
     std::string sample, reads;
     if (!(q >> sample >> reads)) die("malformed query file " + a.positional[1]);
     drprg_hip_ctx* ctx = open_ctx(a);
+    // pandora discover walks the reads twice (mapping, then the candidate regions); here the second walk is over the blocks the
+    // first one left in HBM (up to DRPRG_HIP_KEEP_READS_GB per device, default 32, 0 = read the file again)
+    {
+        double keep_gb = 32;
+        if (const char* e = std::getenv("DRPRG_HIP_KEEP_READS_GB")) keep_gb = std::atof(e);
+        if (keep_gb > 0)
+            if (int rc = drprg_hip_keep_reads(ctx, (uint64_t)(keep_gb * 1e9))) die(drprg_hip_last_error(ctx), -rc);
+    }
     double t0 = now_s();
     if (int rc = drprg_hip_map_fastx(ctx, reads.c_str())) die(drprg_hip_last_error(ctx), -rc);
     report_counters(ctx, now_s() - t0);
@@ -237,8 +245,10 @@ int cmd_discover(const Args& a)
         std::fprintf(stderr,
             "pandora (drprg-hip): WARNING: %u novel variant(s) in %u locus/loci found (%s/denovo_variants.tsv) but denovo_paths.txt reports 0 "
             "loci (DRPRG_HIP_DENOVO_PATHS=0), so the PRG will not be updated.\n", found[1], found[2], a.outdir.c_str());
-    std::printf("[pandora-hip] discover: %u candidate regions, %u novel variants in %u loci%s\n", found[0], found[1], found[2],
-        list_loci ? "" : " (not listed in denovo_paths.txt)");
+    uint64_t ri[4] = { 0, 0, 0, 0 };
+    drprg_hip_resident_info(ctx, ri);
+    std::printf("[pandora-hip] discover: %u candidate regions, %u novel variants in %u loci%s; reads of the second pass %s\n", found[0], found[1], found[2],
+        list_loci ? "" : " (not listed in denovo_paths.txt)", ri[3] ? "resident in device memory" : "from the file");
     drprg_hip_close(ctx);
     return 0;
 }

@@ -131,6 +131,20 @@ class Context:
     def reset(self):
         _check(lib.drprg_hip_reset(self._h), self._h)
 
+    # ---- reads that stay in HBM (include/drprg_hip.h: drprg_hip_keep_reads) --------------------
+    def keep_reads(self, max_bytes):
+        """map_fastx leaves the blocks it copies on the device (up to max_bytes per device; 0 switches it off)"""
+        _check(lib.drprg_hip_keep_reads(self._h, int(max_bytes)), self._h)
+
+    def map_resident(self, other):
+        """maps the reads `other` keeps in HBM against this context's index (DependencyError with code -61 if it does not hold them all)"""
+        _check(lib.drprg_hip_map_resident(self._h, other._h), self._h)
+
+    def resident_info(self):
+        out = (C.c_uint64 * 4)()
+        _check(lib.drprg_hip_resident_info(self._h, out), self._h)
+        return dict(complete=bool(out[0]), bytes=int(out[1]), blocks=int(out[2]), last_discover_from_hbm=bool(out[3]))
+
     def counters(self):
         out = (C.c_uint64 * 8)()
         _check(lib.drprg_hip_counters(self._h, out), self._h)

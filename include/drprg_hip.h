@@ -158,6 +158,22 @@ int drprg_hip_discover(drprg_hip_ctx* ctx, const char* vcf_refs, const char* out
  * variants".  out[0..2] = candidate regions, novel variants, loci with novel variants. */
 int drprg_hip_discover_reads(drprg_hip_ctx* ctx, const char* reads_path, const char* vcf_refs, const char* out_dir, const char* sample,
     int list_loci, uint32_t out[3]);
+/* Reads that stay in HBM.  The reference reads the sample once per pandora process it spawns -- `pandora discover`
+ * (/root/reference/src/predict.rs:248-256), then `pandora map` on the updated PRG (:296-302) -- and pandora discover itself walks
+ * the reads twice (mapping, then local assembly).  A sample is 1-5 GB of bases and the device has 288 GB:
+ *   drprg_hip_keep_reads(ctx, max_bytes): from now on drprg_hip_map_fastx leaves every block it copies to the device there, up to
+ *     max_bytes per device (0 = off, the default; past the limit everything kept is dropped and later calls read files again).
+ *   drprg_hip_discover_reads then finds the reads that hold an anchor k-mer with one kernel over the resident base stream
+ *     (anchor_scan.hip) and runs its pile-up on those alone, when every read mapped since the last reset came from ONE
+ *     drprg_hip_map_fastx call on the same path; otherwise it reads the file, as before.  Same output either way.
+ *   drprg_hip_map_resident(ctx, from): maps the reads `from` keeps against the index of `ctx` (same devices, in the same order;
+ *     `from` stays open during the call).  -ENODATA (-61) when `from` does not hold all of its reads: map the file instead.
+ *   drprg_hip_resident_info: out[0] = 1 if every read mapped since the last reset is resident, out[1] = bytes kept (all devices),
+ *     out[2] = blocks kept, out[3] = 1 if the last drprg_hip_discover_reads took its reads from HBM. */
+int drprg_hip_keep_reads(drprg_hip_ctx* ctx, uint64_t max_bytes);
+int drprg_hip_map_resident(drprg_hip_ctx* ctx, drprg_hip_ctx* from);
+int drprg_hip_resident_info(drprg_hip_ctx* ctx, uint64_t out[4]);
+
 /* What MakePrg::update does in the reference (/root/reference/src/lib.rs:279-456) for a host without make_prg / mafft: writes the
  * context's PRG file again with every novel variant of the last drprg_hip_discover_reads that lies inside one local node of its
  * locus' called path added as a new site (index it with drprg_hip_index, open it, map again).  *n_applied: sites added. */

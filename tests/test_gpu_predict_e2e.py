@@ -44,14 +44,16 @@ def _reads(panel, choose, n_reads, seed):
     return block.reshape(-1), np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(150)
 
 
-def _predict(tmp_path, idx, bases, offs, name, illumina=True):
+def _predict(tmp_path, idx, bases, offs, name, illumina=True, env=None, outname=None):
     from drprg_amd import synth
     fq = str(tmp_path / f"{name}.fq")
-    synth.write_fastq(fq, bases, offs)
-    out = tmp_path / f"out_{name}"
+    if not os.path.exists(fq):
+        synth.write_fastq(fq, bases, offs)
+    out = tmp_path / f"out_{outname or name}"
     r = subprocess.run([os.path.join(BIN, "drprg"), "predict", "-x", str(idx), "-i", fq, "-o", str(out), "-s", name, "-v"]
-                       + (["-I"] if illumina else []), capture_output=True, text=True)
+                       + (["-I"] if illumina else []), capture_output=True, text=True, env=dict(os.environ, **(env or {})))
     assert r.returncode == 0, r.stderr
+    _predict.stderr = r.stderr
     for f in ("pandora_genotyped.vcf", f"{name}.drprg.vcf", f"{name}.drprg.json", "discover/denovo_paths.txt"):
         assert (out / f).exists(), f
     return json.load(open(out / f"{name}.drprg.json")), out
@@ -160,6 +162,16 @@ def test_off_panel_variant_is_discovered_and_reported_as_unknown(tmp_path, tech)
     assert {d for d, _, _ in evid} == {"Isoniazid"}
     # every other drug stays susceptible
     assert all(v["predict"] == "S" for d, v in res["susceptibility"].items() if d != "Isoniazid")
+    # the file was read ONCE: discover took its reads from the blocks the mapping pass left in HBM, and so did the second mapping
+    # pass (include/drprg_hip.h: drprg_hip_keep_reads) -- and reading the file three times instead gives the same bytes
+    assert "(reads resident in device memory)" in _predict.stderr and "reads mapped again (resident in device memory)" in _predict.stderr
+    res2, out2 = _predict(tmp_path, idx, bases, offs, "novel", illumina=tech == "illumina", env={"DRPRG_HIP_KEEP_READS_GB": "0"}, outname="novel_file")
+    assert "(reads from the file)" in _predict.stderr and "reads mapped again (from the file)" in _predict.stderr
+    import re
+    # (the record IDs of the annotated VCF are random, as the reference's are: Uuid::new_v4, /root/reference/src/predict.rs:447)
+    strip = lambda t: re.sub(r'(?m)^(\S+\t\d+\t)[0-9a-f]{8}\t', r'\1ID\t', re.sub(r'"vcfid": "[0-9a-f]{8}"', '"vcfid": "ID"', t.replace("out_novel_file", "out_novel")))
+    for f in ("pandora_genotyped.vcf", "novel.drprg.vcf", "novel.drprg.json", "discover/denovo_paths.txt", "discover/denovo_variants.tsv", "updated.dr.prg"):
+        assert strip(open(out2 / f).read()) == strip(open(out / f).read()), f
 
 
 _CODONS = {a + b + c: aa for (a, b, c), aa in zip(((x, y, z) for x in "TCAG" for y in "TCAG" for z in "TCAG"),

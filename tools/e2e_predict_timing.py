@@ -39,14 +39,32 @@ for label in ("wild_type", "off_panel_snp"):
     fq = os.path.join(tmp, label + ".fq")
     synth.write_fastq_fixed(fq, bases, 150)
     out = os.path.join(tmp, "out_" + label)
-    t = time.time()
-    r = subprocess.run([os.path.join(exe, "drprg"), "predict", "-x", idx, "-i", fq, "-o", out, "-s", label, "-I", "-t", threads, "-v"], capture_output=True, text=True,
-                       env=dict(os.environ, DRPRG_HIP_T0=repr(t)))
-    dt = time.time() - t
-    assert r.returncode == 0, r.stderr
-    res = json.load(open(os.path.join(out, label + ".drprg.json")))
-    calls = {d: v["predict"] for d, v in res["susceptibility"].items() if v["predict"] != "S"}
-    print(f"{label}: {n} reads ({os.path.getsize(fq) / 1e9:.2f} GB FASTQ), process start -> JSON {dt:.2f}s = {n / dt / 1e6:.1f} M reads/s; non-S: {calls}", flush=True)
+    # E2E_REPS=N: N runs per variant (min / median / max); E2E_VARIANTS="name:ENV=v,ENV=v;name2:..." runs each set of environment
+    # variables on the same file (an A/B on one box: boxes differ by more than most changes do)
+    reps = int(os.environ.get("E2E_REPS", "1"))
+    variants = [("default", {})]
+    for spec in filter(None, os.environ.get("E2E_VARIANTS", "").split(";")):
+        name, _, kv = spec.partition(":")
+        variants.append((name, dict(x.split("=", 1) for x in kv.split(",") if x)))
+    import re
+    for vname, venv in variants:
+        totals, exits = [], []
+        for rep in range(reps):
+            shutil.rmtree(out, ignore_errors=True)
+            t = time.time()
+            r = subprocess.run([os.path.join(exe, "drprg"), "predict", "-x", idx, "-i", fq, "-o", out, "-s", label, "-I", "-t", threads, "-v"], capture_output=True,
+                               text=True, env=dict(os.environ, DRPRG_HIP_T0=repr(t), **venv))
+            dt = time.time() - t
+            assert r.returncode == 0, r.stderr
+            wrote = [float(m.group(1)) for m in re.finditer(r"\+([0-9.]+)s\] wrote", r.stderr)]
+            totals.append(dt)
+            exits.append(dt - wrote[-1] if wrote else float("nan"))
+        res = json.load(open(os.path.join(out, label + ".drprg.json")))
+        calls = {d: v["predict"] for d, v in res["susceptibility"].items() if v["predict"] != "S"}
+        stat = lambda v: f"{min(v):.3f} / {sorted(v)[len(v) // 2]:.3f} / {max(v):.3f}"
+        print(f"{label} [{vname}]: {n} reads ({os.path.getsize(fq) / 1e9:.2f} GB FASTQ), process start -> exit, {reps} run(s), min / median / max: {stat(totals)} s "
+              f"= {n / sorted(totals)[len(totals) // 2] / 1e6:.1f} M reads/s; of that after the JSON was on disk: {stat(exits)} s; non-S: {calls}", flush=True)
+    dt = totals[-1]
     print("   " + " | ".join(l for l in r.stderr.splitlines() if "discover" in l or "novel" in l), flush=True)
     if os.environ.get("E2E_STDERR"):
         print(r.stderr, flush=True)
