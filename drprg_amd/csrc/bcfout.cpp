@@ -122,6 +122,7 @@ struct Buf {
             const bool m = s == "." || s.empty();
             missing.push_back(m);
             const int64_t x = m ? 0 : std::strtoll(s.c_str(), nullptr, 10);
+            if (x < INT32_MIN + 8 || x > INT32_MAX) throw Error(DRPRG_EFORMAT, "BCF writer: integer " + s + " does not fit 32 bits"); // (the 8 lowest are reserved)
             v.push_back(x);
             lo = std::min(lo, x);
             hi = std::max(hi, x);
@@ -211,20 +212,25 @@ void encode_record(const VcfRecord& r, const Dict& d, Buf& out)
         ind.typed_int(it->second.idx);
         const std::string& v = i < r.sample.size() ? r.sample[i] : std::string(".");
         if (r.format[i] == "GT") { // (allele + 1) << 1 | phased per allele; "." = 0
-            std::vector<int8_t> g;
+            // (the width follows the largest value, as htslib's does: allele 63 of a very multi-allelic site no longer fits int8)
+            std::vector<int64_t> g;
             size_t a = 0;
             bool phased = false;
+            int64_t hi = 0;
             while (a <= v.size()) {
                 size_t e = v.find_first_of("/|", a);
                 const std::string tok = v.substr(a, e == std::string::npos ? std::string::npos : e - a);
-                const int allele = (tok == "." || tok.empty()) ? -1 : std::atoi(tok.c_str());
-                g.push_back((int8_t)(((allele + 1) << 1) | (phased ? 1 : 0)));
+                const int64_t allele = (tok == "." || tok.empty()) ? -1 : std::strtoll(tok.c_str(), nullptr, 10);
+                if (allele < -1 || allele > (INT32_MAX >> 1) - 1) throw Error(DRPRG_EFORMAT, "BCF writer: GT " + v + " is out of range");
+                g.push_back(((allele + 1) << 1) | (phased ? 1 : 0));
+                hi = std::max(hi, g.back());
                 if (e == std::string::npos) break;
                 phased = v[e] == '|';
                 a = e + 1;
             }
-            ind.descriptor(g.size(), 1);
-            for (int8_t x : g) ind.put<int8_t>(x);
+            const int t = Buf::int_type(0, hi);
+            ind.descriptor(g.size(), t);
+            for (int64_t x : g) ind.raw_int(x, t);
         } else {
             typed_value(ind, it->second, v, "FORMAT " + r.format[i]);
         }

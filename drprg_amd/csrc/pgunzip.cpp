@@ -640,7 +640,14 @@ struct ParallelGunzip::Impl {
     }
 
     size_t expect_symbols() const { return chunk * 10; } // (address space: only what is written gets pages)
-    size_t soft_cap() const { return std::max<size_t>(chunk * 48, size_t(1) << 24); }
+    // symbols after which a chunk's inflater stops even without having reached the next chunk (the stitcher goes on from there);
+    // DRPRG_GZ_SOFT_CAP: a small one, for the tests of that path
+    size_t soft_cap() const
+    {
+        if (const char* e = std::getenv("DRPRG_GZ_SOFT_CAP"))
+            if (const long v = std::atol(e); v > 0) return (size_t)v;
+        return std::max<size_t>(chunk * 48, size_t(1) << 24);
+    }
 
     // one round: `threads` chunks inflated at once, then stitched onto `ready`
     void round()
@@ -821,6 +828,14 @@ struct ParallelGunzip::Impl {
                     if (!failed.empty()) throw Error(DRPRG_EIO, failed);
                     break;
                 }
+            }
+            if (ready.front()->read_pos == ready.front()->n && ready.front()->ends_done == ready.front()->ends.size()) {
+                // a segment without text and without a member end (a chunk that was inflated again and held nothing but an
+                // empty stored block, what a flush leaves): nothing to hand over -- and it must not look like "dst is full"
+                used.push_back(std::move(ready.front()));
+                ready.pop_front();
+                cv.notify_all();
+                continue;
             }
             Segment& s = *ready.front();
             // the next unchecked member end bounds the piece: a CRC never runs across it

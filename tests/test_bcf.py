@@ -107,3 +107,28 @@ def test_bcf_is_a_bgzf_container_with_eof_marker(tmp_path):
         members += 1
     assert off == len(raw) and members >= 2
     assert raw[-28:] == bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+
+
+@pytest.mark.parametrize("allele", [0, 62, 63, 200, 16383, 16384])
+def test_genotype_of_a_very_multi_allelic_site_takes_the_width_it_needs(tmp_path, allele):
+    """GT is stored as (allele + 1) << 1: allele 63 no longer fits the int8 the writer used for every GT (the byte read back as -128,
+    the reserved 'missing'); htslib widens to int16 / int32, and so does the writer now"""
+    n_alt = max(allele, 1)
+    alts = ",".join("A" + "C" * (i % 7) + "G" * (i // 7 % 11) + "T" * (i // 77) for i in range(n_alt))
+    vcf = tmp_path / "m.vcf"
+    vcf.write_text("##fileformat=VCFv4.3\n##contig=<ID=g,length=100>\n##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n"
+                   "##FORMAT=<ID=DP,Number=1,Type=Integer,Description=\"Depth\">\n"
+                   "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tsample\n"
+                   f"g\t5\t.\tT\t{alts}\t.\tPASS\t.\tGT:DP\t{allele}:2000000000\n"
+                   f"g\t9\t.\tT\tA\t.\tPASS\t.\tGT:DP\t.:.\n")
+    bcf = str(tmp_path / "m.bcf")
+    _to_bcf(str(vcf), bcf)
+    _, recs = decode(bcf)
+    assert dict(recs[0]["format"])["GT"][0] == str(allele) and dict(recs[0]["format"])["DP"][0] == [2000000000]
+    assert dict(recs[1]["format"])["GT"][0] == "." and len(recs[0]["alleles"]) == n_alt + 1
+    # an integer that does not fit 32 bits is an error, not a wrapped value
+    bad = tmp_path / "bad.vcf"
+    bad.write_text(vcf.read_text().replace("2000000000", "5000000000"))
+    from drprg_amd._lib import lib
+    err = C.create_string_buffer(512)
+    assert lib.drprg_hip_vcf_to_bcf(os.fsencode(str(bad)), os.fsencode(str(tmp_path / "bad.bcf")), err, len(err)) != 0 and b"32 bits" in err.value

@@ -224,3 +224,26 @@ def test_random_member_layouts(tmp_path, seed):
     want = b"".join(pieces)
     chunk = [0, 1500, 20_000, 300_000][int(rng.integers(0, 4))]
     _check(tmp_path, blob, want, threads=int(rng.integers(1, 9)), chunk=chunk, name=f"rand{seed}.gz")
+
+
+@pytest.mark.parametrize("cap", [300, 5000, 70000])
+def test_a_small_symbol_cap_and_flush_points_everywhere(tmp_path, monkeypatch, cap):
+    """chunks that stop at the symbol cap are taken up again from where they stopped; with flush points (empty stored blocks) every
+    few hundred bytes some of those continuations hold no text at all -- a segment like that is skipped, it does not end the stream"""
+    rng = np.random.default_rng(cap)
+    monkeypatch.setenv("DRPRG_GZ_PARALLEL", "1")
+    monkeypatch.setenv("DRPRG_GZ_SOFT_CAP", str(cap))
+    pieces = []
+    for i in range(60):
+        kind = int(rng.integers(0, 3))
+        n = int(rng.integers(1, 40000))
+        pieces.append(_fastq_text(n // 330 + 1, seed=i)[:n] if kind == 0 else bytes(n) if kind == 1 else rng.integers(0, 256, size=n, dtype=np.uint8).tobytes())
+    data = b"".join(pieces)
+    blob = b"".join(_member(data[a:a + 400000], level=int(rng.integers(1, 10)), flush_every=int(rng.integers(150, 3000)),
+                            flush_mode=[zlib.Z_SYNC_FLUSH, zlib.Z_FULL_FLUSH][int(rng.integers(0, 2))]) for a in range(0, len(data), 400000))
+    gz = tmp_path / "f.gz"
+    gz.write_bytes(blob)
+    for threads, chunk in ((3, 2048), (8, 4096), (5, 30000)):
+        out = tmp_path / f"o{threads}"
+        n, _, redone = _gunzip(gz, out, threads=threads, chunk=chunk)
+        assert n == len(data) and out.read_bytes() == data
