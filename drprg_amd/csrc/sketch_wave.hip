@@ -78,6 +78,15 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Volatile accesses to a wave's LDS go through pointers that SAY they point into LDS: a volatile access through a generic pointer
+// is left alone by the address-space inference and comes out as flat_load ... sc0 sc1 + s_waitcnt vmcnt(0) -- the slow path into
+// LDS, and a wait that also drains every global load in flight (the three Bloom words of stage A were requested "in one round
+// trip" and fetched one after the other).
+typedef volatile __attribute__((address_space(3))) uint32_t lds_vu32;
+typedef volatile __attribute__((address_space(3))) uint16_t lds_vu16;
+#define LDS_U32(p) ((lds_vu32*)(p))
+#define LDS_U16(p) ((lds_vu16*)(p))
+
 // LDS of one wave (nothing in it is shared between waves)
 struct alignas(16) WaveLds {
     uint32_t hv[SW_LOAD];   // hash + 1 of every position of the wave's tile (0 = invalid); later the slot of a found one
@@ -163,11 +172,11 @@ __device__ __forceinline__ void sketch_wave_tile(const SketchArgs& a, uint32_t t
         for (int d = 0; d < K; ++d) inv |= win >> d;           // k-mer j holds bases j .. j + K - 1
     }
     wave_lds_fence();
-    inv |= *reinterpret_cast<volatile uint32_t*>(&lds.inv[lane]);
+    inv |= *LDS_U32(&lds.inv[lane]);
     const uint32_t validbits = ~inv & 0xFFFFu;
     { // read that holds the base just before my first position = first_read - 1 + reads that start before it in this tile
-        const uint32_t c = *reinterpret_cast<volatile uint32_t*>(&lds.rcnt[lane]);
-        const uint32_t rb = *reinterpret_cast<volatile uint32_t*>(&lds.rbits[lane]);
+        const uint32_t c = *LDS_U32(&lds.rcnt[lane]);
+        const uint32_t rb = *LDS_U32(&lds.rbits[lane]);
         const uint32_t before = wave_inclusive_scan(c) - c;
         if (c != (uint32_t)__popc(rb)) lds.rbits[lane] = rb | 0x10000u; // empty reads: the popcount shortcut does not hold here
         lds.rcnt[lane] = first_read - 1u + before;
@@ -269,8 +278,8 @@ __device__ __forceinline__ void sketch_wave_tile(const SketchArgs& a, uint32_t t
         }
     }
     wave_lds_fence();
-    volatile uint16_t* list = lds.list;
-    volatile uint32_t* hvs = lds.hv;
+    lds_vu16* list = LDS_U16(lds.list);
+    lds_vu32* hvs = LDS_U32(lds.hv);
 
     // ---- stage A: the Bloom tier in front of a table that outgrows the L2 stops most minimizers at one word ----
     uint32_t n_a = nmin;
@@ -339,8 +348,8 @@ __device__ __forceinline__ void sketch_wave_tile(const SketchArgs& a, uint32_t t
         e.p = list[i] & 0x7FFFu;
         e.slot = hvs[e.p];
         const uint64_t gp = (uint64_t)(origin + (int64_t)e.p);
-        const uint32_t rb = *reinterpret_cast<volatile uint32_t*>(&lds.rbits[e.p >> 4]);
-        e.read = *reinterpret_cast<volatile uint32_t*>(&lds.rcnt[e.p >> 4]) + (uint32_t)__popc(rb & ((2u << (e.p & 15)) - 1u));
+        const uint32_t rb = *LDS_U32(&lds.rbits[e.p >> 4]);
+        e.read = *LDS_U32(&lds.rcnt[e.p >> 4]) + (uint32_t)__popc(rb & ((2u << (e.p & 15)) - 1u));
         bool ok = !(rb & 0x10000u) && e.read < a.n_reads;
         // (the slot's record and the read's two offsets in one round trip: the offsets unconditionally, of read 0 if the count is off)
         const uint32_t rd = ok ? e.read : 0u;
@@ -354,7 +363,7 @@ __device__ __forceinline__ void sketch_wave_tile(const SketchArgs& a, uint32_t t
             e.o1 = a.offsets[e.read + 1];
         }
         e.pos = gp - e.o0;
-        e.strand = (*reinterpret_cast<volatile uint32_t*>(&lds.strand[e.p >> 4]) >> (e.p & 15)) & 1u;
+        e.strand = (*LDS_U32(&lds.strand[e.p >> 4]) >> (e.p & 15)) & 1u;
         e.kn = e.sf.z;
         e.prg = e.sf.w & 0xFFFu;
         e.rev = ((e.kn & 1u) == e.strand) ? 0u : 1u;
@@ -476,7 +485,7 @@ __device__ __forceinline__ void sketch_wave_tile(const SketchArgs& a, uint32_t t
     uint32_t base = 0, wg_total = 0;
 #pragma unroll
     for (int v = 0; v < SW_WAVES; ++v) {
-        const uint32_t x = *reinterpret_cast<volatile uint32_t*>(&s_nb[v]);
+        const uint32_t x = *LDS_U32(&s_nb[v]);
         if (v < wave) base += x;
         wg_total += x;
     }
