@@ -692,6 +692,7 @@ IngestStats ingest_fastx(const std::string& path, int threads, const IngestHooks
             for (int t = 0; t < std::min(threads, 8); ++t) pool.emplace_back(worker); // (the inflater feeds them: more only pin more blocks)
             // text source: fills dst with up to cap bytes of inflated text, returns the number written (0 = end)
             gzFile gzf = nullptr;
+            std::unique_ptr<Crew> bgzf_crew;
             size_t next_block = 0, whole_off = 0;
             std::function<size_t(char*, size_t)> read_text;
             if (!blocks.empty()) {
@@ -706,24 +707,29 @@ IngestStats ingest_fastx(const std::string& path, int threads, const IngestHooks
                     if (next_block == first && next_block < blocks.size()) throw Error(DRPRG_EIO, "BGZF block larger than a slice in " + path);
                     const size_t last = next_block;
                     const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)threads, (last - first + 15) / 16)); // >= 16 members (1 MB of text) per thread
-                    std::vector<std::thread> infl;
                     std::atomic<size_t> cursor { first };
                     std::atomic<bool> bad { false };
                     auto job = [&]() {
-                        void* dec = ld.alloc();
-                        if (!dec) { bad = true; return; }
+                        thread_local struct Dec { // (one decompressor per thread of the crew, not one per window)
+                            const LibDeflate* l = nullptr;
+                            void* d = nullptr;
+                            ~Dec() { if (d && l) l->release(d); }
+                        } dec;
+                        if (!dec.d) {
+                            dec.l = &ld;
+                            dec.d = ld.alloc();
+                        }
+                        if (!dec.d) { bad = true; return; }
                         try {
-                            for (size_t b; (b = cursor.fetch_add(8)) < last;)
-                                for (size_t i = b; i < std::min(b + 8, last); ++i)
-                                    inflate_member(dec, gz_data + blocks[i].in_off, blocks[i].in_len, dst + blocks[i].out_off, blocks[i].out_len, path);
+                            for (size_t b; (b = cursor.fetch_add(2)) < last;) // (two members = 128 KB of text per grab: the window ends on a barrier)
+                                for (size_t i = b; i < std::min(b + 2, last); ++i)
+                                    inflate_member(dec.d, gz_data + blocks[i].in_off, blocks[i].in_len, dst + blocks[i].out_off, blocks[i].out_len, path);
                         } catch (const Error&) {
                             bad = true;
                         }
-                        ld.release(dec);
                     };
-                    for (int t = 1; t < nt; ++t) infl.emplace_back(job);
-                    job();
-                    for (auto& t : infl) t.join();
+                    if (!bgzf_crew) bgzf_crew.reset(new Crew(threads - 1)); // (threads that stay: 39 windows x 31 thread starts otherwise)
+                    bgzf_crew->run(job, nt);
                     if (bad) throw Error(DRPRG_EIO, "corrupt gzip block in " + path);
                     return total;
                 };
@@ -768,13 +774,28 @@ IngestStats ingest_fastx(const std::string& path, int threads, const IngestHooks
             } close_gz { gzf };
             std::vector<char> carry;
             bool eof = false;
+            int64_t ns_text = 0, ns_acquire = 0, ns_push = 0, t_mark = 0; // (DRPRG_INGEST_DEBUG: where the window loop's time goes)
+            struct LoopTimes {
+                Shared& sh;
+                int64_t &text, &acquire, &push;
+                ~LoopTimes()
+                {
+                    if (sh.debug)
+                        std::fprintf(stderr, "[ingest] compressed input, window loop of the calling thread until %.1f ms: inflating %.1f ms, window buffers %.1f ms, "
+                                             "handing windows to the parser threads %.1f ms\n", sh.now_ns() / 1e6, text / 1e6, acquire / 1e6, push / 1e6);
+                }
+            } loop_times { sh, ns_text, ns_acquire, ns_push };
             while (!eof && !sh.failed) {
                 // (one size for every window -- the carry is at most the 1 MB the cut is looked for in --, so a recycled buffer always fits)
+                t_mark = sh.debug ? sh.now_ns() : 0;
                 auto buf = gz_pool.acquire(std::max(carry.size(), size_t(1) << 20) + SLICE_BYTES);
                 if (!carry.empty()) std::memcpy(buf->data(), carry.data(), carry.size());
                 size_t have = carry.size();
                 carry.clear();
+                if (sh.debug) ns_acquire += sh.now_ns() - t_mark;
+                t_mark = sh.debug ? sh.now_ns() : 0;
                 const size_t got = read_text(buf->data() + have, SLICE_BYTES);
+                if (sh.debug) ns_text += sh.now_ns() - t_mark;
                 have += got;
                 if (got < SLICE_BYTES - (1u << 17)) // a short window: the source has nothing left (BGZF windows end up to 64 KB short)
                     eof = blocks.empty() ? true : next_block >= blocks.size();
@@ -796,14 +817,18 @@ IngestStats ingest_fastx(const std::string& path, int threads, const IngestHooks
                     cut = last;
                     carry.assign(cut, e);
                 }
+                t_mark = sh.debug ? sh.now_ns() : 0;
                 queue.push(Slice { b, cut, buf });
+                if (sh.debug) ns_push += sh.now_ns() - t_mark;
             }
         }
     } catch (const Error& e) {
         sh.fail(e.code, e.what());
     }
+    const int64_t t_loop_end = sh.debug ? sh.now_ns() : 0;
     queue.close();
     for (auto& t : pool) t.join();
+    if (sh.debug) std::fprintf(stderr, "[ingest] parser threads done %.1f ms after the last slice was queued (at %.1f ms)\n", (sh.now_ns() - t_loop_end) / 1e6, t_loop_end / 1e6);
     if (map && map != MAP_FAILED) munmap(map, map_len);
     close(fd);
     if (sh.failed) throw Error(sh.error_code, sh.error);

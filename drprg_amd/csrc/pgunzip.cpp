@@ -9,6 +9,8 @@
 #include <cstring>
 #include <condition_variable>
 #include <deque>
+#include <functional>
+#include <memory>
 #include <mutex>
 #include <dlfcn.h>
 #include <sys/mman.h>
@@ -281,6 +283,41 @@ struct Segment {
     Segment(uint16_t* b, size_t c) : buf(b), cap(c) {}
     Segment(const Segment&) = delete;
     Segment& operator=(const Segment&) = delete;
+};
+
+// Symbol buffers outlive a ParallelGunzip: handing ~1 GB of them back to the kernel took 25 ms at the end of every file, and the
+// next file faulted the same pages in again.  The process keeps at most CACHE_BYTES of them (the largest first to go).
+struct SymbolCache {
+    static constexpr size_t CACHE_BYTES = size_t(3) << 29; // 1.5 GB
+    std::mutex mu;
+    std::vector<std::pair<uint16_t*, size_t>> bufs; // (pointer, capacity in symbols)
+    size_t bytes = 0;
+    static SymbolCache& get()
+    {
+        static SymbolCache* c = new SymbolCache; // (never destroyed: nothing to gain from unmapping at exit)
+        return *c;
+    }
+    bool take(std::pair<uint16_t*, size_t>& out)
+    {
+        std::lock_guard<std::mutex> g(mu);
+        if (bufs.empty()) return false;
+        out = bufs.back();
+        bufs.pop_back();
+        bytes -= out.second * sizeof(uint16_t);
+        return true;
+    }
+    void give(uint16_t* p, size_t cap)
+    {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            if (bytes + cap * sizeof(uint16_t) <= CACHE_BYTES) {
+                bufs.push_back({ p, cap });
+                bytes += cap * sizeof(uint16_t);
+                return;
+            }
+        }
+        std::free(p);
+    }
 };
 
 enum class Status { OK, BAD_FIRST_BLOCK, FAILED };
@@ -600,12 +637,14 @@ struct ParallelGunzip::Impl {
     std::mutex mu;
     std::condition_variable cv;
     std::thread producer;
+    std::unique_ptr<Crew> round_crew, read_crew; // (one each: a round runs while read() resolves the round before it)
     bool started = false, done_pub = false, stop = false;
     std::string failed;
     std::vector<uint8_t> window = std::vector<uint8_t>(WINDOW, 0); // the 32 KB before the next segment to be stitched
     uint32_t run_crc = 0;
     uint64_t run_len = 0;
     std::atomic<uint64_t> accepted { 0 }, redone { 0 };
+    double t_read = 0;
     double t_decode = 0, t_stitch = 0, t_resolve = 0, t_wait = 0; // wall seconds (DRPRG_GZ_DEBUG=1 prints them)
     uint64_t n_rounds = 0, n_reads = 0;
     static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -614,11 +653,17 @@ struct ParallelGunzip::Impl {
     std::vector<std::pair<uint16_t*, size_t>> pool;
     Segment* new_segment()
     {
-        std::lock_guard<std::mutex> g(pool_mu);
-        if (pool.empty()) return new Segment;
-        const auto b = pool.back();
-        pool.pop_back();
-        return new Segment(b.first, b.second);
+        {
+            std::lock_guard<std::mutex> g(pool_mu);
+            if (!pool.empty()) {
+                const auto b = pool.back();
+                pool.pop_back();
+                return new Segment(b.first, b.second);
+            }
+        }
+        std::pair<uint16_t*, size_t> b;
+        if (SymbolCache::get().take(b)) return new Segment(b.first, b.second);
+        return new Segment;
     }
     void recycle(Segment& s)
     {
@@ -631,12 +676,23 @@ struct ParallelGunzip::Impl {
     }
     ~Impl()
     {
+        const double d0 = now();
         shutdown();
+        const double d1 = now();
+        round_crew.reset();
+        read_crew.reset();
+        if (std::getenv("DRPRG_GZ_DEBUG"))
+            std::fprintf(stderr, "[pgunzip] inside read() %.3f s in all; closing: producer %.3f s, crews %.3f s\n", t_read, d1 - d0, now() - d1);
         if (std::getenv("DRPRG_GZ_DEBUG"))
             std::fprintf(stderr, "[pgunzip] threads %d chunk %zu: %llu rounds decode %.3f s stitch %.3f s | %llu reads resolve %.3f s wait-for-producer %.3f s | accepted %llu redone %llu\n",
                 threads, chunk, (unsigned long long)n_rounds, t_decode, t_stitch, (unsigned long long)n_reads, t_resolve, t_wait,
                 (unsigned long long)accepted.load(), (unsigned long long)redone.load());
-        for (auto& b : pool) std::free(b.first);
+        for (auto& b : pool) SymbolCache::get().give(b.first, b.second);
+        for (auto& sgm : ready) // (a reader that stopped early)
+            if (sgm && sgm->buf) {
+                SymbolCache::get().give(sgm->buf, sgm->cap);
+                sgm->buf = nullptr;
+            }
     }
 
     size_t expect_symbols() const { return chunk * 10; } // (address space: only what is written gets pages)
@@ -655,7 +711,6 @@ struct ParallelGunzip::Impl {
         const size_t n_chunks = (len + chunk - 1) / chunk;
         const size_t first = next_chunk, last = std::min(n_chunks, first + (size_t)threads);
         std::vector<std::unique_ptr<Segment>> seg(last - first);
-        std::vector<std::thread> pool;
         std::atomic<size_t> cursor { 0 };
         const uint64_t stand = next_bit;
         const bool stand_header = at_header;
@@ -675,9 +730,8 @@ struct ParallelGunzip::Impl {
         };
         const int nt = (int)std::min<size_t>((size_t)threads, seg.size());
         const double t0 = now();
-        for (int t = 1; t < nt; ++t) pool.emplace_back(job);
-        job();
-        for (auto& t : pool) t.join();
+        if (!round_crew) round_crew.reset(new Crew(threads - 1));
+        round_crew->run(job, nt);
         const double t1 = now();
         t_decode += t1 - t0;
         ++n_rounds;
@@ -809,10 +863,15 @@ struct ParallelGunzip::Impl {
 
     size_t read(char* dst, size_t cap)
     {
+        struct Tock {
+            double& acc;
+            double from;
+            ~Tock() { acc += now() - from; }
+        } tock { t_read, now() };
         std::vector<Job> jobs;
         std::vector<std::unique_ptr<Segment>> used; // segments handed out completely: freed when the jobs are done
         size_t total = 0;
-        constexpr size_t PIECE = size_t(1) << 20;
+        constexpr size_t PIECE = size_t(1) << 18; // (a read ends on a barrier: several pieces per thread even out who is late)
         if (!started) {
             started = true;
             producer = std::thread([this] { produce(); });
@@ -888,10 +947,8 @@ struct ParallelGunzip::Impl {
         };
         const int nt = (int)std::min<size_t>((size_t)threads, (jobs.size() + 1) / 2);
         const double r0 = now();
-        std::vector<std::thread> pool;
-        for (int t = 1; t < nt; ++t) pool.emplace_back(work);
-        work();
-        for (auto& t : pool) t.join();
+        if (!read_crew) read_crew.reset(new Crew(threads - 1));
+        read_crew->run(work, nt);
         t_resolve += now() - r0;
         ++n_reads;
         for (auto& u : used) recycle(*u);

@@ -17,7 +17,7 @@ gz = os.path.join(tmp, "r.plain.gz")
 with open(gz, "wb") as fh:
     subprocess.run(["gzip", "-6", "-c", fq], stdout=fh, check=True)
 print("sizes", os.path.getsize(fq), os.path.getsize(bg), os.path.getsize(gz), flush=True)
-for threads in (8, 16, 32, 64):
+for threads in [int(x) for x in os.environ.get("E2E_THREADS", "8,16,32,64").split(",")]:
     ctx = Context(prg, 11, 15, device=0, from_files=False, threads=8)
     ctx.set_opts(illumina=True); ctx.set_threads(threads)
     ctx.map_fastx(fq)
