@@ -207,3 +207,37 @@ def test_pandora_discover_takes_its_second_pass_from_hbm(tmp_path):
         assert ("resident in device memory" in r.stdout) == (gb is None), r.stdout
         outs[name] = _files(tmp_path / name)
     assert outs["hbm"] == outs["file"] and b"1 denovo variants" in outs["hbm"]["denovo_paths.txt"]
+
+
+def test_resident_reads_of_a_context_over_several_devices(tmp_path):
+    """drprg_hip_open_multi (here: device 0 listed twice, two Mapper objects): every device keeps the blocks it mapped, discover asks
+    all of them, and the context of the updated PRG maps each device's blocks on that device"""
+    from drprg_amd import Context
+    panel, prg, genes, fq = _sample(tmp_path, n_background=120000)
+    one, want = _discover(prg, genes, fq, tmp_path / "one", 0, threads=8)
+    two = Context(prg, W, K, from_files=False, devices=[0, 0])
+    two.set_opts(illumina=True, genome_size=4000)
+    two.set_threads(8)
+    two.keep_reads(1 << 30)
+    two.map_fastx(fq)
+    (tmp_path / "two").mkdir()
+    got = two.discover_reads(fq, genes, str(tmp_path / "two"))
+    info = two.resident_info()
+    assert info["complete"] and info["last_discover_from_hbm"] and info["blocks"] >= 2
+    assert got == want and _files(tmp_path / "two") == _files(tmp_path / "one")
+    assert np.array_equal(two.coverage()[0], one.coverage()[0])
+    new_prg = str(tmp_path / "updated.dr.prg")
+    assert two.update_prg(new_prg) == 1
+    nxt = Context(new_prg, W, K, from_files=False, devices=[0, 0])
+    nxt.set_opts(illumina=True, genome_size=4000)
+    nxt.map_resident(two)
+    ref = Context(new_prg, W, K, device=0, from_files=False)
+    ref.set_opts(illumina=True, genome_size=4000)
+    ref.set_threads(4)
+    ref.map_fastx(fq)
+    assert np.array_equal(nxt.coverage()[0], ref.coverage()[0]) and np.array_equal(nxt.coverage()[1], ref.coverage()[1])
+    assert nxt.counters()["reads"] == ref.counters()["reads"] == 120000 + 2700
+    # a context over one device cannot take the reads of one over two
+    single = Context(new_prg, W, K, device=0, from_files=False)
+    with pytest.raises(Exception):
+        single.map_resident(two)
