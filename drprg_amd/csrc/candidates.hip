@@ -580,6 +580,10 @@ __global__ __launch_bounds__(TG_THREADS) void tile_gather_kernel(SketchArgs a, F
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
+// (Round 3 tried to do without the two single-workgroup scans of this sequence, cand_scan_kernel and hit_scan_kernel, 10 + 6 us:
+// every workgroup of cand_gather_kernel summing the slice counts before its own, and every workgroup of verify_count_kernel adding
+// its totals to the batch counters with three atomics.  Measured: cand_gather 11 -> 38 us (8192 workgroups x up to 8192 loads),
+// verify_count 116 -> 231 us (12 k atomics on one 64-byte line take their turn in the L2), step 0.59 -> 0.72 ms.  The scans stay.)
 hipError_t launch_candidate_stage(const SketchArgs& a, const FilterWork& fw, const ReadClusterArgs& rc, hipStream_t stream)
 {
     hipLaunchKernelGGL(cand_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, fw);

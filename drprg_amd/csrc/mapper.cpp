@@ -139,7 +139,7 @@ Mapper::Mapper(const FlatIndex& idx, const MapParams& p, int device) : device_(d
             HIPCHK(hipMemcpy(d_midc_, idx.midc.data(), idx.midc.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
             if (const char* e = std::getenv("DRPRG_FT_STATS"); e && std::atoi(e)) {
                 dmalloc(d_ft_stat_, (size_t)4);
-                HIPCHK(hipMemset(d_ft_stat_, 0, 4 * sizeof(unsigned long long)));
+                zero_now(d_ft_stat_, 0, 4 * sizeof(unsigned long long));
             }
         }
     }
@@ -199,6 +199,17 @@ Mapper::~Mapper()
     if (ev0_) (void)hipEventDestroy(ev0_);
     if (ev1_) (void)hipEventDestroy(ev1_);
     if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+// Zeroes device memory and returns when it IS zero.  hipMemset on device memory runs on the null stream and may return before it
+// has run; this class's streams are non-blocking, so nothing they do waits for the null stream -- a freshly allocated cand_pos1
+// was zeroed AFTER verify_count_kernel had written the first batch into it (cold start, several contexts busy on one device:
+// one run in ten lost 5 % of its clusters; tools/stress_multi.py).
+void Mapper::zero_now(void* p, int value, size_t bytes)
+{
+    (void)value;
+    HIPCHK(hipMemsetAsync(p, 0, bytes, stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
 }
 
 // Page-locked memory for the ingest's parser threads.  Portable: they call this with whatever device is current on their
@@ -311,7 +322,7 @@ void Mapper::grow_lane(Lane& lane, uint64_t cap)
     dmalloc(lane.raw_pos, cap); dmalloc(lane.cand_info, cap); dmalloc(lane.cand_pos1, cap); dmalloc(lane.cand_rec, cap);
     // the slices form of the direct sequence uses cand_pos1 as an array of "handled" marks (mark = a batch's epoch): fresh device
     // memory may hold anything, including a value some later epoch of this or an earlier Mapper takes
-    HIPCHK(hipMemset(lane.cand_pos1, 0, cap * sizeof(uint32_t)));
+    zero_now(lane.cand_pos1, 0, cap * sizeof(uint32_t));
 }
 
 void Mapper::ensure_lanes(int n, uint64_t cap)
@@ -327,7 +338,7 @@ void Mapper::ensure_lanes(int n, uint64_t cap)
         dmalloc(lane.small, dev::filter_small_words());
         dmalloc(lane.d_scratch, (size_t)L_N);
         HIPCHK(hipHostMalloc((void**)&lane.h_scratch, L_N * sizeof(unsigned long long), hipHostMallocDefault));
-        HIPCHK(hipMemset(lane.d_scratch, 0, L_N * sizeof(unsigned long long)));
+        zero_now(lane.d_scratch, 0, L_N * sizeof(unsigned long long));
         lane.scratch_zero = true;
     }
     for (int j = 0; j < n; ++j) grow_lane(lanes_[j], cap);
@@ -759,7 +770,7 @@ void Mapper::map_device_async(const uint8_t* d_bases, const uint64_t* d_offsets,
             dmalloc(lane.small, dev::filter_small_words());
             dmalloc(lane.d_scratch, (size_t)L_N);
             HIPCHK(hipHostMalloc((void**)&lane.h_scratch, L_N * sizeof(unsigned long long), hipHostMallocDefault));
-            HIPCHK(hipMemset(lane.d_scratch, 0, L_N * sizeof(unsigned long long)));
+            zero_now(lane.d_scratch, 0, L_N * sizeof(unsigned long long));
             lane.scratch_zero = true;
         }
     }

@@ -104,6 +104,7 @@ public:
     void reset_kernel_timing() { sketch_ms_ = 0; sketch_launches_ = 0; }
 
 private:
+    void zero_now(void* p, int value, size_t bytes);
     void ensure_workspace(uint64_t hit_capacity);
     // One filtered launch sequence (sketch_filter -> refine -> candidates -> read_cluster) and everything private to it.
     // A batch is cut into as many read ranges as there are lanes (default: one); lane 0 runs on the caller's stream, the

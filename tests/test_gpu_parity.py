@@ -547,6 +547,16 @@ def test_multi_device_context_equals_single(tmp_path, oracle):
     cs, cm = single.counters(), multi.counters()
     for key in ("reads", "bases", "hits", "clusters_kept", "hits_kept"):
         assert cs[key] == cm[key], key
+    # ... and again with contexts that have never mapped anything (first-call allocations while the other mappers of the device are
+    # busy: a fresh candidate array used to be zeroed by a null-stream memset that could land after the first batch had written it --
+    # one such run in ten lost clusters; tools/stress_multi.py runs this hundreds of times)
+    for _ in range(12):
+        cold = Context(prg, w, k, from_files=False, devices=[0, 0, 0])
+        cold.set_opts(illumina=True, genome_size=60000)
+        cold.set_threads(8)
+        cold.map_fastx(fq)
+        assert np.array_equal(cold.coverage()[0], want)
+        cold.close()
     idx = oracle.build_index(panel.prgs, w, k)
     ocov, oprg, _ = _oracle_map(oracle, idx, bases, offs, w, k, True, threads=ORACLE_THREADS)
     assert np.array_equal(got, ocov) and np.array_equal(got_prg, oprg)
