@@ -144,6 +144,7 @@ Mapper::Mapper(const FlatIndex& idx, const MapParams& p, int device) : device_(d
         }
     }
     HIPCHK(hipDeviceGetAttribute(&n_cus_, hipDeviceAttributeMultiprocessorCount, device_));
+    HIPCHK(hipStreamSynchronize(nullptr)); // every table is on the device before a kernel of a non-blocking stream can ask for it
     set_params(p); // again: the kernel choice depends on the filter being available
     {
         const char* f = std::getenv("DRPRG_WAVE_FUSE");
@@ -266,6 +267,7 @@ void Mapper::set_params(const MapParams& p)
         for (uint32_t i = 0; i < n_prgs_; ++i) thr[i] = (uint32_t)((double)h_min_path_len_[i] * fraction);
         HIPCHK(hipSetDevice(device_));
         HIPCHK(hipMemcpy(d_prg_thr_, thr.data(), n_prgs_ * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIPCHK(hipStreamSynchronize(nullptr)); // (the copies of this file run on the null stream, which the non-blocking streams do not wait for)
     }
     use_filter_ = p.kernel_mode == 2 || (p.kernel_mode == 0 && filter_ok);
     use_mid_ = use_filter_ && bloom_wbits_ == 0;
@@ -1240,6 +1242,7 @@ void Mapper::upload(const std::vector<uint32_t>& covg, const std::vector<uint32_
     HIPCHK(hipSetDevice(device_));
     HIPCHK(hipMemcpy(d_covg_, covg.data(), covg.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_prg_reads_, prg_reads.data(), prg_reads.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIPCHK(hipStreamSynchronize(nullptr));
 }
 
 void Mapper::device_tables(uint64_t out[6]) const
