@@ -68,6 +68,20 @@ for label in ("wild_type", "off_panel_snp"):
     print("   " + " | ".join(l for l in r.stderr.splitlines() if "discover" in l or "novel" in l), flush=True)
     if os.environ.get("E2E_STDERR"):
         print(r.stderr, flush=True)
+    if os.environ.get("E2E_ROCPROF") and label == "off_panel_snp":
+        # the same command once more under rocprofv3 (kernel trace): where the device time of the whole prediction goes
+        import csv, glob
+        pdir = os.path.join(tmp, "prof")
+        shutil.rmtree(out, ignore_errors=True)
+        subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", pdir, "-o", "cli", "--", os.path.join(exe, "drprg"), "predict", "-x", idx,
+                        "-i", fq, "-o", out, "-s", label, "-I", "-t", threads], cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", DRPRG_HIP_SLOW_EXIT="1"),
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        for f in glob.glob(os.path.join(pdir, "**", "*kernel_stats.csv"), recursive=True):
+            rows = list(csv.DictReader(open(f)))
+            rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
+            print("   kernels of the whole command (rocprofv3 --kernel-trace --stats): name, calls, total ms, average us")
+            for r in rows[:14]:
+                print(f"   {r['Name'][:70]:70s} {int(r['Calls']):6d} {float(r['TotalDurationNs']) / 1e6:9.3f} {float(r['AverageNs']) / 1e3:9.1f}", flush=True)
     if label == "wild_type" and os.environ.get("E2E_GZ", "1") != "0":
         # the same sample as one plain gzip stream (what `gzip` writes; inflated by all -t threads, csrc/pgunzip.cpp)
         gz = fq + ".gz"
