@@ -4,7 +4,7 @@
 # usage: bash tools/flaky_record.sh <runs per lane setting> <out file>
 n=${1:-13}; out=${2:-gpurun_out/r03/flaky_hunt.txt}
 mkdir -p $(dirname $out)
-k="config1 or config2 or several_groups or randomized or dense or long_reads or short_reads or do_not_fit or staged_range or many_small or batches or deferred or second_stage or middle_tier or scaled"
+k="config1 or config2 or several_groups or randomized or dense or long_reads or short_reads or do_not_fit or staged_range or many_small or batches or deferred or second_stage or middle_tier or scaled or multi_device"
 echo "# $(date -u +%FT%TZ)  pytest tests/test_gpu_parity.py -m gpu -k \"$k\"" > $out
 total=0; bad=0
 for lanes in 1 2 3 4; do
@@ -17,4 +17,7 @@ for lanes in 1 2 3 4; do
   done
 done
 echo "# $total runs, $bad not green" >> $out
+# ... and the cold-context stress of the multi-device ingest (tools/stress_multi.py: fresh contexts every round, device 0 listed three / two times / once)
+echo "# STRESS_COLD=1 python tools/stress_multi.py 100" >> $out
+STRESS_COLD=1 timeout 600 python tools/stress_multi.py 100 2>&1 | grep -v amdgpu.ids >> $out
 tail -3 $out
