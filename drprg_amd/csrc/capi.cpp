@@ -338,7 +338,7 @@ int drprg_hip_map_fastx(drprg_hip_ctx* ctx, const char* reads_path)
     ctx->mapped_paths.push_back(reads_path);
     // multi-threaded ingest into pinned blocks (ingest.cpp); multi-line FASTQ falls back to the serial reader
     IngestHooks hooks;
-    // pinned ingest blocks are kept by the context between calls (pinning 32 MB costs milliseconds of driver time)
+    // page-locked ingest blocks are kept by the process between calls and contexts (PinPool)
     hooks.alloc = [](size_t n) -> void* { return PinPool::get().take(n); };
     hooks.release = [](void* p) { PinPool::get().give_back(p); };
     // One device: one submitter at a time (the ingest serialises the calls).  Several devices (drprg_hip_open_multi): the
