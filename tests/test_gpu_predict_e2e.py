@@ -180,3 +180,36 @@ _CODONS = {a + b + c: aa for (a, b, c), aa in zip(((x, y, z) for x in "TCAG" for
 
 def _aa(codon):
     return _CODONS[codon]
+
+
+def test_gzip_input_is_read_once_too(tmp_path):
+    """the same off-panel sample as `.fq.gz` (what the reference's users feed it, docs/src/guide/predict.md): inflated once, discover and
+    the second mapping pass take the reads from HBM, and the calls equal those of the run that inflates the file three times"""
+    from drprg_amd import synth
+    idx, panel, sites = _make_index(tmp_path)
+    g = panel.names.index("katG")
+    ref = panel.refs[g]
+    taken = [p for _, p, r, _ in sites["katG"] for p in range(p - 40, p + len(r) + 40)]
+    pos = next(p for p in range(100 + 3 * 250, len(ref) - 400, 3) if p not in taken and p + 1 not in taken and p + 2 not in taken)
+    codon = ref[pos:pos + 3]
+    alt_base = next(b for b in "ACGT" if b != codon[1] and _aa(codon[0] + b + codon[2]) not in (_aa(codon), "*"))
+    mutated = ref[:pos + 1] + alt_base + ref[pos + 2:]
+    rng = np.random.default_rng(11)
+    spacer = synth.random_seq(rng, 300)
+    gn = np.frombuffer((spacer + spacer.join(mutated if gi == g else r for gi, r in enumerate(panel.refs)) + spacer).encode(), np.uint8)
+    starts = rng.integers(0, len(gn) - 150, size=16000)
+    block = gn[starts[:, None] + np.arange(150)]
+    rev = rng.random(len(starts)) < 0.5
+    block[rev] = synth._COMP[block[rev][:, ::-1]]
+    fq = str(tmp_path / "s.fq.gz")
+    synth.write_fastq(fq, block.reshape(-1), np.arange(len(starts) + 1, dtype=np.uint64) * np.uint64(150), gz=True)
+    outs = {}
+    for name, env in (("hbm", {}), ("file", {"DRPRG_HIP_KEEP_READS_GB": "0"})):
+        out = tmp_path / name
+        r = subprocess.run([os.path.join(BIN, "drprg"), "predict", "-x", str(idx), "-i", fq, "-o", str(out), "-s", "s", "-I", "-v"], capture_output=True, text=True,
+                           env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr
+        assert ("reads mapped again (resident in device memory)" in r.stderr) == (name == "hbm"), r.stderr
+        outs[name] = (open(out / "pandora_genotyped.vcf").read(), json.load(open(out / "s.drprg.json"))["susceptibility"]["Isoniazid"]["predict"],
+                      open(out / "discover" / "denovo_variants.tsv").read())
+    assert outs["hbm"] == outs["file"] and outs["hbm"][1] == "U"
