@@ -18,7 +18,7 @@ try:
     bases, offs = synth.sample_short_reads(gen, n, seed=2)
     fq = os.path.join(d, "r.fq"); synth.write_fastq_fixed(fq, bases, 150)
     ctx.set_threads(threads)
-    for rep in range(4):
+    for rep in range(int(os.environ.get("E2E_REPS", "4"))):
         ctx.reset()
         t = time.perf_counter(); ctx.map_fastx(fq); dt = time.perf_counter() - t
         print("rep %d: %.1f ms  %.2e reads/s" % (rep, dt * 1e3, n / dt), flush=True)
