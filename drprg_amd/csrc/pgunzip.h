@@ -50,12 +50,20 @@ public:
             g.unlock();
             cv_.notify_all();
         }
-        fn();
-        if (helpers > 0) {
-            std::unique_lock<std::mutex> g(mu_);
-            done_.wait(g, [&] { return running_ == 0; });
-            job_ = nullptr;
+        auto join = [&] {
+            if (helpers > 0) {
+                std::unique_lock<std::mutex> g(mu_);
+                done_.wait(g, [&] { return running_ == 0; });
+                job_ = nullptr;
+            }
+        };
+        try {
+            fn();
+        } catch (...) { // (the helpers still run fn: it must outlive them)
+            join();
+            throw;
         }
+        join();
     }
 
 private:
