@@ -14,6 +14,7 @@
 #pragma once
 #include "common.h"
 #include <condition_variable>
+#include <exception>
 #include <functional>
 #include <memory>
 #include <mutex>
@@ -50,11 +51,14 @@ public:
             g.unlock();
             cv_.notify_all();
         }
+        std::exception_ptr helper_failed;
         auto join = [&] {
             if (helpers > 0) {
                 std::unique_lock<std::mutex> g(mu_);
                 done_.wait(g, [&] { return running_ == 0; });
                 job_ = nullptr;
+                helper_failed = failed_;
+                failed_ = nullptr;
             }
         };
         try {
@@ -64,6 +68,7 @@ public:
             throw;
         }
         join();
+        if (helper_failed) std::rethrow_exception(helper_failed); // (what a helper threw comes out of run() on the calling thread)
     }
 
 private:
@@ -78,8 +83,14 @@ private:
             --tickets_;
             std::function<void()> job = job_;
             g.unlock();
-            job();
+            std::exception_ptr err;
+            try {
+                job();
+            } catch (...) {
+                err = std::current_exception();
+            }
             g.lock();
+            if (err && !failed_) failed_ = err;
             if (--running_ == 0) done_.notify_all();
         }
     }
@@ -91,6 +102,7 @@ private:
     uint64_t gen_ = 0;
     int tickets_ = 0, running_ = 0;
     bool quit_ = false;
+    std::exception_ptr failed_;
 };
 
 
