@@ -315,6 +315,12 @@ __global__ __launch_bounds__(EX_THREADS) void verify_count_kernel(SketchArgs a, 
 // (19 hashes per candidate instead of 42), hashing is under half of the lane form's instructions, and the bookkeeping -- segments,
 // quad origins, 64-bit positions, LDS round trips -- costs what the sharing saves.  DESIGN.md section 6.)
 
+// (... and a nearest-first form: every wave takes 128 candidates, two per lane, scans the w-1 LEFT-hand neighbours of each, emits those a
+// window ending with them already settles -- 54 % of the true minimizers --, parks the others in a queue of its own in LDS and finishes
+// them 64 at a time with w-1 RIGHT-hand steps.  Fewer hashes (~31 instead of 42 steps per 2 candidates) and bit-identical results, but
+// 71 VGPRs instead of 54, 18 KB of LDS per workgroup and the queue traffic: 115.7 us against 114-116 on the 8d index, 895 against 825 us
+// on the 8-fold one.  Not kept.)
+
 // one workgroup: wg_base = exclusive scan of wg_hits; batch totals
 __global__ __launch_bounds__(SCAN_THREADS) void hit_scan_kernel(SketchArgs a, FilterWork fw, int recount)
 {
