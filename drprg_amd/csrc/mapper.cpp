@@ -5,6 +5,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <set>
 #include <hip/hip_runtime.h>
 #include <sys/mman.h>
 
@@ -213,6 +215,9 @@ void Mapper::zero_now(void* p, int value, size_t bytes)
     HIPCHK(hipStreamSynchronize(stream_));
 }
 
+static std::mutex g_pinned_mu;
+static std::set<void*> g_pinned_by_runtime; // blocks that came from hipHostMalloc (pinned_alloc's second choice)
+
 // Page-locked memory for the ingest's parser threads.  Portable: they call this with whatever device is current on their
 // thread, and a portable registration is page-locked for every device, so the copy engine of the mapper's device takes it at
 // DMA speed.  Ordinary memory (2 MB aligned, transparent huge pages asked for), touched by the calling thread and THEN
@@ -228,8 +233,16 @@ void* Mapper::pinned_alloc(size_t bytes)
     (void)madvise(p, n, MADV_HUGEPAGE);
     for (size_t i = 0; i < n; i += 4096) static_cast<volatile char*>(p)[i] = 0;
     if (hipHostRegister(p, n, hipHostRegisterPortable) != hipSuccess) {
+        // (a host that refuses the registration -- a limit on locked pages, an old driver --: the runtime's own allocation, slower to get)
+        (void)hipGetLastError();
         std::free(p);
-        return nullptr;
+        p = nullptr;
+        if (hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        std::lock_guard<std::mutex> g(g_pinned_mu);
+        g_pinned_by_runtime.insert(p);
     }
     return p;
 }
@@ -237,6 +250,13 @@ void* Mapper::pinned_alloc(size_t bytes)
 void Mapper::pinned_free(void* p)
 {
     if (!p) return;
+    {
+        std::lock_guard<std::mutex> g(g_pinned_mu);
+        if (g_pinned_by_runtime.erase(p)) {
+            (void)hipHostFree(p);
+            return;
+        }
+    }
     (void)hipHostUnregister(p);
     std::free(p);
 }
