@@ -295,8 +295,8 @@ def e2e_leg(torch, ctx, synth, bases, n_reads, read_len, covg):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="mtb", choices=sorted(WORKLOADS),
                     help="mtb = configs[1] (the bench line); mtb-random = the same reads against a random-backbone panel; "
                          "nanopore = configs[2]; big = configs[4]'s index; mtb-xN = the 8d index grown N-fold")
