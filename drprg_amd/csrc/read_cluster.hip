@@ -416,6 +416,7 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
         RC_MARK(8);
         cur = s_chunk; // (written by thread 0 before the barrier that closed phase B)
         nx = request(cur);
+        RC_MARK(12); // (asking for the next chunk's candidates; what follows until mark 9 is the wave path of thread 0's wave)
         // ---- G: reads with hits in several groups, one wave per read: lane j holds cluster j, the hits are broadcast one by one
         // (clusters per group split at gaps, size threshold, the overlap sweep of cluster_filter_kernel) ----
         const uint32_t n_irr = s_n_irr < (uint32_t)RC_POOL ? s_n_irr : (uint32_t)RC_POOL;
@@ -592,8 +593,8 @@ hipError_t launch_read_cluster(const SketchArgs& a, const FilterWork& fw, const 
     static unsigned long long* d_phase = nullptr;
     const bool debug = std::getenv("DRPRG_RC_DEBUG") != nullptr;
     if (debug) {
-        if (!d_phase) HIP_TRY(hipMalloc(&d_phase, 12 * sizeof(unsigned long long)));
-        HIP_TRY(hipMemsetAsync(d_phase, 0, 12 * sizeof(unsigned long long), stream));
+        if (!d_phase) HIP_TRY(hipMalloc(&d_phase, 14 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemsetAsync(d_phase, 0, 14 * sizeof(unsigned long long), stream));
         rcd.phase_clock = d_phase;
     }
     const size_t dyn = (size_t)rc.n_prgs * sizeof(uint32_t); // the per-PRG histogram, behind ~70 KB of static LDS
@@ -607,13 +608,15 @@ hipError_t launch_read_cluster(const SketchArgs& a, const FilterWork& fw, const 
         hipLaunchKernelGGL(read_cluster_kernel<false>, dim3((uint32_t)n_cus * 2), dim3(RC_THREADS), dyn, stream, a, fw, rcd);
     }
     if (debug) { // cycles of thread 0, summed over the workgroups, per phase (the marks follow the barriers of the chunk loop)
-        unsigned long long h[12];
+        unsigned long long h[14];
         HIP_TRY(hipStreamSynchronize(stream));
         HIP_TRY(hipMemcpy(h, d_phase, sizeof h, hipMemcpyDeviceToHost));
         unsigned long long sum = 0;
         for (int i = 0; i < 10; ++i) sum += h[i];
+        sum += h[12];
         std::fprintf(stderr, "[read_cluster phases, %% of %llu Mcycles]", sum / 1000000);
         for (int i = 0; i < 10; ++i) std::fprintf(stderr, " %d:%.1f", i, sum ? 100.0 * (double)h[i] / (double)sum : 0.0);
+        std::fprintf(stderr, " request:%.1f", sum ? 100.0 * (double)h[12] / (double)sum : 0.0);
         std::fprintf(stderr, " | %llu reads on the wave path in %llu chunks\n", h[10], h[11]);
     }
     return hipGetLastError();
