@@ -111,7 +111,8 @@ struct drprg_hip_ctx {
     // (the page-locked ingest blocks of drprg_hip_map_fastx are recycled process-wide: PinPool above)
     // multi-device context: RCCL communicators of its devices (created on first use; empty when RCCL is not used)
     std::vector<Rccl::Comm> comms;
-    std::string reduce_how; // how the last drprg_hip_reduce summed the vectors (drprg_hip_reduce_info)
+    std::string reduce_how; // how the last drprg_hip_reduce / drprg_hip_allreduce summed the vectors (drprg_hip_reduce_info)
+    bool needs_reset = false; // a reduce failed half way: the devices' vectors are in no defined state until drprg_hip_reset
     ~drprg_hip_ctx()
     {
         if (!comms.empty())
@@ -193,14 +194,29 @@ static void reduce_devices(drprg_hip_ctx* ctx)
         }
     }
     if (r) {
-        const size_t nc = 2 * (size_t)m.n_knodes(), np = m.n_prgs();
+        // one ncclReduce per device over [coverage | reads per PRG] (one allocation: Mapper).  A group that was opened is
+        // always closed: the first failure is remembered and thrown behind ncclGroupEnd, and the context is marked so that
+        // nothing reads vectors of which some may be reduced and others not (drprg_hip_reset clears the mark).
+        const size_t nv = 2 * (size_t)m.n_knodes() + m.n_prgs();
         chk(r->GroupStart(), "ncclGroupStart");
-        for (size_t d = 0; d < all.size(); ++d) {
-            if (hipSetDevice(all[d]->device()) != hipSuccess) throw Error(DRPRG_EIO, "hipSetDevice failed");
-            chk(r->Reduce(all[d]->d_covg(), all[d]->d_covg(), nc, Rccl::Uint32, Rccl::Sum, 0, ctx->comms[d], all[d]->stream()), "ncclReduce");
-            chk(r->Reduce(all[d]->d_prg_reads(), all[d]->d_prg_reads(), np, Rccl::Uint32, Rccl::Sum, 0, ctx->comms[d], all[d]->stream()), "ncclReduce");
+        int first_rc = Rccl::Success;
+        const char* first_what = "";
+        for (size_t d = 0; d < all.size() && first_rc == Rccl::Success; ++d) {
+            if (hipSetDevice(all[d]->device()) != hipSuccess) {
+                first_rc = -1;
+                first_what = "hipSetDevice";
+                break;
+            }
+            first_rc = r->Reduce(all[d]->d_covg(), all[d]->d_covg(), nv, Rccl::Uint32, Rccl::Sum, 0, ctx->comms[d], all[d]->stream());
+            first_what = "ncclReduce";
         }
-        chk(r->GroupEnd(), "ncclGroupEnd");
+        const int end_rc = r->GroupEnd();
+        if (first_rc != Rccl::Success || end_rc != Rccl::Success) {
+            ctx->needs_reset = true;
+            if (first_rc == -1) throw Error(DRPRG_EIO, "hipSetDevice failed inside the reduce (drprg_hip_reset the context)");
+            chk(first_rc, first_what);
+            chk(end_rc, "ncclGroupEnd");
+        }
         for (Mapper* x : all) {
             if (hipSetDevice(x->device()) != hipSuccess || hipStreamSynchronize(x->stream()) != hipSuccess) throw Error(DRPRG_EIO, "stream synchronisation after ncclReduce failed");
         }
@@ -321,6 +337,18 @@ int drprg_hip_set_opts(drprg_hip_ctx* ctx, const drprg_hip_map_opts* opts)
     if (ctx->mapper) ctx->mapper->set_params(ctx->params);
     for (auto& m : ctx->extra) m->set_params(ctx->params);
     API_END(ctx)
+}
+
+int drprg_hip_set_opts_sized(drprg_hip_ctx* ctx, const drprg_hip_map_opts* opts, size_t opts_size)
+{
+    static_assert(sizeof(drprg_hip_map_opts) == DRPRG_HIP_MAP_OPTS_SIZE, "drprg_hip_map_opts changed size: bump DRPRG_HIP_MAP_OPTS_SIZE");
+    if (!ctx) return DRPRG_EINVAL;
+    if (opts && opts_size != sizeof(drprg_hip_map_opts)) {
+        ctx->last_error = "drprg_hip_map_opts: the caller's struct has " + std::to_string(opts_size) + " bytes, this library's "
+            + std::to_string(sizeof(drprg_hip_map_opts)) + " (header / library mismatch)";
+        return DRPRG_EINVAL;
+    }
+    return drprg_hip_set_opts(ctx, opts);
 }
 
 static Mapper& need_mapper(drprg_hip_ctx* ctx)
@@ -524,10 +552,23 @@ int drprg_hip_allreduce(drprg_hip_ctx* ctx, void* comm, void* d_covg, void* d_pr
     auto chk = [&](int rc, const char* what) {
         if (rc != Rccl::Success) throw Error(DRPRG_EIO, std::string("RCCL ") + what + ": " + r->GetErrorString(rc));
     };
-    chk(r->GroupStart(), "ncclGroupStart");
-    chk(r->AllReduce(c, c, 2 * (size_t)m.n_knodes(), Rccl::Uint32, Rccl::Sum, comm, st), "ncclAllReduce");
-    chk(r->AllReduce(p, p, (size_t)m.n_prgs(), Rccl::Uint32, Rccl::Sum, comm, st), "ncclAllReduce");
-    chk(r->GroupEnd(), "ncclGroupEnd");
+    const size_t nc = 2 * (size_t)m.n_knodes(), np = m.n_prgs();
+    if (p == c + nc) {
+        // the sample's additive state is ONE vector [coverage | reads per PRG] -- the context's accumulators are laid out that
+        // way, and so is a caller's buffer of drprg_hip_coverage_size's n_covg + n_prgs words -- : a single ncclAllReduce
+        chk(r->AllReduce(c, c, nc + np, Rccl::Uint32, Rccl::Sum, comm, st), "ncclAllReduce");
+        ctx->reduce_how = "rccl: one ncclAllReduce(sum, u32) of " + std::to_string(nc + np) + " words";
+    } else {
+        // two separate buffers of the caller's: one group of two (closed whatever happens inside)
+        chk(r->GroupStart(), "ncclGroupStart");
+        const int rc1 = r->AllReduce(c, c, nc, Rccl::Uint32, Rccl::Sum, comm, st);
+        const int rc2 = rc1 == Rccl::Success ? r->AllReduce(p, p, np, Rccl::Uint32, Rccl::Sum, comm, st) : rc1;
+        const int rc3 = r->GroupEnd();
+        chk(rc1, "ncclAllReduce");
+        chk(rc2, "ncclAllReduce");
+        chk(rc3, "ncclGroupEnd");
+        ctx->reduce_how = "rccl: two grouped ncclAllReduce(sum, u32) (separate buffers)";
+    }
     ctx->host_coverage_valid = false; // (asynchronous on the stream: the caller synchronises it, or reads through this context, which does)
     API_END(ctx)
 }
@@ -542,6 +583,7 @@ int drprg_hip_coverage_size(const drprg_hip_ctx* ctx, uint64_t* n_covg, uint64_t
 
 static void sync_host_coverage(drprg_hip_ctx* ctx)
 {
+    if (ctx->needs_reset) throw Error(DRPRG_EIO, "a reduce over the context's devices failed half way: drprg_hip_reset the context and map again");
     if (ctx->host_coverage_valid) return;
     if (ctx->mapper) {
         ctx->mapper->download(ctx->covg, ctx->prg_reads);
@@ -597,6 +639,7 @@ int drprg_hip_reset(drprg_hip_ctx* ctx)
     ctx->host_coverage_valid = false;
     ctx->total_bases = 0;
     ctx->mapped_paths.clear();
+    ctx->needs_reset = false;
     API_END(ctx)
 }
 

@@ -310,6 +310,17 @@ int main(int argc, char** argv)
     // 0.15 s between the line above and the parent seeing the exit with `return 0`, 0.001 s this way for a sample without a
     // novel variant (with one, the kernel still takes ~0.13 s to take the process apart; hipDeviceReset first changes nothing).
     std::fflush(nullptr);
-    if (const char* e = std::getenv("DRPRG_HIP_SLOW_EXIT"); e && *e && *e != '0') return 0; // (a profiler that writes its files from exit handlers)
+    // Not when anything is evidently attached that does its work from exit handlers (a profiler's output files, a sanitizer's
+    // report, a preloaded library): then the process returns normally.  DRPRG_HIP_SLOW_EXIT=1 forces the normal return,
+    // DRPRG_HIP_FAST_EXIT=0 as well.
+    auto set = [](const char* name) { const char* e = std::getenv(name); return e && *e; };
+    auto on = [](const char* name) { const char* e = std::getenv(name); return e && *e && *e != '0'; };
+    bool tool = set("LD_PRELOAD") || set("ROCP_TOOL_LIBRARIES") || set("ROCPROFILER_REGISTER_FORCE_LOAD") || set("ROCPROF_OUTPUT_PATH")
+        || set("ASAN_OPTIONS") || set("UBSAN_OPTIONS") || set("LSAN_OPTIONS") || set("GCOV_PREFIX") || set("LLVM_PROFILE_FILE");
+#if defined(__SANITIZE_ADDRESS__)
+    tool = true;
+#endif
+    if (const char* e = std::getenv("DRPRG_HIP_FAST_EXIT"); e && *e == '0') tool = true;
+    if (tool || on("DRPRG_HIP_SLOW_EXIT")) return 0;
     _exit(0);
 }

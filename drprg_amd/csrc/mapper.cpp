@@ -159,8 +159,10 @@ Mapper::Mapper(const FlatIndex& idx, const MapParams& p, int device) : device_(d
     }
     if (const char* e = std::getenv("DRPRG_HIP_LANES")) max_lanes_ = std::min(4, std::max(1, std::atoi(e)));
     if (const char* e = std::getenv("DRPRG_HIP_LANES_MIN_BASES")) lanes_min_bases_ = std::strtoull(e, nullptr, 10); // (tests: 0)
-    dmalloc(d_covg_, 2 * (size_t)n_knodes_);
-    dmalloc(d_prg_reads_, (size_t)n_prgs_);
+    // ONE allocation [coverage | reads per PRG]: the sample's whole additive state is one contiguous u32 vector, so the
+    // collective of the path is a single ncclAllReduce / ncclReduce over it (capi.cpp)
+    dmalloc(d_covg_, 2 * (size_t)n_knodes_ + (size_t)n_prgs_);
+    d_prg_reads_ = d_covg_ + 2 * (size_t)n_knodes_;
     dmalloc(d_counters_, (size_t)C_N);
     HIPCHK(hipHostMalloc((void**)&h_counters_, C_N * sizeof(unsigned long long), hipHostMallocDefault));
     HIPCHK(hipEventCreate(&ev0_));
@@ -180,7 +182,7 @@ Mapper::~Mapper()
     if (stream_) (void)hipStreamSynchronize(stream_);
     dfree(d_slot_rec_); dfree(d_slot_first_); dfree(d_rec_knode_); dfree(d_rec_prg_); dfree(d_min_path_len_); dfree(d_prg_thr_);
     if (d_slot_key_) (void)hipFree(d_slot_key_);
-    dfree(d_covg_); dfree(d_prg_reads_); dfree(d_counters_);
+    dfree(d_covg_); d_prg_reads_ = nullptr; dfree(d_counters_);
     dfree(d_key_a_); dfree(d_key_b_); dfree(d_val_a_); dfree(d_val_b_);
     dfree(d_head_); dfree(d_scan_); dfree(d_cstart_); dfree(d_order_); dfree(d_clusters_);
     if (d_temp_) (void)hipFree(d_temp_);
@@ -298,8 +300,7 @@ void Mapper::reset_coverage(bool new_sample)
 {
     sync();
     HIPCHK(hipSetDevice(device_));
-    HIPCHK(hipMemsetAsync(d_covg_, 0, 2 * (size_t)n_knodes_ * sizeof(uint32_t), stream_));
-    HIPCHK(hipMemsetAsync(d_prg_reads_, 0, (size_t)n_prgs_ * sizeof(uint32_t), stream_));
+    HIPCHK(hipMemsetAsync(d_covg_, 0, (2 * (size_t)n_knodes_ + (size_t)n_prgs_) * sizeof(uint32_t), stream_)); // [coverage | reads per PRG]
     HIPCHK(hipMemsetAsync(d_counters_, 0, C_N * sizeof(unsigned long long), stream_));
     HIPCHK(hipStreamSynchronize(stream_));
     tot_reads_ = tot_bases_ = tot_hits_ = tot_leftover_ = tot_minimizers_ = 0;
@@ -1038,6 +1039,8 @@ void Mapper::keep_reads(uint64_t max_bytes)
 {
     drop_kept();
     kept_cap_ = max_bytes;
+    // reads mapped before this call are not resident: kept_complete() must not claim them (map_resident would map a subset)
+    kept_broken_ = tot_reads_ != 0;
 }
 
 void Mapper::drop_kept()
@@ -1229,16 +1232,13 @@ void Mapper::add_vectors_from(Mapper& other)
     sync();
     HIPCHK(hipSetDevice(device_));
     const size_t nc = 2 * (size_t)n_knodes_, np = n_prgs_;
-    const uint32_t *src_c = other.d_covg_, *src_p = other.d_prg_reads_;
+    const uint32_t* src = other.d_covg_; // [coverage | reads per PRG], one vector on either side
     if (other.device_ != device_) {
         if (!d_peer_tmp_) dmalloc(d_peer_tmp_, nc + np);
-        HIPCHK(hipMemcpyPeerAsync(d_peer_tmp_, device_, other.d_covg_, other.device_, nc * sizeof(uint32_t), stream_));
-        HIPCHK(hipMemcpyPeerAsync(d_peer_tmp_ + nc, device_, other.d_prg_reads_, other.device_, np * sizeof(uint32_t), stream_));
-        src_c = d_peer_tmp_;
-        src_p = d_peer_tmp_ + nc;
+        HIPCHK(hipMemcpyPeerAsync(d_peer_tmp_, device_, other.d_covg_, other.device_, (nc + np) * sizeof(uint32_t), stream_));
+        src = d_peer_tmp_;
     }
-    HIPCHK(dev::launch_vector_add_u32(d_covg_, src_c, nc, stream_));
-    HIPCHK(dev::launch_vector_add_u32(d_prg_reads_, src_p, np, stream_));
+    HIPCHK(dev::launch_vector_add_u32(d_covg_, src, nc + np, stream_));
     HIPCHK(hipStreamSynchronize(stream_));
 }
 

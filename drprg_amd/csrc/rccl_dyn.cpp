@@ -1,5 +1,6 @@
 // rccl_dyn.cpp -- see rccl_dyn.h
 #include "rccl_dyn.h"
+#include <cstdlib>
 #include <dlfcn.h>
 #include <mutex>
 
@@ -13,12 +14,21 @@ const Rccl* Rccl::get(std::string* why)
     static std::once_flag once;
     std::call_once(once, [] {
         void* h = nullptr;
-        for (const char* name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) {
+        // DRPRG_HIP_RCCL_LIB names the one library to try (a host with its own build of RCCL; the test suite points it at a
+        // file that does not exist to reach the no-library paths: -ENODEV from the communicator entries, the peer copy +
+        // add kernel in drprg_hip_reduce)
+        const char* forced = getenv("DRPRG_HIP_RCCL_LIB");
+        std::string first_err;
+        for (const char* name : { forced, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) {
+            if (!name || !*name) continue;
             h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
             if (h) break;
+            const char* e = dlerror(); // one call: dlerror() clears the message it returns
+            if (first_err.empty()) first_err = e ? e : "?";
+            if (forced) break;
         }
         if (!h) {
-            error = std::string("librccl.so.1 not found: ") + (dlerror() ? dlerror() : "?");
+            error = std::string(forced && *forced ? forced : "librccl.so.1") + " not found: " + (first_err.empty() ? "?" : first_err);
             return;
         }
         auto bind = [&](const char* sym, void** slot) {

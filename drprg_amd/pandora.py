@@ -77,7 +77,7 @@ class Context:
         kernel in its candidate form (read_cluster_kernel)"""
         o = MapOpts(max_diff, error_rate, min_cluster_size, 1 if illumina else 0, genome_size, genotyping_error_rate, kernel,
                     1 if binomial else 0)
-        _check(lib.drprg_hip_set_opts(self._h, C.byref(o)), self._h)
+        _check(lib.drprg_hip_set_opts_sized(self._h, C.byref(o), C.sizeof(o)), self._h)
 
     # ---- mapping -------------------------------------------------------------------------------
     def set_threads(self, threads):

@@ -26,7 +26,13 @@ extern "C" {
 typedef struct drprg_hip_ctx drprg_hip_ctx;
 
 /* Mapping options = the argv drprg builds for `pandora map/discover`
- * (/root/reference/src/predict.rs:236-245, src/lib.rs:594-618). */
+ * (/root/reference/src/predict.rs:236-245, src/lib.rs:594-618).
+ * ZERO-INITIALISE the struct (memset / `= {0}` / Rust `Default`) before setting fields: every field has a default at 0 and new
+ * fields are only ever added where 0 keeps the previous behaviour (`binomial` took what was tail padding in round 3:
+ * sizeof stayed 48, and a host that filled the struct field by field without zeroing it would pass an indeterminate value).
+ * DRPRG_HIP_MAP_OPTS_SIZE is checked by drprg_hip_set_opts_sized, the entry a host built against another header revision
+ * should call: a size other than this library's is refused with -EINVAL instead of being read past or short. */
+#define DRPRG_HIP_MAP_OPTS_SIZE 48
 typedef struct drprg_hip_map_opts {
     int32_t max_diff;          /* --max-diff; <=0: default (250, or 2k+1 with illumina) */
     double error_rate;         /* -e; <=0: default (0.11, or 0.001 with illumina) */
@@ -88,6 +94,8 @@ void drprg_hip_close(drprg_hip_ctx* ctx);
 const char* drprg_hip_last_error(const drprg_hip_ctx* ctx);
 
 int drprg_hip_set_opts(drprg_hip_ctx* ctx, const drprg_hip_map_opts* opts);
+/* The same with the caller's sizeof(drprg_hip_map_opts): -EINVAL when it differs from this library's (header / library mismatch). */
+int drprg_hip_set_opts_sized(drprg_hip_ctx* ctx, const drprg_hip_map_opts* opts, size_t opts_size);
 
 /* Read mapping: the loop inside `pandora map` / `pandora discover` that
  * Pandora::genotype_with / discover_with wait on (/root/reference/src/lib.rs:580-642, :513-578).

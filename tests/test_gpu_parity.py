@@ -841,6 +841,27 @@ def test_native_rccl_communicator_single_rank(tmp_path, oracle):
     assert np.array_equal(got, ocov) and np.array_equal(got_prg, oprg) and got.sum() > 0
     comm.allreduce(ctx)  # twice: still the same vector with one rank
     assert np.array_equal(ctx.coverage()[0], ocov)
+    # north_star: "a single RCCL reduce" -- the context's accumulators are one vector [coverage | reads per PRG]
+    import ctypes as C
+    from drprg_amd._lib import lib
+    buf = C.create_string_buffer(256)
+    lib.drprg_hip_reduce_info(ctx._h, buf, len(buf))
+    assert buf.value.decode().startswith("rccl: one ncclAllReduce(sum, u32) of %d words" % (got.size + got_prg.size)), buf.value
+    # a caller's own packed buffer (n_covg + n_prgs words, what bench.py --comm native passes) takes the same single call;
+    # two separate buffers still work (one group of two)
+    import torch
+    packed = torch.zeros(got.size + got_prg.size, dtype=torch.int32, device="cuda")
+    packed[:got.size] = torch.from_numpy(ocov.view(np.int32)).cuda()
+    comm.allreduce(ctx, packed.data_ptr(), packed.data_ptr() + 4 * got.size, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    lib.drprg_hip_reduce_info(ctx._h, buf, len(buf))
+    assert buf.value.decode().startswith("rccl: one ncclAllReduce")
+    assert np.array_equal(packed[:got.size].cpu().numpy().view(np.uint32), ocov)
+    a, b = torch.ones(got.size, dtype=torch.int32, device="cuda"), torch.ones(got_prg.size, dtype=torch.int32, device="cuda")
+    comm.allreduce(ctx, a.data_ptr(), b.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    lib.drprg_hip_reduce_info(ctx._h, buf, len(buf))
+    assert buf.value.decode().startswith("rccl: two grouped") and int(a.sum()) == got.size and int(b.sum()) == got_prg.size
     comm.close()
 
 

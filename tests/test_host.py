@@ -152,6 +152,45 @@ def test_hot_path_fails_loudly_without_a_device(tmp_path):
         ctx.map_fastx(str(tmp_path / "nothing.fq"))
 
 
+def test_missing_rccl_library_is_enodev_not_a_crash():
+    """ADVICE r03 (medium): with no librccl to open, Rccl::get() used to call dlerror() twice (the second call returns NULL once
+    the first has cleared the message) and build a std::string from the null pointer -- a crash exactly where the run-time
+    binding is supposed to report -ENODEV.  A fresh process (the binding is resolved once per process) with the library name
+    pointed at a file that does not exist."""
+    code = (
+        "import ctypes, sys\n"
+        "from drprg_amd._lib import lib\n"
+        "ident = (ctypes.c_uint8 * 128)()\n"
+        "rc = lib.drprg_hip_comm_unique_id(ident)\n"
+        "comm = ctypes.c_void_p()\n"
+        "rc2 = lib.drprg_hip_comm_init_rank(ctypes.byref(comm), 1, ident, 0, 0)\n"
+        "msg = lib.drprg_hip_last_error(None)\n"
+        "print(rc, rc2, (msg or b'').decode())\n")
+    r = subprocess.run([os.sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT,
+                       env=dict(os.environ, DRPRG_HIP_RCCL_LIB="/nonexistent/librccl-missing.so.1"))
+    assert r.returncode == 0, (r.returncode, r.stderr)
+    rc, rc2, msg = r.stdout.strip().split(" ", 2)
+    assert (int(rc), int(rc2)) == (-19, -19), r.stdout  # -ENODEV from both communicator entries
+    assert "librccl-missing.so.1 not found" in msg and "cannot open shared object file" in msg, msg
+
+
+def test_map_opts_of_another_size_are_refused(tmp_path):
+    """drprg_hip_set_opts_sized: a host built against another revision of the header is told so (-EINVAL)."""
+    import ctypes as C
+    from drprg_amd import Context, synth
+    from drprg_amd._lib import MapOpts, lib
+    hdr = open(os.path.join(ROOT, "include", "drprg_hip.h")).read()
+    assert int(re.search(r"#define DRPRG_HIP_MAP_OPTS_SIZE (\d+)", hdr).group(1)) == C.sizeof(MapOpts)
+    panel = synth.small_panel(seed=1, n_loci=1, length=200)
+    prg = str(tmp_path / "dr.prg")
+    panel.write(prg)
+    ctx = Context(prg, 11, 15, device=-1, from_files=False)
+    o = MapOpts()
+    assert lib.drprg_hip_set_opts_sized(ctx._h, C.byref(o), C.sizeof(o)) == 0
+    assert lib.drprg_hip_set_opts_sized(ctx._h, C.byref(o), C.sizeof(o) - 8) == -22
+    assert b"mismatch" in lib.drprg_hip_last_error(ctx._h)
+
+
 def _parse_vcf(path):
     recs = []
     for line in open(path):

@@ -188,6 +188,32 @@ def test_the_limit_and_everything_that_makes_the_resident_reads_stand_for_someth
     assert not two.resident_info()["complete"]
 
 
+def test_keep_reads_switched_on_after_reads_were_mapped(tmp_path):
+    """keep_reads on a context that has already mapped reads -- the earlier reads are not in HBM, so the context does
+    not hold "every read mapped since the last reset" and map_resident must refuse (-ENODATA) instead of mapping a subset."""
+    from drprg_amd import Context
+    from drprg_amd.pandora import DependencyError
+    panel, prg, genes, fq = _sample(tmp_path)
+    late = Context(prg, W, K, device=0, from_files=False)
+    late.set_opts(illumina=True, genome_size=4000)
+    late.map_fastx(fq)          # mapped, not kept
+    late.keep_reads(1 << 30)
+    late.map_fastx(fq)          # mapped and kept
+    info = late.resident_info()
+    assert not info["complete"]
+    other = Context(prg, W, K, device=0, from_files=False)
+    other.set_opts(illumina=True, genome_size=4000)
+    with pytest.raises(DependencyError) as e:
+        other.map_resident(late)
+    assert e.value.code == 61 and other.counters()["reads"] == 0
+    # after a reset the same context keeps everything it maps
+    late.reset()
+    late.map_fastx(fq)
+    assert late.resident_info()["complete"]
+    other.map_resident(late)
+    assert other.counters()["reads"] == 2700
+
+
 def test_pandora_discover_takes_its_second_pass_from_hbm(tmp_path):
     """the `pandora discover` executable drprg spawns: same files with DRPRG_HIP_KEEP_READS_GB=0 (the file is read twice)"""
     panel, prg, genes, fq = _sample(tmp_path, n_background=20000)
