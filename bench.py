@@ -6,8 +6,11 @@ sum-reduce of the coverage vector across ranks) over one batch of synthetic read
 resident in HBM.  At N=1 the workload is BASELINE.json configs[1]: 10M synthetic 150 bp Illumina reads
 against the mtb-like PRG index of SURVEY.md section 8d (backbone = the reference's test genes.fa, sites =
 its panel.bcf records + seeded random bubbles; 18 loci, k=15, w=11).  With N>1 every rank maps its own
-10M-read shard (weak scaling, reads shard embarrassingly) and the only data-path collective is one RCCL
-all-reduce of the u32 coverage vector per step.
+shard of BASELINE.json configs[3] -- 200M reads over 8 GPUs = 25M reads per GPU; N = 2 and 4 map the same 25M-read shard
+per GPU (weak-scaling points of configs[3]) -- and the only data-path collective is ONE RCCL all-reduce of the u32 vector
+[coverage | reads per PRG] per step: `--comm native` (the default with RCCL) issues it through the C ABI
+(drprg_hip_comm_unique_id / comm_init_rank / drprg_hip_allreduce: what a Rust host would call; rank 0's id travels over the
+torch.distributed group the launcher set up), `--comm torch` through torch.distributed's own RCCL binding.
 
 `--gpus N` with N > 1 and no launcher in the environment starts the N ranks itself (a child
 `python -m torch.distributed.run --nproc-per-node N bench.py ...`, spawned before this process touches
@@ -124,6 +127,9 @@ def gpu_sample_long_reads(torch, hap_pad, hap_lens, n_reads, seed, device, mean_
     offsets[1:] = torch.cumsum(out_lens, 0)
     return torch.cat(pieces), offsets
 
+
+CONFIGS3_TOTAL_READS = 200_000_000  # BASELINE.json configs[3]: 8 x MI355X, 200M synthetic 150 bp reads sharded across the GPUs
+CONFIGS3_GPUS = 8
 
 WORKLOADS = {
     # name: (BASELINE.json config, description, default reads per GPU, illumina, panel)
@@ -300,7 +306,12 @@ def main():
     ap.add_argument("--workload", default="mtb", choices=sorted(WORKLOADS),
                     help="mtb = configs[1] (the bench line); mtb-random = the same reads against a random-backbone panel; "
                          "nanopore = configs[2]; big = configs[4]'s index; mtb-xN = the 8d index grown N-fold")
-    ap.add_argument("--reads-per-gpu", type=int, default=0, help="0 = the workload's size")
+    ap.add_argument("--reads-per-gpu", type=int, default=0, help="0 = the workload's size (N > 1 with the mtb workload: 25M, the per-GPU "
+                                                                 "shard of configs[3])")
+    ap.add_argument("--comm", default="auto", choices=("auto", "native", "torch"),
+                    help="N > 1: who issues the all-reduce.  native = the C ABI (drprg_hip_comm_* / drprg_hip_allreduce, ONE "
+                         "ncclAllReduce of [coverage | reads per PRG]); torch = torch.distributed.all_reduce on the same buffer; "
+                         "auto = native with the nccl backend, torch otherwise")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--cpu-sample", type=int, default=-1, help="reads timed on the CPU oracle (0 = skip, -1 = ~10 s worth)")
     ap.add_argument("--e2e", type=int, default=1, help="1: add the end-to-end leg (FASTQ text in /dev/shm -> coverage through map_fastx, "
@@ -359,6 +370,12 @@ def main():
     hap_pad = torch.from_numpy(genomes.padded()).to(device)
     hap_lens = torch.from_numpy(genomes.lens).to(device)
     n_reads = args.reads_per_gpu or default_reads
+    if world > 1 and args.workload == "mtb" and not args.reads_per_gpu:
+        # BASELINE.json configs[3]: 200M reads sharded over 8 GPUs = 25M per GPU; N = 2 / 4 map the same per-GPU shard (weak scaling)
+        n_reads = CONFIGS3_TOTAL_READS // CONFIGS3_GPUS
+        cfg_name = "configs[3]" if world == CONFIGS3_GPUS else f"configs[3] weak-scaling point ({world} of {CONFIGS3_GPUS} GPUs, the same {n_reads // 1_000_000}M-read shard per GPU)"
+        cfg_desc = (f"{world} x MI355X, {n_reads * world // 1_000_000}M synthetic 150 bp Illumina reads sharded across the GPUs ({n_reads // 1_000_000}M per GPU), "
+                    "RCCL-reduced coverage vs mtb-like PRG index (SURVEY 8d)")
     if args.workload == "nanopore":
         bases, offsets = gpu_sample_long_reads(torch, hap_pad, hap_lens, n_reads, 3 + rank, device)
     else:
@@ -387,6 +404,59 @@ def main():
     step_no = [0]
     unreduced = [None]  # N > 1: the buffer of the batch queued last, not reduced yet
 
+    # Who issues the collective.  native: the communicator of the C ABI (include/drprg_hip.h layout B) -- rank 0 makes the id,
+    # the torch.distributed group that the launcher's environment set up carries its 128 bytes to the other ranks, every rank
+    # calls drprg_hip_comm_init_rank, and drprg_hip_allreduce issues ONE ncclAllReduce(sum, u32) over the packed buffer
+    # [coverage | reads per PRG] on a stream of its own (ordered against the hot path's stream by events, never by the host).
+    # Under the one-GPU test hook (DRPRG_BENCH_BACKEND=gloo: every rank on GPU 0, which RCCL refuses as duplicate devices) every
+    # rank's native communicator has ONE rank -- the call sequence runs, the sum over the ranks is gloo's.
+    comm_mode = args.comm if args.comm != "auto" else ("native" if backend == "nccl" else "torch")
+    native = None
+    cstream = None
+    if world > 1 and comm_mode == "native":
+        from drprg_amd.distributed import NativeComm
+
+        def exchange(ident):
+            box = [ident]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+
+        if backend == "nccl":
+            native = NativeComm(rank, world, local_rank, exchange)
+        else:
+            native = NativeComm(0, 1, local_rank, lambda ident: ident)
+        cstream = torch.cuda.Stream(device)
+
+    class _Done:  # what the stream of the hot path waits for before it reuses a buffer
+        def __init__(self, event=None, work=None):
+            self.event, self.work = event, work
+
+        def wait(self):
+            if self.work is not None:
+                self.work.wait()  # (torch: the current stream waits, not the host)
+            if self.event is not None:
+                torch.cuda.current_stream().wait_event(self.event)
+
+    def all_reduce_async(buf, after=None):
+        """sum of `buf` over the ranks, asynchronous: returns what to wait for.  `after`: an event behind which the reduce
+        must run (None: the buffer's batch is already complete on the device, as the host has seen)."""
+        if native is None:
+            if after is not None:
+                torch.cuda.current_stream().wait_event(after)
+            return _Done(work=dist.all_reduce(buf, async_op=True))
+        if after is not None:
+            cstream.wait_event(after)
+        native.allreduce(ctx, buf.data_ptr(), buf.data_ptr() + 8 * ctx.n_knodes, cstream.cuda_stream)
+        work = None
+        if backend != "nccl":  # test hook: the one-rank native call ran; gloo sums over the ranks behind it
+            ev = torch.cuda.Event()
+            ev.record(cstream)
+            ev.synchronize()
+            work = dist.all_reduce(buf, async_op=True)
+        ev = torch.cuda.Event()
+        ev.record(cstream)
+        return _Done(event=ev, work=work)
+
     def step():
         b = step_no[0] % len(accs)
         step_no[0] += 1
@@ -401,20 +471,20 @@ def main():
                                      acc.data_ptr() + 8 * ctx.n_knodes, stream.cuda_stream)
                 if world > 1:
                     if unreduced[0] is not None:  # the batch before this one is complete now
-                        pending[unreduced[0]] = dist.all_reduce(accs[unreduced[0]], async_op=True)
+                        pending[unreduced[0]] = all_reduce_async(accs[unreduced[0]])
                     unreduced[0] = b
             else:
                 ctx.map_device(bases.data_ptr(), offsets.data_ptr(), n_reads, n_bases, acc.data_ptr(),
                                acc.data_ptr() + 8 * ctx.n_knodes, stream.cuda_stream)
                 if world > 1:
-                    dist.all_reduce(acc)
+                    all_reduce_async(acc).wait()
         return acc
 
     def drain():
         ctx.sync()
         with torch.cuda.stream(stream):
             if unreduced[0] is not None:
-                pending[unreduced[0]] = dist.all_reduce(accs[unreduced[0]], async_op=True)
+                pending[unreduced[0]] = all_reduce_async(accs[unreduced[0]])
                 unreduced[0] = None
             for b, w in enumerate(pending):
                 if w is not None:
@@ -460,6 +530,8 @@ def main():
         with torch.cuda.stream(stream):
             ctx.map_device(bases.data_ptr(), offsets.data_ptr(), n_reads, n_bases, own.data_ptr(), own.data_ptr() + 8 * ctx.n_knodes,
                            stream.cuda_stream)
+            # (through the OTHER binding than the timed steps used, when there are two: native and torch must agree)
+            torch.cuda.synchronize()
             dist.all_reduce(own)
         torch.cuda.synchronize()
         ok = torch.tensor([1 if torch.equal(own, acc) else 0], dtype=torch.int32, device=device)
@@ -525,8 +597,14 @@ def main():
                 "workload": f"{cfg_name}: {cfg_desc}",
                 "reads_per_gpu": n_reads, "bases_per_gpu": n_bases, "mean_read_len": n_bases / max(n_reads, 1), "w": W, "k": K,
                 "loci": ctx.n_prgs, "index_keys": ctx.n_keys, "kmer_nodes": ctx.n_knodes, "sharding": f"reads x{world}",
-                "collective": (("all_reduce(u32 coverage) per step, overlapped with the next step's mapping" if overlap
-                                else "all_reduce(u32 coverage) per step") if world > 1 else "none"),
+                "collective": (("one all_reduce(sum, u32) of [coverage | reads per PRG] per step, overlapped with the next step's mapping" if overlap
+                                else "one all_reduce(sum, u32) of [coverage | reads per PRG] per step") if world > 1 else "none"),
+                "comm": (None if world == 1 else
+                         ("native: drprg_hip_comm_unique_id / comm_init_rank / drprg_hip_allreduce (C ABI, RCCL bound at run time), id broadcast "
+                          "over the torch.distributed group" + ("" if backend == "nccl" else "; ONE-GPU TEST HOOK: one-rank native communicators, "
+                                                                 "the sum over the ranks by gloo"))
+                         if native is not None else f"torch.distributed.all_reduce ({backend})"),
+                "reduced_words": n_acc,
                 "all_ranks_hold_the_sum_of_the_ranks_vectors": reduce_consistent,
                 "bases_per_s": n_bases * world * args.steps / elapsed,
                 "hits_per_batch": counters.get("hits", 0) // (args.warmup + args.steps),
@@ -596,6 +674,8 @@ def main():
             except Exception as exc:  # (no room in /dev/shm, ...: the bench line must not depend on this leg)
                 out["e2e"] = {"error": f"{type(exc).__name__}: {exc}"}
         print(json.dumps(out), flush=True)
+    if native is not None:
+        native.close()
     ctx.close()
     if world > 1:
         dist.barrier()

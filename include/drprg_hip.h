@@ -82,9 +82,11 @@ int drprg_hip_reduce_info(const drprg_hip_ctx* ctx, char* out, size_t cap);
 /* Layout B, one process per GPU (what `north_star` describes and bench.py --gpus N runs): rank 0 makes an id
  * (drprg_hip_comm_unique_id, 128 bytes) and hands it to the other ranks by whatever channel the host has; every rank calls
  * drprg_hip_comm_init_rank(&comm, nranks, id, rank, device) and, after its last batch, drprg_hip_allreduce(ctx, comm, ...):
- * an in-place ncclAllReduce(sum, u32) of the coverage vector and of the reads-per-PRG vector (NULL: the context's own
- * accumulators) on `hip_stream` (NULL: the context's stream), asynchronous on that stream -- every rank then holds the sample's
- * vectors and rank 0 genotypes.  `comm` is an ncclComm_t: a host that already has one (its own RCCL binding) may pass it. */
+ * ONE in-place ncclAllReduce(sum, u32) over the vector [coverage | reads per PRG] (n_covg + n_prgs words of
+ * drprg_hip_coverage_size) on `hip_stream` (NULL: the context's stream), asynchronous on that stream -- every rank then holds the
+ * sample's vectors and rank 0 genotypes.  d_covg NULL: the context's own accumulators (which are laid out that way; a batch
+ * still queued by drprg_hip_map_device_async is completed first).  d_covg given: d_prg_reads == d_covg + n_covg takes the same
+ * single call, anything else two calls in one group; the CALLER orders the reduce behind the batch that filled the buffers.  `comm` is an ncclComm_t: a host that already has one (its own RCCL binding) may pass it. */
 int drprg_hip_comm_unique_id(uint8_t id[128]);
 int drprg_hip_comm_init_rank(void** comm, int nranks, const uint8_t id[128], int rank, int device);
 int drprg_hip_comm_destroy(void* comm);
