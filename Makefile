@@ -40,8 +40,8 @@ $(BIN): $(SRC)/pandora_main.cpp $(LIB)
 	@mkdir -p $(dir $@)
 	$(HIPCC) $(CXXFLAGS) -x c++ $< -o $@ -Ldrprg_amd/lib -ldrprg_hip -Wl,-rpath,'$$ORIGIN/../lib'
 
-$(ORACLE): oracle/oracle.c oracle/oracle_index.c oracle/oracle_params.c
-	$(CC) -O2 -fPIC -shared -Wall -o $@ oracle/oracle.c oracle/oracle_index.c oracle/oracle_params.c -lm
+$(ORACLE): oracle/oracle.c oracle/oracle_index.c oracle/oracle_params.c oracle/oracle_vcf.c oracle/oracle_index.h
+	$(CC) -O2 -fPIC -shared -Wall -o $@ oracle/oracle.c oracle/oracle_index.c oracle/oracle_params.c oracle/oracle_vcf.c -lm
 
 clean:
 	rm -rf build $(LIB) $(BIN) $(ORACLE)

@@ -566,7 +566,10 @@ def main():
                 traffic = traffic / launches_per_step  # (measured per batch)
         # secondary bound (SURVEY 8d "report honestly"): the dominant kernel's VALU issue slots.  Wave instructions per launch come
         # from offline rocprofv3 SQ-counter passes of this workload (profiles/valu.json, SQ_INSTS_VALU); the duration is the live one.
-        # One wave64 VALU instruction occupies its SIMD for 4 cycles (measured: tools/microbench.hip), 1024 SIMDs at 2.4 GHz.
+        # One wave64 VALU instruction of the kinds the sketch kernels are made of occupies its SIMD for 4 cycles, however many waves
+        # share the SIMD (measured at 1 / 2 / 4 / 8 waves per SIMD: tools/mb_issue.hip -> profiles/r04/mb_issue.txt: v_lshl_add_u32 4.2,
+        # v_bfe_u32 4.4, v_bitop3_b32 4.0, v_min3_u32 4.5, v_dot4_u32_u8 4.1, DPP moves 4.5; plain v_add / v_xor / v_and / v_not reach 2.5 in
+        # a stream of their own and 4.2 interleaved with VOP3 instructions); 1024 SIMDs at 2.4 GHz.
         secondary = None
         vfile = os.path.join(ROOT, "profiles", "valu.json")
         if n_reads == default_reads and os.path.exists(vfile) and avg_ms > 0:
@@ -576,7 +579,9 @@ def main():
                 peak = 1024 * 2.4e9 / 4
                 secondary = {"bound": "valu_issue", "wave_insts": v, "achieved": v / (avg_ms * 1e-3), "peak": peak, "unit": "wave-instructions/s",
                              "frac": v / (avg_ms * 1e-3) / peak,
-                             "source": "profiles/valu.json (offline rocprofv3 --pmc SQ_INSTS_VALU of this workload) over the live kernel duration"}
+                             "source": "wave_insts: profiles/valu.json (offline rocprofv3 --pmc SQ_INSTS_VALU of this workload) over the live kernel "
+                                       "duration; peak: 4 cycles per wave64 integer VALU instruction per SIMD, measured at 1/2/4/8 waves per SIMD in "
+                                       "profiles/r04/mb_issue.txt (tools/mb_issue.hip)"}
         out = {
             "metric": "reads/sec (+ achieved HBM GB/s) predicting on mtb index, 1/2/4/8 GPUs",
             "value": value,

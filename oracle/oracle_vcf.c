@@ -1,0 +1,581 @@
+/*
+ * oracle_vcf.c -- CPU restatement of the VCF-site half of `pandora map --genotype --local` (TEST INFRASTRUCTURE ONLY, part of
+ * liboracle.so): which records a locus gets and which k-mer nodes every allele's statistics are taken over.
+ *
+ * Row a-9 of SURVEY.md section 8, front half ("build VCF: reference path = genes.fa sequence threaded through
+ * the local graph; enumerate bubbles -> REF/ALT alleles; tag VC, GRAPHTYPE ... per record/allele: collect fwd/rev covg of the k-mer
+ * nodes overlapping the allele's path").  The reference consumes exactly these fields: REF must equal genes.fa at POS
+ * (/root/reference/src/consequence.rs:105-113), GT / GT_CONF / the covg FORMAT fields drive the null-call rule and every filter
+ * (/root/reference/src/predict.rs:440-444, /root/reference/src/filter.rs:149), and the file layout is
+ * /root/reference/tests/cases/predict/ERR4796933.pandora.vcf.  pandora's source is absent from /root/reference, so this is a
+ * second, separately written statement of DESIGN.md section 4 "VCF sites" (the product's is drprg_amd/csrc/genotype.cpp).
+ *
+ *   PARITY STATUS: the allele -> k-mer-node rule and the sketch / index semantics under it are held against the reference's own
+ *   seven fixture VCFs through the per-allele minimizer count n that SUM / MEAN / GAPS leak (tests/golden/kmer_count_kat.tsv,
+ *   tests/test_kmer_count_kat.py); site enumeration on nested PRGs beyond what those records show stays this build's statement.
+ *
+ * Written the other way round from the product.  The product parses the PRG into a tree of chains and sites and recurses over it;
+ * here nothing but PRG-STRING COORDINATES is used: the markers are scanned once more into (site, allele) spans, a node belongs to
+ * an allele iff its interval lies inside the allele's span, routes are depth-first walks over the local graph's edges between the
+ * node before the site and the node behind it, and "k-mer node lies on a route" is decided by comparing the k-mer's own item list
+ * (bases and crossed empty nodes) with the route written out base by base.
+ *
+ * Semantics restated:
+ *   reference path   the walk from the first to the last local node that spells --vcf-refs exactly (depth first, alleles in PRG order);
+ *                    none, or no sequence given: the walk that takes the first allele everywhere.
+ *   records          one per site whose opening node is on the reference path (sites nested in the reference allele included, sites
+ *                    nested in other alleles not).  REF = the reference walk between the site's two flanking nodes.  ALT = the distinct
+ *                    strings, other than REF, of the first 256 routes (PRG order) through every other allele, in ascending byte order;
+ *                    more than 10: the first 10.  No ALT: no record.  An empty REF or ALT: every allele gets the reference base before
+ *                    the site in front (POS moves back by one), or, at the very start, the base behind it at the end.
+ *   VC               from (REF, first ALT): SNP (both one base) / PH_SNPs (equal length) / INDEL (one is a prefix of the other) / COMPLEX.
+ *   GRAPHTYPE        TOO_MANY_ALTS if routes or ALTs were cut; else NESTED if the site lies inside an allele or one of its alleles holds
+ *                    a site; else SIMPLE.
+ *   allele k-mers    the k-mer nodes that lie on (reference walk before the site + the allele's route + reference walk behind it)
+ *                    and overlap the allele's bases [A, B) -- a k-mer at base s: s < B and s + k > A; an empty allele (A == B): the
+ *                    k-mers that span the junction, s < A and s + k > A.
+ */
+#include "oracle_index.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_API __attribute__((visibility("default")))
+
+#define MAX_ROUTES_PER_ALLELE 256
+#define MAX_ALTS_PER_RECORD 10
+
+/* experiments (tests/test_kmer_count_kat.py, tools): how a k-mer must lie to the allele [A, B) to count for it.
+ * 0 = DESIGN.md section 4 (the rule above); 1 = the end is inclusive (s <= B); 2 = the k-mer must lie inside [A - k + 1 .. B) AND
+ * start at or behind A - k + 1 (same as 0, kept for symmetry); 3 = k-mers that START inside the allele only. */
+static int g_overlap_rule = 0;
+ORC_API void orc_vcf_set_overlap_rule(int rule) { g_overlap_rule = rule; }
+
+typedef struct {
+    int marker, level;
+    uint32_t n_alleles, cap;
+    uint32_t* a_start; /* coordinates of the allele's first character ... */
+    uint32_t* a_end;   /* ... and one past its last (the separator's / closing marker's own space excluded) */
+    uint32_t pre_end;  /* where the node in front of the site ends (= where the opening marker's token starts) */
+    uint32_t pre_start; /* ... and where that node starts */
+    uint32_t post_start; /* where the node behind the site starts */
+} vsite;
+
+typedef struct {
+    char* buf;
+    size_t len, cap;
+} sbuf;
+
+static void sb_put(sbuf* b, const char* s, size_t n)
+{
+    if (b->len + n + 1 > b->cap) {
+        while (b->len + n + 1 > b->cap) b->cap = b->cap ? 2 * b->cap : 4096;
+        b->buf = (char*)realloc(b->buf, b->cap);
+    }
+    memcpy(b->buf + b->len, s, n);
+    b->len += n;
+    b->buf[b->len] = 0;
+}
+static void sb_str(sbuf* b, const char* s) { sb_put(b, s, strlen(s)); }
+static void sb_u(sbuf* b, unsigned long long v)
+{
+    char t[32];
+    snprintf(t, sizeof t, "%llu", v);
+    sb_str(b, t);
+}
+
+static int dig(char c) { return c >= '0' && c <= '9'; }
+static char up(char c) { return (c >= 'a' && c <= 'z') ? (char)(c - 32) : c; }
+
+/* ---- the markers once more: spans of every site and allele in PRG-string coordinates ------------------------------------------- */
+static vsite* scan_sites(const char* s, uint32_t n, uint32_t* n_sites_out)
+{
+    vsite* sites = NULL;
+    uint32_t n_sites = 0, cap_sites = 0;
+    uint32_t* open = NULL; /* stack of indexes into sites[] */
+    uint32_t depth = 0, cap_open = 0;
+    uint32_t i = 0, seg_start = 0;
+    while (i < n) {
+        if (!dig(s[i])) {
+            ++i;
+            continue;
+        }
+        uint32_t tok_start = (i > 0 && s[i - 1] == ' ') ? i - 1 : i; /* the marker owns one space in front ... */
+        if (tok_start < seg_start) tok_start = seg_start;           /* (... unless the previous marker already took it: "5  6") */
+        int m = 0;
+        while (i < n && dig(s[i])) m = m * 10 + (s[i++] - '0');
+        if (i < n && s[i] == ' ') ++i; /* ... and one behind */
+        const uint32_t tok_end = i;
+        if ((m & 1) && !(depth && sites[open[depth - 1]].marker == m)) { /* a site opens */
+            if (n_sites == cap_sites) {
+                cap_sites = cap_sites ? 2 * cap_sites : 64;
+                sites = (vsite*)realloc(sites, sizeof(vsite) * cap_sites);
+            }
+            vsite* v = &sites[n_sites];
+            memset(v, 0, sizeof *v);
+            v->marker = m;
+            v->level = (int)depth;
+            v->pre_start = seg_start;
+            v->pre_end = tok_start;
+            v->cap = 4;
+            v->a_start = (uint32_t*)malloc(sizeof(uint32_t) * v->cap);
+            v->a_end = (uint32_t*)malloc(sizeof(uint32_t) * v->cap);
+            v->a_start[0] = tok_end;
+            v->n_alleles = 1;
+            if (depth == cap_open) {
+                cap_open = cap_open ? 2 * cap_open : 16;
+                open = (uint32_t*)realloc(open, sizeof(uint32_t) * cap_open);
+            }
+            open[depth++] = n_sites++;
+        } else if (m & 1) { /* the innermost open site closes */
+            vsite* v = &sites[open[depth - 1]];
+            v->a_end[v->n_alleles - 1] = tok_start;
+            v->post_start = tok_end;
+            --depth;
+        } else { /* next allele of the innermost open site */
+            vsite* v = &sites[open[depth - 1]];
+            v->a_end[v->n_alleles - 1] = tok_start;
+            if (v->n_alleles == v->cap) {
+                v->cap *= 2;
+                v->a_start = (uint32_t*)realloc(v->a_start, sizeof(uint32_t) * v->cap);
+                v->a_end = (uint32_t*)realloc(v->a_end, sizeof(uint32_t) * v->cap);
+            }
+            v->a_start[v->n_alleles++] = tok_end;
+        }
+        seg_start = tok_end;
+    }
+    free(open);
+    *n_sites_out = n_sites;
+    return sites;
+}
+
+static uint32_t node_at(const orc_kgraph* g, uint32_t start, uint32_t end)
+{
+    for (uint32_t q = 0; q < g->n_ln; ++q)
+        if (g->ln[q].start == start && g->ln[q].end == end) return q;
+    return 0xFFFFFFFFu;
+}
+static uint32_t node_starting_at(const orc_kgraph* g, uint32_t start)
+{
+    for (uint32_t q = 0; q < g->n_ln; ++q)
+        if (g->ln[q].start == start) return q;
+    return 0xFFFFFFFFu;
+}
+
+/* ---- the reference walk ----------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    const orc_kgraph* g;
+    const char* ref;
+    uint32_t reflen;
+    uint8_t* dead; /* bit (node * (reflen + 1) + pos): no walk from here spells the rest */
+    uint32_t* path;
+    uint32_t n_path;
+} threader;
+
+static int thread_from(threader* t, uint32_t node, uint32_t pos)
+{
+    const lnode* ln = &t->g->ln[node];
+    const uint32_t len = ln->end - ln->start;
+    const uint64_t bit = (uint64_t)node * (t->reflen + 1) + pos;
+    if (t->dead[bit >> 3] & (1u << (bit & 7))) return 0;
+    int ok = pos + len <= t->reflen;
+    for (uint32_t i = 0; ok && i < len; ++i) ok = up(t->g->s[ln->start + i]) == up(t->ref[pos + i]);
+    if (ok) {
+        t->path[t->n_path++] = node;
+        if (ln->n_out == 0) {
+            if (pos + len == t->reflen) return 1;
+        } else {
+            for (uint32_t o = 0; o < ln->n_out; ++o)
+                if (thread_from(t, ln->out[o], pos + len)) return 1;
+        }
+        --t->n_path;
+    }
+    t->dead[bit >> 3] |= (uint8_t)(1u << (bit & 7));
+    return 0;
+}
+
+/* ---- routes through an allele ------------------------------------------------------------------------------------------------------ */
+typedef struct {
+    uint32_t* nodes;
+    uint32_t n;
+    char* seq;
+} route;
+
+typedef struct {
+    const orc_kgraph* g;
+    uint32_t post;
+    route* out;
+    uint32_t n_out;
+    int truncated;
+    uint32_t stack[4096];
+    uint32_t depth;
+} router;
+
+static void route_from(router* r, uint32_t node)
+{
+    if (node == r->post) { /* the walk has left the allele: one route */
+        if (r->n_out >= MAX_ROUTES_PER_ALLELE) {
+            r->truncated = 1;
+            return;
+        }
+        route* rt = &r->out[r->n_out++];
+        rt->n = r->depth;
+        rt->nodes = (uint32_t*)malloc(sizeof(uint32_t) * (r->depth ? r->depth : 1));
+        memcpy(rt->nodes, r->stack, sizeof(uint32_t) * r->depth);
+        uint32_t L = 0;
+        for (uint32_t i = 0; i < r->depth; ++i) L += r->g->ln[r->stack[i]].end - r->g->ln[r->stack[i]].start;
+        rt->seq = (char*)malloc(L + 1);
+        uint32_t at = 0;
+        for (uint32_t i = 0; i < r->depth; ++i)
+            for (uint32_t c = r->g->ln[r->stack[i]].start; c < r->g->ln[r->stack[i]].end; ++c) rt->seq[at++] = up(r->g->s[c]);
+        rt->seq[at] = 0;
+        return;
+    }
+    if (r->truncated || r->depth >= 4096) {
+        r->truncated = 1;
+        return;
+    }
+    r->stack[r->depth++] = node;
+    const lnode* ln = &r->g->ln[node];
+    for (uint32_t o = 0; o < ln->n_out && !r->truncated; ++o) route_from(r, ln->out[o]);
+    --r->depth;
+}
+
+static int route_cmp(const void* a, const void* b) { return strcmp(((const route*)a)->seq, ((const route*)b)->seq); }
+
+/* ---- k-mer nodes of a walk ---------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    uint32_t coord; /* PRG coordinate of the base, or of the empty node */
+    uint8_t empty;
+} witem;
+
+static const orc_kgraph* g_cmp_graph;
+static int by_first_coord(const void* a, const void* b)
+{
+    const uint32_t x = g_cmp_graph->kn[*(const uint32_t*)a].iv[0], y = g_cmp_graph->kn[*(const uint32_t*)b].iv[0];
+    return x < y ? -1 : x > y;
+}
+static int u32_cmp(const void* a, const void* b)
+{
+    const uint32_t x = *(const uint32_t*)a, y = *(const uint32_t*)b;
+    return x < y ? -1 : x > y;
+}
+
+/* ids (1..n) of the k-mer nodes on walk[0..n_walk) that count for the allele at bases [A, B) of the walk; sorted */
+static uint32_t allele_kmers(const orc_kgraph* g, const uint32_t* sorted_kn, const uint32_t* walk, uint32_t n_walk, uint32_t A, uint32_t B,
+    uint32_t* out, uint32_t cap)
+{
+    /* the walk written out: one item per base and per crossed empty node */
+    uint32_t n_items = 0;
+    for (uint32_t i = 0; i < n_walk; ++i) {
+        const uint32_t l = g->ln[walk[i]].end - g->ln[walk[i]].start;
+        n_items += l ? l : 1;
+    }
+    witem* it = (witem*)malloc(sizeof(witem) * (n_items ? n_items : 1));
+    uint32_t* base_item = (uint32_t*)malloc(sizeof(uint32_t) * (n_items ? n_items : 1)); /* item index of base number b */
+    uint32_t n_it = 0, n_bases = 0;
+    for (uint32_t i = 0; i < n_walk; ++i) {
+        const lnode* ln = &g->ln[walk[i]];
+        if (ln->start == ln->end) {
+            it[n_it].coord = ln->start;
+            it[n_it++].empty = 1;
+            continue;
+        }
+        for (uint32_t c = ln->start; c < ln->end; ++c) {
+            base_item[n_bases++] = n_it;
+            it[n_it].coord = c;
+            it[n_it++].empty = 0;
+        }
+    }
+    const int k = g->k;
+    uint32_t n_out = 0;
+    int64_t lo = (int64_t)A - k + 1, hi; /* k-mer start positions (base numbers) to look at: [lo, hi) */
+    if (lo < 0) lo = 0;
+    switch (g_overlap_rule) {
+    case 1: hi = (int64_t)B + 1; break;
+    case 3: lo = A; hi = B; break;
+    case 4: hi = (A == B) ? (int64_t)A : (int64_t)B; lo = lo + 1; break;   /* not the k-mer that only touches the allele's first base with its last */
+    case 5: hi = ((A == B) ? (int64_t)A : (int64_t)B) - 1; break;          /* not the k-mer that starts at the allele's last base */
+    case 6: hi = ((A == B) ? (int64_t)A : (int64_t)B) - 1; lo = lo + 1; break;
+    default: hi = (A == B) ? (int64_t)A : (int64_t)B; break;
+    }
+    for (int64_t s = lo; s < hi && s + k <= (int64_t)n_bases; ++s) {
+        const uint32_t first = base_item[s], c0 = it[first].coord;
+        /* the k-mer nodes whose first base is PRG coordinate c0 (sorted_kn is ordered by that coordinate) */
+        uint32_t a = 0, b = g->n_kn;
+        while (a < b) {
+            uint32_t mid = (a + b) / 2;
+            if (g->kn[sorted_kn[mid]].iv[0] < c0) a = mid + 1; else b = mid;
+        }
+        for (; a < g->n_kn && g->kn[sorted_kn[a]].iv[0] == c0; ++a) {
+            const knode* kn = &g->kn[sorted_kn[a]];
+            if (first + kn->n_items > n_it) continue;
+            int same = 1;
+            for (uint32_t j = 0; same && j < kn->n_items; ++j) {
+                const item* q = &kn->items[j];
+                const uint8_t e = q->off == NO_OFF;
+                const uint32_t c = g->ln[q->node].start + (e ? 0 : q->off);
+                same = it[first + j].empty == e && it[first + j].coord == c;
+            }
+            if (same && n_out < cap) out[n_out++] = kn->id;
+        }
+    }
+    free(it);
+    free(base_item);
+    qsort(out, n_out, sizeof(uint32_t), u32_cmp);
+    return n_out;
+}
+
+static const char* variant_class(const char* ref, const char* alt)
+{
+    const size_t r = strlen(ref), a = strlen(alt);
+    if (r == 1 && a == 1) return "SNP";
+    if (r == a) return "PH_SNPs";
+    if (r < a && !strncmp(alt, ref, r)) return "INDEL";
+    if (a < r && !strncmp(ref, alt, a)) return "INDEL";
+    return "COMPLEX";
+}
+
+typedef struct {
+    uint32_t pos;
+    char* text; /* the record's lines */
+} rec_out;
+static int rec_cmp(const void* a, const void* b)
+{
+    const rec_out *x = (const rec_out*)a, *y = (const rec_out*)b;
+    if (x->pos != y->pos) return x->pos < y->pos ? -1 : 1;
+    return strcmp(x->text, y->text);
+}
+
+/*
+ * The records of one locus as text (caller frees with orc_free), one line per ALLELE, sorted by (POS, REF, ALTs):
+ *   POS \t REF \t ALT1,ALT2,.. \t VC \t GRAPHTYPE \t allele number \t n \t id,id,..      (ids = k-mer node ids 1..n of this locus, ascending)
+ * followed by one line "#refpath \t used \t node,node,.." (used = 1 if refseq threaded through the graph, 0 = first-allele walk).
+ * refseq may be NULL.  Returns NULL for an inconsistent graph.
+ */
+ORC_API char* orc_vcf_sites(const orc_kgraph* g, const char* refseq)
+{
+    uint32_t n_sites = 0;
+    vsite* sites = scan_sites(g->s, g->len, &n_sites);
+    sbuf out = { NULL, 0, 0 };
+    /* reference walk */
+    uint32_t* path = (uint32_t*)malloc(sizeof(uint32_t) * (g->n_ln + 1));
+    uint32_t n_path = 0;
+    int used_ref = 0;
+    if (refseq && *refseq) {
+        threader t;
+        t.g = g;
+        t.ref = refseq;
+        t.reflen = (uint32_t)strlen(refseq);
+        t.dead = (uint8_t*)calloc(((uint64_t)g->n_ln * (t.reflen + 1) + 7) / 8 + 1, 1);
+        t.path = path;
+        t.n_path = 0;
+        used_ref = thread_from(&t, 0, 0);
+        n_path = used_ref ? t.n_path : 0;
+        free(t.dead);
+    }
+    if (!used_ref) {
+        uint32_t node = 0;
+        n_path = 0;
+        for (;;) {
+            path[n_path++] = node;
+            if (g->ln[node].n_out == 0) break;
+            node = g->ln[node].out[0];
+        }
+    }
+    int32_t* on_ref = (int32_t*)malloc(sizeof(int32_t) * g->n_ln);
+    uint32_t* ref_off = (uint32_t*)malloc(sizeof(uint32_t) * (n_path + 1));
+    for (uint32_t q = 0; q < g->n_ln; ++q) on_ref[q] = -1;
+    uint32_t L = 0;
+    for (uint32_t i = 0; i < n_path; ++i) {
+        on_ref[path[i]] = (int32_t)i;
+        ref_off[i] = L;
+        L += g->ln[path[i]].end - g->ln[path[i]].start;
+    }
+    ref_off[n_path] = L;
+    char* rs = (char*)malloc(L + 1);
+    {
+        uint32_t at = 0;
+        for (uint32_t i = 0; i < n_path; ++i)
+            for (uint32_t c = g->ln[path[i]].start; c < g->ln[path[i]].end; ++c) rs[at++] = up(g->s[c]);
+        rs[at] = 0;
+    }
+    uint32_t* sorted_kn = (uint32_t*)malloc(sizeof(uint32_t) * (g->n_kn ? g->n_kn : 1));
+    for (uint32_t i = 0; i < g->n_kn; ++i) sorted_kn[i] = i;
+    g_cmp_graph = g;
+    qsort(sorted_kn, g->n_kn, sizeof(uint32_t), by_first_coord);
+
+    rec_out* recs = (rec_out*)malloc(sizeof(rec_out) * (n_sites ? n_sites : 1));
+    uint32_t n_recs = 0;
+    int bad = 0;
+    uint32_t* walk = (uint32_t*)malloc(sizeof(uint32_t) * (g->n_ln + 8));
+    uint32_t* ids = (uint32_t*)malloc(sizeof(uint32_t) * (g->n_kn ? g->n_kn : 1));
+    for (uint32_t si = 0; si < n_sites && !bad; ++si) {
+        const vsite* v = &sites[si];
+        const uint32_t pre = node_at(g, v->pre_start, v->pre_end), post = node_starting_at(g, v->post_start);
+        if (pre == 0xFFFFFFFFu || post == 0xFFFFFFFFu) {
+            bad = 1;
+            break;
+        }
+        if (on_ref[pre] < 0) continue; /* a site inside an allele the reference does not take */
+        if (on_ref[post] < 0) {
+            bad = 1;
+            break;
+        }
+        const uint32_t ip = (uint32_t)on_ref[pre], iq = (uint32_t)on_ref[post];
+        const uint32_t start = ref_off[ip] + (g->ln[pre].end - g->ln[pre].start), end = ref_off[iq];
+        /* which allele the reference takes: the one whose span holds the node behind `pre` on the walk */
+        const lnode* nx = &g->ln[path[ip + 1]];
+        int ref_allele = -1;
+        for (uint32_t a = 0; a < v->n_alleles; ++a)
+            if (v->a_start[a] <= nx->start && nx->end <= v->a_end[a]) ref_allele = (int)a;
+        if (ref_allele < 0) {
+            bad = 1;
+            break;
+        }
+        char* ref = (char*)malloc(end - start + 1);
+        memcpy(ref, rs + start, end - start);
+        ref[end - start] = 0;
+        int nested = v->level > 0, truncated = 0;
+        for (uint32_t a = 0; a < v->n_alleles; ++a)
+            for (uint32_t c = v->a_start[a]; c < v->a_end[a]; ++c)
+                if (dig(g->s[c])) nested = 1;
+        /* ALT routes */
+        route* alts = (route*)malloc(sizeof(route) * MAX_ROUTES_PER_ALLELE * (v->n_alleles ? v->n_alleles : 1));
+        uint32_t n_alts = 0;
+        for (uint32_t a = 0; a < v->n_alleles; ++a) {
+            if ((int)a == ref_allele) continue;
+            router* r = (router*)malloc(sizeof(router));
+            r->g = g;
+            r->post = post;
+            r->out = (route*)malloc(sizeof(route) * MAX_ROUTES_PER_ALLELE);
+            r->n_out = 0;
+            r->truncated = 0;
+            r->depth = 0;
+            const uint32_t first = node_starting_at(g, v->a_start[a]);
+            if (first == 0xFFFFFFFFu) bad = 1;
+            else route_from(r, first);
+            truncated |= r->truncated;
+            for (uint32_t x = 0; x < r->n_out; ++x) {
+                int keep = strcmp(r->out[x].seq, ref) != 0;
+                for (uint32_t y = 0; keep && y < n_alts; ++y) keep = strcmp(alts[y].seq, r->out[x].seq) != 0;
+                if (keep) alts[n_alts++] = r->out[x];
+                else {
+                    free(r->out[x].nodes);
+                    free(r->out[x].seq);
+                }
+            }
+            free(r->out);
+            free(r);
+        }
+        if (n_alts && !bad) {
+            qsort(alts, n_alts, sizeof(route), route_cmp);
+            if (n_alts > MAX_ALTS_PER_RECORD) {
+                for (uint32_t x = MAX_ALTS_PER_RECORD; x < n_alts; ++x) {
+                    free(alts[x].nodes);
+                    free(alts[x].seq);
+                }
+                n_alts = MAX_ALTS_PER_RECORD;
+                truncated = 1;
+            }
+            int any_empty = ref[0] == 0;
+            for (uint32_t x = 0; x < n_alts; ++x) any_empty |= alts[x].seq[0] == 0;
+            char pad_l[2] = { 0, 0 }, pad_r[2] = { 0, 0 };
+            uint32_t pos0 = start;
+            if (any_empty) {
+                if (start > 0) {
+                    pad_l[0] = rs[start - 1];
+                    pos0 = start - 1;
+                } else if (end < L) {
+                    pad_r[0] = rs[end];
+                }
+            }
+            sbuf head = { NULL, 0, 0 }; /* POS REF ALTS VC GRAPHTYPE */
+            sb_u(&head, pos0 + 1);
+            sb_str(&head, "\t");
+            sb_str(&head, pad_l); sb_str(&head, ref); sb_str(&head, pad_r);
+            sb_str(&head, "\t");
+            for (uint32_t x = 0; x < n_alts; ++x) {
+                if (x) sb_str(&head, ",");
+                sb_str(&head, pad_l); sb_str(&head, alts[x].seq); sb_str(&head, pad_r);
+            }
+            sb_str(&head, "\t");
+            {
+                sbuf r0 = { NULL, 0, 0 }, a0 = { NULL, 0, 0 };
+                sb_str(&r0, pad_l); sb_str(&r0, ref); sb_str(&r0, pad_r);
+                sb_str(&a0, pad_l); sb_str(&a0, alts[0].seq); sb_str(&a0, pad_r);
+                sb_str(&head, variant_class(r0.buf, a0.buf));
+                free(r0.buf);
+                free(a0.buf);
+            }
+            sb_str(&head, "\t");
+            sb_str(&head, truncated ? "TOO_MANY_ALTS" : (nested ? "NESTED" : "SIMPLE"));
+            sbuf body = { NULL, 0, 0 };
+            for (uint32_t al = 0; al <= n_alts; ++al) {
+                /* the walk of this allele: reference up to `pre`, the allele's nodes, reference from `post` */
+                uint32_t nw = 0, A = ref_off[ip] + (g->ln[pre].end - g->ln[pre].start), B = A;
+                for (uint32_t i = 0; i <= ip; ++i) walk[nw++] = path[i];
+                if (al == 0) {
+                    for (uint32_t i = ip + 1; i < iq; ++i) {
+                        walk[nw++] = path[i];
+                        B += g->ln[path[i]].end - g->ln[path[i]].start;
+                    }
+                } else {
+                    for (uint32_t i = 0; i < alts[al - 1].n; ++i) {
+                        walk[nw++] = alts[al - 1].nodes[i];
+                        B += g->ln[alts[al - 1].nodes[i]].end - g->ln[alts[al - 1].nodes[i]].start;
+                    }
+                }
+                /* (only the next k bases of the reference can matter, but the whole tail keeps this statement trivial) */
+                for (uint32_t i = iq; i < n_path; ++i) walk[nw++] = path[i];
+                const uint32_t n = allele_kmers(g, sorted_kn, walk, nw, A, B, ids, g->n_kn);
+                sb_str(&body, head.buf);
+                sb_str(&body, "\t");
+                sb_u(&body, al);
+                sb_str(&body, "\t");
+                sb_u(&body, n);
+                sb_str(&body, "\t");
+                for (uint32_t i = 0; i < n; ++i) {
+                    if (i) sb_str(&body, ",");
+                    sb_u(&body, ids[i]);
+                }
+                sb_str(&body, "\n");
+            }
+            recs[n_recs].pos = pos0 + 1;
+            recs[n_recs].text = body.buf;
+            ++n_recs;
+            free(head.buf);
+        }
+        for (uint32_t x = 0; x < n_alts; ++x) {
+            free(alts[x].nodes);
+            free(alts[x].seq);
+        }
+        free(alts);
+        free(ref);
+    }
+    qsort(recs, n_recs, sizeof(rec_out), rec_cmp);
+    for (uint32_t i = 0; i < n_recs; ++i) {
+        sb_str(&out, recs[i].text);
+        free(recs[i].text);
+    }
+    sb_str(&out, "#refpath\t");
+    sb_u(&out, (unsigned)used_ref);
+    sb_str(&out, "\t");
+    for (uint32_t i = 0; i < n_path; ++i) {
+        if (i) sb_str(&out, ",");
+        sb_u(&out, path[i]);
+    }
+    sb_str(&out, "\n");
+    for (uint32_t si = 0; si < n_sites; ++si) {
+        free(sites[si].a_start);
+        free(sites[si].a_end);
+    }
+    free(sites); free(path); free(on_ref); free(ref_off); free(rs); free(sorted_kn); free(recs); free(walk); free(ids);
+    if (bad) {
+        free(out.buf);
+        return NULL;
+    }
+    return out.buf;
+}
+
+ORC_API void orc_free(void* p) { free(p); }

@@ -68,6 +68,50 @@ class Oracle:
         L.orc_kg_path.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
         L.orc_kg_walk_check.restype = C.c_int
         L.orc_kg_walk_check.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        # oracle_vcf.c
+        L.orc_vcf_sites.restype = C.c_void_p
+        L.orc_vcf_sites.argtypes = [C.c_void_p, C.c_char_p]
+        L.orc_free.restype = None
+        L.orc_free.argtypes = [C.c_void_p]
+        L.orc_vcf_set_overlap_rule.restype = None
+        L.orc_vcf_set_overlap_rule.argtypes = [C.c_int]
+        L.orc_set_hash_mode.restype = None
+        L.orc_set_hash_mode.argtypes = [C.c_int, C.c_uint64]
+
+    # ---- a-9, front half: the oracle's own VCF sites and allele -> k-mer nodes (oracle/oracle_vcf.c) ---------------
+    def set_hash_mode(self, mode, seed=0):
+        """0 = the hash of the path (minimap hash64); 1.. = control hashes (tests/test_kmer_count_kat.py only)"""
+        self.lib.orc_set_hash_mode(int(mode), int(seed))
+
+    def vcf_sites(self, prg_string, w, k, refseq=None):
+        """records of one locus: [dict(pos, ref, alts, vc, graphtype, knodes=[per allele: sorted local k-mer node ids])],
+        plus (threaded, [local nodes of the reference walk])"""
+        L = self.lib
+        g = L.orc_index_prg(prg_string.encode() if isinstance(prg_string, str) else prg_string, w, k)
+        if not g:
+            raise ValueError("malformed PRG string")
+        try:
+            p = L.orc_vcf_sites(g, refseq.encode() if isinstance(refseq, str) else refseq)
+            if not p:
+                raise ValueError("inconsistent local graph")
+            text = C.string_at(p).decode()
+            L.orc_free(p)
+        finally:
+            L.orc_kg_free(g)
+        recs, refpath = [], None
+        for line in text.splitlines():
+            t = line.split("\t")
+            if t[0] == "#refpath":
+                refpath = (t[1] == "1", [int(x) for x in t[2].split(",")] if t[2] else [])
+                continue
+            key = (int(t[0]), t[1], t[2])
+            if not recs or recs[-1]["key"] != key:
+                recs.append(dict(key=key, pos=int(t[0]), ref=t[1], alts=t[2].split(","), vc=t[3], graphtype=t[4], knodes=[]))
+            assert int(t[5]) == len(recs[-1]["knodes"])
+            ids = [int(x) for x in t[7].split(",")] if len(t) > 7 and t[7] else []
+            assert len(ids) == int(t[6])
+            recs[-1]["knodes"].append(ids)
+        return recs, refpath
 
     # ---- a-4: the oracle's own index (oracle/oracle_index.c); nothing here comes from the product ----------------
     def sketch_prg(self, prg_string, w, k, paths=False, walk_check=False):
