@@ -6,8 +6,9 @@
  * coverage `pandora map` accumulates) and a minimizer -> (prg, k-mer node, strand) table; outputs are named at
  * /root/reference/src/builder.rs:263-269.  pandora's source is absent from /root/reference, so -- like oracle.c --
  * this is a restatement of its published algorithm (LocalPRG::build_graph, LocalPRG::minimizer_sketch,
- * KmerGraph::min_path_length) and **parity with pandora is unpinned**.  What the reference does pin, and what the
- * tests check this file against: the PRG string syntax (/root/reference/tests/cases/expected/dr.prg) and the node
+ * KmerGraph::min_path_length).  Parity with pandora: the NODE SET is pinned since round 4 by the per-allele k-mer counts the
+ * reference's fixture VCFs leak (tests/test_kmer_count_kat.py: the forward-greedy nodes included); node numbering, edges and
+ * min_path_length stay unpinned.  What else the reference pins, and what the tests check this file against: the PRG string syntax (/root/reference/tests/cases/expected/dr.prg) and the node
  * interval convention (character offsets into the PRG string, markers and their spaces included:
  * /root/reference/src/lib.rs:3009-3050).
  *

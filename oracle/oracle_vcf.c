@@ -31,9 +31,11 @@
  *   VC               from (REF, first ALT): SNP (both one base) / PH_SNPs (equal length) / INDEL (one is a prefix of the other) / COMPLEX.
  *   GRAPHTYPE        TOO_MANY_ALTS if routes or ALTs were cut; else NESTED if the site lies inside an allele or one of its alleles holds
  *                    a site; else SIMPLE.
- *   allele k-mers    the k-mer nodes that lie on (reference walk before the site + the allele's route + reference walk behind it)
- *                    and overlap the allele's bases [A, B) -- a k-mer at base s: s < B and s + k > A; an empty allele (A == B): the
- *                    k-mers that span the junction, s < A and s + k > A.
+ *   allele k-mers    the k-mer nodes that lie on (reference walk before the site + the allele's route + reference walk behind it) and
+ *                    touch the allele AS THE RECORD PRINTS IT, i.e. with its padding base: bases [A, B) of that walk -- a k-mer at base s
+ *                    counts iff s < B and s + k >= A (the k-mer that ends exactly where the allele starts is in: pinned by the
+ *                    reference's fixture VCFs, tests/golden/kmer_count_kat.tsv -- 257 of 262 informative alleles of in.vcf against 204
+ *                    with s + k > A).
  */
 #include "oracle_index.h"
 #include <stdio.h>
@@ -45,9 +47,8 @@
 #define MAX_ROUTES_PER_ALLELE 256
 #define MAX_ALTS_PER_RECORD 10
 
-/* experiments (tests/test_kmer_count_kat.py, tools): how a k-mer must lie to the allele [A, B) to count for it.
- * 0 = DESIGN.md section 4 (the rule above); 1 = the end is inclusive (s <= B); 2 = the k-mer must lie inside [A - k + 1 .. B) AND
- * start at or behind A - k + 1 (same as 0, kept for symmetry); 3 = k-mers that START inside the allele only. */
+/* 0 = the rule the reference's fixtures pin (below); 1 = the rule this build had in rounds 1-3 (strict overlap with the unpadded
+ * allele), kept only so that tests/test_kmer_count_kat.py can show that the fixture VCFs reject it. */
 static int g_overlap_rule = 0;
 ORC_API void orc_vcf_set_overlap_rule(int rule) { g_overlap_rule = rule; }
 
@@ -289,16 +290,16 @@ static uint32_t allele_kmers(const orc_kgraph* g, const uint32_t* sorted_kn, con
     }
     const int k = g->k;
     uint32_t n_out = 0;
-    int64_t lo = (int64_t)A - k + 1, hi; /* k-mer start positions (base numbers) to look at: [lo, hi) */
-    if (lo < 0) lo = 0;
-    switch (g_overlap_rule) {
-    case 1: hi = (int64_t)B + 1; break;
-    case 3: lo = A; hi = B; break;
-    case 4: hi = (A == B) ? (int64_t)A : (int64_t)B; lo = lo + 1; break;   /* not the k-mer that only touches the allele's first base with its last */
-    case 5: hi = ((A == B) ? (int64_t)A : (int64_t)B) - 1; break;          /* not the k-mer that starts at the allele's last base */
-    case 6: hi = ((A == B) ? (int64_t)A : (int64_t)B) - 1; lo = lo + 1; break;
-    default: hi = (A == B) ? (int64_t)A : (int64_t)B; break;
+    /* k-mer start positions (base numbers) to look at: [lo, hi) */
+    int64_t lo, hi;
+    if (g_overlap_rule == 1) { /* the rule of rounds 1-3: strict overlap with the unpadded allele (kept so that the test can show the fixtures reject it) */
+        lo = (int64_t)A - k + 1;
+        hi = (A == B) ? (int64_t)A : (int64_t)B;
+    } else { /* s < B and s + k >= A */
+        lo = (int64_t)A - k;
+        hi = (int64_t)B;
     }
+    if (lo < 0) lo = 0;
     for (int64_t s = lo; s < hi && s + k <= (int64_t)n_bases; ++s) {
         const uint32_t first = base_item[s], c0 = it[first].coord;
         /* the k-mer nodes whose first base is PRG coordinate c0 (sorted_kn is ordered by that coordinate) */
@@ -528,7 +529,13 @@ ORC_API char* orc_vcf_sites(const orc_kgraph* g, const char* refseq)
                 }
                 /* (only the next k bases of the reference can matter, but the whole tail keeps this statement trivial) */
                 for (uint32_t i = iq; i < n_path; ++i) walk[nw++] = path[i];
-                const uint32_t n = allele_kmers(g, sorted_kn, walk, nw, A, B, ids, g->n_kn);
+                /* the range is the allele as printed: the padding base belongs to it (rule 1: the bare allele) */
+                uint32_t PA = A, PB = B;
+                if (g_overlap_rule != 1) {
+                    if (pad_l[0]) PA = A - 1;
+                    if (pad_r[0]) PB = B + 1;
+                }
+                const uint32_t n = allele_kmers(g, sorted_kn, walk, nw, PA, PB, ids, g->n_kn);
                 sb_str(&body, head.buf);
                 sb_str(&body, "\t");
                 sb_u(&body, al);

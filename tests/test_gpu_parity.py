@@ -82,6 +82,21 @@ def _compare(ctx, oracle, bases, offsets, w, k, illumina, kernel, min_cluster_si
     return ocnt
 
 
+def _vcf_equals_oracle(ctx, oracle, tmp_path, panel, total_bases, illumina, genome_size, w=11, k=15):
+    """pandora_genotyped.vcf of the coverage the DEVICE accumulated == the oracle's own VCF of that vector, byte for byte minus
+    ##fileDate (tests/util.py oracle_vcf_text: oracle_params.c + oracle_vcf.c + oracle.c)"""
+    from util import oracle_vcf_text, vcf_without_date
+    vcf = str(tmp_path / "pandora_genotyped.vcf")
+    info = ctx.genotype(str(tmp_path / "genes.fa"), vcf)
+    covg, prg_reads = ctx.coverage()
+    md, er = map_params(k, illumina)
+    want, oinfo = oracle_vcf_text(oracle, panel.names, panel.prgs, dict(zip(panel.names, panel.refs)), covg, prg_reads, total_bases, w, k,
+                                  genome_size, er)
+    assert oinfo["e"] == info["exp_depth_covg"] and len(oinfo["present"]) == info["loci_present"]
+    assert vcf_without_date(vcf) == want
+    return info
+
+
 CASES = [(11, 15, 1), (11, 15, 2), (11, 15, 3), (14, 15, 1), (14, 15, 2), (14, 15, 3), (5, 9, 1), (5, 9, 2), (5, 9, 3), (16, 13, 2),
          (16, 13, 3), (19, 21, 1), (19, 21, 3), (1, 15, 1), (1, 15, 2), (1, 15, 3), (11, 31, 1), (11, 31, 3)]
 
@@ -443,6 +458,9 @@ def test_config1_illumina_reads_vs_mtb_index(tmp_path, oracle, name, kernel):
     assert cnt["clusters_kept"] > 5000
     if not FORCED_GENERIC:
         assert ctx.counters()["leftover_reads"] == 0
+    if kernel == 0:
+        info = _vcf_equals_oracle(ctx, oracle, tmp_path, panel, int(offs[-1]), True, synth.MTB_GENOME_SIZE)
+        assert info["records"] > 200 and info["loci_present"] == 18
 
 
 @pytest.mark.parametrize("kernel", [0, 1, 3])
@@ -475,6 +493,9 @@ def test_config4_500_locus_index(tmp_path, oracle, kernel):
     cnt = _compare(ctx, oracle, bases, offs, 11, 15, True, kernel or 3, threads=ORACLE_THREADS)
     assert ctx.counters()["kernel"] == _expected_kernel("big", kernel)
     assert cnt["clusters_kept"] > 50_000
+    if kernel == 0:
+        info = _vcf_equals_oracle(ctx, oracle, tmp_path, panel, int(offs[-1]), True, synth.MTB_GENOME_SIZE)
+        assert info["records"] > 20_000 and info["loci_present"] == 500
 
 
 def _device_reads(torch, genomes, n_reads, seed, long_reads=False):

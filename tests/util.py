@@ -223,3 +223,184 @@ def cluster_fraction(error_rate, k):
 def map_params(k, illumina):
     """(max_diff, error_rate) exactly as drprg_hip_set_opts defaults them"""
     return (2 * k + 1, 0.001) if illumina else (250, 0.11)
+
+
+# ---- PRGs made of a fixture VCF's own sites (tests/test_kmer_count_kat.py, tests/test_vcf_sites.py) ------------------------------
+def read_fasta_dict(path):
+    out, name = {}, None
+    for line in open(path):
+        if line.startswith(">"):
+            name = line[1:].split()[0]
+            out[name] = ""
+        elif name:
+            out[name] += line.strip().upper()
+    return out
+
+
+def flat_prgs_from_sites(genes, records):
+    """One PRG string per gene of `genes` (name -> sequence): the gene's sequence with every record (dicts with chrom, pos (1-based),
+    ref, alts) that fits turned into a flat site REF | ALT1 | ALT2 ... in make_prg syntax.  A record whose alleles all start with the
+    same base and one of which is that base alone is a padded indel (pandora pads an empty allele with the reference base in front
+    of the site): the site is put back behind that base.  Returns (names, prg strings, keys (chrom, pos) of the records that were
+    placed, as (chrom, pos, REF as printed)); a record that overlaps one already placed (a nested site of the real PRG) or whose REF is not the gene's sequence at POS
+    is left out."""
+    from drprg_amd import synth
+    by = {}
+    for r in records:
+        by.setdefault(r["chrom"], []).append(r)
+    names, prgs, placed = [], [], set()
+    for gname, gseq in genes.items():
+        segs, cur = [], 0
+        for r in sorted(by.get(gname, []), key=lambda r: (r["pos"], -len(r["ref"]))):
+            p0, ref, alts = r["pos"] - 1, r["ref"], list(r["alts"])
+            if gseq[p0:p0 + len(ref)] != ref:
+                continue
+            if all(a[:1] == ref[:1] for a in alts) and min(len(x) for x in alts + [ref]) == 1:
+                p0, ref, alts = p0 + 1, ref[1:], [a[1:] for a in alts]
+            if p0 < cur:
+                continue
+            segs += [gseq[cur:p0], synth.Site([[ref]] + [[a] for a in alts])]
+            cur = p0 + len(ref)
+            placed.add((gname, r["pos"], r["ref"]))
+        segs.append(gseq[cur:])
+        names.append(gname)
+        prgs.append(synth.prg_string(segs))
+    return names, prgs, placed
+
+
+def product_sites(names, prgs, refs, w, k, tmpdir):
+    """The product's records and per-allele k-mer nodes for PRG strings (host-only context, every locus present):
+    {name: [dict(pos, ref, alts, vc, graphtype, knodes=[per allele: sorted LOCAL k-mer node ids])]} in VCF order."""
+    from drprg_amd import Context
+    prg, genes = os.path.join(str(tmpdir), "dr.prg"), os.path.join(str(tmpdir), "genes.fa")
+    with open(prg, "w") as fh:
+        for n, s in zip(names, prgs):
+            fh.write(f">{n}\n{s}\n")
+    if refs is not None:
+        with open(genes, "w") as fh:
+            for n, s in zip(names, refs):
+                fh.write(f">{n}\n{s}\n")
+    ctx = Context(prg, w, k, device=-1, from_files=False)
+    ctx.set_opts(illumina=True, genome_size=4411532)
+    ctx.set_coverage(np.ones(2 * ctx.n_knodes, np.uint32), np.full(ctx.n_prgs, 100, np.uint32), 1000)  # every locus has clusters, none is dropped
+    vcf, tsv = os.path.join(str(tmpdir), "o.vcf"), os.path.join(str(tmpdir), "alleles.tsv")
+    ctx.genotype(genes if refs is not None else None, vcf)
+    ctx.genotype_alleles(tsv)
+    base = {n: int(b) for n, b in zip(names, ctx.export_index()["knode_base"])}
+    rows = iter([line.rstrip("\n").split("\t") for line in open(tsv) if not line.startswith("#")])  # (in the order of the VCF's records)
+    out = {n: [] for n in names}
+    for line in open(vcf):
+        if line.startswith("#"):
+            continue
+        t = line.rstrip("\n").split("\t")
+        info = dict(x.split("=") for x in t[7].split(";"))
+        rec = dict(pos=int(t[1]), ref=t[3], alts=t[4].split(","), vc=info["VC"], graphtype=info["GRAPHTYPE"], knodes=[])
+        for a in range(1 + len(rec["alts"])):
+            row = next(rows)
+            assert (row[0], int(row[1]), int(row[2])) == (t[0], rec["pos"], a)
+            rec["knodes"].append(sorted(int(x) - base[t[0]] for x in row[4].split(",") if x))
+        out[t[0]].append(rec)
+    ctx.close()
+    return out
+
+
+# ---- the oracle's whole pandora_genotyped.vcf: oracle_params.c (model, best path, presence) + oracle_vcf.c (records, allele -> k-mer
+# nodes) + oracle.c (statistics, likelihood) + the text layout of the reference's fixture -----------------------------------------
+def oracle_vcf_text(oracle, names, prgs, refs, covg, prg_reads, total_bases, w, k, genome_size, error_rate, binomial=False, eps=0.01,
+                    sample="sample"):
+    """What drprg_hip_genotype writes (minus the ##fileDate line), from the oracle's own pieces.  refs: {name: sequence} or None.
+    Returns (text, dict(e, min_kmer_covg, present, dropped))."""
+    L = oracle.lib
+    L.orc_estimate_parameters.restype = None
+    L.orc_estimate_parameters.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int, C.c_double, C.c_int, C.c_void_p]
+    L.orc_kmer_log_prob.restype = C.c_float
+    L.orc_kmer_log_prob.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_uint32, C.c_uint32, C.c_uint32]
+    L.orc_prob_threshold.restype = C.c_int
+    L.orc_prob_threshold.argtypes = [C.c_void_p, C.c_int64]
+    L.orc_max_path.restype = C.c_int64
+    L.orc_max_path.argtypes = [C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_int64]
+    L.orc_path_coverage_too_low.restype = C.c_int
+    L.orc_path_coverage_too_low.argtypes = [C.c_void_p, C.c_int64, C.c_uint32]
+    L.orc_kg_base_coverage.restype = C.c_int64
+    L.orc_kg_base_coverage.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64]
+    covg = np.minimum(np.asarray(covg, np.uint32), 65535).astype(np.uint32)  # pandora's u16 counters
+    graphs = [L.orc_index_prg(s.encode(), w, k) for s in prgs]
+    try:
+        assert all(graphs)
+        n_nodes = [int(L.orc_kg_n_nodes(g)) for g in graphs]
+        base = np.concatenate([[0], np.cumsum(n_nodes)]).astype(np.int64)
+        assert covg.size == 2 * base[-1]
+        fwd = [covg[2 * base[i]:2 * base[i + 1]:2] for i in range(len(prgs))]
+        rev = [covg[2 * base[i] + 1:2 * base[i + 1]:2] for i in range(len(prgs))]
+        with_reads = [i for i in range(len(prgs)) if prg_reads[i] > 0]
+        kc = np.concatenate([(fwd[i] + rev[i])[1:-1] for i in with_reads]).astype(np.uint32) if with_reads else np.zeros(0, np.uint32)
+        gcov = int(min(int(total_bases) // max(int(genome_size), 1), 0xFFFFFFFF))
+        a = np.zeros(10)
+        L.orc_estimate_parameters(_p(np.ascontiguousarray(kc)), len(kc), int(sum(int(prg_reads[i]) for i in with_reads)), len(with_reads), gcov, k,
+                                  error_rate, 1 if binomial else 0, _p(a))
+        e = int(a[0])
+
+        def logp(i):
+            out = np.zeros(n_nodes[i], np.float32)
+            for j in range(1, n_nodes[i] - 1):
+                out[j] = L.orc_kmer_log_prob(int(a[1]), a[3], a[4], a[9], int(fwd[i][j]), int(rev[i][j]), int(prg_reads[i]))
+            return out
+
+        lps = {i: logp(i) for i in with_reads}
+        all_lp = np.ascontiguousarray(np.concatenate([lps[i][1:-1] for i in with_reads]) if with_reads else np.zeros(0, np.float32), np.float32)
+        thresh = L.orc_prob_threshold(_p(all_lp), len(all_lp))
+        present, dropped = [], []
+        for i in with_reads:
+            n = n_nodes[i]
+            ne = int(L.orc_kg_n_edges(graphs[i]))
+            ef, et = np.zeros(ne, np.uint32), np.zeros(ne, np.uint32)
+            L.orc_kg_edges(graphs[i], _p(ef), _p(et))
+            path = np.zeros(n, np.uint32)
+            m = L.orc_max_path(n, ne, _p(ef), _p(et), _p(lps[i]), thresh, 100, _p(path), n)
+            if m == 0:
+                continue
+            total = np.ascontiguousarray(fwd[i] + rev[i], np.uint32)
+            cap = 1 << 20
+            ob = np.zeros(cap, np.uint32)
+            nb = L.orc_kg_base_coverage(graphs[i], _p(path), m, _p(total), _p(ob), cap)
+            assert nb <= cap
+            if L.orc_path_coverage_too_low(_p(ob), nb, gcov):
+                dropped.append(names[i])
+                continue
+            present.append(i)
+    finally:
+        for g in graphs:
+            if g:
+                L.orc_kg_free(g)
+    thr = e // 10
+    recs = []
+    for i in present:
+        for r in oracle.vcf_sites(prgs[i], w, k, refs.get(names[i]) if refs else None)[0]:
+            stats, gaps = [], []
+            for ids in r["knodes"]:
+                idx = np.asarray(ids, np.int64)
+                st, g = oracle.allele_stats(fwd[i][idx], rev[i][idx], thr)
+                stats.append(st)
+                gaps.append(g)
+            lik, gt, conf = oracle.genotype([s[0] for s in stats], [s[1] for s in stats], gaps, float(e), eps)
+            recs.append((names[i], r["pos"], r["ref"], r["alts"], r["vc"], r["graphtype"], stats, gaps, lik, gt, conf))
+    recs.sort(key=lambda x: (x[0], x[1], x[2], x[3]))
+    head = []
+    for line in open(os.path.join(GOLDEN, "pandora_vcf_surface", "header.vcf")):
+        if line.startswith("##contig") or line.startswith("#CHROM"):
+            break
+        if not line.startswith("##fileDate") and not line.startswith("##FILTER=<ID=PASS"):  # (the PASS line is bcftools', from when the fixture was cut down)
+            head.append(line)
+    out = head + [f"##contig=<ID={n}>\n" for n in sorted(names[i] for i in present)]
+    out.append("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + sample + "\n")
+    g6 = lambda v: "%g" % v
+    for chrom, pos, ref, alts, vc, gtype, stats, gaps, lik, gt, conf in recs:
+        cols = [",".join(str(s[j]) for s in stats) for j in range(6)]
+        out.append(f"{chrom}\t{pos}\t.\t{ref}\t{','.join(alts)}\t.\t.\tVC={vc};GRAPHTYPE={gtype}\t"
+                   "GT:MEAN_FWD_COVG:MEAN_REV_COVG:MED_FWD_COVG:MED_REV_COVG:SUM_FWD_COVG:SUM_REV_COVG:GAPS:LIKELIHOOD:GT_CONF\t"
+                   f"{gt}:{':'.join(cols)}:{','.join(g6(x) for x in gaps)}:{','.join(g6(x) for x in lik)}:{g6(conf)}\n")
+    return "".join(out), dict(e=e, min_kmer_covg=thr, present=sorted(names[i] for i in present), dropped=sorted(dropped))
+
+
+def vcf_without_date(path):
+    return "".join(line for line in open(path) if not line.startswith("##fileDate"))

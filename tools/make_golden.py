@@ -8,6 +8,11 @@ reference's test VCFs and verbatim copies of small data files its tests hold.
                            (exp_depth_covg e, MEAN_FWD, MEAN_REV, GAPS per allele) -> expected LIKELIHOOD,
                            GT, GT_CONF.  Three hand-assembled records are flagged `excluded`.
   stats_kat.tsv            MEAN/MED/SUM consistency vectors (integer-mean rule) from the same records
+  kmer_count_kat.tsv       per allele of the same records: the set of k-mer counts n that its SUM / MEAN / GAPS admit
+                           (floor(SUM_FWD / n) == MEAN_FWD, floor(SUM_REV / n) == MEAN_REV, GAPS == j / n printed with six
+                           significant digits) -- n is the number of minimizer k-mers pandora took the allele's statistics
+                           over, a function of genes.fa, the hash, the canonical rule, the window rule, the PRG sketch and
+                           the allele -> k-mer rule (tests/test_kmer_count_kat.py holds oracle and product against it)
   pandora_vcf_surface/     header of ERR4796933.pandora.vcf (the raw pandora output format)
   prg_syntax/dr.prg        /root/reference/tests/cases/expected/dr.prg (PRG-string syntax, 2 loci)
   denovo_paths_example.txt the denovo_paths.txt embedded in /root/reference/src/lib.rs:3010-3038
@@ -47,6 +52,33 @@ def main():
                              g("LIKELIHOOD"), gt, fmt["GT_CONF"], str(excl)])
                 stats.append([fname, t[0], t[1], str(a), g("MEAN_FWD_COVG"), g("MEAN_REV_COVG"), g("MED_FWD_COVG"),
                               g("MED_REV_COVG"), g("SUM_FWD_COVG"), g("SUM_REV_COVG"), g("GAPS"), str(excl)])
+    # ---- k-mer counts the statistics admit (1 <= n <= N_MAX; '*' = every n: an allele without coverage and GAPS 1 says nothing) ----
+    N_MAX = 300
+    with open(os.path.join(OUT, "kmer_count_kat.tsv"), "w") as fh:
+        fh.write("#file\tchrom\tpos\tref\talts\tallele\tsum_fwd\tsum_rev\tmean_fwd\tmean_rev\tgaps\tfeasible_n\texcluded\n")
+        n_inf = 0
+        for fname in E:
+            for line in open(os.path.join(PRED, fname)):
+                if line.startswith("#"):
+                    continue
+                t = line.rstrip("\n").split("\t")
+                fmt = dict(zip(t[8].split(":"), t[9].split(":")))
+                excl = int((fname, t[0], t[1]) in EXCLUDED)
+                for a in range(len(fmt["MEAN_FWD_COVG"].split(","))):
+                    g = lambda key: fmt[key].split(",")[a]
+                    sf, sr, mf, mr, gaps = int(g("SUM_FWD_COVG")), int(g("SUM_REV_COVG")), int(g("MEAN_FWD_COVG")), int(g("MEAN_REV_COVG")), g("GAPS")
+                    ok = []
+                    for n in range(1, N_MAX + 1):
+                        if sf // n != mf or sr // n != mr:
+                            continue
+                        j = round(float(gaps) * n)
+                        if 0 <= j <= n and "%g" % (j / n) == gaps:
+                            ok.append(n)
+                    feas = "*" if len(ok) >= 200 else (",".join(map(str, ok)) if ok else "-")
+                    n_inf += feas not in ("*", "-")
+                    fh.write("\t".join([fname, t[0], t[1], t[3], t[4], str(a), str(sf), str(sr), str(mf), str(mr), gaps, feas, str(excl)]) + "\n")
+    print(f"kmer_count_kat.tsv: {n_inf} informative alleles")
+
     with open(os.path.join(OUT, "likelihood_kat.tsv"), "w") as fh:
         fh.write("#file\tchrom\tpos\te\tn_alleles\tallele\tmean_fwd\tmean_rev\tgaps\tlikelihood\tgt\tgt_conf\texcluded\n")
         for r in rows:
