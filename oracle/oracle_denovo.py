@@ -85,3 +85,164 @@ def pile_up(consensus, regions, reads, anchor=15, min_support=3, min_fraction=0.
             suf += 1
         out.append((locus, start + pre, ref[pre:len(ref) - suf], best[pre:len(best) - suf], best_n, spanning))
     return sorted(out, key=lambda v: (v[0], v[1]))
+
+
+# ---- noisy long reads (no -I): the column vote -------------------------------------------------------------------------------------------
+# A second statement of the product's rules for reads that carry their own errors (drprg_amd/csrc/denovo.cpp column_consensus +
+# assemble_candidate_regions with accurate_reads = false; DESIGN.md section 4 "Discover"), again in plain Python over whole reads:
+# str.find for the anchors, a list-of-lists edit-distance table, dictionaries for the votes.  Like pile_up above it checks the
+# IMPLEMENTATION of this build's rules; pandora's local assembly is not restated anywhere.
+# Rules: up to three consecutive `anchor`-mers of consensus on either side of the padded region are searched exactly (either
+# orientation); a read votes once per (region, orientation) with the innermost pair it holds (smallest jl + jr; among equals the first
+# found scanning the read's anchor hits in position order, left anchor outermost loop) whose spelled length is within max_len_change of
+# the expected one; a string with an N does not vote.  Every voting string is aligned globally at unit costs to the consensus slice
+# between ITS anchors; the traceback prefers the diagonal, then a deletion, then an insertion (gaps end up as far left as the costs
+# allow).  A column of the region collects votes A / C / G / T / deleted, the gap in front of a column the inserted strings.  With
+# need = max(min_support, ceil(min_fraction * spanning)): an insertion is made where >= need reads insert something (its length the most
+# frequent one -- the shortest among equally frequent --, its bases the per-place majority -- A < C < G < T on ties -- of the strings
+# of that length); a column takes its most voted state (the consensus base wins ties, then the order A C G T deleted) if that state is the
+# consensus base or has >= need votes.  The result is aligned to again, up to three rounds, until it stops changing.  Reported support =
+# reads whose string is closer (edit distance) to the new allele than to the consensus, both extended by the skipped anchors.
+def _align_votes(ref, s, shift, R, weight, col, ins):
+    E, S = len(ref), len(s)
+    D = [[0] * (S + 1) for _ in range(E + 1)]
+    for i in range(E + 1):
+        D[i][0] = i
+    for j in range(S + 1):
+        D[0][j] = j
+    for i in range(1, E + 1):
+        for j in range(1, S + 1):
+            D[i][j] = min(D[i - 1][j - 1] + (ref[i - 1] != s[j - 1]), D[i - 1][j] + 1, D[i][j - 1] + 1)
+    i, j, pending = E, S, []
+
+    def flush(before):
+        if pending:
+            if shift <= before <= shift + R:
+                key = "".join(reversed(pending))
+                ins[before - shift][key] = ins[before - shift].get(key, 0) + weight
+            del pending[:]
+
+    while i > 0 or j > 0:
+        if i > 0 and j > 0 and D[i][j] == D[i - 1][j - 1] + (ref[i - 1] != s[j - 1]):
+            flush(i)
+            if s[j - 1] in "ACGT" and shift <= i - 1 < shift + R:
+                col[i - 1 - shift]["ACGT".index(s[j - 1])] += weight
+            i, j = i - 1, j - 1
+        elif i > 0 and D[i][j] == D[i - 1][j] + 1:
+            flush(i)
+            if shift <= i - 1 < shift + R:
+                col[i - 1 - shift][4] += weight
+            i -= 1
+        else:
+            pending.append(s[j - 1])
+            j -= 1
+    flush(0)
+    return D[E][S]
+
+
+def _edit(a, b):
+    prev = list(range(len(b) + 1))
+    for i in range(1, len(a) + 1):
+        cur = [i] + [0] * len(b)
+        for j in range(1, len(b) + 1):
+            cur[j] = min(prev[j - 1] + (a[i - 1] != b[j - 1]), prev[j] + 1, cur[j - 1] + 1)
+        prev = cur
+    return prev[len(b)]
+
+
+def column_vote(consensus, regions, reads, anchor=15, min_support=4, min_fraction=0.6, max_len_change=30, max_anchors=3):
+    """Same arguments and result layout as pile_up: [(locus, pos0, ref, alt, support, spanning)]."""
+    import math
+    out = []
+    for locus, start, end in regions:
+        cons = consensus[locus]
+        if start < anchor or end + anchor > len(cons):
+            continue
+        nl, nr = min(max_anchors, start // anchor), min(max_anchors, (len(cons) - end) // anchor)
+        left = [cons[start - anchor * (j + 1):start - anchor * j] for j in range(nl)]    # left[0] is next to the region
+        right = [cons[end + anchor * j:end + anchor * (j + 1)] for j in range(nr)]
+        core0 = cons[start:end]
+        votes = {}
+        for read in reads:
+            read = read.upper()
+            if len(read) < 2 * anchor:
+                continue
+            for reverse in (False, True):
+                hits = []  # (position, side, j): side 0 = a left anchor of the consensus, 1 = a right one
+                for side, lst in ((0, left), (1, right)):
+                    for j, a in enumerate(lst):
+                        pat = revcomp(a) if reverse else a
+                        hits += [(p, side, j) for p in _occurrences(read, pat)]
+                hits.sort()
+                best = None
+                for x in hits:
+                    for y in hits:
+                        first_ok = (x[1] == 1 and y[1] == 0) if reverse else (x[1] == 0 and y[1] == 1)
+                        if not first_ok or y[0] < x[0] + anchor:
+                            continue
+                        jl, jr = (y[2], x[2]) if reverse else (x[2], y[2])
+                        got, want = y[0] - (x[0] + anchor), (end - start) + anchor * (jl + jr)
+                        if got > want + max_len_change or got + max_len_change < want:
+                            continue
+                        if best is None or jl + jr < best[2] + best[3]:
+                            best = (x[0] + anchor, got, jl, jr)
+                if best is None:
+                    continue
+                s = read[best[0]:best[0] + best[1]]
+                if reverse:
+                    s = revcomp(s)
+                if any(c not in "ACGT" for c in s):
+                    continue
+                votes[(best[2], best[3], s)] = votes.get((best[2], best[3], s), 0) + 1
+        spanning = sum(votes.values())
+        if spanning < min_support:
+            continue
+        need = max(min_support, int(math.ceil(min_fraction * spanning)))
+        ext = lambda core, jl, jr: cons[start - anchor * jl:start] + core + cons[end:end + anchor * jr]
+        allele = core0
+        for _ in range(3):
+            R = len(allele)
+            col = [[0, 0, 0, 0, 0] for _ in range(R)]
+            ins = [dict() for _ in range(R + 1)]
+            for (jl, jr, s), n in votes.items():
+                _align_votes(ext(allele, jl, jr), s, anchor * jl, R, n, col, ins)
+            nxt = []
+            for i in range(R + 1):
+                if sum(ins[i].values()) >= need:
+                    by_len = {}
+                    for t, n in ins[i].items():
+                        by_len[len(t)] = by_len.get(len(t), 0) + n
+                    top = max(by_len.values())
+                    ln = min(l for l, n in by_len.items() if n == top)
+                    for p in range(ln):
+                        cnt = [0, 0, 0, 0]
+                        for t, n in ins[i].items():
+                            if len(t) == ln and t[p] in "ACGT":
+                                cnt["ACGT".index(t[p])] += n
+                        nxt.append("ACGT"[cnt.index(max(cnt))])
+                if i == R:
+                    break
+                rc = "ACGT".index(allele[i])
+                arg = rc
+                for c in range(5):
+                    if col[i][c] > col[i][arg]:
+                        arg = c
+                if arg != rc and col[i][arg] < need:
+                    arg = rc
+                if arg < 4:
+                    nxt.append("ACGT"[arg])
+            nxt = "".join(nxt)
+            if nxt == allele:
+                break
+            allele = nxt
+        if allele == core0:
+            continue
+        support = sum(n for (jl, jr, s), n in votes.items() if _edit(s, ext(allele, jl, jr)) < _edit(s, ext(core0, jl, jr)))
+        pre = 0
+        while pre < len(core0) and pre < len(allele) and core0[pre] == allele[pre]:
+            pre += 1
+        suf = 0
+        while suf < len(core0) - pre and suf < len(allele) - pre and core0[len(core0) - 1 - suf] == allele[len(allele) - 1 - suf]:
+            suf += 1
+        out.append((locus, start + pre, core0[pre:len(core0) - suf], allele[pre:len(allele) - suf], support, spanning))
+    return sorted(out, key=lambda v: (v[0], v[1]))

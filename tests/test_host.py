@@ -674,6 +674,10 @@ def test_discover_with_noisy_long_reads(tmp_path, oracle, kind):
     locus, pos1, ref, alt, support, spanning = variants[0]
     assert locus == "g1" and support >= 4 and spanning >= support
     assert _same_variant((pos1 - 1, ref, alt), want, ref1)
+    # the oracle's own statement of the column vote (oracle/oracle_denovo.py column_vote: whole reads, str.find, its own alignment):
+    # the same variant, support and spanning count
+    from util import oracle_denovo
+    assert oracle_denovo(out, dict(zip(panel.names, panel.refs)), bases, offs, noisy=True) == [(l, p - 1, r, a, s, n) for l, p, r, a, s, n in variants]
 
 
 def test_discover_lists_several_loci_several_variants_and_a_variant_inside_a_nested_allele(tmp_path, oracle):

@@ -79,6 +79,13 @@ def _sample(tmp_path, n_background=0, kind="snp", noisy=False, odd_bases=False, 
     return panel, prg, genes, fq
 
 
+def _fastq_arrays(fq):
+    seqs = [line.strip() for i, line in enumerate(open(fq)) if i % 4 == 1]
+    offs = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(x) for x in seqs])
+    return np.frombuffer("".join(seqs).encode(), np.uint8), offs
+
+
 def _files(d):
     return {f: open(os.path.join(str(d), f), "rb").read() for f in ("candidate_regions.tsv", "denovo_variants.tsv", "denovo_paths.txt", "denovo_sequences.fa")}
 
@@ -107,6 +114,13 @@ def test_discover_from_resident_reads_writes_what_discover_from_the_file_writes(
     assert len(va) == 1 and va == vb
     assert _files(tmp_path / "file") == _files(tmp_path / "hbm")
     assert np.array_equal(a.coverage()[0], b.coverage()[0]) and a.counters() == b.counters()
+    # ... and what came out of the anchor-scan path is what the ORACLE's separate statement of the pile-up finds in the whole read set
+    # (oracle/oracle_denovo.py: pile_up for accurate reads, column_vote for noisy ones -- whole reads and str.find, no k-mer tables, no
+    # device): the same variant with the same support and spanning counts (f-2's GPU tests compared the HIP path with itself)
+    from util import oracle_denovo
+    bases, offs = _fastq_arrays(fq)
+    want = oracle_denovo(tmp_path / "hbm", dict(zip(panel.names, panel.refs)), bases, offs, noisy=noisy)
+    assert want == [(l, p - 1, r, alt, s, n) for l, p, r, alt, s, n in vb]
 
 
 def test_many_blocks_and_reads_without_anchors(tmp_path):
@@ -117,6 +131,9 @@ def test_many_blocks_and_reads_without_anchors(tmp_path):
     b, vb = _discover(prg, genes, fq, tmp_path / "hbm", 1 << 30, threads=8)
     assert b.resident_info()["last_discover_from_hbm"] and b.resident_info()["blocks"] >= 2
     assert len(va) == 1 and va == vb and _files(tmp_path / "file") == _files(tmp_path / "hbm")
+    from util import oracle_denovo
+    bases, offs = _fastq_arrays(fq)
+    assert oracle_denovo(tmp_path / "hbm", dict(zip(panel.names, panel.refs)), bases, offs) == [(l, p - 1, r, alt, s, n) for l, p, r, alt, s, n in vb]
 
 
 def test_mapping_the_resident_reads_against_the_updated_prg(tmp_path):

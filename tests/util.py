@@ -404,3 +404,21 @@ def oracle_vcf_text(oracle, names, prgs, refs, covg, prg_reads, total_bases, w, 
 
 def vcf_without_date(path):
     return "".join(line for line in open(path) if not line.startswith("##fileDate"))
+
+
+# ---- discover: the oracle's two pile-ups (oracle/oracle_denovo.py) on the candidate regions a discover run wrote -------------------
+def oracle_denovo(discover_dir, consensus, bases, offs, noisy=False):
+    """[(locus, pos0, ref, alt, support, spanning)] by the oracle's separate statement of the accurate-read pile-up (noisy = False) or of the
+    noisy-read column vote, over the regions in <discover_dir>/candidate_regions.tsv and the consensus {locus: sequence} the test knows"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("oracle_denovo", os.path.join(ROOT, "oracle", "oracle_denovo.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    regions = []
+    for line in open(os.path.join(str(discover_dir), "candidate_regions.tsv")):
+        if not line.startswith("#"):
+            f = line.split("\t")
+            regions.append((f[0], int(f[1]), int(f[2])))
+    text = np.asarray(bases, np.uint8).tobytes().decode()
+    reads = [text[int(offs[i]):int(offs[i + 1])] for i in range(len(offs) - 1)]
+    return (mod.column_vote if noisy else mod.pile_up)(consensus, regions, reads)
