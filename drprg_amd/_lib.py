@@ -69,6 +69,14 @@ SIGNATURES = {
     "drprg_hip_map_device_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p,
                                              C.c_void_p, C.c_void_p]),
     "drprg_hip_sync": (C.c_int, [C.c_void_p]),
+    "drprg_hip_set_input_format": (C.c_int, [C.c_void_p, C.c_int]),
+    "drprg_hip_pack_reads": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "drprg_hip_map_host_packed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]),
+    "drprg_hip_map_device_packed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p,
+                                              C.c_void_p, C.c_void_p]),
+    "drprg_hip_map_device_packed_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p,
+                                                    C.c_void_p, C.c_void_p]),
+    "drprg_hip_pack_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p]),
     "drprg_hip_coverage_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "drprg_hip_coverage": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]),
     "drprg_hip_set_coverage": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64]),

@@ -78,6 +78,29 @@ __device__ inline uint4 load16_guarded(const uint8_t* __restrict__ bases, int64_
     return make_uint4(t4[0], t4[1], t4[2], t4[3]);
 }
 
+// 16 bases of a packed batch (SketchArgs::packed: letters A0 C1 T2 G3, first base in the lowest bits) -> the form pack16n makes of 16
+// ASCII bases: A0 C1 G2 T3, first base highest.  letter ^ (letter >> 1) swaps T and G; v_bfrev reverses the order of the sixteen
+// 2-bit fields and the two bits of each, which are then swapped back.
+__device__ __forceinline__ uint32_t packed_to_hash_order(uint32_t x)
+{
+    const uint32_t y = x ^ ((x >> 1) & 0x55555555u);
+    const uint32_t r = __brev(y);
+    return ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);
+}
+
+// bit i: base a0 + i of a packed batch is not one of ACGTacgt (npos: ascending positions; most batches have none)
+__device__ inline uint64_t packed_bad_bases(const uint64_t* __restrict__ npos, uint64_t n_npos, int64_t a0)
+{
+    uint64_t lo = 0, hi = n_npos;
+    while (lo < hi) { // first position >= a0
+        const uint64_t mid = (lo + hi) >> 1;
+        if ((int64_t)npos[mid] < a0) lo = mid + 1; else hi = mid;
+    }
+    uint64_t bad = 0;
+    for (; lo < n_npos && (int64_t)npos[lo] < a0 + 64; ++lo) bad |= 1ull << ((int64_t)npos[lo] - a0);
+    return bad;
+}
+
 // slices -> one dense, ordered candidate list (cand_info[t] holds the position until verify_count_kernel replaces it)
 __global__ __launch_bounds__(64) void cand_gather_kernel(FilterWork fw)
 {
@@ -148,7 +171,7 @@ __device__ __forceinline__ void verify_emit(const SketchArgs& a, const ReadClust
 }
 
 // One candidate, start to finish, by one lane (the whole algorithm described above verify_count_kernel)
-template <int KC>
+template <int KC, bool PACKED>
 __device__ __forceinline__ void verify_one_lane(const SketchArgs& a, const FilterWork& fw, const ReadClusterArgs& rc, const VerifyConsts& c, int64_t gp, VerifyOut& o,
     uint32_t& my_hits, uint32_t& my_nmin, uint32_t& my_maxlen)
 {
@@ -170,7 +193,21 @@ __device__ __forceinline__ void verify_one_lane(const SketchArgs& a, const Filte
         const uint64_t o0 = a.offsets[guess], o1 = a.offsets[guess + 1];
         const int64_t a0 = (gp > 15 ? gp - 15 : 0) & ~(int64_t)15;
         uint4 b0, b1, b2, b3;
-        if (a0 + 64 <= n_bases) {
+        uint32_t x0 = 0, x1 = 0, x2 = 0, x3 = 0; // packed input: the four words of [a0, a0 + 64)
+        (void)b0; (void)b1; (void)b2; (void)b3; (void)x0; (void)x1; (void)x2; (void)x3;
+        if constexpr (PACKED) {
+            const uint32_t* __restrict__ wp = reinterpret_cast<const uint32_t*>(a.bases) + (a0 >> 4);
+            const int64_t left = ((n_bases + 15) >> 4) - (a0 >> 4); // words from a0 on: >= 1 (gp + k <= n_bases)
+            x0 = wp[0];
+            if (left >= 4) {
+                x1 = wp[1];
+                x2 = wp[2];
+                x3 = wp[3];
+            } else {
+                if (left > 1) x1 = wp[1];
+                if (left > 2) x2 = wp[2];
+            }
+        } else if (a0 + 64 <= n_bases) {
             const uint4* __restrict__ bp = reinterpret_cast<const uint4*>(a.bases + a0);
             b0 = bp[0];
             b1 = bp[1];
@@ -191,12 +228,23 @@ __device__ __forceinline__ void verify_one_lane(const SketchArgs& a, const Filte
             r0 = (int64_t)a.offsets[read];
             r1 = (int64_t)a.offsets[read + 1];
         }
-        uint32_t r0w, r1w, r2w, r3w, n0, n1, n2, n3;
-        pack16n(b0, r0w, n0);
-        pack16n(b1, r1w, n1);
-        pack16n(b2, r2w, n2);
-        pack16n(b3, r3w, n3);
-        uint64_t bad = (uint64_t)(n0 | (n1 << 16)) | ((uint64_t)(n2 | (n3 << 16)) << 32); // bit i: base a0+i is not ACGT
+        uint32_t r0w, r1w, r2w, r3w;
+        uint64_t bad; // bit i: base a0+i is not ACGT (or lies behind the last base of the batch)
+        if constexpr (PACKED) {
+            r0w = packed_to_hash_order(x0);
+            r1w = packed_to_hash_order(x1);
+            r2w = packed_to_hash_order(x2);
+            r3w = packed_to_hash_order(x3);
+            bad = a.n_npos ? packed_bad_bases(a.npos, a.n_npos, a0) : 0ull;
+            if (a0 + 64 > n_bases) bad |= ~0ull << (n_bases - a0);
+        } else {
+            uint32_t n0, n1, n2, n3;
+            pack16n(b0, r0w, n0);
+            pack16n(b1, r1w, n1);
+            pack16n(b2, r2w, n2);
+            pack16n(b3, r3w, n3);
+            bad = (uint64_t)(n0 | (n1 << 16)) | ((uint64_t)(n2 | (n3 << 16)) << 32);
+        }
         if (bad) { // -> bit i: the k-mer starting at a0+i holds such a base
             uint64_t m = bad;
             for (int i = 1; i < k; ++i) m |= bad >> i;
@@ -267,7 +315,7 @@ __device__ __forceinline__ void verify_one_lane(const SketchArgs& a, const Filte
     }
 }
 
-template <int KC>
+template <int KC, bool PACKED>
 __global__ __launch_bounds__(EX_THREADS) void verify_count_kernel(SketchArgs a, FilterWork fw, ReadClusterArgs rc)
 {
     __shared__ uint32_t s_red[3][EX_THREADS / 64];
@@ -282,7 +330,7 @@ __global__ __launch_bounds__(EX_THREADS) void verify_count_kernel(SketchArgs a, 
         const int64_t gp = gp_next; // position now, (slot, strand, read) when this lane is done
         if (t + EX_THREADS < t_end) gp_next = (int64_t)fw.cand_info[t + EX_THREADS];
         VerifyOut o;
-        verify_one_lane<KC>(a, fw, rc, c, gp, o, my_hits, my_nmin, my_maxlen);
+        verify_one_lane<KC, PACKED>(a, fw, rc, c, gp, o, my_hits, my_nmin, my_maxlen);
         fw.cand_pos1[t] = o.pos1;
         fw.cand_info[t] = ((uint64_t)o.slot << 32) | ((uint64_t)o.strand << 31) | (uint64_t)o.read;
         fw.cand_rec[t] = o.crec;
@@ -594,8 +642,11 @@ hipError_t launch_candidate_stage(const SketchArgs& a, const FilterWork& fw, con
 {
     hipLaunchKernelGGL(cand_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, fw);
     hipLaunchKernelGGL(cand_gather_kernel, dim3(fw.n_slices), dim3(64), 0, stream, fw);
-    if (a.k == 15) hipLaunchKernelGGL(verify_count_kernel<15>, dim3(fw.ex_grid), dim3(EX_THREADS), 0, stream, a, fw, rc);
-    else hipLaunchKernelGGL(verify_count_kernel<0>, dim3(fw.ex_grid), dim3(EX_THREADS), 0, stream, a, fw, rc);
+    if (a.packed) {
+        if (a.k == 15) hipLaunchKernelGGL((verify_count_kernel<15, true>), dim3(fw.ex_grid), dim3(EX_THREADS), 0, stream, a, fw, rc);
+        else hipLaunchKernelGGL((verify_count_kernel<0, true>), dim3(fw.ex_grid), dim3(EX_THREADS), 0, stream, a, fw, rc);
+    } else if (a.k == 15) hipLaunchKernelGGL((verify_count_kernel<15, false>), dim3(fw.ex_grid), dim3(EX_THREADS), 0, stream, a, fw, rc);
+    else hipLaunchKernelGGL((verify_count_kernel<0, false>), dim3(fw.ex_grid), dim3(EX_THREADS), 0, stream, a, fw, rc);
     hipLaunchKernelGGL(hit_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, a, fw, 0);
     return hipGetLastError();
 }

@@ -13,6 +13,7 @@
 #include "denovo.h"
 #include "mapper.h"
 #include "rccl_dyn.h"
+#include "pack.h"
 #include <cstdlib>
 #include <cstring>
 #include <fcntl.h>
@@ -97,6 +98,7 @@ struct drprg_hip_ctx {
     bool host_coverage_valid = false;
     uint64_t total_bases = 0;
     int threads = 4; // parser threads of drprg_hip_map_fastx
+    bool packed_input = false; // drprg_hip_set_input_format: map_fastx packs the reads to 2 bits on the parser threads
     uint32_t ginfo[4] = { 0, 0, 0, 0 };
     std::vector<VcfRecord> last_records; // of the last drprg_hip_genotype (drprg_hip_genotype_alleles)
     CoverageModel last_model;            // of the last drprg_hip_genotype (drprg_hip_coverage_model)
@@ -366,6 +368,17 @@ int drprg_hip_map_fastx(drprg_hip_ctx* ctx, const char* reads_path)
     ctx->mapped_paths.push_back(reads_path);
     // multi-threaded ingest into pinned blocks (ingest.cpp); multi-line FASTQ falls back to the serial reader
     IngestHooks hooks;
+    hooks.packed = ctx->packed_input;
+    auto host_batch = [](const PinnedBatch& b) {
+        Mapper::HostBatch hb;
+        hb.bases = b.bases;
+        hb.offsets = b.offsets;
+        hb.n_reads = b.n_reads;
+        hb.packed = b.packed;
+        hb.npos = b.npos;
+        hb.n_npos = b.n_npos;
+        return hb;
+    };
     // page-locked ingest blocks are kept by the process between calls and contexts (PinPool)
     hooks.alloc = [](size_t n) -> void* { return PinPool::get().take(n); };
     hooks.release = [](void* p) { PinPool::get().give_back(p); };
@@ -378,7 +391,7 @@ int drprg_hip_map_fastx(drprg_hip_ctx* ctx, const char* reads_path)
     auto mapper_of = [&](size_t d) -> Mapper& { return d == 0 ? m : *ctx->extra[d - 1]; };
     if (ndev == 1) {
         // (the copy of a block overlaps the kernels of the block before it: Mapper::map_host_async)
-        hooks.submit = [&](const PinnedBatch& b) { m.map_host_async(b.bases, b.offsets, b.n_reads); };
+        hooks.submit = [&](const PinnedBatch& b) { m.map_host_async(host_batch(b)); };
     } else {
         hooks.concurrent_submit = true;
         hooks.submit = [&](const PinnedBatch& b) {
@@ -387,11 +400,11 @@ int drprg_hip_map_fastx(drprg_hip_ctx* ctx, const char* reads_path)
                 const size_t d = (first + i) % ndev;
                 std::unique_lock<std::mutex> l(dev_mu[d], std::try_to_lock);
                 if (!l.owns_lock()) continue;
-                mapper_of(d).map_host_async(b.bases, b.offsets, b.n_reads);
+                mapper_of(d).map_host_async(host_batch(b));
                 return;
             }
             std::lock_guard<std::mutex> l(dev_mu[first]); // all busy: wait for the round-robin choice
-            mapper_of(first).map_host_async(b.bases, b.offsets, b.n_reads);
+            mapper_of(first).map_host_async(host_batch(b));
         };
     }
     // the coverage vectors of the other devices are summed into device 0 ON THE DEVICE (drprg_hip_reduce: one RCCL reduce over
@@ -435,6 +448,92 @@ int drprg_hip_map_host(drprg_hip_ctx* ctx, const uint8_t* bases, const uint64_t*
         ctx->total_bases += offsets[n_reads];
     }
     ctx->host_coverage_valid = false;
+    API_END(ctx)
+}
+
+// ---- 2-bit packed reads (SURVEY.md section 8f NEXT-4) ----
+int drprg_hip_set_input_format(drprg_hip_ctx* ctx, int packed)
+{
+    if (!ctx) return DRPRG_EINVAL;
+    ctx->packed_input = packed != 0;
+    return DRPRG_OK;
+}
+
+int drprg_hip_pack_reads(const uint8_t* bases, uint64_t n_bases, uint32_t* words, uint64_t* npos, uint64_t npos_cap, uint64_t* n_npos)
+{
+    if ((n_bases && (!bases || !words)) || !n_npos) return DRPRG_EINVAL;
+    try {
+        // (pack_append works on 64-bit words and writes one word past the last base: through a buffer of its own)
+        std::vector<uint64_t> w64(n_bases / 32 + 2, 0);
+        std::vector<uint64_t> np;
+        uint64_t n = 0;
+        if (n_bases) pack_append(w64.data(), n, reinterpret_cast<const char*>(bases), n_bases, np);
+        std::memcpy(words, w64.data(), (n_bases + 15) / 16 * sizeof(uint32_t));
+        *n_npos = np.size();
+        if (np.size() > npos_cap) return DRPRG_EOVERFLOW;
+        if (!np.empty()) {
+            if (!npos) return DRPRG_EINVAL;
+            std::memcpy(npos, np.data(), np.size() * sizeof(uint64_t));
+        }
+    } catch (const std::bad_alloc&) {
+        return DRPRG_ENOMEM;
+    }
+    return DRPRG_OK;
+}
+
+int drprg_hip_map_host_packed(drprg_hip_ctx* ctx, const uint32_t* words, const uint64_t* offsets, uint64_t n_reads, const uint64_t* npos, uint64_t n_npos)
+{
+    API_BEGIN(ctx)
+    if (n_reads && (!words || !offsets)) throw Error(DRPRG_EINVAL, "null buffer");
+    if (n_npos && !npos) throw Error(DRPRG_EINVAL, "n_npos > 0 without the positions");
+    Mapper& m = need_mapper(ctx);
+    if (n_reads) {
+        Mapper::HostBatch hb;
+        hb.bases = reinterpret_cast<const uint8_t*>(words);
+        hb.offsets = offsets;
+        hb.n_reads = n_reads;
+        hb.packed = true;
+        hb.npos = npos;
+        hb.n_npos = n_npos;
+        m.map_host(hb);
+        ctx->total_bases += offsets[n_reads];
+    }
+    ctx->host_coverage_valid = false;
+    API_END(ctx)
+}
+
+static int map_device_packed(drprg_hip_ctx* ctx, const void* d_words, const void* d_offsets, uint64_t n_reads, uint64_t n_bases, const void* d_npos,
+    uint64_t n_npos, void* d_covg, void* d_prg_reads, void* hip_stream, bool deferred)
+{
+    API_BEGIN(ctx)
+    Mapper& m = need_mapper(ctx);
+    m.map_device_packed((const uint32_t*)d_words, (const uint64_t*)d_offsets, n_reads, n_bases, (const uint64_t*)d_npos, n_npos, (uint32_t*)d_covg,
+        (uint32_t*)d_prg_reads, (hipStream_t)hip_stream, deferred);
+    ctx->total_bases += n_bases;
+    ctx->host_coverage_valid = false;
+    API_END(ctx)
+}
+
+int drprg_hip_map_device_packed(drprg_hip_ctx* ctx, const void* d_words, const void* d_offsets, uint64_t n_reads, uint64_t n_bases, const void* d_npos,
+    uint64_t n_npos, void* d_covg, void* d_prg_reads, void* hip_stream)
+{
+    return map_device_packed(ctx, d_words, d_offsets, n_reads, n_bases, d_npos, n_npos, d_covg, d_prg_reads, hip_stream, false);
+}
+
+int drprg_hip_map_device_packed_async(drprg_hip_ctx* ctx, const void* d_words, const void* d_offsets, uint64_t n_reads, uint64_t n_bases, const void* d_npos,
+    uint64_t n_npos, void* d_covg, void* d_prg_reads, void* hip_stream)
+{
+    return map_device_packed(ctx, d_words, d_offsets, n_reads, n_bases, d_npos, n_npos, d_covg, d_prg_reads, hip_stream, true);
+}
+
+int drprg_hip_pack_device(drprg_hip_ctx* ctx, const void* d_bases, uint64_t n_bases, void* d_words, void* d_npos, uint64_t npos_cap, uint64_t* n_npos,
+    void* hip_stream)
+{
+    API_BEGIN(ctx)
+    Mapper& m = need_mapper(ctx);
+    if (!n_npos) throw Error(DRPRG_EINVAL, "null n_npos");
+    *n_npos = m.pack_on_device((const uint8_t*)d_bases, n_bases, (uint32_t*)d_words, (uint64_t*)d_npos, npos_cap, (hipStream_t)hip_stream);
+    if (*n_npos > npos_cap) throw Error(DRPRG_EOVERFLOW, "more non-ACGT bases than the position buffer holds");
     API_END(ctx)
 }
 
@@ -1193,8 +1292,36 @@ extern "C" int drprg_hip_parse_fastx(const char* reads_path, int threads, uint64
             n_bases += offsets[n];
             ++batches;
         };
+        // DRPRG_PARSE_FORMAT (self-check of the packing ingest, no device needed): "normalized" = the digest of the ASCII blocks with every
+        // base upper-cased and every byte that is not ACGTacgt read as N; "packed" = the parser threads pack (IngestHooks::packed) and the
+        // digest is taken over what the packed block says (letters back to A C G T, N at the positions in npos): the two must be equal
+        const char* fmt = std::getenv("DRPRG_PARSE_FORMAT");
+        const bool packed = fmt && std::string(fmt) == "packed", normalized = fmt && std::string(fmt) == "normalized";
+        std::vector<uint8_t> tmp;
+        auto digest_any = [&](const PinnedBatch& b) {
+            if (!packed && !normalized) {
+                digest(b.bases, b.offsets, b.n_reads);
+                return;
+            }
+            tmp.resize(b.n_bases);
+            if (b.packed) {
+                const uint32_t* w = reinterpret_cast<const uint32_t*>(b.bases);
+                for (uint64_t i = 0; i < b.n_bases; ++i) tmp[i] = (uint8_t)"ACTG"[(w[i >> 4] >> (2 * (i & 15))) & 3u];
+                for (uint64_t i = 0; i < b.n_npos; ++i) {
+                    if (b.npos[i] >= b.n_bases || (i && b.npos[i] <= b.npos[i - 1])) throw Error(DRPRG_EIO, "packed block: positions not ascending");
+                    tmp[b.npos[i]] = 'N';
+                }
+            } else {
+                for (uint64_t i = 0; i < b.n_bases; ++i) {
+                    const uint8_t u = b.bases[i] & 0xDFu;
+                    tmp[i] = (u == 'A' || u == 'C' || u == 'G' || u == 'T') ? u : (uint8_t)'N';
+                }
+            }
+            digest(tmp.data(), b.offsets, b.n_reads);
+        };
         IngestHooks hooks;
-        hooks.submit = [&](const PinnedBatch& b) { digest(b.bases, b.offsets, b.n_reads); };
+        hooks.packed = packed;
+        hooks.submit = digest_any;
         out[4] = 0;
         try {
             out[4] = (uint64_t)ingest_fastx(reads_path, threads, hooks).gz_mode;

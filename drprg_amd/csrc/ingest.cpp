@@ -1,5 +1,6 @@
 // ingest.cpp -- see ingest.h
 #include "ingest.h"
+#include "pack.h"
 #include "pgunzip.h"
 #include <atomic>
 #include <chrono>
@@ -56,9 +57,21 @@ inline size_t block_bases_now()
 #define BLOCK_READS (BLOCK_BASES / 96) // ... and read capacity (flushed early when either fills up: reads under 96 bases)
 
 struct Block {
-    uint8_t* bases = nullptr;
+    uint8_t* bases = nullptr; // ASCII, or (packed) the 2-bit words, 8-byte aligned
     uint64_t* offsets = nullptr;
     uint64_t n_reads = 0, n_bases = 0;
+    bool packed = false;
+    std::vector<uint64_t> npos; // packed: positions of the bases that are not ACGTacgt
+    // the bases of one read (or one line of a multi-line record) behind what the block holds
+    inline void append(const char* seq, size_t len)
+    {
+        if (packed) {
+            pack_append(reinterpret_cast<uint64_t*>(bases), n_bases, seq, len, npos);
+        } else {
+            std::memcpy(bases + n_bases, seq, len);
+            n_bases += len;
+        }
+    }
     // the block is handed over once it holds this many bases: BLOCK_BASES, except for a worker's first hand-over, which comes
     // early and at a different fill for every worker -- otherwise all workers fill their first block at the same moment, the
     // copy engine idles until then and works through a burst afterwards (measured: 10 M x 150 bp, first copies at 67 of 95 ms)
@@ -92,6 +105,9 @@ struct Shared {
     {
         if (b.n_reads == 0) return;
         PinnedBatch pb { b.bases, b.offsets, b.n_reads, b.n_bases };
+        pb.packed = b.packed;
+        pb.npos = b.npos.data();
+        pb.n_npos = b.npos.size();
         const int64_t t0 = debug ? now_ns() : 0;
         if (debug) {
             int64_t none = -1;
@@ -112,16 +128,20 @@ struct Shared {
         batches += 1;
         b.n_reads = 0;
         b.n_bases = 0;
+        b.npos.clear();
+        if (b.packed) reinterpret_cast<uint64_t*>(b.bases)[0] = 0; // (pack_append: a fresh stream)
         b.flush_at = BLOCK_BASES;
     }
     Block new_block()
     {
         Block b;
-        const size_t bytes_b = BLOCK_BASES + 64, bytes_o = (BLOCK_READS + 2) * sizeof(uint64_t);
+        b.packed = hooks.packed;
+        const size_t bytes_b = (b.packed ? BLOCK_BASES / 4 + 16 : BLOCK_BASES) + 64, bytes_o = (BLOCK_READS + 2) * sizeof(uint64_t);
         b.bases = (uint8_t*)(hooks.alloc ? hooks.alloc(bytes_b) : std::malloc(bytes_b));
         b.offsets = (uint64_t*)(hooks.alloc ? hooks.alloc(bytes_o) : std::malloc(bytes_o));
         if (!b.bases || !b.offsets) throw Error(DRPRG_ENOMEM, "cannot allocate an ingest block");
         b.offsets[0] = 0;
+        if (b.packed) reinterpret_cast<uint64_t*>(b.bases)[0] = 0;
         // first hand-over: between 1/16 and 16/16 of a block, a different sixteenth for consecutive workers
         b.flush_at = BLOCK_BASES / 16 * (1 + (size_t)(first_flush.fetch_add(1) % 16));
         return b;
@@ -218,8 +238,7 @@ __attribute__((target("avx2"))) const char* parse_fastq_avx2(const char* p, cons
         const size_t len = (size_t)(s_stop - seq);
         if (len > BLOCK_BASES) return p;
         if (blk.n_bases + len > blk.flush_at || blk.n_reads + 1 > BLOCK_READS) sh.submit(blk);
-        std::memcpy(blk.bases + blk.n_bases, seq, len);
-        blk.n_bases += len;
+        blk.append(seq, len);
         blk.offsets[++blk.n_reads] = blk.n_bases;
         p = q_end + 1;
     }
@@ -256,8 +275,7 @@ void parse_slice(const char* p, const char* e, bool fastq, Block& blk, Shared& s
             const size_t len = (size_t)(s_stop - cursor);
             if (len > BLOCK_BASES) throw Error(DRPRG_EOVERFLOW, "a read is longer than the ingest block");
             if (blk.n_bases + len > blk.flush_at || blk.n_reads + 1 > BLOCK_READS) sh.submit(blk);
-            std::memcpy(blk.bases + blk.n_bases, cursor, len);
-            blk.n_bases += len;
+            blk.append(cursor, len);
             blk.offsets[++blk.n_reads] = blk.n_bases;
             p = q_end ? q_end + 1 : e;
         } else {
@@ -276,8 +294,7 @@ void parse_slice(const char* p, const char* e, bool fastq, Block& blk, Shared& s
                 const char* stop = nl ? nl : rec_end;
                 const char* next = nl ? nl + 1 : rec_end;
                 strip_cr(cursor, stop);
-                std::memcpy(blk.bases + blk.n_bases, cursor, (size_t)(stop - cursor));
-                blk.n_bases += (size_t)(stop - cursor);
+                blk.append(cursor, (size_t)(stop - cursor));
                 cursor = next;
             }
             blk.offsets[++blk.n_reads] = blk.n_bases;

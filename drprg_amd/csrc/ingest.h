@@ -11,9 +11,12 @@
 namespace drprg {
 
 struct PinnedBatch {
-    uint8_t* bases = nullptr;
-    uint64_t* offsets = nullptr; // offsets[0] == 0
+    uint8_t* bases = nullptr;    // ASCII; packed: the 2-bit words (pack.h), 16 bases per u32
+    uint64_t* offsets = nullptr; // offsets[0] == 0 (in bases, whatever the format)
     uint64_t n_reads = 0, n_bases = 0;
+    bool packed = false;
+    const uint64_t* npos = nullptr; // packed: ascending positions of the bases that are not ACGTacgt (pageable memory)
+    uint64_t n_npos = 0;
 };
 
 struct IngestHooks {
@@ -21,6 +24,8 @@ struct IngestHooks {
     std::function<void(void*)> release;
     std::function<void(const PinnedBatch&)> submit; // called by one thread at a time ...
     bool concurrent_submit = false;                 // ... unless set: then by any parser thread, and submit does its own locking
+    bool packed = false;                            // the parser threads pack the bases to 2 bits as they copy them (pack.h): a block is a
+                                                    // quarter of the bytes to page-lock and to move over PCIe
 };
 
 struct IngestStats {

@@ -36,11 +36,20 @@ DRPRG_HD inline uint32_t pbloom_word(uint32_t m, uint32_t wbits) { return m >> (
 DRPRG_HD inline uint32_t pbloom_bits(uint32_t m) { return (1u << (m & 31)) | (1u << ((m >> 5) & 31)); }
 
 struct SketchArgs {
-    const uint8_t* bases;    // 16-byte aligned
-    const uint64_t* offsets; // n_reads + 1
+    const uint8_t* bases;    // 16-byte aligned.  packed != 0: the same pointer is u32 words[ceil(n_bases / 16)], 2 bits per base
+    const uint64_t* offsets; // n_reads + 1 (in bases, whatever the format)
     uint64_t n_bases;
     uint32_t n_reads;
     int w, k, halo;
+    // 2-bit packed reads (SURVEY.md section 8f NEXT-4; include/drprg_hip.h "packed reads"): base i of the batch is bits
+    // [2 (i & 15) + 1 : 2 (i & 15)] of word i >> 4, letter = bits 2:1 of its ASCII code (A 0, C 1, T 2, G 3 -- the alphabet of the
+    // filter's k-mer codes, sketch_filter.hip pack16le -- for ANY byte, so that both formats give the filter the same codes);
+    // npos: the ascending positions of the bases that are not one of ACGTacgt (they poison every k-mer that holds them, exactly
+    // as in the ASCII form).  Only the kernels of the filtered sequence read this form; every other consumer of bases gets an
+    // ASCII copy made on the device (launch_unpack).
+    int packed;
+    const uint64_t* npos;
+    uint64_t n_npos;
     // index
     const void* slot_key; // u32[2^bits] (k <= 15) or u64[2^bits]
     const uint2* slot_rec; // {record offset, record count}; count 0 = empty slot
@@ -253,6 +262,14 @@ hipError_t launch_cluster_flags(const uint64_t* key, uint32_t n, int max_diff, u
 hipError_t launch_cluster_starts(const uint32_t* head, const uint32_t* scan, uint32_t n, uint32_t* cstart, hipStream_t stream);
 hipError_t launch_cluster_pipeline(const ClusterArgs& a, uint32_t n_hits, uint32_t n_prgs, hipStream_t stream);
 hipError_t launch_vector_add_u32(uint32_t* dst, const uint32_t* src, uint64_t n, hipStream_t stream); // dst[i] += src[i]
+// packed.hip: 2-bit packed reads -> ASCII (A C G T, 'N' at the positions in npos and in the 64 bytes behind the last base): what the
+// direct sketch kernels and the anchor scan read.  out: n_bases + 64 bytes, 16-byte aligned.
+hipError_t launch_unpack(const uint32_t* words, uint64_t n_bases, const uint64_t* npos, uint64_t n_npos, uint8_t* out, hipStream_t stream);
+// ... and ASCII -> packed on the device (harnesses: bench.py packs its synthetic batch with it).  words: ceil(n_bases / 16); npos: room
+// for npos_cap positions, *n_npos (zeroed by the caller) counts all of them (more than npos_cap: overflow); positions come out
+// unordered: sort them before use.
+hipError_t launch_pack(const uint8_t* bases, uint64_t n_bases, uint32_t* words, uint64_t* npos, uint64_t npos_cap, unsigned long long* n_npos,
+    hipStream_t stream);
 
 // anchor_scan.hip: reads of a resident batch that hold one of the (sorted) anchor k-mers of length A -- every such read once,
 // in any order, appended to `list` (count keeps counting past list_cap).  prefilter: 2^16 bits, bit (kmer & 0xFFFF) set for every

@@ -183,6 +183,8 @@ Mapper::~Mapper()
     dfree(d_slot_rec_); dfree(d_slot_first_); dfree(d_rec_knode_); dfree(d_rec_prg_); dfree(d_min_path_len_); dfree(d_prg_thr_);
     if (d_slot_key_) (void)hipFree(d_slot_key_);
     dfree(d_covg_); d_prg_reads_ = nullptr; dfree(d_counters_);
+    for (int i = 0; i < 3; ++i) dfree(d_unpacked_[i]);
+    dfree(d_npos_);
     dfree(d_key_a_); dfree(d_key_b_); dfree(d_val_a_); dfree(d_val_b_);
     dfree(d_head_); dfree(d_scan_); dfree(d_cstart_); dfree(d_order_); dfree(d_clusters_);
     if (d_temp_) (void)hipFree(d_temp_);
@@ -190,7 +192,7 @@ Mapper::~Mapper()
     dfree(d_bases_); dfree(d_offsets_); dfree(d_bloom_); dfree(d_bloom0_); dfree(d_bloom0f_); dfree(d_bloomr_); dfree(d_pbloom_); dfree(d_mid0_); dfree(d_mid_bitmap_); dfree(d_midc_); dfree(d_ft_stat_);
     for (Lane& lane : lanes_) free_lane(lane);
     for (Stage& st : stage_) {
-        dfree(st.d_bases); dfree(st.d_offsets);
+        dfree(st.d_bases); dfree(st.d_offsets); dfree(st.d_npos);
         if (st.copied) (void)hipEventDestroy(st.copied);
     }
     dfree(d_peer_tmp_);
@@ -491,7 +493,29 @@ dev::SketchArgs Mapper::sketch_args(const uint8_t* d_bases, const uint64_t* d_of
     a.n_hits = &d_counters_[C_HITS];
     a.n_minimizers = &d_counters_[C_MINIMIZERS];
     a.overflow = reinterpret_cast<uint32_t*>(&d_counters_[C_OVERFLOW]);
+    const auto it = packed_.find(d_bases);
+    if (it != packed_.end()) {
+        a.packed = 1;
+        a.npos = it->second.d_npos;
+        a.n_npos = it->second.n_npos;
+    }
     return a;
+}
+
+const uint8_t* Mapper::ascii_view(int slot, const uint8_t* d_bases, uint64_t n_bases, hipStream_t stream)
+{
+    const auto it = packed_.find(d_bases);
+    if (it == packed_.end()) return d_bases;
+    const uint64_t need = (n_bases + 15) / 16 * 16 + 64;
+    if (need > unpacked_cap_[slot]) {
+        sync(); // (a batch in flight may still read the old buffer)
+        HIPCHK(hipStreamSynchronize(stream));
+        dfree(d_unpacked_[slot]);
+        unpacked_cap_[slot] = need + need / 4;
+        dmalloc(d_unpacked_[slot], unpacked_cap_[slot]);
+    }
+    HIPCHK(dev::launch_unpack(reinterpret_cast<const uint32_t*>(d_bases), n_bases, it->second.d_npos, it->second.n_npos, d_unpacked_[slot], stream));
+    return d_unpacked_[slot];
 }
 
 void Mapper::read_counters(hipStream_t stream)
@@ -600,7 +624,8 @@ void Mapper::direct_launch(int set, const uint8_t* d_bases, const uint64_t* d_of
     if (!lane.scratch_zero) HIPCHK(hipMemsetAsync(lane.d_scratch, 0, L_N * sizeof(unsigned long long), stream));
     lane.scratch_zero = false;
     HIPCHK(hipMemsetAsync(t.d_tile_count + n_tiles, 0, sizeof(uint32_t), stream)); // the scan's closing zero
-    dev::SketchArgs a = sketch_args(d_bases, d_offsets, n_reads, n_bases);
+    // (a packed batch: the direct sketch kernels read its ASCII expansion, made here on the same stream -- packed.hip)
+    dev::SketchArgs a = sketch_args(ascii_view(set, d_bases, n_bases, stream), d_offsets, n_reads, n_bases);
     a.n_hits = &lane.d_scratch[L_HITS];
     a.n_minimizers = &lane.d_scratch[L_MINIMIZERS];
     a.overflow = reinterpret_cast<uint32_t*>(&lane.d_scratch[L_OVERFLOW]);
@@ -737,11 +762,18 @@ void Mapper::finish_lane(Lane& lane, const uint8_t* d_bases, const uint64_t* d_o
 void Mapper::map_device_async(const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n_reads, uint64_t n_bases, uint32_t* covg,
     uint32_t* prg_reads, hipStream_t stream)
 {
+    packed_.erase(d_bases);
+    map_device_async_impl(d_bases, d_offsets, n_reads, n_bases, covg, prg_reads, stream);
+}
+
+void Mapper::map_device_async_impl(const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n_reads, uint64_t n_bases, uint32_t* covg,
+    uint32_t* prg_reads, hipStream_t stream)
+{
     if (n_reads == 0) return;
     const bool deferred_filter = use_filter_ && max_lanes_ == 1;
     const bool deferred_direct = !use_filter_ && use_direct_cands_ && !fuse_in_kernel_;
     if ((!deferred_filter && !deferred_direct) || n_bases == 0) { // (no deferred form of the other sequences: the batch is complete on return,
-        map_device(d_bases, d_offsets, n_reads, n_bases, covg, prg_reads, stream); // including what its tail queued for the leftover reads)
+        map_device_impl(d_bases, d_offsets, n_reads, n_bases, covg, prg_reads, stream); // including what its tail queued for the leftover reads)
         HIPCHK(hipSetDevice(device_));
         wait_stream(stream ? stream : stream_);
         return;
@@ -951,10 +983,11 @@ void Mapper::run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32
         ts_->first_cap = n_tiles + n_tiles / 4 + 16;
         dmalloc(ts_->d_tile_first, (size_t)ts_->first_cap);
     }
+    const uint8_t* const ascii = ascii_view(2, d_bases, n_bases, stream); // (a packed batch: expanded on the device for this kernel)
     for (int attempt = 0;; ++attempt) {
         HIPCHK(hipMemsetAsync(&d_counters_[C_HITS], 0, 2 * sizeof(unsigned long long), stream)); // hits + minimizers of this attempt
         HIPCHK(hipMemsetAsync(&d_counters_[C_OVERFLOW], 0, sizeof(unsigned long long), stream));
-        const dev::SketchArgs a = sketch_args(d_bases, d_offsets, n_reads, n_bases);
+        const dev::SketchArgs a = sketch_args(ascii, d_offsets, n_reads, n_bases);
         HIPCHK(dev::launch_sketch_probe(a, wide_hash_, stream, timer));
         read_counters(stream);
         note_kernel_time();
@@ -975,6 +1008,23 @@ void Mapper::run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32
 void Mapper::map_device(const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n_reads, uint64_t n_bases,
     uint32_t* covg, uint32_t* prg_reads, hipStream_t stream)
 {
+    packed_.erase(d_bases); // (an ASCII batch: whatever packed batch lived at this address before is gone)
+    map_device_impl(d_bases, d_offsets, n_reads, n_bases, covg, prg_reads, stream);
+}
+
+void Mapper::map_device_packed(const uint32_t* d_words, const uint64_t* d_offsets, uint64_t n_reads, uint64_t n_bases, const uint64_t* d_npos, uint64_t n_npos,
+    uint32_t* covg, uint32_t* prg_reads, hipStream_t stream, bool deferred)
+{
+    if (n_npos && !d_npos) throw Error(DRPRG_EINVAL, "n_npos > 0 without the positions");
+    const uint8_t* key = reinterpret_cast<const uint8_t*>(d_words);
+    packed_[key] = PackedInfo { d_npos, n_npos };
+    if (deferred) map_device_async_impl(key, d_offsets, n_reads, n_bases, covg, prg_reads, stream);
+    else map_device_impl(key, d_offsets, n_reads, n_bases, covg, prg_reads, stream);
+}
+
+void Mapper::map_device_impl(const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n_reads, uint64_t n_bases,
+    uint32_t* covg, uint32_t* prg_reads, hipStream_t stream)
+{
     if (n_reads == 0) return;
     if (!d_bases || !d_offsets) throw Error(DRPRG_EINVAL, "null device pointer");
     if ((reinterpret_cast<uintptr_t>(d_bases) & 15u) != 0) throw Error(DRPRG_EINVAL, "d_bases must be 16-byte aligned");
@@ -991,14 +1041,24 @@ void Mapper::map_device(const uint8_t* d_bases, const uint64_t* d_offsets, uint6
 
 void Mapper::map_host(const uint8_t* bases, const uint64_t* offsets, uint64_t n_reads)
 {
+    HostBatch b;
+    b.bases = bases;
+    b.offsets = offsets;
+    b.n_reads = n_reads;
+    map_host(b);
+}
+
+void Mapper::map_host(const HostBatch& b)
+{
+    const uint64_t n_reads = b.n_reads;
     if (n_reads == 0) return;
     sync();
     HIPCHK(hipSetDevice(device_));
-    if (offsets[0] != 0) throw Error(DRPRG_EINVAL, "offsets[0] must be 0");
-    const uint64_t n_bases = offsets[n_reads];
-    if (n_bases + 64 > stage_bases_cap_) {
+    if (b.offsets[0] != 0) throw Error(DRPRG_EINVAL, "offsets[0] must be 0");
+    const uint64_t n_bases = b.n_bases(), bytes = b.payload_bytes();
+    if (bytes + 64 > stage_bases_cap_) {
         dfree(d_bases_);
-        stage_bases_cap_ = n_bases + n_bases / 4 + 64;
+        stage_bases_cap_ = bytes + bytes / 4 + 64;
         dmalloc(d_bases_, stage_bases_cap_);
     }
     if (n_reads + 1 > stage_reads_cap_) {
@@ -1006,10 +1066,45 @@ void Mapper::map_host(const uint8_t* bases, const uint64_t* offsets, uint64_t n_
         stage_reads_cap_ = n_reads + n_reads / 4 + 1;
         dmalloc(d_offsets_, stage_reads_cap_);
     }
-    HIPCHK(hipMemcpyAsync(d_bases_, bases, n_bases, hipMemcpyHostToDevice, stream_));
-    HIPCHK(hipMemcpyAsync(d_offsets_, offsets, (n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream_));
-    map_device(d_bases_, d_offsets_, n_reads, n_bases, nullptr, nullptr, stream_);
+    if (b.packed && b.n_npos > stage_npos_cap_) {
+        dfree(d_npos_);
+        stage_npos_cap_ = b.n_npos + b.n_npos / 4 + 16;
+        dmalloc(d_npos_, stage_npos_cap_);
+    }
+    HIPCHK(hipMemcpyAsync(d_bases_, b.bases, bytes, hipMemcpyHostToDevice, stream_));
+    HIPCHK(hipMemcpyAsync(d_offsets_, b.offsets, (n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream_));
+    if (b.packed) {
+        if (b.n_npos) HIPCHK(hipMemcpyAsync(d_npos_, b.npos, b.n_npos * sizeof(uint64_t), hipMemcpyHostToDevice, stream_));
+        map_device_packed(reinterpret_cast<const uint32_t*>(d_bases_), d_offsets_, n_reads, n_bases, b.n_npos ? d_npos_ : nullptr, b.n_npos, nullptr, nullptr, stream_,
+            false);
+    } else {
+        map_device(d_bases_, d_offsets_, n_reads, n_bases, nullptr, nullptr, stream_);
+    }
     HIPCHK(hipStreamSynchronize(stream_)); // the staging buffers are reused by the next call
+}
+
+uint64_t Mapper::pack_on_device(const uint8_t* d_bases, uint64_t n_bases, uint32_t* d_words, uint64_t* d_npos, uint64_t npos_cap, hipStream_t stream)
+{
+    HIPCHK(hipSetDevice(device_));
+    if (!stream) stream = stream_;
+    if (n_bases == 0) return 0;
+    if (!d_bases || !d_words) throw Error(DRPRG_EINVAL, "null device pointer");
+    unsigned long long* d_n = nullptr;
+    HIPCHK(hipMalloc((void**)&d_n, sizeof(unsigned long long)));
+    unsigned long long n = 0;
+    hipError_t e = hipMemsetAsync(d_n, 0, sizeof(unsigned long long), stream);
+    if (e == hipSuccess) e = dev::launch_pack(d_bases, n_bases, d_words, d_npos, d_npos ? npos_cap : 0, d_n, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&n, d_n, sizeof n, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipFree(d_n);
+    HIPCHK(e);
+    if (n > 1 && n <= npos_cap) { // the positions come out in any order: sorted on the host (few; the harness path)
+        std::vector<uint64_t> h(n);
+        HIPCHK(hipMemcpy(h.data(), d_npos, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        std::sort(h.begin(), h.end());
+        HIPCHK(hipMemcpy(d_npos, h.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice));
+    }
+    return n;
 }
 
 void* Mapper::arena_take(size_t bytes)
@@ -1065,7 +1160,8 @@ uint64_t Mapper::map_kept_from(const Mapper& other)
     if (!other.kept_complete()) throw Error(DRPRG_ENODATA, "the other context does not hold all of its reads");
     uint64_t n = 0;
     for (const KeptBatch& b : other.kept_) {
-        map_device_async(b.d_bases, b.d_offsets, b.n_reads, b.n_bases, nullptr, nullptr, stream_);
+        if (b.packed) map_device_packed(reinterpret_cast<const uint32_t*>(b.d_bases), b.d_offsets, b.n_reads, b.n_bases, b.d_npos, b.n_npos, nullptr, nullptr, stream_, true);
+        else map_device_async(b.d_bases, b.d_offsets, b.n_reads, b.n_bases, nullptr, nullptr, stream_);
         n += b.n_reads;
     }
     sync();
@@ -1113,10 +1209,30 @@ void Mapper::select_reads_with_anchors(std::vector<uint64_t> anchors, uint32_t A
     HIPCHK(hipMemcpyAsync(d_anchors, anchors.data(), anchors.size() * sizeof(uint64_t), hipMemcpyHostToDevice, stream_));
     HIPCHK(hipMemcpyAsync(d_pf, pf.data(), pf.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
     HIPCHK(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), stream_));
+    // batches kept in the packed form: the scan and the gather read an ASCII expansion, made here for the duration of this call
+    // (all of them at once: the selected reads are gathered after the last scan)
+    std::vector<const uint8_t*> ascii(kept_.size(), nullptr);
+    {
+        uint64_t need = 0;
+        for (const KeptBatch& kb : kept_)
+            if (kb.packed) need += (kb.n_bases + 15) / 16 * 16 + 64;
+        uint8_t* d_ascii = need ? static_cast<uint8_t*>(scratch.get(need)) : nullptr;
+        uint64_t at = 0;
+        for (size_t b = 0; b < kept_.size(); ++b) {
+            const KeptBatch& kb = kept_[b];
+            if (!kb.packed) {
+                ascii[b] = kb.d_bases;
+                continue;
+            }
+            HIPCHK(dev::launch_unpack(reinterpret_cast<const uint32_t*>(kb.d_bases), kb.n_bases, kb.d_npos, kb.n_npos, d_ascii + at, stream_));
+            ascii[b] = d_ascii + at;
+            at += (kb.n_bases + 15) / 16 * 16 + 64;
+        }
+    }
     for (size_t b = 0; b < kept_.size(); ++b) {
         const KeptBatch& kb = kept_[b];
         HIPCHK(hipMemsetAsync(d_flags, 0, kb.n_reads * sizeof(uint32_t), stream_));
-        HIPCHK(dev::launch_anchor_scan(kb.d_bases, kb.d_offsets, (uint32_t)kb.n_reads, kb.n_bases, d_anchors, (uint32_t)anchors.size(), A, d_pf, (uint32_t)b,
+        HIPCHK(dev::launch_anchor_scan(ascii[b], kb.d_offsets, (uint32_t)kb.n_reads, kb.n_bases, d_anchors, (uint32_t)anchors.size(), A, d_pf, (uint32_t)b,
             d_flags, d_count, d_list, total_reads, n_cus_, stream_));
     }
     unsigned long long count = 0;
@@ -1130,7 +1246,7 @@ void Mapper::select_reads_with_anchors(std::vector<uint64_t> anchors, uint32_t A
     std::vector<dev::GatherEntry> table(count);
     uint64_t at = 0;
     for (size_t i = 0; i < count; ++i) {
-        table[i].src = kept_[list[i].batch].d_bases + list[i].offset;
+        table[i].src = ascii[list[i].batch] + list[i].offset;
         table[i].dst = at;
         table[i].len = list[i].len;
         table[i].pad = 0;
@@ -1149,29 +1265,47 @@ void Mapper::select_reads_with_anchors(std::vector<uint64_t> anchors, uint32_t A
 
 void Mapper::map_host_async(const uint8_t* bases, const uint64_t* offsets, uint64_t n_reads)
 {
+    HostBatch b;
+    b.bases = bases;
+    b.offsets = offsets;
+    b.n_reads = n_reads;
+    map_host_async(b);
+}
+
+void Mapper::map_host_async(const HostBatch& hb)
+{
+    const uint64_t n_reads = hb.n_reads;
+    const uint64_t* offsets = hb.offsets;
     if (n_reads == 0) return;
     if (kept_cap_ && !kept_broken_) {
         // the block goes into device memory of its own and stays there
         HIPCHK(hipSetDevice(device_));
         if (offsets[0] != 0) throw Error(DRPRG_EINVAL, "offsets[0] must be 0");
-        const uint64_t n_bases = offsets[n_reads];
-        uint8_t* db = n_bases ? static_cast<uint8_t*>(arena_take(n_bases + 64)) : nullptr;
+        const uint64_t n_bases = hb.n_bases(), bytes = hb.payload_bytes();
+        uint8_t* db = n_bases ? static_cast<uint8_t*>(arena_take(bytes + 64)) : nullptr;
         uint64_t* doff = n_bases && db ? static_cast<uint64_t*>(arena_take((n_reads + 1) * sizeof(uint64_t))) : nullptr;
+        uint64_t* dnp = n_bases && doff && hb.packed && hb.n_npos ? static_cast<uint64_t*>(arena_take(hb.n_npos * sizeof(uint64_t))) : nullptr;
         if (n_bases == 0) {
             tot_reads_ += n_reads; // (only empty reads: nothing to keep)
             return;
         }
-        if (db && doff) {
+        if (db && doff && (dnp || !(hb.packed && hb.n_npos))) {
             if (!copy_stream_) HIPCHK(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
             if (!kept_copied_) HIPCHK(hipEventCreateWithFlags(&kept_copied_, hipEventDisableTiming));
-            HIPCHK(hipMemcpyAsync(db, bases, n_bases, hipMemcpyHostToDevice, copy_stream_));
+            HIPCHK(hipMemcpyAsync(db, hb.bases, bytes, hipMemcpyHostToDevice, copy_stream_));
             HIPCHK(hipMemcpyAsync(doff, offsets, (n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, copy_stream_));
+            if (dnp) HIPCHK(hipMemcpyAsync(dnp, hb.npos, hb.n_npos * sizeof(uint64_t), hipMemcpyHostToDevice, copy_stream_));
             HIPCHK(hipEventRecord(kept_copied_, copy_stream_));
             HIPCHK(hipStreamWaitEvent(stream_, kept_copied_, 0));
-            kept_.push_back(KeptBatch { db, doff, n_reads, n_bases });
+            KeptBatch kb { db, doff, n_reads, n_bases };
+            kb.packed = hb.packed;
+            kb.d_npos = dnp;
+            kb.n_npos = hb.packed ? hb.n_npos : 0;
+            kept_.push_back(kb);
             in_keep_call_ = true;
             try {
-                map_device_async(db, doff, n_reads, n_bases, nullptr, nullptr, stream_);
+                if (hb.packed) map_device_packed(reinterpret_cast<const uint32_t*>(db), doff, n_reads, n_bases, dnp, kb.n_npos, nullptr, nullptr, stream_, true);
+                else map_device_async(db, doff, n_reads, n_bases, nullptr, nullptr, stream_);
             } catch (...) {
                 in_keep_call_ = false;
                 throw;
@@ -1187,12 +1321,12 @@ void Mapper::map_host_async(const uint8_t* bases, const uint64_t* offsets, uint6
         kept_broken_ = true;
     }
     if (!use_filter_ || max_lanes_ > 1) { // no deferred form of this sequence
-        map_host(bases, offsets, n_reads);
+        map_host(hb);
         return;
     }
     HIPCHK(hipSetDevice(device_));
     if (offsets[0] != 0) throw Error(DRPRG_EINVAL, "offsets[0] must be 0");
-    const uint64_t n_bases = offsets[n_reads];
+    const uint64_t n_bases = hb.n_bases(), bytes = hb.payload_bytes();
     if (n_bases == 0) { // only empty reads: nothing to copy, nothing to map (the counters still see them)
         tot_reads_ += n_reads;
         return;
@@ -1203,10 +1337,10 @@ void Mapper::map_host_async(const uint8_t* bases, const uint64_t* offsets, uint6
     Stage& st = stage_[stage_next_];
     stage_next_ ^= 1;
     if (!st.copied) HIPCHK(hipEventCreateWithFlags(&st.copied, hipEventDisableTiming));
-    if (n_bases + 64 > st.bases_cap) {
+    if (bytes + 64 > st.bases_cap) {
         sync(); // (freeing device memory waits for the device; be explicit about the batch in flight)
         dfree(st.d_bases);
-        st.bases_cap = n_bases + n_bases / 4 + 64;
+        st.bases_cap = bytes + bytes / 4 + 64;
         dmalloc(st.d_bases, st.bases_cap);
     }
     if (n_reads + 1 > st.reads_cap) {
@@ -1215,11 +1349,20 @@ void Mapper::map_host_async(const uint8_t* bases, const uint64_t* offsets, uint6
         st.reads_cap = n_reads + n_reads / 4 + 1;
         dmalloc(st.d_offsets, st.reads_cap);
     }
-    HIPCHK(hipMemcpyAsync(st.d_bases, bases, n_bases, hipMemcpyHostToDevice, copy_stream_));
+    if (hb.packed && hb.n_npos > st.npos_cap) {
+        sync();
+        dfree(st.d_npos);
+        st.npos_cap = hb.n_npos + hb.n_npos / 4 + 16;
+        dmalloc(st.d_npos, st.npos_cap);
+    }
+    HIPCHK(hipMemcpyAsync(st.d_bases, hb.bases, bytes, hipMemcpyHostToDevice, copy_stream_));
     HIPCHK(hipMemcpyAsync(st.d_offsets, offsets, (n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, copy_stream_));
+    if (hb.packed && hb.n_npos) HIPCHK(hipMemcpyAsync(st.d_npos, hb.npos, hb.n_npos * sizeof(uint64_t), hipMemcpyHostToDevice, copy_stream_));
     HIPCHK(hipEventRecord(st.copied, copy_stream_));
     HIPCHK(hipStreamWaitEvent(stream_, st.copied, 0));
-    map_device_async(st.d_bases, st.d_offsets, n_reads, n_bases, nullptr, nullptr, stream_);
+    if (hb.packed) map_device_packed(reinterpret_cast<const uint32_t*>(st.d_bases), st.d_offsets, n_reads, n_bases, hb.n_npos ? st.d_npos : nullptr, hb.n_npos, nullptr,
+        nullptr, stream_, true);
+    else map_device_async(st.d_bases, st.d_offsets, n_reads, n_bases, nullptr, nullptr, stream_);
     HIPCHK(hipEventSynchronize(st.copied)); // the caller's block is free again; the kernels run on
 }
 

@@ -6,6 +6,7 @@
 #pragma once
 #include "index.h"
 #include "kernels.h"
+#include <unordered_map>
 #include <vector>
 
 namespace drprg {
@@ -47,6 +48,11 @@ public:
     void map_device_async(const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n_reads, uint64_t n_bases,
         uint32_t* d_covg, uint32_t* d_prg_reads, hipStream_t stream);
     void sync(); // completes the batch map_device_async left in flight and waits for its stream
+    // The same two entries for a batch in the 2-bit packed form (kernels.h SketchArgs::packed): d_words = u32[ceil(n_bases / 16)], 8-byte
+    // aligned; d_npos = the n_npos ascending positions of the bases that are not ACGTacgt (may be null when n_npos == 0).  The filtered
+    // sequence reads the words directly; the direct sequences get an ASCII expansion made on the device (packed.hip).
+    void map_device_packed(const uint32_t* d_words, const uint64_t* d_offsets, uint64_t n_reads, uint64_t n_bases, const uint64_t* d_npos, uint64_t n_npos,
+        uint32_t* d_covg, uint32_t* d_prg_reads, hipStream_t stream, bool deferred);
 
     // Map a host batch (copies through pinned staging buffers, then map_device on the own accumulators).
     void map_host(const uint8_t* bases, const uint64_t* offsets, uint64_t n_reads);
@@ -55,15 +61,34 @@ public:
     // may be reused then -- so that the next block's copy overlaps this block's kernels.  sync() (or anything that reads
     // results) completes what is in flight.  Sequences without a deferred form fall back to map_host.
     void map_host_async(const uint8_t* bases, const uint64_t* offsets, uint64_t n_reads);
+    // ASCII -> packed on the device (harnesses: bench.py packs its synthetic batch; tests).  Returns the number of non-ACGT bases; their
+    // positions are in d_npos, ascending, if there are at most npos_cap of them.  Synchronises `stream`.
+    uint64_t pack_on_device(const uint8_t* d_bases, uint64_t n_bases, uint32_t* d_words, uint64_t* d_npos, uint64_t npos_cap, hipStream_t stream);
+    // a host batch in either form (packed: `bases` points at the words, npos / n_npos as above, in host memory)
+    struct HostBatch {
+        const uint8_t* bases = nullptr;
+        const uint64_t* offsets = nullptr;
+        uint64_t n_reads = 0;
+        bool packed = false;
+        const uint64_t* npos = nullptr;
+        uint64_t n_npos = 0;
+        uint64_t n_bases() const { return offsets[n_reads]; }
+        uint64_t payload_bytes() const { return packed ? ((n_bases() + 15) / 16) * 4 : n_bases(); }
+    };
+    void map_host(const HostBatch& b);
+    void map_host_async(const HostBatch& b);
     // Reads that stay in HBM (off by default).  keep_reads(max_bytes > 0): from now on map_host_async copies every block into
     // device memory of its own instead of a staging set and leaves it there -- at most max_bytes of it; one byte more and
     // everything kept is dropped and the staging sets are back.  kept_complete(): every read mapped since keep_reads() /
     // reset_coverage() is among kept().  What they are for: select_reads_with_anchors below (the pile-up of `discover` without a
     // second pass over the file) and mapping the same reads again against another index (map_kept_from).
     struct KeptBatch {
-        const uint8_t* d_bases;
+        const uint8_t* d_bases; // (packed: the words)
         const uint64_t* d_offsets;
         uint64_t n_reads, n_bases;
+        bool packed = false;
+        const uint64_t* d_npos = nullptr;
+        uint64_t n_npos = 0;
     };
     void keep_reads(uint64_t max_bytes);
     bool kept_complete() const { return kept_cap_ > 0 && !kept_broken_; }
@@ -138,6 +163,23 @@ private:
     void cluster_hits(const uint64_t* d_offsets, uint32_t n_hits, bool ordered, unsigned long long* d_unsorted, uint32_t* d_covg,
         uint32_t* d_prg_reads, hipStream_t stream);
     dev::SketchArgs sketch_args(const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads, uint64_t n_bases) const;
+    // Batches in the packed form are known by their device address (the launch sequences pass the batch pointer through a dozen
+    // functions and keep it for re-runs: the address is the one thing all of them have).  An ASCII batch at the same address takes
+    // the entry out again.
+    struct PackedInfo {
+        const uint64_t* d_npos;
+        uint64_t n_npos;
+    };
+    std::unordered_map<const void*, PackedInfo> packed_;
+    // d_bases itself, or -- for a packed batch -- its ASCII expansion in scratch buffer `slot` (0 / 1: the two tile sets of the direct
+    // sequence's candidate form, 2: the generic sequence), made on `stream`
+    const uint8_t* ascii_view(int slot, const uint8_t* d_bases, uint64_t n_bases, hipStream_t stream);
+    uint8_t* d_unpacked_[3] = { nullptr, nullptr, nullptr };
+    uint64_t unpacked_cap_[3] = { 0, 0, 0 };
+    void map_device_impl(const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n_reads, uint64_t n_bases, uint32_t* d_covg, uint32_t* d_prg_reads,
+        hipStream_t stream);
+    void map_device_async_impl(const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n_reads, uint64_t n_bases, uint32_t* d_covg, uint32_t* d_prg_reads,
+        hipStream_t stream);
     void read_counters(hipStream_t stream);
     void note_kernel_time();
     // deferred completion: two lanes take the batches in turn; `pending_` is the batch whose read-back nobody has looked at yet
@@ -246,12 +288,14 @@ private:
     uint64_t* h_offsets_ = nullptr;
     uint8_t* d_bases_ = nullptr;
     uint64_t* d_offsets_ = nullptr;
-    uint64_t stage_bases_cap_ = 0, stage_reads_cap_ = 0;
+    uint64_t* d_npos_ = nullptr;
+    uint64_t stage_bases_cap_ = 0, stage_reads_cap_ = 0, stage_npos_cap_ = 0;
     // map_host_async: two staging sets taken in turn, their copies on a stream of their own
     struct Stage {
         uint8_t* d_bases = nullptr;
         uint64_t* d_offsets = nullptr;
-        uint64_t bases_cap = 0, reads_cap = 0;
+        uint64_t* d_npos = nullptr;
+        uint64_t bases_cap = 0, reads_cap = 0, npos_cap = 0;
         hipEvent_t copied = nullptr;
     };
     Stage stage_[2];

@@ -39,6 +39,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <string>
+#include <type_traits>
 
 namespace drprg {
 namespace dev {
@@ -105,7 +106,10 @@ __device__ __forceinline__ uint32_t canon12_dev(uint32_t x)
 // LDS-resident filter.  Level 0 is keyed on the canonical 12-mer; a group that passes it is looked up in the exact bitmap of the
 // canonical index 12-mers in global memory (2 MB: L2-resident; one exec-masked four-byte load per surviving group, all of a tile's
 // loads in flight together), and the second stage tests the four codes of a group against a one-word Bloom filter in global memory.
-template <bool SHORT_K, bool LEVEL0, bool FUSED = false, int MID = 0>
+// PACKED: the batch arrives as 2-bit packed words (SketchArgs::packed; the letters ARE the filter's alphabet): a lane's 32 positions
+// are the two words it loads -- 8 bytes instead of 32, no pack16le (eight v_and + eight v_dot4 + the merges per tile), a quarter of
+// the bytes from HBM.  Everything behind the two words is the same code, so both formats leave the same candidates.
+template <bool SHORT_K, bool LEVEL0, bool FUSED = false, int MID = 0, bool PACKED = false>
 __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a, FilterWork fw)
 {
     static_assert(!FUSED || LEVEL0, "the fused second stage belongs to the level-0 form");
@@ -161,21 +165,32 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
         }
         return make_uint4(t4[0], t4[1], t4[2], t4[3]);
     };
-    struct Pair { // the 32 bases of one lane in one tile
+    (void)load16;
+    struct PairAscii { // the 32 bases of one lane in one tile
         uint4 a, b;
     };
+    using Pair = typename std::conditional<PACKED, uint2, PairAscii>::type; // (packed: the two words themselves)
+    const uint32_t* const words = reinterpret_cast<const uint32_t*>(a.bases);
+    const int64_t n_pwords = (n_bases + 15) >> 4; // words of a packed batch
+    (void)words; (void)n_pwords;
     // Tiles whose 64 x 32 bytes lie inside the buffer are loaded without any guard, so that the compiler can count the
     // loads in flight (a guarded byte path inside the loop forces s_waitcnt vmcnt(0) everywhere); the one or two
     // tiles at the very end of the buffer take the guarded path after the pipelined loop.
-    const uint32_t n_full = n_bases >= 64 * FT_G ? (uint32_t)((n_bases - 64 * FT_G) / FT_WPOS) + 1 : 0u;
+    // (packed: a tile is 126 words, its 64 lanes read 128: full while those lie inside the ceil(n_bases / 16) words of the batch)
+    const uint32_t n_full = PACKED ? (n_pwords >= 2 * 64 ? (uint32_t)((n_pwords - 2 * 64) / (FT_WPOS / 16)) + 1 : 0u)
+                                   : (n_bases >= 64 * FT_G ? (uint32_t)((n_bases - 64 * FT_G) / FT_WPOS) + 1 : 0u);
     const uint32_t full_end = tile_end < n_full ? tile_end : n_full;
     auto fetch = [&](uint32_t t, Pair& p) { // unconditional (a prefetch past the wave's range re-reads its last full tile)
         const uint32_t tc = t < full_end ? t : full_end - 1;
-        const uint8_t* g = a.bases + (int64_t)tc * FT_WPOS + (int64_t)lane * FT_G;
-        // (plain loads: non-temporal ones were measured on 10 M x 150 bp -- this kernel 382 -> 409 us, refine_kernel 45 -> 38 us
-        // because the group records then survive in the L2, the step 0.720 -> 0.746 ms)
-        p.a = *reinterpret_cast<const uint4*>(g);
-        p.b = *reinterpret_cast<const uint4*>(g + 16);
+        if constexpr (PACKED) {
+            p = *reinterpret_cast<const uint2*>(words + (int64_t)tc * (FT_WPOS / 16) + (int64_t)lane * (FT_G / 16));
+        } else {
+            const uint8_t* g = a.bases + (int64_t)tc * FT_WPOS + (int64_t)lane * FT_G;
+            // (plain loads: non-temporal ones were measured on 10 M x 150 bp -- this kernel 382 -> 409 us, refine_kernel 45 -> 38 us
+            // because the group records then survive in the L2, the step 0.720 -> 0.746 ms)
+            p.a = *reinterpret_cast<const uint4*>(g);
+            p.b = *reinterpret_cast<const uint4*>(g + 16);
+        }
     };
     uint64_t* out = fw.raw_pos + (size_t)slice * fw.raw_slice;
     uint4* grp_out = LEVEL0 ? fw.raw_grp + (size_t)slice * fw.raw_slice : nullptr;
@@ -291,7 +306,14 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
             if (LEVEL0) grp_out += fw.raw_slice;
             wcur = 0;
         }
-        const uint32_t wa = pack16le(p.a), wb = pack16le(p.b);
+        uint32_t wa, wb;
+        if constexpr (PACKED) {
+            wa = p.x;
+            wb = p.y;
+        } else {
+            wa = pack16le(p.a);
+            wb = pack16le(p.b);
+        }
         const uint32_t wc = __builtin_amdgcn_update_dpp(0u, wa, 0x130 /* wave_shl:1: lane i <- lane i+1 */, 0xF, 0xF, false);
         if constexpr (LEVEL0) {
             // ---- level 0: one 12-mer per four positions (the one at 4g+3 lies inside every 15-mer starting at 4g..4g+3); group g
@@ -455,8 +477,14 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
     for (; tile < tile_end; tile += step) { // the end of the buffer, guarded loads
         const int64_t g = (int64_t)tile * FT_WPOS + (int64_t)lane * FT_G;
         Pair p;
-        p.a = load16(g);
-        p.b = load16(g + 16);
+        if constexpr (PACKED) {
+            const int64_t wi = g >> 4; // (words past the end read as 'A's: candidates there fail verify_count_kernel's bounds)
+            p.x = wi < n_pwords ? words[wi] : 0u;
+            p.y = wi + 1 < n_pwords ? words[wi + 1] : 0u;
+        } else {
+            p.a = load16(g);
+            p.b = load16(g + 16);
+        }
         process(tile, p);
     }
     close_slice();
@@ -607,15 +635,22 @@ hipError_t launch_sketch_filter(const SketchArgs& a, uint32_t read_begin, uint32
     {
         using Kernel = void (*)(SketchArgs, FilterWork);
         const int which = mid ? (bt.mid0_bits == 3 ? 4 : 5) : level0 ? (fused ? 3 : 2) : (a.k < 12 ? 1 : 0);
-        const Kernel kernel = which == 5 ? &sketch_filter_kernel<false, true, true, 1>
-            : which == 4                 ? &sketch_filter_kernel<false, true, true, 3>
-            : which == 3                 ? &sketch_filter_kernel<false, true, true>
-            : which == 2                 ? &sketch_filter_kernel<false, true>
-            : which == 1                 ? &sketch_filter_kernel<true, false>
-                                         : &sketch_filter_kernel<false, false>;
+        const Kernel ascii = which == 5 ? &sketch_filter_kernel<false, true, true, 1>
+            : which == 4                ? &sketch_filter_kernel<false, true, true, 3>
+            : which == 3                ? &sketch_filter_kernel<false, true, true>
+            : which == 2                ? &sketch_filter_kernel<false, true>
+            : which == 1                ? &sketch_filter_kernel<true, false>
+                                        : &sketch_filter_kernel<false, false>;
+        const Kernel packed = which == 5 ? &sketch_filter_kernel<false, true, true, 1, true>
+            : which == 4                 ? &sketch_filter_kernel<false, true, true, 3, true>
+            : which == 3                 ? &sketch_filter_kernel<false, true, true, 0, true>
+            : which == 2                 ? &sketch_filter_kernel<false, true, false, 0, true>
+            : which == 1                 ? &sketch_filter_kernel<true, false, false, 0, true>
+                                         : &sketch_filter_kernel<false, false, false, 0, true>;
+        const Kernel kernel = a.packed ? packed : ascii;
         const size_t dyn = level0 ? (size_t)FT_L0_WORDS * 4 + (fused ? (size_t)FT_WAVES * 2048 : 0) : ((size_t)4 << bt.bloom_wbits);
-        static size_t configured[6][MAX_HIP_DEVICES] = {};
-        HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), dyn, configured[which]));
+        static size_t configured[12][MAX_HIP_DEVICES] = {};
+        HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), dyn, configured[which + (a.packed ? 6 : 0)]));
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(FT_THREADS), dyn, stream, a, fw);
     }
     HIP_TRY(hipGetLastError());

@@ -92,6 +92,27 @@ class Context:
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         _check(lib.drprg_hip_map_host(self._h, _ptr(bases), _ptr(offsets), len(offsets) - 1), self._h)
 
+    # ---- 2-bit packed reads (include/drprg_hip.h "packed reads") -----------------------------------
+    def set_input_format(self, packed):
+        """map_fastx packs the reads to 2 bits on its parser threads (True) or hands ASCII blocks to the device (False, the default)"""
+        _check(lib.drprg_hip_set_input_format(self._h, 1 if packed else 0), self._h)
+
+    def map_host_packed(self, words, offsets, npos=None):
+        words = np.ascontiguousarray(words, dtype=np.uint32)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        npos = np.ascontiguousarray(npos if npos is not None else [], dtype=np.uint64)
+        _check(lib.drprg_hip_map_host_packed(self._h, _ptr(words), _ptr(offsets), len(offsets) - 1, _ptr(npos) if npos.size else None, npos.size), self._h)
+
+    def map_device_packed(self, d_words, d_offsets, n_reads, n_bases, d_npos=None, n_npos=0, d_covg=None, d_prg_reads=None, stream=None, deferred=False):
+        fn = lib.drprg_hip_map_device_packed_async if deferred else lib.drprg_hip_map_device_packed
+        _check(fn(self._h, d_words, d_offsets, n_reads, n_bases, d_npos, n_npos, d_covg, d_prg_reads, stream), self._h)
+
+    def pack_device(self, d_bases, n_bases, d_words, d_npos=None, npos_cap=0, stream=None):
+        """ASCII -> packed on the device; returns the number of non-ACGT bases (their positions, ascending, in d_npos)"""
+        n = C.c_uint64()
+        _check(lib.drprg_hip_pack_device(self._h, d_bases, n_bases, d_words, d_npos, npos_cap, C.byref(n), stream), self._h)
+        return int(n.value)
+
     def map_device(self, d_bases, d_offsets, n_reads, n_bases, d_covg=None, d_prg_reads=None, stream=None):
         """Pointers are integer device addresses (e.g. torch.Tensor.data_ptr())."""
         _check(lib.drprg_hip_map_device(self._h, d_bases, d_offsets, n_reads, n_bases, d_covg, d_prg_reads, stream), self._h)
@@ -402,3 +423,19 @@ class Pandora:
             raise DependencyError("NovelVariantParsingError",
                                   f"Expected {expected} genes with novel variants, but found {len(genes)}")
         return genes
+
+
+def pack_reads(bases):
+    """host helper: uint8 ASCII bases -> (uint32 words, uint64 ascending positions of the bases that are not ACGTacgt)"""
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    words = np.zeros((bases.size + 15) // 16, dtype=np.uint32)
+    cap = 1024
+    while True:
+        npos = np.zeros(cap, dtype=np.uint64)
+        n = C.c_uint64()
+        rc = lib.drprg_hip_pack_reads(_ptr(bases), bases.size, _ptr(words), _ptr(npos), cap, C.byref(n))
+        if rc == 0:
+            return words, npos[:n.value].copy()
+        if rc != -75:  # -EOVERFLOW: n holds the number needed
+            _check(rc)
+        cap = int(n.value)

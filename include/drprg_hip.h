@@ -131,6 +131,29 @@ int drprg_hip_map_device_async(drprg_hip_ctx* ctx, const void* d_bases, const vo
     uint64_t n_bases, void* d_covg, void* d_prg_reads, void* hip_stream);
 int drprg_hip_sync(drprg_hip_ctx* ctx); /* completes the batch in flight and waits for its stream */
 
+/* ---- 2-bit packed reads: a second input format (SURVEY.md section 8f NEXT-4 "optional 2-bit packing"; the reference takes any fasta /
+ * fastq, /root/reference/src/predict.rs:166-170 -- this is about what crosses PCIe and what the streaming kernel reads, a quarter of the
+ * bytes).  Base i of a batch is bits [2 (i & 15) + 1 : 2 (i & 15)] of u32 word i >> 4; the letter is bits 2:1 of the base's ASCII
+ * code (A 0, C 1, T 2, G 3, either case -- and of any other byte too); npos lists, ascending, the positions of the bases that are
+ * not one of ACGTacgt (they invalidate every k-mer that holds them, as in the ASCII form).  Offsets stay u64[n_reads + 1] in BASES.
+ * Results are identical to the ASCII form's, bit for bit (the parity suite runs every case through both).
+ *   drprg_hip_set_input_format(ctx, 1): drprg_hip_map_fastx packs on its parser threads (0: ASCII blocks, the default).
+ *   drprg_hip_pack_reads: host helper, bases[n_bases] -> words[ceil(n_bases / 16)] + npos (-EOVERFLOW, *n_npos set, when npos_cap is
+ *     too small).
+ *   drprg_hip_map_host_packed / drprg_hip_map_device_packed(_async): the packed counterparts of map_host / map_device(_async); d_words
+ *     8-byte aligned, d_npos may be NULL when n_npos == 0.
+ *   drprg_hip_pack_device: the same conversion for a batch that is already on the device (harnesses); d_npos: room for npos_cap
+ *     positions, *n_npos receives their number (positions ascending). */
+int drprg_hip_set_input_format(drprg_hip_ctx* ctx, int packed);
+int drprg_hip_pack_reads(const uint8_t* bases, uint64_t n_bases, uint32_t* words, uint64_t* npos, uint64_t npos_cap, uint64_t* n_npos);
+int drprg_hip_map_host_packed(drprg_hip_ctx* ctx, const uint32_t* words, const uint64_t* offsets, uint64_t n_reads, const uint64_t* npos, uint64_t n_npos);
+int drprg_hip_map_device_packed(drprg_hip_ctx* ctx, const void* d_words, const void* d_offsets, uint64_t n_reads, uint64_t n_bases, const void* d_npos,
+    uint64_t n_npos, void* d_covg, void* d_prg_reads, void* hip_stream);
+int drprg_hip_map_device_packed_async(drprg_hip_ctx* ctx, const void* d_words, const void* d_offsets, uint64_t n_reads, uint64_t n_bases, const void* d_npos,
+    uint64_t n_npos, void* d_covg, void* d_prg_reads, void* hip_stream);
+int drprg_hip_pack_device(drprg_hip_ctx* ctx, const void* d_bases, uint64_t n_bases, void* d_words, void* d_npos, uint64_t npos_cap, uint64_t* n_npos,
+    void* hip_stream);
+
 /* The per-k-mer-node coverage vector (what gets sum-reduced across GPUs):
  * covg[2g] forward, covg[2g+1] reverse coverage of global k-mer node g; prg_reads[p] clusters on PRG p. */
 int drprg_hip_coverage_size(const drprg_hip_ctx* ctx, uint64_t* n_covg, uint64_t* n_prgs);

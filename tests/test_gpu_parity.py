@@ -79,6 +79,17 @@ def _compare(ctx, oracle, bases, offsets, w, k, illumina, kernel, min_cluster_si
     assert gcnt["hits_kept"] == ocnt["hits_kept"]
     assert np.array_equal(gprg, oprg)
     assert np.array_equal(gcov, ocov)
+    # ... and the same batch in the 2-bit packed form (include/drprg_hip.h "packed reads"): identical vectors and counters, whatever
+    # kernel sequence the context runs (the filtered sequence reads the words, the direct ones an expansion made on the device)
+    from drprg_amd.pandora import pack_reads
+    words, npos = pack_reads(bases)
+    ctx.reset()
+    ctx.map_host_packed(words, offsets, npos)
+    pcov, pprg = ctx.coverage()
+    pcnt = ctx.counters()
+    assert np.array_equal(pcov, ocov) and np.array_equal(pprg, oprg)
+    for key in ("reads", "bases", "minimizers", "hits", "clusters_kept", "hits_kept", "leftover_reads"):
+        assert pcnt[key] == gcnt[key], key
     return ocnt
 
 
@@ -912,3 +923,77 @@ def test_reopened_direct_context_with_leftover_reads(tmp_path, oracle):
         if not FORCED_GENERIC:
             assert ctx.counters()["leftover_reads"] > 0
         ctx.close()
+
+
+def test_packed_reads_on_the_device_and_through_the_ingest(tmp_path, oracle):
+    """2-bit packed reads end to end: drprg_hip_pack_device == the host packer; a device-resident packed batch through map_device_packed
+    (synchronous and deferred) == the oracle; drprg_hip_map_fastx with drprg_hip_set_input_format(ctx, 1) (the parser threads pack) ==
+    the ASCII ingest, on a FASTQ with N, lower case and ragged reads; the reads kept in HBM in the packed form serve discover and
+    drprg_hip_map_resident."""
+    import torch
+    from drprg_amd import Context, synth
+    from drprg_amd.pandora import pack_reads
+    panel = synth.small_panel(seed=42)
+    ctx = _ctx(tmp_path, panel, 11, 15, True, kernel=0)
+    gen = synth.HaplotypeGenomes(panel, genome_size=20000, n_hap=4, seed=3)
+    bases, offs = synth.sample_short_reads(gen, 40000, seed=7)
+    bases = bases.copy()
+    rng = np.random.default_rng(1)
+    bases[rng.integers(0, bases.size, 300)] = ord("N")
+    low = rng.integers(0, bases.size - 30, 200)
+    for a in low:
+        bases[a:a + 20] |= 0x20
+    idx = _oracle_index(oracle, ctx.prg_strings, 11, 15)
+    ocov, oprg, _ = _oracle_map(oracle, idx, bases, offs, 11, 15, True)
+    words, npos = pack_reads(bases)
+    assert npos.size >= 250
+    d_bases = torch.from_numpy(bases).cuda()
+    d_words = torch.zeros(words.size, dtype=torch.int32, device="cuda")
+    d_npos = torch.zeros(1024, dtype=torch.int64, device="cuda")
+    n = ctx.pack_device(d_bases.data_ptr(), bases.size, d_words.data_ptr(), d_npos.data_ptr(), 1024)
+    assert n == npos.size and np.array_equal(d_words.cpu().numpy().view(np.uint32), words)
+    assert np.array_equal(d_npos[:n].cpu().numpy().astype(np.uint64), npos)
+    d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
+    for deferred in (False, True):
+        ctx.reset()
+        ctx.map_device_packed(d_words.data_ptr(), d_offs.data_ptr(), len(offs) - 1, int(bases.size), d_npos.data_ptr(), n, deferred=deferred)
+        ctx.sync()
+        got, got_prg = ctx.coverage()
+        assert np.array_equal(got, ocov) and np.array_equal(got_prg, oprg)
+    # an ASCII batch at the address a packed batch had is an ASCII batch
+    d_alias = d_words.view(torch.uint8)
+    n_alias = min(int(d_alias.numel()), int(bases.size)) // 16 * 16
+    d_alias[:n_alias] = d_bases[:n_alias]
+    k = int(np.searchsorted(offs, n_alias, side="right")) - 1
+    ctx.reset()
+    ctx.map_device(d_alias.data_ptr(), d_offs.data_ptr(), k, int(offs[k]))
+    want_k = _oracle_map(oracle, idx, bases[:int(offs[k])], offs[:k + 1], 11, 15, True)[0]
+    assert np.array_equal(ctx.coverage()[0], want_k)
+    # ---- the ingest ----
+    fq = str(tmp_path / "reads.fq")
+    synth.write_fastq(fq, bases, offs)
+    for threads in (1, 8):
+        ctx.reset()
+        ctx.set_input_format(True)
+        ctx.set_threads(threads)
+        ctx.map_fastx(fq)
+        got, got_prg = ctx.coverage()
+        assert np.array_equal(got, ocov) and np.array_equal(got_prg, oprg), threads
+        assert ctx.counters()["reads"] == len(offs) - 1 and ctx.counters()["bases"] == bases.size
+    # every kernel sequence takes the packed ingest
+    for kernel in (1, 3):
+        c2 = _ctx(tmp_path, panel, 11, 15, True, kernel=kernel)
+        c2.set_input_format(True)
+        c2.set_threads(4)
+        c2.map_fastx(fq)
+        assert np.array_equal(c2.coverage()[0], ocov), kernel
+        c2.close()
+    # ---- resident packed reads: discover's read selection and the second mapping pass ----
+    ctx.reset()
+    ctx.keep_reads(1 << 30)
+    ctx.map_fastx(fq)
+    info = ctx.resident_info()
+    assert info["complete"] and 0 < info["bytes"] < bases.size  # (a quarter of the bases + offsets)
+    other = _ctx(tmp_path, panel, 11, 15, True, kernel=0)
+    other.map_resident(ctx)
+    assert np.array_equal(other.coverage()[0], ocov)

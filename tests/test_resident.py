@@ -90,12 +90,13 @@ def _files(d):
     return {f: open(os.path.join(str(d), f), "rb").read() for f in ("candidate_regions.tsv", "denovo_variants.tsv", "denovo_paths.txt", "denovo_sequences.fa")}
 
 
-def _discover(prg, genes, fq, out, keep, illumina=True, threads=4):
+def _discover(prg, genes, fq, out, keep, illumina=True, threads=4, packed=False):
     from drprg_amd import Context
     out.mkdir()
     ctx = Context(prg, W, K, device=0, from_files=False)
     ctx.set_opts(illumina=illumina, genome_size=4000)
     ctx.set_threads(threads)
+    ctx.set_input_format(packed)
     if keep:
         ctx.keep_reads(keep)
     ctx.map_fastx(fq)
@@ -121,6 +122,15 @@ def test_discover_from_resident_reads_writes_what_discover_from_the_file_writes(
     bases, offs = _fastq_arrays(fq)
     want = oracle_denovo(tmp_path / "hbm", dict(zip(panel.names, panel.refs)), bases, offs, noisy=noisy)
     assert want == [(l, p - 1, r, alt, s, n) for l, p, r, alt, s, n in vb]
+    # ... and with the reads kept in HBM in the 2-bit packed form (a quarter of the device memory): the same files
+    c, vc = _discover(prg, genes, fq, tmp_path / "hbm_packed", 1 << 30, illumina=not noisy, packed=True)
+    assert c.resident_info()["last_discover_from_hbm"] and c.resident_info()["bytes"] < info["bytes"]
+    assert vc == vb and np.array_equal(c.coverage()[0], b.coverage()[0])
+    fa, fc = _files(tmp_path / "hbm"), _files(tmp_path / "hbm_packed")
+    if odd:  # (reads with lower-case stretches come back upper-cased from a packed block: the sequences file may differ in case only)
+        fa = {k: v.upper() for k, v in fa.items()}
+        fc = {k: v.upper() for k, v in fc.items()}
+    assert fa == fc
 
 
 def test_many_blocks_and_reads_without_anchors(tmp_path):
