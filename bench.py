@@ -269,6 +269,14 @@ def e2e_leg(torch, ctx, synth, bases, n_reads, read_len, covg):
         run(fq, n_reads)  # (first pass: pinned blocks and workspaces are allocated)
         res["plain"], got = run(fq, n_reads)
         res["plain"]["coverage_equals_hbm_resident_run"] = bool(np.array_equal(got, want))
+        # the same file with the parser threads packing the bases to 2 bits (drprg_hip_set_input_format): a quarter of the bytes to
+        # page-lock and to move over PCIe
+        ctx.set_input_format(True)
+        run(fq, n_reads)
+        res["plain_packed"], got = run(fq, n_reads)
+        res["plain_packed"]["coverage_equals_hbm_resident_run"] = bool(np.array_equal(got, want))
+        res["plain_packed"]["pcie_floor_s"] = ((int(host.size) + 15) // 16 * 4 + 8 * (n_reads + 1)) / 63e9
+        ctx.set_input_format(False)
         # what the link alone would take for the bases + offsets of this batch (PCIe Gen5 x16: 63 GB/s spec, MI355X_MICROARCH.md):
         # the gap to `seconds` is host work (file reads, parse, hand-over) that the copies do not hide
         res["plain"]["pcie_floor_s"] = (int(host.size) + 8 * (n_reads + 1)) / 63e9
@@ -308,6 +316,10 @@ def main():
                          "nanopore = configs[2]; big = configs[4]'s index; mtb-xN = the 8d index grown N-fold")
     ap.add_argument("--reads-per-gpu", type=int, default=0, help="0 = the workload's size (N > 1 with the mtb workload: 25M, the per-GPU "
                                                                  "shard of configs[3])")
+    ap.add_argument("--input", default="ascii", choices=("ascii", "packed"),
+                    help="format of the HBM-resident batch: ascii (one byte per base; the headline) or packed (2 bits per base, "
+                         "include/drprg_hip.h 'packed reads': the batch is packed on the device before the timed region).  Either way "
+                         "the roofline prices the SURVEY 8d bytes, L + 8 per read (packing is an optimisation, not a change of work)")
     ap.add_argument("--comm", default="auto", choices=("auto", "native", "torch"),
                     help="N > 1: who issues the all-reduce.  native = the C ABI (drprg_hip_comm_* / drprg_hip_allreduce, ONE "
                          "ncclAllReduce of [coverage | reads per PRG]); torch = torch.distributed.all_reduce on the same buffer; "
@@ -383,6 +395,13 @@ def main():
     n_bases = int(bases.numel())
     del hap_pad
     torch.cuda.empty_cache()
+    packed = args.input == "packed"
+    d_words = d_npos = None
+    n_npos = 0
+    if packed:  # the same batch, 2 bits per base (outside the timed region: what a packing ingest hands over)
+        d_words = torch.zeros((n_bases + 15) // 16 + 4, dtype=torch.int32, device=device)
+        d_npos = torch.zeros(1 << 16, dtype=torch.int64, device=device)
+        n_npos = ctx.pack_device(bases.data_ptr(), n_bases, d_words.data_ptr(), d_npos.data_ptr(), d_npos.numel())
     # the reduced vector: per-node coverage and per-PRG cluster counts in one buffer (one memset, one all-reduce).  With
     # N > 1 two buffers alternate: the all-reduce of step i runs on RCCL's stream while step i+1 maps into the other
     # buffer; a buffer is only zeroed again once its reduce has finished (every step's collective completes inside the
@@ -466,17 +485,19 @@ def main():
                 pending[b].wait()  # (the stream waits, not the host)
                 pending[b] = None
             acc.zero_()
-            if deferred:
-                ctx.map_device_async(bases.data_ptr(), offsets.data_ptr(), n_reads, n_bases, acc.data_ptr(),
-                                     acc.data_ptr() + 8 * ctx.n_knodes, stream.cuda_stream)
-                if world > 1:
+            out = (acc.data_ptr(), acc.data_ptr() + 8 * ctx.n_knodes, stream.cuda_stream)
+            if packed:
+                ctx.map_device_packed(d_words.data_ptr(), offsets.data_ptr(), n_reads, n_bases, d_npos.data_ptr(), n_npos, *out, deferred=deferred)
+            elif deferred:
+                ctx.map_device_async(bases.data_ptr(), offsets.data_ptr(), n_reads, n_bases, *out)
+            else:
+                ctx.map_device(bases.data_ptr(), offsets.data_ptr(), n_reads, n_bases, *out)
+            if world > 1:
+                if deferred:
                     if unreduced[0] is not None:  # the batch before this one is complete now
                         pending[unreduced[0]] = all_reduce_async(accs[unreduced[0]])
                     unreduced[0] = b
-            else:
-                ctx.map_device(bases.data_ptr(), offsets.data_ptr(), n_reads, n_bases, acc.data_ptr(),
-                               acc.data_ptr() + 8 * ctx.n_knodes, stream.cuda_stream)
-                if world > 1:
+                else:
                     all_reduce_async(acc).wait()
         return acc
 
@@ -537,8 +558,12 @@ def main():
         ok = torch.tensor([1 if torch.equal(own, acc) else 0], dtype=torch.int32, device=device)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         reduce_consistent = bool(ok.item())
-    shard_invariant = kernels_agree = None
+    shard_invariant = kernels_agree = packed_equals_ascii = None
     if world == 1 and not args.no_checks:
+        if packed:  # the packed batch must give what the ASCII batch gives, at full size
+            ref = torch.zeros_like(acc)
+            map_range(ctx, bases, offsets, 0, n_reads, ref[: 2 * ctx.n_knodes], ref[2 * ctx.n_knodes:], stream, torch)
+            packed_equals_ascii = bool(torch.equal(ref, acc))
         shard_invariant, kernels_agree = full_size_checks(torch, ctx, opts, bases, offsets, n_reads, covg, prg_reads, stream)
 
     if rank == 0:
@@ -560,7 +585,7 @@ def main():
         # the microarch guide prescribes for wide coalesced loads on gfx950): measured offline, committed under profiles/
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
-        if n_reads == default_reads and os.path.exists(tfile):
+        if n_reads == default_reads and os.path.exists(tfile) and not packed:
             traffic = json.load(open(tfile)).get(args.workload, {}).get(kernel_name, {}).get("hbm_bytes_per_launch")
             if traffic is not None:
                 traffic = traffic / launches_per_step  # (measured per batch)
@@ -573,7 +598,8 @@ def main():
         secondary = None
         vfile = os.path.join(ROOT, "profiles", "valu.json")
         if n_reads == default_reads and os.path.exists(vfile) and avg_ms > 0:
-            v = json.load(open(vfile)).get(args.workload, {}).get(kernel_name, {}).get("valu_wave_insts_per_launch")
+            vkey = args.workload + ("-packed" if packed else "")
+            v = json.load(open(vfile)).get(vkey, {}).get(kernel_name, {}).get("valu_wave_insts_per_launch")
             if v:
                 v = v / launches_per_step
                 peak = 1024 * 2.4e9 / 4
@@ -600,6 +626,10 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{cfg_name}: {cfg_desc}",
+                "input_format": ("packed: 2 bits per base, u32 words + u64 read offsets + sparse non-ACGT positions (HBM-resident; "
+                                 f"{(n_bases + 15) // 16 * 4 + 8 * (n_reads + 1)} bytes per batch)" if packed
+                                 else "ascii: one byte per base + u64 read offsets"),
+                "full_size_packed_equals_ascii": packed_equals_ascii,
                 "reads_per_gpu": n_reads, "bases_per_gpu": n_bases, "mean_read_len": n_bases / max(n_reads, 1), "w": W, "k": K,
                 "loci": ctx.n_prgs, "index_keys": ctx.n_keys, "kmer_nodes": ctx.n_knodes, "sharding": f"reads x{world}",
                 "collective": (("one all_reduce(sum, u32) of [coverage | reads per PRG] per step, overlapped with the next step's mapping" if overlap
@@ -626,6 +656,7 @@ def main():
                 "traffic_source": "profiles/traffic.json (offline rocprofv3 PMC passes of this workload, FETCH_SIZE doubled + WRITE_SIZE)"
                                   if traffic is not None else None,
                 "algorithmic_bytes_per_launch": alg_bytes,
+                "bytes_of_the_batch_as_stored": ((n_bases + 15) // 16 * 4 if packed else n_bases) + 8 * (n_reads + 1),
                 "avg_launch_ms": avg_ms, "launches_timed": k_launches, "launches_per_step": launches_per_step,
                 "secondary": secondary,
             },
