@@ -9,8 +9,10 @@ namespace dev {
 
 constexpr int FT_THREADS = 1024;
 constexpr int FT_WAVES = FT_THREADS / 64;
-constexpr int FT_G = 32;                // positions per lane
+constexpr int FT_G = 32;                // positions per lane (ASCII input, and the forms without level 0)
 constexpr int FT_WPOS = 63 * FT_G;      // positions per wave tile: lane 63's word is only lane 62's right neighbour
+// the level-0 form on packed input takes 64 positions per lane: one 16-byte load per lane and tile
+DRPRG_HD constexpr int filter_positions_per_lane(bool level0, bool packed) { return level0 && packed ? 64 : 32; }
 constexpr int FT_BLOOM_WORDS = 1 << 14; // levels 1+2 of the filter, at most (64 KB of LDS)
 constexpr int FT_L0_WORDS = 1 << 15;    // level 0 (128 KB; levels 1+2 then get 32 KB: all 160 KB of a CU)
 constexpr int EX_THREADS = 256;

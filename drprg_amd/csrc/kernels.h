@@ -137,7 +137,7 @@ uint32_t direct_candidate_tiles(uint64_t n_bases, int halo, int k, int w, bool w
 bool direct_uses_wave_form(int k, int w, bool wide_hash); // sketch_wave_kernel serves these parameters
 uint32_t direct_first_read_tiles(uint64_t n_bases, int halo, int k, int w, bool wide_hash); // entries of tile_first_read
 // filtered form (k <= 15, w <= 16): bloom = 2^bloom_wbits words of index k-mer codes
-uint32_t filter_n_tiles(uint64_t n_bases);
+uint32_t filter_n_tiles(uint64_t n_bases, int positions_per_lane = 32);
 uint32_t filter_grid(bool level0, int n_cus, uint32_t n_tiles);
 // device copies of FlatIndex::bloom / bloom0 (bloom0 == nullptr: no level 0)
 struct BloomTables {

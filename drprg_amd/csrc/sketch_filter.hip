@@ -115,6 +115,9 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
     static_assert(!FUSED || LEVEL0, "the fused second stage belongs to the level-0 form");
     static_assert(MID == 0 || (LEVEL0 && FUSED), "the middle tier is a variant of the level-0 form with the second stage inside");
     extern __shared__ uint32_t s_dyn[]; // [level 0: FT_L0_WORDS] then [levels 1+2: 2^bloom_wbits words] or, FUSED, [stage: 2 KB per wave]
+    // positions per lane and tile: 32 (two packed words), or -- packed input with level 0 -- 64: one 16-byte load per lane and tile, and
+    // everything a tile costs once (loop control, slice bookkeeping, the ballots and prefix sums of the ordered append) is paid half as often
+    constexpr int G = filter_positions_per_lane(LEVEL0, PACKED), WPOS = 63 * G, NW = G / 16, NG = G / 4;
     constexpr uint32_t L12_BASE = LEVEL0 ? FT_L0_WORDS * 4u : 0u;
     constexpr uint32_t STAGE_RECORDS = 128, STAGE_BASE_WORDS = FT_L0_WORDS;
 
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
     const uint32_t gw = blockIdx.x * FT_WAVES + (uint32_t)(tid >> 6);
     // the tiles that cover the bases of reads [read_begin, read_end), split evenly over the waves of the grid
     const uint64_t win_lo = a.offsets[fw.read_begin], win_hi = a.offsets[fw.read_end];
-    const uint32_t t_lo = (uint32_t)(win_lo / FT_WPOS), t_hi = (uint32_t)((win_hi + FT_WPOS - 1) / FT_WPOS);
+    const uint32_t t_lo = (uint32_t)(win_lo / WPOS), t_hi = (uint32_t)((win_hi + WPOS - 1) / WPOS);
     const uint32_t n_waves = gridDim.x * FT_WAVES;
     const uint32_t tiles_per_wave = (t_hi - t_lo + n_waves - 1) / n_waves, tiles_per_slice = tiles_per_wave ? (tiles_per_wave + FT_SUB - 1) / FT_SUB : 1u;
     uint32_t tile = t_lo + gw * tiles_per_wave;
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
     struct PairAscii { // the 32 bases of one lane in one tile
         uint4 a, b;
     };
-    using Pair = typename std::conditional<PACKED, uint2, PairAscii>::type; // (packed: the two words themselves)
+    using Pair = typename std::conditional<PACKED, typename std::conditional<NW == 4, uint4, uint2>::type, PairAscii>::type; // (packed: the words themselves)
     const uint32_t* const words = reinterpret_cast<const uint32_t*>(a.bases);
     const int64_t n_pwords = (n_bases + 15) >> 4; // words of a packed batch
     (void)words; (void)n_pwords;
@@ -177,15 +180,15 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
     // loads in flight (a guarded byte path inside the loop forces s_waitcnt vmcnt(0) everywhere); the one or two
     // tiles at the very end of the buffer take the guarded path after the pipelined loop.
     // (packed: a tile is 126 words, its 64 lanes read 128: full while those lie inside the ceil(n_bases / 16) words of the batch)
-    const uint32_t n_full = PACKED ? (n_pwords >= 2 * 64 ? (uint32_t)((n_pwords - 2 * 64) / (FT_WPOS / 16)) + 1 : 0u)
-                                   : (n_bases >= 64 * FT_G ? (uint32_t)((n_bases - 64 * FT_G) / FT_WPOS) + 1 : 0u);
+    const uint32_t n_full = PACKED ? (n_pwords >= NW * 64 ? (uint32_t)((n_pwords - NW * 64) / (WPOS / 16)) + 1 : 0u)
+                                   : (n_bases >= 64 * G ? (uint32_t)((n_bases - 64 * G) / WPOS) + 1 : 0u);
     const uint32_t full_end = tile_end < n_full ? tile_end : n_full;
     auto fetch = [&](uint32_t t, Pair& p) { // unconditional (a prefetch past the wave's range re-reads its last full tile)
         const uint32_t tc = t < full_end ? t : full_end - 1;
         if constexpr (PACKED) {
-            p = *reinterpret_cast<const uint2*>(words + (int64_t)tc * (FT_WPOS / 16) + (int64_t)lane * (FT_G / 16));
+            p = *reinterpret_cast<const Pair*>(words + (int64_t)tc * (WPOS / 16) + (int64_t)lane * NW);
         } else {
-            const uint8_t* g = a.bases + (int64_t)tc * FT_WPOS + (int64_t)lane * FT_G;
+            const uint8_t* g = a.bases + (int64_t)tc * WPOS + (int64_t)lane * G;
             // (plain loads: non-temporal ones were measured on 10 M x 150 bp -- this kernel 382 -> 409 us, refine_kernel 45 -> 38 us
             // because the group records then survive in the L2, the step 0.720 -> 0.746 ms)
             p.a = *reinterpret_cast<const uint4*>(g);
@@ -306,32 +309,38 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
             if (LEVEL0) grp_out += fw.raw_slice;
             wcur = 0;
         }
-        uint32_t wa, wb;
+        uint32_t wv[NW + 1]; // my words, then the first word of lane + 1 (it completes the last k-mers)
         if constexpr (PACKED) {
-            wa = p.x;
-            wb = p.y;
+            wv[0] = p.x;
+            wv[1] = p.y;
+            if constexpr (NW == 4) {
+                wv[2] = p.z;
+                wv[3] = p.w;
+            }
         } else {
-            wa = pack16le(p.a);
-            wb = pack16le(p.b);
+            wv[0] = pack16le(p.a);
+            wv[1] = pack16le(p.b);
         }
-        const uint32_t wc = __builtin_amdgcn_update_dpp(0u, wa, 0x130 /* wave_shl:1: lane i <- lane i+1 */, 0xF, 0xF, false);
+        wv[NW] = __builtin_amdgcn_update_dpp(0u, wv[0], 0x130 /* wave_shl:1: lane i <- lane i+1 */, 0xF, 0xF, false);
+        const uint32_t wa = wv[0], wb = wv[1], wc = wv[2];
+        (void)wa; (void)wb; (void)wc;
         if constexpr (LEVEL0) {
             // ---- level 0: one 12-mer per four positions (the one at 4g+3 lies inside every 15-mer starting at 4g..4g+3); group g
             // ends up in bit g of grp.  The ~2 % of the groups that pass leave the kernel as they are, with their bases: levels 1+2
             // run in refine_kernel, one lane per group (here they would run for the whole wave as often as its busiest lane
             // needs: a third of this kernel's instructions) ----
-            uint32_t grp = 0, xs[FT_G / 4], hs[FT_G / 4], ws[FT_G / 4];
+            uint32_t grp = 0, xs[NG], hs[NG], ws[NG];
 #pragma unroll
-            for (int g = 0; g < FT_G / 4; ++g) { // all eight LDS reads in flight before the first test
+            for (int g = 0; g < NG; ++g) { // all the LDS reads in flight before the first test
                 const int j = 4 * g + 3;
-                const uint32_t lo = j < 16 ? wa : wb, hi = j < 16 ? wb : wc;
+                const uint32_t lo = wv[j >> 4], hi = wv[(j >> 4) + 1];
                 xs[g] = __builtin_amdgcn_alignbit(hi, lo, 2 * (j & 15));
                 if constexpr (MID != 0) xs[g] = canon12_dev(xs[g]);
                 hs[g] = __umul24(xs[g], BLOOM_C0);
                 ws[g] = lds_at((hs[g] >> 15) & amask0);
             }
 #pragma unroll
-            for (int g = FT_G / 4 - 1; g >= 0; --g)
+            for (int g = NG - 1; g >= 0; --g)
                 grp = __builtin_amdgcn_alignbit(grp, MID == 1 ? ws[g] << (hs[g] & 31) : bloom_test(ws[g], hs[g], xs[g]), 31);
             if (lane == 63 || (fw.debug & 1u)) grp = 0;
             if constexpr (MID != 0) {
@@ -339,65 +348,78 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
                 // each, all in flight before the first test (the L2 serves ~267 G such probes per second chip-wide whatever their
                 // width, so every group level 0 rejects is 3.7 ps saved) ----
                 st_a += (uint32_t)__popc(grp);
-                uint32_t bw[FT_G / 4];
+                uint32_t bw[NG];
 #pragma unroll
-                for (int g = 0; g < FT_G / 4; ++g) {
+                for (int g = 0; g < NG; ++g) {
                     bw[g] = 0;
                     if (grp & (1u << g)) bw[g] = fw.mid_bitmap[xs[g] >> 5];
                 }
                 uint32_t keep = 0;
 #pragma unroll
-                for (int g = 0; g < FT_G / 4; ++g) keep |= ((bw[g] >> (xs[g] & 31)) & 1u) << g;
+                for (int g = 0; g < NG; ++g) keep |= ((bw[g] >> (xs[g] & 31)) & 1u) << g;
                 grp &= keep;
                 st_b += (uint32_t)__popc(grp);
             }
-            // ---- append in (lane, group) = position order: exclusive prefix of the per-lane counts (0..8) from four ballots ----
+            // ---- append in (lane, group) = position order: exclusive prefix of the per-lane counts (0..NG) from four or five ballots ----
             const uint32_t cnt = (uint32_t)__popc(grp);
             const uint64_t b0 = __ballot(cnt & 1u), b1 = __ballot(cnt & 2u), b2 = __ballot(cnt & 4u), b3 = __ballot(cnt & 8u);
-            if (b0 | b1 | b2 | b3) {
+            const uint64_t b4 = NG > 8 ? __ballot(cnt & 16u) : 0ull;
+            if (b0 | b1 | b2 | b3 | b4) {
                 auto below = [&](uint64_t m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); };
-                const uint64_t base = (uint64_t)t * FT_WPOS + (uint64_t)lane * FT_G;
+                auto lanes_below = [&]() { return below(b0) + 2u * below(b1) + 4u * below(b2) + 8u * below(b3) + (NG > 8 ? 16u * below(b4) : 0u); };
+                const uint32_t wave_total = (uint32_t)(__popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2) + 8 * __popcll(b3) + (NG > 8 ? 16 * __popcll(b4) : 0));
+                const uint64_t base = (uint64_t)t * WPOS + (uint64_t)lane * G;
                 auto record = [&](int g) {
-                    const uint32_t lo = g < 4 ? wa : wb, hi = g < 4 ? wb : wc;
+                    const int q = g >> 2; // the word the group's sixteen bases start in (a select chain: no dynamic register index)
+                    uint32_t lo = wv[0], hi = wv[1];
+#pragma unroll
+                    for (int u = 1; u < NW; ++u) {
+                        lo = q == u ? wv[u] : lo;
+                        hi = q == u ? wv[u + 1] : hi;
+                    }
                     const uint32_t sh = (8u * (uint32_t)g) & 31u;
                     const uint64_t pos = base + 4u * (uint32_t)g;
                     return make_uint4((uint32_t)pos, (uint32_t)(pos >> 32), __funnelshift_r(lo, hi, sh), hi >> sh);
                 };
                 if constexpr (FUSED) {
-                    const uint32_t total = (uint32_t)(__popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2) + 8 * __popcll(b3));
+                    const uint32_t total = wave_total;
+                    // (running only the full rounds of 64 here and keeping the remainder staged was measured: 159.8 -> 156.7 M VALU
+                    // wave-instructions per 10 M reads and no change in the kernel's time, 318 against 321 us)
                     if (lcnt + total > STAGE_RECORDS) DRPRG_SECOND_STAGE(); // wave-uniform
                     if (total <= STAGE_RECORDS) {
-                        uint32_t at = lcnt + below(b0) + 2u * below(b1) + 4u * below(b2) + 8u * below(b3);
+                        uint32_t at = lcnt + lanes_below();
                         while (grp) {
                             const int g = __ffs(grp) - 1;
                             grp &= grp - 1;
                             stage[at++] = record(g);
                         }
                         lcnt += total;
-                    } else { // a tile dense with index k-mers (amplicon reads): sixteen lanes (<= 128 groups) at a time, in lane order
-                        for (int part = 0; part < 4; ++part) {
-                            uint32_t gq = (lane >> 4) == part ? grp : 0u;
+                    } else { // a tile dense with index k-mers (amplicon reads): as many lanes at a time as the stage surely holds, in lane order
+                        constexpr int PART_LANES = (int)STAGE_RECORDS / NG;
+                        for (int part = 0; part < 64 / PART_LANES; ++part) {
+                            uint32_t gq = (lane / PART_LANES) == part ? grp : 0u;
                             const uint32_t cq = (uint32_t)__popc(gq);
                             const uint64_t q0 = __ballot(cq & 1u), q1 = __ballot(cq & 2u), q2 = __ballot(cq & 4u), q3 = __ballot(cq & 8u);
-                            uint32_t at = below(q0) + 2u * below(q1) + 4u * below(q2) + 8u * below(q3);
+                            const uint64_t q4 = NG > 8 ? __ballot(cq & 16u) : 0ull;
+                            uint32_t at = below(q0) + 2u * below(q1) + 4u * below(q2) + 8u * below(q3) + (NG > 8 ? 16u * below(q4) : 0u);
                             while (gq) {
                                 const int g = __ffs(gq) - 1;
                                 gq &= gq - 1;
                                 stage[at++] = record(g);
                             }
-                            lcnt = (uint32_t)(__popcll(q0) + 2 * __popcll(q1) + 4 * __popcll(q2) + 8 * __popcll(q3));
+                            lcnt = (uint32_t)(__popcll(q0) + 2 * __popcll(q1) + 4 * __popcll(q2) + 8 * __popcll(q3) + (NG > 8 ? 16 * __popcll(q4) : 0));
                             DRPRG_SECOND_STAGE();
                         }
                     }
                 } else {
-                    uint32_t at = wcur + below(b0) + 2u * below(b1) + 4u * below(b2) + 8u * below(b3);
+                    uint32_t at = wcur + lanes_below();
                     while (grp) {
                         const int g = __ffs(grp) - 1;
                         grp &= grp - 1;
                         if (at < fw.raw_slice) grp_out[at] = record(g);
                         ++at;
                     }
-                    wcur += (uint32_t)(__popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2) + 8 * __popcll(b3));
+                    wcur += wave_total;
                 }
             }
             return;
@@ -435,7 +457,7 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
             m &= m - 1;
             const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cand, l);
             if (lane == l) {
-                const uint64_t base = (uint64_t)t * FT_WPOS + (uint64_t)lane * FT_G;
+                const uint64_t base = (uint64_t)t * WPOS + (uint64_t)lane * G;
                 uint32_t cc = c, at = wcur;
                 while (cc) {
                     const int j = __ffs(cc) - 1;
@@ -475,12 +497,16 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
         tile += step;
     }
     for (; tile < tile_end; tile += step) { // the end of the buffer, guarded loads
-        const int64_t g = (int64_t)tile * FT_WPOS + (int64_t)lane * FT_G;
+        const int64_t g = (int64_t)tile * WPOS + (int64_t)lane * G;
         Pair p;
         if constexpr (PACKED) {
             const int64_t wi = g >> 4; // (words past the end read as 'A's: candidates there fail verify_count_kernel's bounds)
             p.x = wi < n_pwords ? words[wi] : 0u;
             p.y = wi + 1 < n_pwords ? words[wi + 1] : 0u;
+            if constexpr (NW == 4) {
+                p.z = wi + 2 < n_pwords ? words[wi + 2] : 0u;
+                p.w = wi + 3 < n_pwords ? words[wi + 3] : 0u;
+            }
         } else {
             p.a = load16(g);
             p.b = load16(g + 16);
@@ -495,7 +521,7 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
             atomicAdd(&fw.stat[1], (unsigned long long)st_a);
             atomicAdd(&fw.stat[2], (unsigned long long)st_b);
             atomicAdd(&fw.stat[3], (unsigned long long)st_c);
-            if (lane == 0) atomicAdd(&fw.stat[0], (unsigned long long)(tile_end > t_lo + gw * tiles_per_wave ? tile_end - (t_lo + gw * tiles_per_wave) : 0u) * 63ull * (FT_G / 4));
+            if (lane == 0) atomicAdd(&fw.stat[0], (unsigned long long)(tile_end > t_lo + gw * tiles_per_wave ? tile_end - (t_lo + gw * tiles_per_wave) : 0u) * 63ull * (G / 4));
         }
 }
 #undef DRPRG_SECOND_STAGE
@@ -561,7 +587,11 @@ __global__ __launch_bounds__(RF_THREADS) void refine_kernel(SketchArgs a, Filter
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-uint32_t filter_n_tiles(uint64_t n_bases) { return (uint32_t)((n_bases + FT_WPOS - 1) / FT_WPOS); }
+uint32_t filter_n_tiles(uint64_t n_bases, int positions_per_lane)
+{
+    const uint64_t wpos = 63ull * (uint64_t)positions_per_lane;
+    return (uint32_t)((n_bases + wpos - 1) / wpos);
+}
 
 uint32_t filter_grid(bool level0, int n_cus, uint32_t n_tiles)
 {
@@ -618,7 +648,7 @@ hipError_t launch_sketch_filter(const SketchArgs& a, uint32_t read_begin, uint32
     fw.midc = bt.midc;
     fw.midc_wbits = bt.midc_wbits;
     fw.stat = mid ? b.stat : nullptr;
-    const uint32_t grid = filter_grid(level0, n_cus, filter_n_tiles(a.n_bases));
+    const uint32_t grid = filter_grid(level0, n_cus, filter_n_tiles(a.n_bases, filter_positions_per_lane(level0, a.packed != 0)));
     fw.n_slices = grid * FT_WAVES * FT_SUB;
     fw.raw_slice = (uint32_t)std::min<uint64_t>(b.raw_capacity / fw.n_slices, 0x7FFFFFFFull / fw.n_slices);
     fw.raw_pos = b.raw_pos;
