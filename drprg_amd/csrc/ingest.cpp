@@ -238,7 +238,8 @@ __attribute__((target("avx2"))) const char* parse_fastq_avx2(const char* p, cons
         const size_t len = (size_t)(s_stop - seq);
         if (len > BLOCK_BASES) return p;
         if (blk.n_bases + len > blk.flush_at || blk.n_reads + 1 > BLOCK_READS) sh.submit(blk);
-        blk.append(seq, len);
+        if (blk.packed) pack_append_overread_avx2(reinterpret_cast<uint64_t*>(blk.bases), blk.n_bases, seq, len, blk.npos); // (s_end + 64 < e: readable)
+        else blk.append(seq, len);
         blk.offsets[++blk.n_reads] = blk.n_bases;
         p = q_end + 1;
     }

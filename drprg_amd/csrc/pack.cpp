@@ -2,9 +2,6 @@
 // per byte, one byte shuffle gathers the eight bytes), the validity test in the same registers; scalar for tails and other CPUs.
 #include "pack.h"
 #include <cstdlib>
-#if defined(__x86_64__)
-#include <immintrin.h>
-#endif
 
 namespace drprg {
 
@@ -30,21 +27,6 @@ inline uint64_t pack_scalar(const char* p, size_t n, uint32_t& bad)
 }
 
 #if defined(__x86_64__)
-__attribute__((target("avx2"))) inline uint64_t pack32_avx2(const char* p, uint32_t& bad)
-{
-    const __m256i b = _mm256_loadu_si256((const __m256i*)p);
-    const __m256i c = _mm256_and_si256(_mm256_srli_epi16(b, 1), _mm256_set1_epi8(3)); // the letters, one per byte
-    // a byte is a base iff its upper-case form is the letter its two bits stand for
-    const __m256i lut = _mm256_setr_epi8('A', 'C', 'T', 'G', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 'A', 'C', 'T', 'G', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0);
-    const __m256i upper = _mm256_and_si256(b, _mm256_set1_epi8((char)0xDF));
-    bad = ~(uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(upper, _mm256_shuffle_epi8(lut, c)));
-    const __m256i p2 = _mm256_maddubs_epi16(c, _mm256_set1_epi16(0x0401));   // byte pairs: first + 4 * second
-    const __m256i p4 = _mm256_madd_epi16(p2, _mm256_set1_epi32(0x00100001)); // 16-bit pairs: first + 16 * second -> one byte of four letters per dword
-    const __m256i g = _mm256_shuffle_epi8(p4,
-        _mm256_setr_epi8(0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1));
-    return (uint64_t)(uint32_t)_mm256_extract_epi32(g, 0) | ((uint64_t)(uint32_t)_mm256_extract_epi32(g, 4) << 32);
-}
-
 __attribute__((target("avx2"))) void pack_append_avx2(uint64_t* words64, uint64_t& n_bases, const char* seq, size_t len, std::vector<uint64_t>& npos)
 {
     const unsigned shift = (unsigned)(n_bases & 31) * 2;
