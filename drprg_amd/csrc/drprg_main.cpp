@@ -126,6 +126,14 @@ static double since_start()
     return std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count() - t0;
 }
 
+// 2-bit packed ingest (include/drprg_hip.h "packed reads") unless DRPRG_HIP_INPUT=ascii: a quarter of the bytes to page-lock, to move over
+// PCIe and to keep in HBM; same results
+static int packed_input()
+{
+    const char* e = std::getenv("DRPRG_HIP_INPUT");
+    return !(e && std::string(e) == "ascii");
+}
+
 int main(int argc, char** argv)
 {
     const double at_main = since_start();
@@ -233,6 +241,7 @@ int main(int argc, char** argv)
     mo.genome_size = 4411532; // MTB_GENOME_SIZE, /root/reference/src/lib.rs:36
     if (int rc = drprg_hip_set_opts(ctx, &mo)) die(drprg_hip_last_error(ctx), -rc);
     drprg_hip_set_threads(ctx, threads);
+    drprg_hip_set_input_format(ctx, packed_input()); // the parser threads pack the reads to 2 bits (DRPRG_HIP_INPUT=ascii: one byte per base)
     // The reads stay in HBM after the mapping pass (up to DRPRG_HIP_KEEP_READS_GB per device, default 32, 0 = off): discover takes
     // the few reads it needs from there and a novel variant maps them again from there -- the file is read once.
     double keep_gb = 32;
@@ -273,6 +282,7 @@ int main(int argc, char** argv)
                 if (!next) die(std::string("cannot open the updated PRG: ") + drprg_hip_last_error(nullptr));
                 if (int rc = drprg_hip_set_opts(next, &mo)) die(drprg_hip_last_error(next), -rc);
                 drprg_hip_set_threads(next, threads);
+                drprg_hip_set_input_format(next, packed_input()); // the parser threads pack the reads to 2 bits (DRPRG_HIP_INPUT=ascii: one byte per base)
                 // the reads again, against the updated index: from HBM if the first context kept them all, else from the file
                 const int from_hbm = drprg_hip_map_resident(next, ctx);
                 if (from_hbm != 0 && from_hbm != -61 /* ENODATA */) die(drprg_hip_last_error(next), -from_hbm);

@@ -23,6 +23,15 @@
 
 namespace {
 
+// 2-bit packed ingest (include/drprg_hip.h "packed reads") unless DRPRG_HIP_INPUT=ascii: a quarter of the bytes to page-lock, to move over
+// PCIe and to keep in HBM; same results
+static int packed_input()
+{
+    const char* e = std::getenv("DRPRG_HIP_INPUT");
+    return !(e && std::string(e) == "ascii");
+}
+
+
 struct Args {
     std::string cmd;
     int threads = 1, w = 14, k = 15;
@@ -135,6 +144,7 @@ drprg_hip_ctx* open_ctx(const Args& a)
     o.genome_size = a.genome_size;
     if (int rc = drprg_hip_set_opts(ctx, &o)) die(drprg_hip_last_error(ctx), -rc);
     drprg_hip_set_threads(ctx, a.threads);
+    drprg_hip_set_input_format(ctx, packed_input()); // the parser threads pack the reads to 2 bits (DRPRG_HIP_INPUT=ascii: one byte per base)
     return ctx;
 }
 
