@@ -36,6 +36,8 @@ __device__ inline void candidate_range(const FilterWork& fw, uint32_t wg, uint32
 hipError_t launch_candidate_stage(const SketchArgs& a, const FilterWork& fw, const ReadClusterArgs& rc, hipStream_t stream);
 // read_cluster.hip: per-read clustering straight from the candidate list (skip: mark the batch as left over instead)
 hipError_t launch_read_cluster(const SketchArgs& a, const FilterWork& fw, const ReadClusterArgs& rc, int n_cus, bool skip, hipStream_t stream);
+// read_cluster_wave.hip: the same for the reads that fit a wave's 128 staged candidates (one wave per 64 candidates, no workgroup barrier)
+hipError_t launch_read_cluster_wave(const SketchArgs& a, const FilterWork& fw, const ReadClusterArgs& rc, int n_cus, hipStream_t stream);
 
 } // namespace dev
 } // namespace drprg

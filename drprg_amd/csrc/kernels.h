@@ -222,6 +222,11 @@ struct ReadClusterArgs {
     // handled candidates are marked cand_pos1[d] = mark_epoch in the (otherwise unused) dense array
     const uint32_t* slice_prefix; // [n_slices + 1], exclusive scan of the slice counts
     uint32_t n_slices, mark_epoch;
+    // the wave form (read_cluster_wave.hip) runs first and counts in *n_unfit the reads it leaves untouched (long reads, minimizers with many
+    // index records); read_cluster_kernel then runs as a SECOND PASS over what is left: second_pass != 0 makes it return at once when
+    // *n_unfit == 0 and skip the candidates that are handled already
+    unsigned long long* n_unfit;
+    int second_pass;
     unsigned long long* phase_clock; // DRPRG_RC_DEBUG=1: 12 counters, clock cycles thread 0 of every workgroup spent per phase (else null)
 };
 size_t filter_small_words();

@@ -403,6 +403,7 @@ void Mapper::launch_lane(Lane& lane, hipStream_t stream, const uint8_t* d_bases,
     rc.n_clusters_kept = &d_counters_[C_CLUSTERS_KEPT];
     rc.n_hits_kept = &d_counters_[C_HITS_KEPT];
     rc.n_complex = &lane.d_scratch[L_COMPLEX];
+    rc.n_unfit = &lane.d_scratch[L_UNFIT];
     rc.chunk_counter = reinterpret_cast<uint32_t*>(&lane.d_scratch[L_CHUNK]);
     dev::KernelTimer timer;
     if (timing_) { // events bracket the dominant kernel only
@@ -663,6 +664,7 @@ void Mapper::direct_launch(int set, const uint8_t* d_bases, const uint64_t* d_of
     rc.n_clusters_kept = &d_counters_[C_CLUSTERS_KEPT];
     rc.n_hits_kept = &d_counters_[C_HITS_KEPT];
     rc.n_complex = &lane.d_scratch[L_COMPLEX];
+    rc.n_unfit = &lane.d_scratch[L_UNFIT];
     rc.chunk_counter = reinterpret_cast<uint32_t*>(&lane.d_scratch[L_CHUNK]);
     lane.fw = dev::FilterWork {};
     lane.fw.read_begin = 0;

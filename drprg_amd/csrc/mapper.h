@@ -147,7 +147,7 @@ private:
         dev::FilterWork fw {};
         uint32_t r0 = 0, r1 = 0;                 // read range of the current batch
     };
-    enum { L_HITS = 0, L_OVERFLOW = 1, L_MAXLEN = 2, L_UNSORTED = 3, L_COMPLEX = 4, L_CHUNK = 5, L_MINIMIZERS = 6, L_N = 8 };
+    enum { L_HITS = 0, L_OVERFLOW = 1, L_MAXLEN = 2, L_UNSORTED = 3, L_COMPLEX = 4, L_CHUNK = 5, L_MINIMIZERS = 6, L_UNFIT = 7, L_N = 8 };
     void ensure_lanes(int n, uint64_t raw_capacity);
     void grow_lane(Lane& lane, uint64_t raw_capacity);
     void free_lane(Lane& lane);

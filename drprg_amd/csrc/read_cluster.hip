@@ -4,6 +4,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 
 namespace drprg {
 namespace dev {
@@ -90,6 +91,8 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
         }                                                            \
     } while (0)
     if (*reinterpret_cast<volatile uint32_t*>(a.overflow) & 4u) return; // a candidate slice overflowed: the host re-runs the batch
+    // second pass behind read_cluster_wave_kernel: only if that kernel left reads untouched (long reads, mostly)
+    if (rc.second_pass && *reinterpret_cast<volatile unsigned long long*>(rc.n_unfit) == 0ull) return;
     const uint32_t total = SLICES ? rc.slice_prefix[rc.n_slices] : *fw.cand_total;
     const uint32_t handled_mark = SLICES ? rc.mark_epoch : 0u; // what a handled candidate's cand_pos1 becomes
     for (uint32_t i = tid; i < rc.n_prgs; i += RC_THREADS) s_hist[i] = 0;
@@ -171,6 +174,8 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
                 st.info[q] = live ? (uint32_t)a.tile_info[src] : 0u;
                 st.pos1[q] = live ? a.tile_pos1[src] : 0u;
                 st.rec[q] = live ? a.tile_rec[src] : make_uint4(0, 0, 0, 0);
+                // (second pass: what the wave form handled carries this batch's mark in the dense array)
+                if (rc.second_pass && live && i < n_in && fw.cand_pos1[b + i] == rc.mark_epoch) st.pos1[q] = 0u;
             }
             const bool nxt = n_in == (uint32_t)RC_SLOTS && b + n_in < total;
             st.edge_prev = live && b ? (uint32_t)a.tile_info[locate(b - 1)] : 0u;
@@ -590,6 +595,17 @@ hipError_t launch_read_cluster(const SketchArgs& a, const FilterWork& fw, const 
         return hipGetLastError();
     }
     ReadClusterArgs rcd = rc;
+    // The wave form first (read_cluster_wave.hip: no workgroup barriers; everything a 150-base read needs), this kernel behind it for
+    // what that leaves -- it returns at once when that is nothing.  DRPRG_RC_FORM=wg: this kernel alone, as in rounds 1-3.
+    static const bool wave_first = [] {
+        const char* e = std::getenv("DRPRG_RC_FORM");
+        return !(e && std::string(e) == "wg");
+    }();
+    rcd.second_pass = 0;
+    if (wave_first && rc.n_unfit) {
+        HIP_TRY(launch_read_cluster_wave(a, fw, rc, n_cus, stream));
+        rcd.second_pass = 1;
+    }
     static unsigned long long* d_phase = nullptr;
     const bool debug = std::getenv("DRPRG_RC_DEBUG") != nullptr;
     if (debug) {
