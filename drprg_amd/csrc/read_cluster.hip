@@ -36,6 +36,7 @@ constexpr int RC_PER = 2;
 constexpr int RC_SLOTS = RC_THREADS * RC_PER; // staged candidates
 constexpr int RC_AHEAD = 512;                 // look-ahead: a read belongs to the chunk that owns its first candidate
 constexpr int RC_OWN = RC_SLOTS - RC_AHEAD;
+static_assert(RC_OWN == (int)RC_CHUNK_OWN, "kernels.h RC_CHUNK_OWN");
 constexpr int RC_HCAP = 3072;                 // staged hits
 constexpr int RC_POOL = 512;                  // reads per chunk that may take the wave path (sketch_wave_kernel clusters the plain reads itself: what is left is rich in these)
 constexpr uint32_t RC_IRREGULAR = 2u, RC_COMPLEX = 1u;
@@ -183,7 +184,14 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
         }
         return st;
     };
-    if (tid == 0) s_chunk = atomicAdd(rc.chunk_counter, 1u);
+    // (second pass: only the chunks in which the wave form left a read)
+    auto take_ticket = [&]() -> uint32_t {
+        uint32_t t;
+        do t = atomicAdd(rc.chunk_counter, 1u);
+        while (rc.second_pass && (uint64_t)t * RC_OWN < total && !rc.chunk_flags[t]);
+        return t;
+    };
+    if (tid == 0) s_chunk = take_ticket();
     lds_barrier(tid);
     uint32_t cur = s_chunk;
     Staged nx = request(cur);
@@ -200,7 +208,7 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
         // (the ticket of the next chunk: a device-wide atomic that returns a value takes microseconds; it is asked for here and put
         // into LDS two phases later, so that nobody waits for it at the barrier that closes stage A)
         uint32_t ticket = 0;
-        if (tid == 0) ticket = atomicAdd(rc.chunk_counter, 1u);
+        if (tid == 0) ticket = take_ticket();
         // ---- A: stage the candidates (requested one chunk ago) ----
         uint4 crec[RC_PER];
         uint32_t st_read[RC_PER], st_pos1[RC_PER];
@@ -602,7 +610,8 @@ hipError_t launch_read_cluster(const SketchArgs& a, const FilterWork& fw, const 
         return !(e && std::string(e) == "wg");
     }();
     rcd.second_pass = 0;
-    if (wave_first && rc.n_unfit) {
+    // (long reads do not fit a wave's 128 staged candidates: a batch of them goes straight to the workgroup form)
+    if (wave_first && rc.n_unfit && rc.chunk_flags && a.n_bases / (a.n_reads ? a.n_reads : 1u) <= 600) {
         HIP_TRY(launch_read_cluster_wave(a, fw, rc, n_cus, stream));
         rcd.second_pass = 1;
     }

@@ -206,16 +206,32 @@ __global__ __launch_bounds__(RW_THREADS) void read_cluster_wave_kernel(SketchArg
         }
         // ---- the further index records of a minimizer (a k-mer that several k-mer nodes share): another group makes the read irregular;
         // more than RW_MAX_REC of them make it unfit ----
+        // (all the loads of both rows are requested before the first is looked at: one after the other -- a loop per lane over its
+        // records -- every record was a round trip to the L2 of its own and the wave as slow as its longest list: 225 us per 10 M reads
+        // where this form takes a tenth)
         bool unfit[2] = { false, false };
+        uint32_t xcov[2][RW_MAX_REC - 1]; // coverage index of records 1 .. cnt - 1
+        {
+            uint32_t kn[2][RW_MAX_REC - 1], pg[2][RW_MAX_REC - 1];
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            if (cnt[r] > (uint32_t)RW_MAX_REC || (p1[r] && pos[r] >= 0xFFFEu)) unfit[r] = true; // (positions travel as 16 bits in the LDS path)
-            else if (cnt[r] > 1) {
+            for (int r = 0; r < 2; ++r) {
+                unfit[r] = cnt[r] > (uint32_t)RW_MAX_REC || (p1[r] && pos[r] >= 0xFFFEu); // (positions travel as 16 bits in the LDS path)
+#pragma unroll
+                for (int q = 1; q < RW_MAX_REC; ++q) {
+                    const bool on = (uint32_t)q < cnt[r] && !unfit[r];
+                    kn[r][q - 1] = on ? a.rec_knode[rec[r].x + (uint32_t)q] : 0u;
+                    pg[r][q - 1] = on ? (uint32_t)a.rec_prg[rec[r].x + (uint32_t)q] : 0u;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
                 const uint32_t strand = rec[r].z >> 31;
-                for (uint32_t q = 1; q < cnt[r]; ++q) {
-                    const uint32_t kn = a.rec_knode[rec[r].x + q], prg = a.rec_prg[rec[r].x + q];
-                    const uint32_t rev = ((kn & 1u) == strand) ? 0u : 1u;
-                    irr[r] |= ((prg << 1) | rev) != grp[r];
+#pragma unroll
+                for (int q = 1; q < RW_MAX_REC; ++q) {
+                    const bool on = (uint32_t)q < cnt[r] && !unfit[r];
+                    const uint32_t rev = ((kn[r][q - 1] & 1u) == strand) ? 0u : 1u;
+                    irr[r] |= on && ((pg[r][q - 1] << 1) | rev) != grp[r];
+                    xcov[r][q - 1] = (kn[r][q - 1] >> 1) * 2u + rev;
                 }
             }
         }
@@ -293,12 +309,9 @@ __global__ __launch_bounds__(RW_THREADS) void read_cluster_wave_kernel(SketchArg
             if (mdec[r] == 1 || mdec[r] == 2) fw.cand_pos1[base + 64u * (uint32_t)r + (uint32_t)lane] = handled_mark;
             if (mdec[r] == 2) {
                 atomicAdd(&rc.covg[rec[r].w], 1u);
-                const uint32_t strand = rec[r].z >> 31;
-                for (uint32_t q = 1; q < cnt[r]; ++q) {
-                    const uint32_t kn = a.rec_knode[rec[r].x + q];
-                    const uint32_t rev = ((kn & 1u) == strand) ? 0u : 1u;
-                    atomicAdd(&rc.covg[(kn >> 1) * 2u + rev], 1u);
-                }
+#pragma unroll
+                for (int q = 1; q < RW_MAX_REC; ++q)
+                    if ((uint32_t)q < cnt[r]) atomicAdd(&rc.covg[xcov[r][q - 1]], 1u);
             }
         }
         // ---- reads that are mine, hold a minimizer (or run on behind the staged range) and do not fit: left to the pass behind this kernel ----
@@ -306,7 +319,9 @@ __global__ __launch_bounds__(RW_THREADS) void read_cluster_wave_kernel(SketchArg
             uint64_t r0m, r1m;
             rw_range(Fs[0] < 0 ? 0 : Fs[0], Es[0], r0m, r1m);
             const bool has_min = ((M0 & r0m) | (M1 & r1m)) != 0;
-            const uint64_t UF0 = __ballot(rs0 && !fit[0] && (has_min || Es[0] == 128));
+            const bool uf = rs0 && !fit[0] && (has_min || Es[0] == 128);
+            if (uf) rc.chunk_flags[(base + (uint32_t)lane) / RC_CHUNK_OWN] = 1u;
+            const uint64_t UF0 = __ballot(uf);
             if (lane == 0) my_unfit += (uint32_t)__popcll(UF0);
         }
         // ---- irregular reads, one after the other: the read's hits to the wave's LDS, then clusters per group split at gaps, size
@@ -324,7 +339,10 @@ __global__ __launch_bounds__(RW_THREADS) void read_cluster_wave_kernel(SketchArg
             const int first_seg = fs0 ? __ffsll((long long)fs0) - 1 : 64 + __ffsll((long long)fs1) - 1;
             const uint32_t rdec = rw_at(dec[0], dec[1], first_seg);
             if (rdec == 0) {
-                if (lane == 0) ++my_unfit;
+                if (lane == 0) {
+                    ++my_unfit;
+                    rc.chunk_flags[(base + (uint32_t)f) / RC_CHUNK_OWN] = 1u;
+                }
                 continue;
             }
             if (rdec != 3) continue; // dropped as a whole: marked above
@@ -411,7 +429,10 @@ __global__ __launch_bounds__(RW_THREADS) void read_cluster_wave_kernel(SketchArg
                 }
             }
             if (complex) { // more than 64 clusters: left alone
-                if (lane == 0) ++my_unfit;
+                if (lane == 0) {
+                    ++my_unfit;
+                    rc.chunk_flags[(base + (uint32_t)f) / RC_CHUNK_OWN] = 1u;
+                }
                 continue;
             }
             const uint64_t expected = expected_minimizers(len, a.w, w1_magic);
