@@ -202,6 +202,7 @@ struct FilterWork {
                              // generic pipeline, 16 / 32 = verify_count_kernel without its window scan / table probe and
                              // everything after it (wrong results: timing only, tools/dbg16.sh)
 };
+constexpr uint32_t RC_WAVE_MAX_WG = 1024; // workgroups of read_cluster_wave_kernel at most
 constexpr uint32_t RC_CHUNK_OWN = 1536; // candidates a chunk of read_cluster_kernel owns (read_cluster.hip RC_OWN)
 constexpr uint32_t READ_NONE = 0x7FFFFFFFu; // "read" of a candidate that lies past the last whole k-mer of the buffer
 
@@ -228,6 +229,8 @@ struct ReadClusterArgs {
     // *n_unfit == 0 and skip the candidates that are handled already
     unsigned long long* n_unfit;
     int second_pass;
+    uint32_t* wg_partials; // [RC_WAVE_MAX_WG][n_prgs + 4]: per-workgroup histogram and counters of the wave form (summed by its last workgroup)
+    uint32_t* wg_done;     // zero before the launch: workgroups of the wave form that have finished
     uint32_t* chunk_flags; // [candidate capacity / RC_CHUNK_OWN + 2], zero before the launch: the wave form sets word c when it leaves a read whose first
                            // candidate lies in read_cluster_kernel's chunk c; the second pass takes only those chunks
     unsigned long long* phase_clock; // DRPRG_RC_DEBUG=1: 12 counters, clock cycles thread 0 of every workgroup spent per phase (else null)

@@ -327,7 +327,7 @@ void Mapper::ensure_workspace(uint64_t cap)
 
 void Mapper::free_lane(Lane& lane)
 {
-    dfree(lane.raw_pos); dfree(lane.raw_grp); dfree(lane.cand_info); dfree(lane.cand_pos1); dfree(lane.cand_rec); dfree(lane.small); dfree(lane.rc_flags);
+    dfree(lane.raw_pos); dfree(lane.raw_grp); dfree(lane.cand_info); dfree(lane.cand_pos1); dfree(lane.cand_rec); dfree(lane.small); dfree(lane.rc_flags); dfree(lane.rc_partials);
     dfree(lane.d_scratch);
     if (lane.h_scratch) (void)hipHostFree(lane.h_scratch);
     lane.h_scratch = nullptr;
@@ -345,7 +345,8 @@ void Mapper::grow_lane(Lane& lane, uint64_t cap)
     lane.raw_capacity = cap;
     if (bloom0_wbits_) dmalloc(lane.raw_grp, cap);
     dmalloc(lane.raw_pos, cap); dmalloc(lane.cand_info, cap); dmalloc(lane.cand_pos1, cap); dmalloc(lane.cand_rec, cap);
-    dmalloc(lane.rc_flags, (size_t)(cap / dev::RC_CHUNK_OWN + 2));
+    dmalloc(lane.rc_flags, (size_t)(cap / dev::RC_CHUNK_OWN + 3));
+    if (!lane.rc_partials) dmalloc(lane.rc_partials, (size_t)dev::RC_WAVE_MAX_WG * ((size_t)n_prgs_ + 4));
     // the slices form of the direct sequence uses cand_pos1 as an array of "handled" marks (mark = a batch's epoch): fresh device
     // memory may hold anything, including a value some later epoch of this or an earlier Mapper takes
     zero_now(lane.cand_pos1, 0, cap * sizeof(uint32_t));
@@ -406,7 +407,9 @@ void Mapper::launch_lane(Lane& lane, hipStream_t stream, const uint8_t* d_bases,
     rc.n_complex = &lane.d_scratch[L_COMPLEX];
     rc.n_unfit = &lane.d_scratch[L_UNFIT];
     rc.chunk_flags = lane.rc_flags;
-    HIPCHK(hipMemsetAsync(lane.rc_flags, 0, (lane.raw_capacity / dev::RC_CHUNK_OWN + 2) * sizeof(uint32_t), stream));
+    rc.wg_partials = lane.rc_partials;
+    rc.wg_done = lane.rc_flags + (lane.raw_capacity / dev::RC_CHUNK_OWN + 2); // (one word behind the flags, cleared with them)
+    HIPCHK(hipMemsetAsync(lane.rc_flags, 0, (lane.raw_capacity / dev::RC_CHUNK_OWN + 3) * sizeof(uint32_t), stream));
     rc.chunk_counter = reinterpret_cast<uint32_t*>(&lane.d_scratch[L_CHUNK]);
     dev::KernelTimer timer;
     if (timing_) { // events bracket the dominant kernel only
@@ -669,7 +672,9 @@ void Mapper::direct_launch(int set, const uint8_t* d_bases, const uint64_t* d_of
     rc.n_complex = &lane.d_scratch[L_COMPLEX];
     rc.n_unfit = &lane.d_scratch[L_UNFIT];
     rc.chunk_flags = lane.rc_flags;
-    HIPCHK(hipMemsetAsync(lane.rc_flags, 0, (lane.raw_capacity / dev::RC_CHUNK_OWN + 2) * sizeof(uint32_t), stream));
+    rc.wg_partials = lane.rc_partials;
+    rc.wg_done = lane.rc_flags + (lane.raw_capacity / dev::RC_CHUNK_OWN + 2); // (one word behind the flags, cleared with them)
+    HIPCHK(hipMemsetAsync(lane.rc_flags, 0, (lane.raw_capacity / dev::RC_CHUNK_OWN + 3) * sizeof(uint32_t), stream));
     rc.chunk_counter = reinterpret_cast<uint32_t*>(&lane.d_scratch[L_CHUNK]);
     lane.fw = dev::FilterWork {};
     lane.fw.read_begin = 0;

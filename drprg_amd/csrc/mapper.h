@@ -141,6 +141,7 @@ private:
         uint64_t *raw_pos = nullptr, *cand_info = nullptr;
         uint4 *raw_grp = nullptr, *cand_rec = nullptr;
         uint32_t *cand_pos1 = nullptr, *small = nullptr;
+        uint32_t* rc_partials = nullptr; // RC_WAVE_MAX_WG x (n_prgs + 4) words: per-workgroup sums of read_cluster_wave_kernel
         uint32_t* rc_flags = nullptr; // raw_capacity / RC_CHUNK_OWN + 2 words: chunks in which read_cluster_wave_kernel left a read (zeroed per batch)
         unsigned long long* d_scratch = nullptr; // L_N x u64 per-sequence counters (below)
         unsigned long long* h_scratch = nullptr; // pinned mirror

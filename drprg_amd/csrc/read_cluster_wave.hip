@@ -8,9 +8,9 @@
 // segments start, how many hits a segment has, whether a read's hits lie in one (prg, strand) group -- is a bit mask or a prefix sum
 // over the wave: ballots, mbcnt / DPP scans and a few ds_bpermute shuffles, all in registers.
 //
-// Unit of work: a tile of 64 candidates of the ordered list (ordered by (read, position)) plus the 64 behind it as look-ahead.  A
-// read belongs to the tile that holds its first candidate; it is handled here if it ends inside the 128 staged slots, none of its
-// minimizers has more than RW_MAX_REC index records, and -- hits in several (prg, strand) groups -- it has at most RW_HCAP hits.
+// Unit of work: a tile of 96 candidates of the ordered list (ordered by (read, position)) plus the 32 behind it as look-ahead.  A
+// read belongs to the tile that holds its first candidate; it is handled here if it ends inside the 128 staged slots, none of
+// its positions is beyond 2^16 - 2, and -- hits in several (prg, strand) groups -- it has at most RW_HCAP hits.
 // Everything else (long reads above all: a 4 kb Nanopore read has ~250 candidates) is left untouched and counted in rc.n_unfit;
 // read_cluster_kernel then runs behind this kernel as a second pass over what is left (it returns at once when nothing is).
 //   reads with all hits in one group: the segments (runs of minimizers without a position gap > max_diff) are the clusters and
@@ -18,8 +18,9 @@
 //   reads with hits in several groups: their hits go to the wave's own 2 KB of LDS and one pass of the cluster algorithm of
 //     read_cluster_kernel's wave path runs on them (lane j = cluster j; pandora define_clusters / filter_clusters).
 // Semantics are exactly read_cluster_kernel's (DESIGN.md section 4 "Clusters", "Filter"); tests/test_gpu_parity.py holds both forms
-// against the oracle, and DRPRG_RC_FORM=wg runs the workgroup form alone.
+// against the oracle.  Opt-in (DRPRG_RC_FORM=wave): it is not faster than the workgroup form, see launch_read_cluster.
 #include "filter_common.h"
+#include <algorithm>
 #include <cstdint>
 #include <cstdlib>
 #include <string>
@@ -27,10 +28,12 @@
 namespace drprg {
 namespace dev {
 
-constexpr int RW_THREADS = 256;
+constexpr int RW_THREADS = 1024;
 constexpr int RW_WAVES = RW_THREADS / 64;
 constexpr int RW_HCAP = 256;    // hits of a multi-group read that fit the wave's LDS region
-constexpr int RW_MAX_REC = 8;   // index records per minimizer handled here
+constexpr int RW_FAST_REC = 4;  // index records per minimizer whose loads are unrolled (99.4 % of the keys of the mtb-like index have <= 4)
+constexpr int RW_OWN = 96;      // candidates a tile owns of its 128 staged ones: a 150-base read has at most ~25 candidates, so 32 slots of
+                                // look-ahead do, and every candidate is staged 1.33 times instead of twice
 
 __device__ __forceinline__ uint32_t rw_mbcnt(uint64_t m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
 // value of slot `idx` (0..127) of a two-row array: row 0 = slots 0..63, row 1 = slots 64..127 (every lane takes part)
@@ -87,15 +90,41 @@ __global__ __launch_bounds__(RW_THREADS) void read_cluster_wave_kernel(SketchArg
     __syncthreads(); // (the only barriers of the kernel: this one and the one in front of the histogram's way out)
     const uint32_t total = SLICES ? rc.slice_prefix[rc.n_slices] : *fw.cand_total;
     const uint32_t handled_mark = SLICES ? rc.mark_epoch : 0u;
+    const uint32_t dbg = (uint32_t)rc.second_pass >> 8; // DRPRG_RW_DEBUG (timing experiments, wrong results): 1 no coverage atomics, 2 no marks, 4 no record loads
     const uint32_t w1_magic = w1_reciprocal(a.w);
     unsigned long long my_kept_hits = 0;
     uint32_t my_kept = 0, my_unfit = 0;
-    const uint32_t n_tiles = (total + 63) / 64;
+    const uint32_t n_tiles = (total + RW_OWN - 1) / RW_OWN;
     const uint32_t gwave = blockIdx.x * RW_WAVES + (uint32_t)wave, n_gwaves = gridDim.x * RW_WAVES;
     uint32_t cursor = 0; // SLICES: a slice at or before the one that holds the wave's current tile (tiles are taken in ascending order)
 
+    // dense list: the raw loads of a tile (unconditional: a slot past the end reads the tile's first candidate and drops it)
+    struct Staged {
+        uint32_t rd[2], p1[2], e_prev, e_next;
+        uint4 rec[2];
+    };
+    auto request = [&](uint32_t t) {
+        Staged st;
+        const uint32_t b = t * (uint32_t)RW_OWN, n = total - b < 128u ? total - b : 128u;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const uint32_t i = 64u * (uint32_t)r + (uint32_t)lane;
+            const uint32_t d = b + (i < n ? i : 0u);
+            st.rd[r] = (uint32_t)fw.cand_info[d];
+            st.p1[r] = fw.cand_pos1[d];
+            st.rec[r] = fw.cand_rec[d];
+        }
+        st.e_prev = (uint32_t)fw.cand_info[b ? b - 1 : 0u];
+        st.e_next = (uint32_t)fw.cand_info[b + 128u < total ? b + 128u : 0u];
+        return st;
+    };
+    Staged nx {};
+    if constexpr (!SLICES)
+        if (gwave < n_tiles) nx = request(gwave);
+    (void)request;
+
     for (uint32_t tile = gwave; tile < n_tiles; tile += n_gwaves) {
-        const uint32_t base = tile * 64u;
+        const uint32_t base = tile * (uint32_t)RW_OWN;
         const uint32_t n_in = total - base < 128u ? total - base : 128u;
         // ---- the 128 slots: read, position + 1, record; the candidate before the tile and the one behind the staged range ----
         uint32_t rd[2], p1[2];
@@ -104,16 +133,16 @@ __global__ __launch_bounds__(RW_THREADS) void read_cluster_wave_kernel(SketchArg
         (void)src;
         uint32_t prev_read = 0xFFFFFFFFu, next_read = 0xFFFFFFFFu;
         if constexpr (!SLICES) {
+            // (requested one tile ago: the candidates of this tile have been travelling while the last one was worked on)
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
-                const uint32_t i = 64u * (uint32_t)r + (uint32_t)lane;
-                const uint32_t d = base + (i < n_in ? i : 0u);
-                rd[r] = (uint32_t)fw.cand_info[d];
-                p1[r] = fw.cand_pos1[d];
-                rec[r] = fw.cand_rec[d];
+                rd[r] = nx.rd[r];
+                p1[r] = nx.p1[r];
+                rec[r] = nx.rec[r];
             }
-            if (base) prev_read = (uint32_t)fw.cand_info[base - 1] & 0x7FFFFFFFu;
-            if (base + 128u < total) next_read = (uint32_t)fw.cand_info[base + 128u] & 0x7FFFFFFFu;
+            if (base) prev_read = nx.e_prev & 0x7FFFFFFFu;
+            if (base + 128u < total) next_read = nx.e_next & 0x7FFFFFFFu;
+            nx = request(tile + n_gwaves < n_tiles ? tile + n_gwaves : tile);
         } else {
             // entry d of the ordered list lives in the slice s with P[s] <= d < P[s + 1].  The wave keeps a cursor; 64 prefix entries from
             // the cursor on go to the lanes and every slot bisects them with shuffles.  Slices so sparsely filled that 130 entries span
@@ -167,8 +196,9 @@ __global__ __launch_bounds__(RW_THREADS) void read_cluster_wave_kernel(SketchArg
             }
             // (every lane takes part in the shuffles of locate: uniform branches only)
             const size_t sp = locate(d_first), sn = locate(base + 128u < total ? base + 128u : d_first);
-            if (base) prev_read = (uint32_t)a.tile_info[sp] & 0x7FFFFFFFu;
-            if (base + 128u < total) next_read = (uint32_t)a.tile_info[sn] & 0x7FFFFFFFu;
+            const uint32_t e_prev = (uint32_t)a.tile_info[sp], e_next = (uint32_t)a.tile_info[sn];
+            if (base) prev_read = e_prev & 0x7FFFFFFFu;
+            if (base + 128u < total) next_read = e_next & 0x7FFFFFFFu;
         }
         bool valid[2];
         uint32_t cnt[2], grp[2], pos[2];
@@ -178,7 +208,10 @@ __global__ __launch_bounds__(RW_THREADS) void read_cluster_wave_kernel(SketchArg
             valid[r] = i < n_in;
             rd[r] = valid[r] ? rd[r] & 0x7FFFFFFFu : READ_NONE;
             if (!valid[r]) p1[r] = 0;
-            if (SLICES && valid[r] && p1[r] && fw.cand_pos1[base + i] == handled_mark) p1[r] = 0; // (handled already: a batch run again)
+            if constexpr (SLICES) { // (handled already: a batch run again)
+                const uint32_t mk = fw.cand_pos1[base + (i < n_in ? i : 0u)];
+                if (mk == handled_mark) p1[r] = 0;
+            }
             cnt[r] = p1[r] ? rec[r].y : 0u;
             grp[r] = (rec[r].z >> 16) & 0x7FFFu;
             pos[r] = p1[r] - 1u;
@@ -205,34 +238,47 @@ __global__ __launch_bounds__(RW_THREADS) void read_cluster_wave_kernel(SketchArg
             irr[r] = is_min && same && pg != grp[r];
         }
         // ---- the further index records of a minimizer (a k-mer that several k-mer nodes share): another group makes the read irregular;
-        // more than RW_MAX_REC of them make it unfit ----
-        // (all the loads of both rows are requested before the first is looked at: one after the other -- a loop per lane over its
-        // records -- every record was a round trip to the L2 of its own and the wave as slow as its longest list: 225 us per 10 M reads
-        // where this form takes a tenth)
+        // a position beyond 2^16 - 2 makes it unfit for the LDS path ----
+        // (the loads of both rows are requested before the first is looked at, without a branch of their own around any of them: one after
+        // the other -- a loop per lane over its records -- every record was a round trip to the L2 and the wave as slow as its longest
+        // list.  Records 1 .. RW_FAST_REC - 1 this way, and only as far as some lane of the wave has that many; the rare minimizer with
+        // more takes the loop after all.)
         bool unfit[2] = { false, false };
-        uint32_t xcov[2][RW_MAX_REC - 1]; // coverage index of records 1 .. cnt - 1
+        uint32_t xcov[2][RW_FAST_REC - 1]; // coverage index of records 1 .. RW_FAST_REC - 1
         {
-            uint32_t kn[2][RW_MAX_REC - 1], pg[2][RW_MAX_REC - 1];
+            uint32_t kn[2][RW_FAST_REC - 1], pg[2][RW_FAST_REC - 1];
+            const uint32_t cmax = cnt[0] > cnt[1] ? cnt[0] : cnt[1];
+            const bool any2 = __ballot(cmax > 1) != 0, any3 = __ballot(cmax > 2) != 0, any4 = __ballot(cmax > 3) != 0, any5 = __ballot(cmax > RW_FAST_REC) != 0;
+            const bool anyq[3] = { any2, any3, any4 };
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
-                unfit[r] = cnt[r] > (uint32_t)RW_MAX_REC || (p1[r] && pos[r] >= 0xFFFEu); // (positions travel as 16 bits in the LDS path)
+                unfit[r] = p1[r] && pos[r] >= 0xFFFEu; // (positions travel as 16 bits in the LDS path)
 #pragma unroll
-                for (int q = 1; q < RW_MAX_REC; ++q) {
-                    const bool on = (uint32_t)q < cnt[r] && !unfit[r];
-                    kn[r][q - 1] = on ? a.rec_knode[rec[r].x + (uint32_t)q] : 0u;
-                    pg[r][q - 1] = on ? (uint32_t)a.rec_prg[rec[r].x + (uint32_t)q] : 0u;
+                for (int q = 1; q < RW_FAST_REC; ++q) {
+                    kn[r][q - 1] = pg[r][q - 1] = 0;
+                    if (anyq[q - 1] && !(dbg & 4u)) { // wave-uniform
+                        const uint32_t ri = (uint32_t)q < cnt[r] ? rec[r].x + (uint32_t)q : 0u; // (a lane without that record reads record 0 and ignores it)
+                        kn[r][q - 1] = a.rec_knode[ri];
+                        pg[r][q - 1] = (uint32_t)a.rec_prg[ri];
+                    }
                 }
             }
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const uint32_t strand = rec[r].z >> 31;
 #pragma unroll
-                for (int q = 1; q < RW_MAX_REC; ++q) {
-                    const bool on = (uint32_t)q < cnt[r] && !unfit[r];
+                for (int q = 1; q < RW_FAST_REC; ++q) {
+                    const bool on = (uint32_t)q < cnt[r];
                     const uint32_t rev = ((kn[r][q - 1] & 1u) == strand) ? 0u : 1u;
                     irr[r] |= on && ((pg[r][q - 1] << 1) | rev) != grp[r];
                     xcov[r][q - 1] = (kn[r][q - 1] >> 1) * 2u + rev;
                 }
+                if (any5) // (wave-uniform) some minimizer of the tile has more records than that: its lane walks the rest
+                    for (uint32_t q = RW_FAST_REC; q < cnt[r]; ++q) {
+                        const uint32_t knq = a.rec_knode[rec[r].x + q], pgq = a.rec_prg[rec[r].x + q];
+                        const uint32_t rev = ((knq & 1u) == strand) ? 0u : 1u;
+                        irr[r] |= ((pgq << 1) | rev) != grp[r];
+                    }
             }
         }
         const uint64_t S0 = __ballot(seg_start[0]), S1 = __ballot(seg_start[1]);
@@ -261,7 +307,7 @@ __global__ __launch_bounds__(RW_THREADS) void read_cluster_wave_kernel(SketchArg
             const int E = rw_next_set(RS0, RS1, r, lane);       // first slot of the next read (128: none staged)
             Fs[r] = F;
             Es[r] = E;
-            mine[r] = F >= 0 && F < 64; // (a read that began before the tile is its own tile's)
+            mine[r] = F >= 0 && F < RW_OWN; // (a read that began before the tile is its own tile's)
             const uint32_t last_rd = (uint32_t)__builtin_amdgcn_readlane((int)rd[1], 63);
             const bool runs_on = E == 128 && n_in == 128u && next_read == last_rd && rd[r] == last_rd; // continues behind the staged range
             uint64_t r0m, r1m;
@@ -306,31 +352,44 @@ __global__ __launch_bounds__(RW_THREADS) void read_cluster_wave_kernel(SketchArg
         }
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            if (mdec[r] == 1 || mdec[r] == 2) fw.cand_pos1[base + 64u * (uint32_t)r + (uint32_t)lane] = handled_mark;
-            if (mdec[r] == 2) {
+            if ((mdec[r] == 1 || mdec[r] == 2) && !(dbg & 2u)) fw.cand_pos1[base + 64u * (uint32_t)r + (uint32_t)lane] = handled_mark;
+            if (mdec[r] == 2 && !(dbg & 1u)) {
                 atomicAdd(&rc.covg[rec[r].w], 1u);
 #pragma unroll
-                for (int q = 1; q < RW_MAX_REC; ++q)
+                for (int q = 1; q < RW_FAST_REC; ++q)
                     if ((uint32_t)q < cnt[r]) atomicAdd(&rc.covg[xcov[r][q - 1]], 1u);
+                const uint32_t strand = rec[r].z >> 31;
+                for (uint32_t q = RW_FAST_REC; q < cnt[r]; ++q) { // (rare)
+                    const uint32_t knq = a.rec_knode[rec[r].x + q];
+                    atomicAdd(&rc.covg[(knq >> 1) * 2u + (((knq & 1u) == strand) ? 0u : 1u)], 1u);
+                }
             }
         }
         // ---- reads that are mine, hold a minimizer (or run on behind the staged range) and do not fit: left to the pass behind this kernel ----
-        {
+        bool rstart[2] = { rs0, rs1 };
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
             uint64_t r0m, r1m;
-            rw_range(Fs[0] < 0 ? 0 : Fs[0], Es[0], r0m, r1m);
+            rw_range(Fs[r] < 0 ? 0 : Fs[r], Es[r], r0m, r1m);
             const bool has_min = ((M0 & r0m) | (M1 & r1m)) != 0;
-            const bool uf = rs0 && !fit[0] && (has_min || Es[0] == 128);
-            if (uf) rc.chunk_flags[(base + (uint32_t)lane) / RC_CHUNK_OWN] = 1u;
-            const uint64_t UF0 = __ballot(uf);
-            if (lane == 0) my_unfit += (uint32_t)__popcll(UF0);
+            const bool uf = rstart[r] && mine[r] && !fit[r] && (has_min || Es[r] == 128);
+            if (uf) rc.chunk_flags[(base + 64u * (uint32_t)r + (uint32_t)lane) / RC_CHUNK_OWN] = 1u;
+            const uint64_t UF = __ballot(uf);
+            if (lane == 0) my_unfit += (uint32_t)__popcll(UF);
         }
         // ---- irregular reads, one after the other: the read's hits to the wave's LDS, then clusters per group split at gaps, size
         // threshold, the overlap sweep (read_cluster_kernel's wave path, on this wave) ----
-        uint64_t todo_reads = __ballot(rs0 && mine[0] && fit[0] && irregular[0]); // read starts (row 0 by definition of "mine")
-        while (todo_reads) {
-            const int f = __ffsll((long long)todo_reads) - 1;
-            todo_reads &= todo_reads - 1;
-            const int E = (int)__shfl(Es[0], f);
+        uint64_t todo0 = __ballot(rs0 && mine[0] && fit[0] && irregular[0]), todo1 = __ballot(rs1 && mine[1] && fit[1] && irregular[1]); // read starts
+        while (todo0 | todo1) {
+            int f;
+            if (todo0) {
+                f = __ffsll((long long)todo0) - 1;
+                todo0 &= todo0 - 1;
+            } else {
+                f = 64 + __ffsll((long long)todo1) - 1;
+                todo1 &= todo1 - 1;
+            }
+            const int E = (int)rw_at((uint32_t)Es[0], (uint32_t)Es[1], f);
             uint64_t r0m, r1m;
             rw_range(f, E, r0m, r1m);
             // the decision of the read's first segment start (all its segments agree by now: 3, 1 or 0)
@@ -347,8 +406,8 @@ __global__ __launch_bounds__(RW_THREADS) void read_cluster_wave_kernel(SketchArg
             }
             if (rdec != 3) continue; // dropped as a whole: marked above
             const uint32_t h_base = rw_at(incl[0], incl[1], f) - rw_at(cnt[0], cnt[1], f); // hits before the read
-            const uint32_t n_hits = (uint32_t)__shfl((int)read_hits[0], f);
-            const uint32_t read = (uint32_t)__shfl((int)rd[0], f);
+            const uint32_t n_hits = rw_at(read_hits[0], read_hits[1], f);
+            const uint32_t read = rw_at(rd[0], rd[1], f);
             const uint64_t len = a.offsets[read + 1] - a.offsets[read];
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -500,7 +559,13 @@ __global__ __launch_bounds__(RW_THREADS) void read_cluster_wave_kernel(SketchArg
             __builtin_amdgcn_wave_barrier();
         }
     }
-    // ---- totals ----
+    // ---- totals.  Every workgroup's histogram and counters go to a slot of its own in global memory -- plain stores --, and a
+    // one-workgroup kernel behind this one adds the slots up (rw_totals_kernel).  What was tried first: one atomic per wave on the
+    // three batch counters -- 8192 waves finishing together on one cache line, ~10 ns each in the L2: 190 us of a 230 us kernel --, and
+    // the last workgroup summing the slots behind a __threadfence(): the fence is an L2 write-back on this chip, 512 of them: 130 us. ----
+    __shared__ uint32_t s_tot[4];
+    if (tid < 4) s_tot[tid] = 0;
+    __syncthreads();
     {
         unsigned long long kh = my_kept_hits;
         uint32_t kp = my_kept, uf = my_unfit;
@@ -511,20 +576,57 @@ __global__ __launch_bounds__(RW_THREADS) void read_cluster_wave_kernel(SketchArg
             uf += (uint32_t)__shfl_xor((int)uf, off);
         }
         if (lane == 0) {
-            if (kp) atomicAdd(rc.n_clusters_kept, (unsigned long long)kp);
-            if (kh) atomicAdd(rc.n_hits_kept, kh);
-            if (uf) atomicAdd(rc.n_unfit, (unsigned long long)uf);
+            if (kp) atomicAdd(&s_tot[0], kp);
+            if (kh) atomicAdd(&s_tot[1], (uint32_t)kh); // (a workgroup's share of a batch stays far below 2^32 hits)
+            if (uf) atomicAdd(&s_tot[2], uf);
         }
     }
     __syncthreads();
-    for (uint32_t i = tid; i < rc.n_prgs; i += RW_THREADS)
-        if (s_hist[i]) atomicAdd(&rc.prg_reads[i], s_hist[i]);
+    const uint32_t n_slot = rc.n_prgs + 4;
+    uint32_t* const mine_slot = rc.wg_partials + (size_t)blockIdx.x * n_slot;
+    for (uint32_t i = tid; i < n_slot; i += RW_THREADS) mine_slot[i] = i < rc.n_prgs ? s_hist[i] : s_tot[i - rc.n_prgs];
 }
 
-hipError_t launch_read_cluster_wave(const SketchArgs& a, const FilterWork& fw, const ReadClusterArgs& rc, int n_cus, hipStream_t stream)
+// the slots of read_cluster_wave_kernel's workgroups summed into the batch's vectors and counters (one workgroup)
+__global__ __launch_bounds__(RW_THREADS) void rw_totals_kernel(SketchArgs a, ReadClusterArgs rc, uint32_t n_wg)
 {
+    if (*reinterpret_cast<volatile uint32_t*>(a.overflow) & 4u) return; // (the slots were not written)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t n_slot = rc.n_prgs + 4;
+    extern __shared__ uint32_t s_hist[];
+    __shared__ unsigned long long s_sum[4];
+    for (uint32_t i = tid; i < rc.n_prgs; i += RW_THREADS) s_hist[i] = 0;
+    if (tid < 4) s_sum[tid] = 0;
+    __syncthreads();
+    auto ld = [&](uint32_t g, uint32_t i) -> uint32_t { return g < n_wg && i < n_slot ? rc.wg_partials[(size_t)g * n_slot + i] : 0u; };
+    auto acc = [&](uint32_t i, uint32_t v) {
+        if (!v) return;
+        if (i < rc.n_prgs) atomicAdd(&s_hist[i], v);
+        else atomicAdd(&s_sum[i - rc.n_prgs], (unsigned long long)v);
+    };
+    // every wave takes every sixteenth group of four slot rows, the four rows' loads in flight together
+    for (uint32_t g0 = (uint32_t)wave * 4u; g0 < n_wg; g0 += RW_WAVES * 4u)
+        for (uint32_t i = (uint32_t)lane; i < n_slot; i += 64u) {
+            const uint32_t v0 = ld(g0, i), v1 = ld(g0 + 1, i), v2 = ld(g0 + 2, i), v3 = ld(g0 + 3, i);
+            acc(i, v0);
+            acc(i, v1);
+            acc(i, v2);
+            acc(i, v3);
+        }
+    __syncthreads();
+    for (uint32_t i = tid; i < rc.n_prgs; i += RW_THREADS)
+        if (s_hist[i]) atomicAdd(&rc.prg_reads[i], s_hist[i]);
+    if (tid == 0 && s_sum[0]) atomicAdd(rc.n_clusters_kept, s_sum[0]);
+    if (tid == 1 && s_sum[1]) atomicAdd(rc.n_hits_kept, s_sum[1]);
+    if (tid == 2 && s_sum[2]) atomicAdd(rc.n_unfit, s_sum[2]);
+}
+
+hipError_t launch_read_cluster_wave(const SketchArgs& a, const FilterWork& fw, const ReadClusterArgs& rc_in, int n_cus, hipStream_t stream)
+{
+    ReadClusterArgs rc = rc_in;
+    if (const char* e = std::getenv("DRPRG_RW_DEBUG")) rc.second_pass |= std::atoi(e) << 8;
     const size_t dyn = (size_t)rc.n_prgs * sizeof(uint32_t);
-    const uint32_t grid = (uint32_t)n_cus * 8; // 8 workgroups of 4 waves per CU: 8 waves per SIMD if the registers allow
+    const uint32_t grid = std::min<uint32_t>((uint32_t)n_cus * 2, RC_WAVE_MAX_WG); // two workgroups of 16 waves per CU
     if (rc.slice_prefix) {
         static size_t configured_slices[MAX_HIP_DEVICES] = {};
         HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&read_cluster_wave_kernel<true>), dyn, configured_slices));
@@ -534,6 +636,10 @@ hipError_t launch_read_cluster_wave(const SketchArgs& a, const FilterWork& fw, c
         HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&read_cluster_wave_kernel<false>), dyn, configured));
         hipLaunchKernelGGL(read_cluster_wave_kernel<false>, dim3(grid), dim3(RW_THREADS), dyn, stream, a, fw, rc);
     }
+    HIP_TRY(hipGetLastError());
+    static size_t configured_totals[MAX_HIP_DEVICES] = {};
+    HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&rw_totals_kernel), dyn, configured_totals));
+    hipLaunchKernelGGL(rw_totals_kernel, dim3(1), dim3(RW_THREADS), dyn, stream, a, rc, grid);
     return hipGetLastError();
 }
 

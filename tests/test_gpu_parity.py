@@ -90,6 +90,19 @@ def _compare(ctx, oracle, bases, offsets, w, k, illumina, kernel, min_cluster_si
     assert np.array_equal(pcov, ocov) and np.array_equal(pprg, oprg)
     for key in ("reads", "bases", "minimizers", "hits", "clusters_kept", "hits_kept", "leftover_reads"):
         assert pcnt[key] == gcnt[key], key
+    # ... and through the opt-in wave form of the last filtered stage (read_cluster_wave.hip; the switch is read at every launch)
+    if len(offsets) > 1 and int(offsets[-1]) // (len(offsets) - 1) <= 600:
+        os.environ["DRPRG_RC_FORM"] = "wave"
+        try:
+            ctx.reset()
+            ctx.map_host(bases, offsets)
+            wcov, wprg = ctx.coverage()
+            wcnt = ctx.counters()
+        finally:
+            del os.environ["DRPRG_RC_FORM"]
+        assert np.array_equal(wcov, ocov) and np.array_equal(wprg, oprg)
+        for key in ("reads", "bases", "minimizers", "hits", "clusters_kept", "hits_kept", "leftover_reads"):
+            assert wcnt[key] == gcnt[key], key
     return ocnt
 
 
