@@ -560,8 +560,9 @@ __device__ __forceinline__ bool tile_overflow(const SketchArgs& a, const uint32_
 // The batch counters: hits and minimizers of all tiles (and what sketch_wave_kernel clustered itself), summed by a small grid --
 // one atomic per counter and workgroup: as part of the gather (6000 workgroups, four atomics each on the same four addresses) the
 // sums cost 0.3 ms of its 0.8 on the 500-locus index.
+// block_first != nullptr (read_cluster_kernel<SLICES> follows): word m = the slice that holds entry 64 m of the ordered list
 __global__ __launch_bounds__(TG_THREADS) void tile_totals_kernel(SketchArgs a, const uint32_t* __restrict__ tile_prefix, uint32_t n_tiles,
-    uint64_t dense_capacity)
+    uint64_t dense_capacity, uint32_t* __restrict__ block_first)
 {
     __shared__ uint32_t s_w[TG_THREADS / 64 + 1];
     const int tid = threadIdx.x;
@@ -573,6 +574,10 @@ __global__ __launch_bounds__(TG_THREADS) void tile_totals_kernel(SketchArgs a, c
     for (uint32_t t = blockIdx.x * TG_THREADS + (uint32_t)tid; t < n_tiles; t += gridDim.x * TG_THREADS) {
         my_hits += a.tile_hits[t];
         my_nmin += a.tile_nmin[t];
+        if (block_first) {
+            const uint32_t lo = tile_prefix[t], hi = tile_prefix[t + 1];
+            for (uint32_t m = (lo + 63u) >> 6; lo < hi && (uint64_t)m << 6 < hi; ++m) block_first[m] = t;
+        }
         if (a.fuse > 0) { // what sketch_wave_kernel clustered itself
             const uint32_t f = a.tile_fast[t];
             my_fc += f & 0xFFFFu;
@@ -684,11 +689,14 @@ hipError_t launch_direct_candidates(const SketchArgs& a, bool wide_hash, uint32_
     HIP_TRY(exclusive_scan_u32(temp, temp_bytes, a.tile_count, tile_prefix, n_tiles + 1, stream));
     fw.cand_total = tile_prefix + n_tiles;
     const dim3 grid((n_tiles + TG_TILES - 1) / TG_TILES);
+    // (the block table of the slices form lives in the dense cand_info array: two words per entry of capacity, one per 64 needed)
+    uint32_t* const block_first = slices_mark && dense_capacity ? reinterpret_cast<uint32_t*>(fw.cand_info) : nullptr;
     hipLaunchKernelGGL(tile_totals_kernel, dim3(std::min<uint32_t>((n_tiles + TG_THREADS - 1) / TG_THREADS, (uint32_t)n_cus)), dim3(TG_THREADS), 0, stream, a,
-        tile_prefix, n_tiles, dense_capacity);
+        tile_prefix, n_tiles, dense_capacity, block_first);
     HIP_TRY(hipGetLastError());
     if (slices_mark) { // read_cluster_kernel takes the candidates from the slices: a dense list only if reads are left over
         ReadClusterArgs rcs = rc;
+        rcs.block_first = block_first;
         rcs.slice_prefix = tile_prefix;
         rcs.n_slices = n_tiles;
         rcs.mark_epoch = slices_mark;

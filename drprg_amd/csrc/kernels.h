@@ -224,6 +224,8 @@ struct ReadClusterArgs {
     // handled candidates are marked cand_pos1[d] = mark_epoch in the (otherwise unused) dense array
     const uint32_t* slice_prefix; // [n_slices + 1], exclusive scan of the slice counts
     uint32_t n_slices, mark_epoch;
+    const uint32_t* block_first;  // [total / 64 + 1]: the slice that holds entry 64 m of the ordered list (tile_totals_kernel writes it into the
+                                  // -- until a dense list is gathered -- unused fw.cand_info)
     // the wave form (read_cluster_wave.hip) runs first and counts in *n_unfit the reads it leaves untouched (long reads, minimizers with many
     // index records); read_cluster_kernel then runs as a SECOND PASS over what is left: second_pass != 0 makes it return at once when
     // *n_unfit == 0 and skip the candidates that are handled already

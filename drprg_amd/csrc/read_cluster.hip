@@ -130,37 +130,39 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
             st.edge_prev = live ? (uint32_t)fw.cand_info[b ? b - 1 : 0u] : 0u;
             st.edge_next = live ? (uint32_t)fw.cand_info[nxt ? b + n_in : b] : 0u;
         } else {
-            // A window of the slice prefix around the slice that entry b should be in if the slices were equally full -- RC_SLOTS
-            // entries, a quarter of them before the guess -- goes to LDS (s_gt is free between phase E and the next phase C); every
-            // slot then finds its slice there by bisection.  If the window does not hold the whole staged range (slices very
-            // unevenly filled), every slot bisects the prefix in global memory instead.
-            uint32_t* const s_pref = s_gt;
+            // Where entry d of the ordered list lives in the slice arrays.  rc.block_first[m] is the slice that holds entry 64 m
+            // (written by tile_totals_kernel), a wave's 64 slots are 64 consecutive entries from a multiple of 64, and the starts of
+            // the 64 slices behind that one are one coalesced load: every start inside the wave's range is scattered to the wave's own
+            // 64 words of LDS as 1 + its lane (the last slice of a run of equal starts -- empty slices -- wins) and an inclusive max
+            // scan over the lanes gives each slot its slice.  No workgroup barrier, two dependent loads where the round-3 form
+            // bisected a window of the prefix in LDS (eleven dependent LDS reads per slot: a quarter of a chunk's time).  If more
+            // than 64 slices start inside the range (a batch with next to no candidates), every slot bisects the prefix in global memory.
             const uint32_t* __restrict__ P = rc.slice_prefix;
-            const uint32_t guess = live ? (uint32_t)((uint64_t)b * rc.n_slices / (total ? total : 1u)) : 0u;
-            uint32_t w0 = guess > (uint32_t)RC_SLOTS / 4 ? guess - (uint32_t)RC_SLOTS / 4 : 0u;
-            if (w0 + (uint32_t)RC_SLOTS > rc.n_slices + 1) w0 = rc.n_slices + 1 > (uint32_t)RC_SLOTS ? rc.n_slices + 1 - (uint32_t)RC_SLOTS : 0u;
-            const uint32_t w_n = rc.n_slices + 1 - w0 < (uint32_t)RC_SLOTS ? rc.n_slices + 1 - w0 : (uint32_t)RC_SLOTS; // entries in the window
+            uint32_t* const s_mine = s_gt + (wave << 6); // (s_gt is free between phase E and the next phase C)
+            auto locate = [&](uint32_t d0, uint32_t d_hi) -> size_t { // entry min(d0 + lane, d_hi); d0 a multiple of 64, d0 <= d_hi < total
+                const uint32_t s0 = __builtin_amdgcn_readfirstlane(rc.block_first[d0 >> 6]);
+                const uint32_t j1 = s0 + 1u + (uint32_t)lane;
+                const uint32_t pj = P[j1 < rc.n_slices ? j1 : rc.n_slices];
+                const uint32_t p0 = P[s0];
+                const uint32_t x = d0 + (uint32_t)lane <= d_hi ? (uint32_t)lane : d_hi - d0;
+                if (__builtin_amdgcn_readlane(pj, 63) > d_hi) {
+                    s_mine[lane] = 0;
+                    const uint32_t pn = __shfl_down(pj, 1);
+                    const uint32_t rel = pj - d0;
+                    if ((lane == 63 || pn != pj) && rel < 64u) s_mine[rel] = (uint32_t)lane + 1u;
+                    __builtin_amdgcn_wave_barrier();
+                    uint32_t c = s_mine[lane];
 #pragma unroll
-            for (int q = 0; q < RC_PER; ++q) {
-                const uint32_t j = (uint32_t)tid + (uint32_t)q * RC_THREADS;
-                s_pref[j] = live && j < w_n ? P[w0 + j] : 0xFFFFFFFFu;
-            }
-            lds_barrier(tid);
-            const uint32_t d_last = b + n_in; // one past the staged range (the edge after it included)
-            const bool in_window = s_pref[0] <= (b ? b - 1 : 0u) && (w0 + w_n == rc.n_slices + 1 || s_pref[w_n - 1] > d_last);
-            auto locate = [&](uint32_t d) -> size_t { // where entry d of the ordered list lives in the slice arrays
-                uint32_t s;
-                if (in_window) {
-                    uint32_t lo = 0, hi = w_n; // s_pref[lo] <= d < s_pref[hi] (hi == w_n: the end)
-                    while (hi - lo > 1) {
-                        const uint32_t mid = (lo + hi) >> 1;
-                        if (s_pref[mid] <= d) lo = mid;
-                        else hi = mid;
+                    for (int off = 1; off < 64; off <<= 1) {
+                        const uint32_t n = __shfl_up(c, off);
+                        if (lane >= off) c = n > c ? n : c;
                     }
-                    s = w0 + lo;
-                    return (size_t)s * a.tile_cap + (d - s_pref[lo]);
+                    c = __shfl(c, (int)x);
+                    const uint32_t before = __shfl(pj, (int)(c ? c - 1u : 0u));
+                    return (size_t)(s0 + c) * a.tile_cap + (d0 + x - (c ? before : p0));
                 }
-                uint32_t lo = 0, hi = rc.n_slices; // P[lo] <= d < P[hi]
+                const uint32_t d = d0 + x;
+                uint32_t lo = s0, hi = rc.n_slices; // P[lo] <= d < P[hi]
                 while (hi - lo > 1) {
                     const uint32_t mid = (lo + hi) >> 1;
                     if (P[mid] <= d) lo = mid;
@@ -168,19 +170,34 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
                 }
                 return (size_t)lo * a.tile_cap + (d - P[lo]);
             };
+            const uint32_t d_last = b + n_in - 1; // (n_in >= 1 when live)
 #pragma unroll
             for (int q = 0; q < RC_PER; ++q) {
                 const uint32_t i = (uint32_t)tid + (uint32_t)q * RC_THREADS;
-                const size_t src = live ? locate(b + (i < n_in ? i : 0u)) : 0;
+                const uint32_t d0 = b + ((uint32_t)(wave << 6) + (uint32_t)q * RC_THREADS);
+                const bool some = live && d0 <= d_last; // (wave-uniform; a wave past the end reads entry 0 of slice 0 and drops it)
+                const size_t src = some ? locate(d0, d_last) : 0;
                 st.info[q] = live ? (uint32_t)a.tile_info[src] : 0u;
                 st.pos1[q] = live ? a.tile_pos1[src] : 0u;
                 st.rec[q] = live ? a.tile_rec[src] : make_uint4(0, 0, 0, 0);
                 // (second pass: what the wave form handled carries this batch's mark in the dense array)
                 if (rc.second_pass && live && i < n_in && fw.cand_pos1[b + i] == rc.mark_epoch) st.pos1[q] = 0u;
             }
+            // the two neighbours of the staged range (thread 0 alone looks at them): entry b - 1 is slot 63 of the 64 entries before
+            // b, entry b + RC_SLOTS the first of its 64 and so in the slice block_first names
             const bool nxt = n_in == (uint32_t)RC_SLOTS && b + n_in < total;
-            st.edge_prev = live && b ? (uint32_t)a.tile_info[locate(b - 1)] : 0u;
-            st.edge_next = live && nxt ? (uint32_t)a.tile_info[locate(b + n_in)] : 0u;
+            st.edge_prev = 0u;
+            st.edge_next = 0u;
+            if (wave == 0) {
+                size_t e_prev = 0, e_next = 0;
+                if (live && b) e_prev = (size_t)__shfl((unsigned long long)locate(b - 64u, b - 1u), 63);
+                if (live && nxt) {
+                    const uint32_t sn = rc.block_first[(b + n_in) >> 6];
+                    e_next = (size_t)sn * a.tile_cap + (b + n_in - P[sn]);
+                }
+                st.edge_prev = live && b ? (uint32_t)a.tile_info[e_prev] : 0u;
+                st.edge_next = live && nxt ? (uint32_t)a.tile_info[e_next] : 0u;
+            }
         }
         return st;
     };
