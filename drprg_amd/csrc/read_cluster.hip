@@ -137,32 +137,52 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
             // scan over the lanes gives each slot its slice.  No workgroup barrier, two dependent loads where the round-3 form
             // bisected a window of the prefix in LDS (eleven dependent LDS reads per slot: a quarter of a chunk's time).  If more
             // than 64 slices start inside the range (a batch with next to no candidates), every slot bisects the prefix in global memory.
+            // The loads go out in two rounds for all of a wave's ranges together -- the block table words (scalar loads), then the
+            // slice starts -- so that a request costs two memory latencies, not two per range.
             const uint32_t* __restrict__ P = rc.slice_prefix;
             uint32_t* const s_mine = s_gt + (wave << 6); // (s_gt is free between phase E and the next phase C)
-            auto locate = [&](uint32_t d0, uint32_t d_hi) -> size_t { // entry min(d0 + lane, d_hi); d0 a multiple of 64, d0 <= d_hi < total
-                const uint32_t s0 = __builtin_amdgcn_readfirstlane(rc.block_first[d0 >> 6]);
-                const uint32_t j1 = s0 + 1u + (uint32_t)lane;
-                const uint32_t pj = P[j1 < rc.n_slices ? j1 : rc.n_slices];
-                const uint32_t p0 = P[s0];
-                const uint32_t x = d0 + (uint32_t)lane <= d_hi ? (uint32_t)lane : d_hi - d0;
-                if (__builtin_amdgcn_readlane(pj, 63) > d_hi) {
+            const uint32_t d_last = b + n_in - 1; // (n_in >= 1 when live)
+            const bool nxt = n_in == (uint32_t)RC_SLOTS && b + n_in < total;
+            // ranges: q < RC_PER the wave's own slots; RC_PER: the 64 entries before b (wave 0: entry b - 1 is its slot 63)
+            uint32_t d0[RC_PER + 1], s0[RC_PER + 1], pj[RC_PER + 1], p0[RC_PER + 1], sn = 0, pn0 = 0;
+            bool some[RC_PER + 1];
+#pragma unroll
+            for (int q = 0; q <= RC_PER; ++q) {
+                d0[q] = q < RC_PER ? b + ((uint32_t)(wave << 6) + (uint32_t)q * RC_THREADS) : b - 64u;
+                some[q] = q < RC_PER ? live && d0[q] <= d_last : live && b && wave == 0; // (wave-uniform)
+                s0[q] = some[q] ? rc.block_first[__builtin_amdgcn_readfirstlane(d0[q] >> 6)] : 0u;
+            }
+            const bool edge_n = live && nxt && wave == 0; // entry b + RC_SLOTS is the first of its 64: in the slice the table names
+            if (edge_n) sn = rc.block_first[__builtin_amdgcn_readfirstlane((b + n_in) >> 6)];
+#pragma unroll
+            for (int q = 0; q <= RC_PER; ++q) {
+                s0[q] = __builtin_amdgcn_readfirstlane(s0[q]);
+                const uint32_t j1 = s0[q] + 1u + (uint32_t)lane;
+                pj[q] = some[q] ? P[j1 < rc.n_slices ? j1 : rc.n_slices] : 0u;
+                p0[q] = some[q] ? P[s0[q]] : 0u;
+            }
+            if (edge_n) pn0 = P[sn];
+            auto locate = [&](int q, uint32_t d_hi) -> size_t { // entry min(d0 + lane, d_hi); d0 a multiple of 64, d0 <= d_hi < total
+                const uint32_t x = d0[q] + (uint32_t)lane <= d_hi ? (uint32_t)lane : d_hi - d0[q];
+                if (__builtin_amdgcn_readlane(pj[q], 63) > d_hi) {
                     s_mine[lane] = 0;
-                    const uint32_t pn = __shfl_down(pj, 1);
-                    const uint32_t rel = pj - d0;
-                    if ((lane == 63 || pn != pj) && rel < 64u) s_mine[rel] = (uint32_t)lane + 1u;
+                    const uint32_t pn = __shfl_down(pj[q], 1);
+                    const uint32_t rel = pj[q] - d0[q];
+                    if ((lane == 63 || pn != pj[q]) && rel < 64u) s_mine[rel] = (uint32_t)lane + 1u;
                     __builtin_amdgcn_wave_barrier();
                     uint32_t c = s_mine[lane];
+                    __builtin_amdgcn_wave_barrier();
 #pragma unroll
                     for (int off = 1; off < 64; off <<= 1) {
                         const uint32_t n = __shfl_up(c, off);
                         if (lane >= off) c = n > c ? n : c;
                     }
                     c = __shfl(c, (int)x);
-                    const uint32_t before = __shfl(pj, (int)(c ? c - 1u : 0u));
-                    return (size_t)(s0 + c) * a.tile_cap + (d0 + x - (c ? before : p0));
+                    const uint32_t before = __shfl(pj[q], (int)(c ? c - 1u : 0u));
+                    return (size_t)(s0[q] + c) * a.tile_cap + (d0[q] + x - (c ? before : p0[q]));
                 }
-                const uint32_t d = d0 + x;
-                uint32_t lo = s0, hi = rc.n_slices; // P[lo] <= d < P[hi]
+                const uint32_t d = d0[q] + x;
+                uint32_t lo = s0[q], hi = rc.n_slices; // P[lo] <= d < P[hi]
                 while (hi - lo > 1) {
                     const uint32_t mid = (lo + hi) >> 1;
                     if (P[mid] <= d) lo = mid;
@@ -170,33 +190,25 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
                 }
                 return (size_t)lo * a.tile_cap + (d - P[lo]);
             };
-            const uint32_t d_last = b + n_in - 1; // (n_in >= 1 when live)
 #pragma unroll
             for (int q = 0; q < RC_PER; ++q) {
                 const uint32_t i = (uint32_t)tid + (uint32_t)q * RC_THREADS;
-                const uint32_t d0 = b + ((uint32_t)(wave << 6) + (uint32_t)q * RC_THREADS);
-                const bool some = live && d0 <= d_last; // (wave-uniform; a wave past the end reads entry 0 of slice 0 and drops it)
-                const size_t src = some ? locate(d0, d_last) : 0;
+                const size_t src = some[q] ? locate(q, d_last) : 0; // (a wave past the end reads entry 0 of slice 0 and drops it)
                 st.info[q] = live ? (uint32_t)a.tile_info[src] : 0u;
                 st.pos1[q] = live ? a.tile_pos1[src] : 0u;
                 st.rec[q] = live ? a.tile_rec[src] : make_uint4(0, 0, 0, 0);
                 // (second pass: what the wave form handled carries this batch's mark in the dense array)
                 if (rc.second_pass && live && i < n_in && fw.cand_pos1[b + i] == rc.mark_epoch) st.pos1[q] = 0u;
             }
-            // the two neighbours of the staged range (thread 0 alone looks at them): entry b - 1 is slot 63 of the 64 entries before
-            // b, entry b + RC_SLOTS the first of its 64 and so in the slice block_first names
-            const bool nxt = n_in == (uint32_t)RC_SLOTS && b + n_in < total;
+            // the two neighbours of the staged range (thread 0 alone looks at them)
             st.edge_prev = 0u;
             st.edge_next = 0u;
             if (wave == 0) {
-                size_t e_prev = 0, e_next = 0;
-                if (live && b) e_prev = (size_t)__shfl((unsigned long long)locate(b - 64u, b - 1u), 63);
-                if (live && nxt) {
-                    const uint32_t sn = rc.block_first[(b + n_in) >> 6];
-                    e_next = (size_t)sn * a.tile_cap + (b + n_in - P[sn]);
-                }
-                st.edge_prev = live && b ? (uint32_t)a.tile_info[e_prev] : 0u;
-                st.edge_next = live && nxt ? (uint32_t)a.tile_info[e_next] : 0u;
+                size_t e_prev = 0;
+                if (some[RC_PER]) e_prev = (size_t)__shfl((unsigned long long)locate(RC_PER, b - 1u), 63);
+                const size_t e_next = edge_n ? (size_t)sn * a.tile_cap + (b + n_in - pn0) : 0;
+                st.edge_prev = some[RC_PER] ? (uint32_t)a.tile_info[e_prev] : 0u;
+                st.edge_next = edge_n ? (uint32_t)a.tile_info[e_next] : 0u;
             }
         }
         return st;
