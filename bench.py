@@ -599,8 +599,8 @@ def main():
         # the microarch guide prescribes for wide coalesced loads on gfx950): measured offline, committed under profiles/
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
-        if n_reads == default_reads and os.path.exists(tfile) and not packed:
-            traffic = json.load(open(tfile)).get(args.workload, {}).get(kernel_name, {}).get("hbm_bytes_per_launch")
+        if n_reads == default_reads and os.path.exists(tfile):
+            traffic = json.load(open(tfile)).get(args.workload + ("-packed" if packed else ""), {}).get(kernel_name, {}).get("hbm_bytes_per_launch")
             if traffic is not None:
                 traffic = traffic / launches_per_step  # (measured per batch)
         # secondary bound (SURVEY 8d "report honestly"): the dominant kernel's VALU issue slots.  Wave instructions per launch come

@@ -91,6 +91,7 @@ SIGNATURES = {
     "drprg_hip_discover": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_uint32)]),
     "drprg_hip_discover_reads": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_uint32)]),
     "drprg_hip_update_prg": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint32)]),
+    "drprg_hip_update_prg_from_paths": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_uint32)]),
     "drprg_hip_save_coverage": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p]),
     "drprg_hip_load_coverage": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_uint64)]),
     "drprg_hip_allele_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_double)]),

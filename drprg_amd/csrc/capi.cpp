@@ -918,7 +918,34 @@ int drprg_hip_update_prg(drprg_hip_ctx* ctx, const char* out_prg, uint32_t* n_ap
     std::vector<std::string> skipped;
     const uint32_t n = update_prgs(prgs, ctx->last_discover, ctx->last_variants, &skipped);
     for (const std::string& s : skipped)
-        std::fprintf(stderr, "drprg-hip: novel variant at %s overlaps an existing site of the PRG and is not added to it\n", s.c_str());
+        std::fprintf(stderr, "drprg-hip: novel variant at %s could not be placed in the PRG\n", s.c_str());
+    std::ofstream o(out_prg);
+    for (auto& p : prgs) o << ">" << p.first << "\n" << p.second << "\n";
+    if (!o) throw Error(DRPRG_EIO, std::string("cannot write ") + out_prg);
+    if (n_applied) *n_applied = n;
+    API_END(ctx)
+}
+
+int drprg_hip_update_prg_from_paths(drprg_hip_ctx* ctx, const char* denovo_paths, const char* out_prg, uint32_t* n_applied)
+{
+    API_BEGIN(ctx)
+    if (!denovo_paths || !out_prg) throw Error(DRPRG_EINVAL, "null path");
+    std::vector<std::pair<std::string, std::string>> prgs;
+    std::vector<std::string> names;
+    for (const LocalGraph& g : ctx->index.prgs) {
+        prgs.emplace_back(g.name, g.prg);
+        names.push_back(g.name);
+    }
+    GenotypeResult gr;
+    std::vector<NovelVariant> variants;
+    read_denovo_paths(denovo_paths, names, gr, variants);
+    for (const LocusConsensus& lc : gr.consensus) // the node intervals must be this PRG's
+        for (const ConsensusNode& n : lc.nodes)
+            if (n.end > prgs[lc.prg].second.size() || prgs[lc.prg].second.compare(n.start, n.end - n.start, n.seq) != 0)
+                throw Error(DRPRG_EINVAL, std::string(denovo_paths) + ": the nodes of " + lc.chrom + " are not intervals of this context's PRG");
+    std::vector<std::string> skipped;
+    const uint32_t n = update_prgs(prgs, gr, variants, &skipped);
+    for (const std::string& s : skipped) std::fprintf(stderr, "drprg-hip: novel variant at %s could not be placed in the PRG\n", s.c_str());
     std::ofstream o(out_prg);
     for (auto& p : prgs) o << ">" << p.first << "\n" << p.second << "\n";
     if (!o) throw Error(DRPRG_EIO, std::string("cannot write ") + out_prg);

@@ -22,6 +22,7 @@
 #include <array>
 #include <atomic>
 #include <cmath>
+#include <cstring>
 #include <fstream>
 #include <map>
 #include <mutex>
@@ -390,22 +391,192 @@ void write_denovo_paths(const std::string& dir, const std::string& sample, const
     if (!o) throw Error(DRPRG_EIO, "cannot write " + dir + "/denovo_paths.txt");
 }
 
-// A variant that lies inside one local node of the called path (no existing site in the way) becomes a new site of the
-// PRG string: "... <M> ref <M+1> alt <M> ..." with M a fresh odd marker.  Returns the number of variants applied.
+// ---- PRG update ---------------------------------------------------------------------------------------------------------------------
+// The reference adds the consensus-with-variants of a locus to the locus' multiple alignment (mafft --add) and lets make_prg build the PRG
+// again (/root/reference/src/lib.rs:279-456); both tools are external.  Here the PRG string itself is edited so that its language grows by
+// exactly the new sequence: the stretch of the string the variant touches -- widened until it holds only whole sites (a variant that runs
+// into or across a site takes the whole site) -- becomes the first allele of a new site whose second allele is what the called path spells
+// there with the variant applied:   ... <M> old stretch <M+1> path with variant <M> ...   Stretches of several variants that overlap are
+// joined first.  A variant inside one node gives the plain  <M> ref <M+1> alt <M>  of rounds 2-3.  Afterwards the markers are numbered
+// again in the order pandora's parser meets them (a site before the sites inside it, then the sites behind it; 5, 7, 9 ...): its
+// LocalPRG::build_graph splits an interval at the NEXT marker number and stops if another site comes first [UPSTREAM-MEMORY], which is
+// also the numbering of the reference's own dr.prg (" 21  23 G 24 T 23").
+namespace {
+
+struct PrgSite {
+    size_t open_off = 0, close_off = 0; // [the space before the opening marker, one past the space behind the closing marker)
+    int parent_ctx = 0;
+};
+struct PrgCtx {
+    int parent = -1, site = -1, depth = 0;
+};
+// context (site, allele) of every base of the string; markers are " <n> " with odd n opening and closing a site and n + 1 between alleles
+bool scan_prg(const std::string& prg, std::vector<PrgSite>& sites, std::vector<PrgCtx>& ctxs, std::vector<int>& ctx_of)
+{
+    sites.clear();
+    ctxs.assign(1, PrgCtx {});
+    ctx_of.assign(prg.size(), -1);
+    struct Open {
+        int marker, site;
+    };
+    std::vector<Open> stack;
+    int cur = 0;
+    for (size_t i = 0; i < prg.size();) {
+        const unsigned char c = (unsigned char)prg[i];
+        if (std::isdigit(c)) {
+            size_t j = i;
+            int m = 0;
+            while (j < prg.size() && std::isdigit((unsigned char)prg[j])) m = m * 10 + (prg[j++] - '0');
+            if (m % 2) {
+                if (!stack.empty() && stack.back().marker == m) { // closes
+                    sites[(size_t)stack.back().site].close_off = std::min(j + 1, prg.size());
+                    cur = sites[(size_t)stack.back().site].parent_ctx;
+                    stack.pop_back();
+                } else { // opens
+                    PrgSite st;
+                    st.open_off = i ? i - 1 : 0;
+                    st.parent_ctx = cur;
+                    sites.push_back(st);
+                    stack.push_back({ m, (int)sites.size() - 1 });
+                    ctxs.push_back({ cur, (int)sites.size() - 1, ctxs[(size_t)cur].depth + 1 });
+                    cur = (int)ctxs.size() - 1;
+                }
+            } else {
+                if (stack.empty() || stack.back().marker + 1 != m) return false;
+                const int st = stack.back().site;
+                ctxs.push_back({ sites[(size_t)st].parent_ctx, st, ctxs[(size_t)sites[(size_t)st].parent_ctx].depth + 1 });
+                cur = (int)ctxs.size() - 1;
+            }
+            i = j;
+        } else {
+            if (c != ' ') ctx_of[i] = cur;
+            ++i;
+        }
+    }
+    return stack.empty();
+}
+
+// markers in the order pandora's parser consumes them: pre-order, left to right
+std::string renumber_prg(const std::string& prg)
+{
+    std::string out;
+    out.reserve(prg.size() + 16);
+    std::vector<std::pair<int, int>> stack; // (old marker, new marker)
+    int next = 5;
+    for (size_t i = 0; i < prg.size();) {
+        if (std::isdigit((unsigned char)prg[i])) {
+            size_t j = i;
+            int m = 0;
+            while (j < prg.size() && std::isdigit((unsigned char)prg[j])) m = m * 10 + (prg[j++] - '0');
+            int nm;
+            if (m % 2) {
+                if (!stack.empty() && stack.back().first == m) {
+                    nm = stack.back().second;
+                    stack.pop_back();
+                } else {
+                    nm = next;
+                    next += 2;
+                    stack.push_back({ m, nm });
+                }
+            } else
+                nm = stack.empty() ? m : stack.back().second + 1;
+            out += std::to_string(nm);
+            i = j;
+        } else
+            out += prg[i++];
+    }
+    return out;
+}
+
+} // namespace
+
+// Returns the number of variants applied; `skipped`: variants that could not be placed (a locus without a called path, a position
+// outside it, a PRG string that does not scan).
 uint32_t update_prgs(std::vector<std::pair<std::string, std::string>>& prgs, const GenotypeResult& gr, const std::vector<NovelVariant>& variants,
     std::vector<std::string>* skipped)
 {
     uint32_t applied = 0;
     std::map<uint32_t, std::vector<const NovelVariant*>> by_prg;
     for (const NovelVariant& v : variants) by_prg[v.prg].push_back(&v);
+    auto skip = [&](const NovelVariant* v) {
+        if (skipped) skipped->push_back(v->chrom + ":" + std::to_string(v->pos + 1));
+    };
     for (auto& kv : by_prg) {
-        if (kv.first >= prgs.size()) continue;
         const LocusConsensus* lc = nullptr;
         for (const LocusConsensus& c : gr.consensus)
             if (c.prg == kv.first) lc = &c;
-        if (!lc) continue;
+        std::vector<PrgSite> sites;
+        std::vector<PrgCtx> ctxs;
+        std::vector<int> ctx_of;
+        if (kv.first >= prgs.size() || !lc || !scan_prg(prgs[kv.first].second, sites, ctxs, ctx_of)) {
+            for (const NovelVariant* v : kv.second) skip(v);
+            continue;
+        }
         std::string& prg = prgs[kv.first].second;
-        int marker = 3; // largest marker in use
+        const std::string& cons = lc->seq;
+        // consensus position -> offset in the PRG string
+        std::vector<uint32_t> cum(lc->nodes.size() + 1, 0);
+        for (size_t i = 0; i < lc->nodes.size(); ++i) cum[i + 1] = cum[i] + (lc->nodes[i].end - lc->nodes[i].start);
+        auto offset_of = [&](uint32_t p) -> size_t {
+            size_t i = (size_t)(std::upper_bound(cum.begin(), cum.end(), p) - cum.begin()) - 1; // the node that holds base p (empty nodes skipped)
+            return (size_t)lc->nodes[i].start + (p - cum[i]);
+        };
+        auto first_path_base_at_or_after = [&](size_t off) -> uint32_t {
+            for (size_t i = 0; i < lc->nodes.size(); ++i)
+                if (lc->nodes[i].start >= off && lc->nodes[i].end > lc->nodes[i].start) return cum[i];
+            return cum.back();
+        };
+        struct Edit {
+            size_t a, b;     // stretch of the PRG string
+            uint32_t p, q;   // the path bases inside it
+            std::vector<const NovelVariant*> vs;
+        };
+        std::vector<Edit> edits;
+        for (const NovelVariant* v : kv.second) {
+            uint32_t p = v->pos, q = v->pos + (uint32_t)v->ref.size();
+            if (q > cons.size() || cum.back() != cons.size() || cons.empty()) {
+                skip(v);
+                continue;
+            }
+            if (p == q) { // an insertion takes the base before it along (the one behind it at the very start)
+                if (p) --p;
+                else ++q;
+            }
+            const size_t xa = offset_of(p), xb = offset_of(q - 1);
+            if (xa >= prg.size() || xb >= prg.size() || ctx_of[xa] < 0 || ctx_of[xb] < 0) {
+                skip(v);
+                continue;
+            }
+            // the deepest context both ends lie in; an end that lies deeper takes the whole site it is in at the next level
+            int ca = ctx_of[xa], cb = ctx_of[xb], sa = -1, sb = -1;
+            while (ctxs[(size_t)ca].depth > ctxs[(size_t)cb].depth) sa = ctxs[(size_t)ca].site, ca = ctxs[(size_t)ca].parent;
+            while (ctxs[(size_t)cb].depth > ctxs[(size_t)ca].depth) sb = ctxs[(size_t)cb].site, cb = ctxs[(size_t)cb].parent;
+            while (ca != cb) {
+                sa = ctxs[(size_t)ca].site, ca = ctxs[(size_t)ca].parent;
+                sb = ctxs[(size_t)cb].site, cb = ctxs[(size_t)cb].parent;
+            }
+            Edit e;
+            e.a = sa >= 0 ? sites[(size_t)sa].open_off : xa;
+            e.b = sb >= 0 ? sites[(size_t)sb].close_off : xb + 1;
+            e.p = sa >= 0 ? first_path_base_at_or_after(e.a) : p;
+            e.q = sb >= 0 ? first_path_base_at_or_after(e.b) : q;
+            e.vs.push_back(v);
+            edits.push_back(std::move(e));
+        }
+        // overlapping stretches lie in one context (each holds whole sites only), so their union is a stretch of the same kind
+        std::sort(edits.begin(), edits.end(), [](const Edit& x, const Edit& y) { return x.a < y.a; });
+        std::vector<Edit> merged;
+        for (Edit& e : edits) {
+            if (!merged.empty() && e.a < merged.back().b) {
+                Edit& m = merged.back();
+                m.b = std::max(m.b, e.b);
+                m.p = std::min(m.p, e.p);
+                m.q = std::max(m.q, e.q);
+                m.vs.insert(m.vs.end(), e.vs.begin(), e.vs.end());
+            } else
+                merged.push_back(std::move(e));
+        }
+        int marker = 3;
         for (size_t i = 0; i < prg.size();) {
             if (std::isdigit((unsigned char)prg[i])) {
                 int v = 0;
@@ -413,31 +584,101 @@ uint32_t update_prgs(std::vector<std::pair<std::string, std::string>>& prgs, con
                 marker = std::max(marker, v);
             } else ++i;
         }
-        int next_marker = marker + 1 + ((marker + 1) % 2 == 0 ? 1 : 0); // the next odd number
-        // where every consensus position sits in the PRG string: walk the nodes
-        std::vector<const NovelVariant*> vs = kv.second;
-        std::sort(vs.begin(), vs.end(), [](const NovelVariant* a, const NovelVariant* b) { return a->pos > b->pos; }); // right to left
-        for (const NovelVariant* v : vs) {
-            uint32_t at = 0;
-            bool done = false;
-            for (const ConsensusNode& n : lc->nodes) {
-                const uint32_t len = n.end - n.start;
-                // strictly inside the node: one base of the node stays on either side, so no marker ends up next to another
-                if (len && v->pos > at && v->pos + v->ref.size() < at + len) {
-                    const size_t a = n.start + (v->pos - at), b = a + v->ref.size();
-                    const std::string m = std::to_string(next_marker), sep = std::to_string(next_marker + 1);
-                    prg = prg.substr(0, a) + " " + m + " " + v->ref + " " + sep + " " + v->alt + " " + m + " " + prg.substr(b);
-                    next_marker += 2;
-                    ++applied;
-                    done = true;
-                    break;
-                }
-                at += len;
+        int next_marker = marker + 1 + ((marker + 1) % 2 == 0 ? 1 : 0); // the next odd number (renumbered below)
+        for (auto it = merged.rbegin(); it != merged.rend(); ++it) { // right to left: the offsets further left stay valid
+            std::string alt = cons.substr(it->p, it->q - it->p);
+            std::vector<const NovelVariant*> vs = it->vs;
+            std::sort(vs.begin(), vs.end(), [](const NovelVariant* x, const NovelVariant* y) { return x->pos > y->pos; });
+            bool ok = true;
+            uint32_t last = it->q;
+            for (const NovelVariant* v : vs) { // (variants of one locus never overlap: one per candidate region)
+                if (v->pos < it->p || v->pos + v->ref.size() > last) ok = false;
+                else alt.replace(v->pos - it->p, v->ref.size(), v->alt);
+                last = v->pos;
             }
-            if (!done && skipped) skipped->push_back(v->chrom + ":" + std::to_string(v->pos + 1));
+            if (!ok) {
+                for (const NovelVariant* v : vs) skip(v);
+                continue;
+            }
+            const std::string m = std::to_string(next_marker), sep = std::to_string(next_marker + 1);
+            prg = prg.substr(0, it->a) + " " + m + " " + prg.substr(it->a, it->b - it->a) + " " + sep + " " + alt + " " + m + " " + prg.substr(it->b);
+            next_marker += 2;
+            applied += (uint32_t)vs.size();
         }
+        prg = renumber_prg(prg);
     }
     return applied;
+}
+
+void read_denovo_paths(const std::string& path, const std::vector<std::string>& names, GenotypeResult& gr, std::vector<NovelVariant>& variants)
+{
+    std::ifstream in(path);
+    if (!in) throw Error(DRPRG_EIO, "cannot open " + path);
+    auto bad = [&](const std::string& what) -> Error { return Error(DRPRG_EINVAL, path + ": " + what); };
+    std::string line;
+    auto next_line = [&]() -> bool {
+        while (std::getline(in, line)) {
+            if (!line.empty() && line.back() == '\r') line.pop_back();
+            if (!line.empty()) return true;
+        }
+        return false;
+    };
+    auto leading_count = [&](const std::string& l, const char* tail) -> long { // "<n> <tail>..." -> n, else -1
+        size_t i = 0;
+        while (i < l.size() && std::isdigit((unsigned char)l[i])) ++i;
+        if (!i || l.compare(i, std::strlen(tail), tail) != 0) return -1;
+        return std::stol(l.substr(0, i));
+    };
+    if (!next_line() || leading_count(line, " samples") < 0) throw bad("no '<n> samples' line");
+    if (!next_line() || line.compare(0, 7, "Sample ") != 0) throw bad("no 'Sample <name>' line");
+    if (!next_line()) throw bad("no '<n> loci with denovo variants' line");
+    const long n_loci = leading_count(line, " loci with denovo variants");
+    if (n_loci < 0) throw bad("no '<n> loci with denovo variants' line");
+    for (long l = 0; l < n_loci; ++l) {
+        if (!next_line()) throw bad("fewer loci than announced");
+        LocusConsensus lc;
+        lc.chrom = line;
+        const auto it = std::find(names.begin(), names.end(), lc.chrom);
+        if (it == names.end()) throw bad("locus " + lc.chrom + " is not in the PRG file");
+        lc.prg = (uint32_t)(it - names.begin());
+        if (!next_line()) throw bad("no '<n> nodes' line for " + lc.chrom);
+        const long n_nodes = leading_count(line, " nodes");
+        if (n_nodes < 0) throw bad("no '<n> nodes' line for " + lc.chrom);
+        for (long i = 0; i < n_nodes; ++i) {
+            if (!next_line()) throw bad("fewer nodes than announced for " + lc.chrom);
+            // (id [start, end) seq)
+            ConsensusNode n;
+            unsigned id = 0, a = 0, b = 0;
+            int used = 0;
+            if (std::sscanf(line.c_str(), "(%u [%u, %u) %n", &id, &a, &b, &used) < 3 || used <= 0 || line.back() != ')') throw bad("node line '" + line + "'");
+            n.id = id;
+            n.start = a;
+            n.end = b;
+            n.seq = line.substr((size_t)used, line.size() - 1 - (size_t)used);
+            if (n.end < n.start || n.seq.size() != n.end - n.start) throw bad("node interval and sequence disagree in '" + line + "'");
+            lc.seq += n.seq;
+            lc.nodes.push_back(std::move(n));
+        }
+        if (!next_line()) throw bad("no '<n> denovo variants for this locus' line for " + lc.chrom);
+        const long n_var = leading_count(line, " denovo variants for this locus");
+        if (n_var < 0) throw bad("no '<n> denovo variants for this locus' line for " + lc.chrom);
+        for (long i = 0; i < n_var; ++i) {
+            if (!next_line()) throw bad("fewer variants than announced for " + lc.chrom);
+            const size_t t1 = line.find('\t'), t2 = t1 == std::string::npos ? t1 : line.find('\t', t1 + 1);
+            if (t2 == std::string::npos) throw bad("variant line '" + line + "'");
+            NovelVariant v;
+            v.chrom = lc.chrom;
+            v.prg = lc.prg;
+            const long pos1 = std::atol(line.substr(0, t1).c_str());
+            v.ref = line.substr(t1 + 1, t2 - t1 - 1);
+            v.alt = line.substr(t2 + 1);
+            if (pos1 < 1 || (size_t)pos1 - 1 + v.ref.size() > lc.seq.size() || lc.seq.compare((size_t)pos1 - 1, v.ref.size(), v.ref) != 0)
+                throw bad("variant '" + line + "' does not lie on the path of " + lc.chrom);
+            v.pos = (uint32_t)(pos1 - 1);
+            variants.push_back(std::move(v));
+        }
+        gr.consensus.push_back(std::move(lc));
+    }
 }
 
 } // namespace drprg

@@ -26,9 +26,16 @@ std::vector<NovelVariant> assemble_candidate_regions(const GenotypeResult& gr, c
 void write_denovo_paths(const std::string& dir, const std::string& sample, const GenotypeResult& gr, const std::vector<NovelVariant>& variants,
     bool list_loci);
 
-// prgs: (name, PRG string) per locus in file order; every variant that lies strictly inside one local node of its locus'
-// called path becomes a new site.  Returns the number applied; `skipped` (may be null) receives locus:pos of the others.
+// prgs: (name, PRG string) per locus in file order; every variant becomes a new site of its locus' PRG string whose first allele is the
+// stretch of the string it touches (whole sites it runs into included) and whose second allele is the called path over that stretch with
+// the variant applied; markers are numbered again in pandora's parse order.  Returns the number applied; `skipped` (may be null)
+// receives locus:pos of the variants that could not be placed.
 uint32_t update_prgs(std::vector<std::pair<std::string, std::string>>& prgs, const GenotypeResult& gr, const std::vector<NovelVariant>& variants,
     std::vector<std::string>* skipped);
+
+// A denovo_paths.txt (pandora discover's, or write_denovo_paths' above; layout of /root/reference/src/lib.rs:3010-3038) read back into
+// the called paths and variants update_prgs takes.  names: the loci of the PRG file in order.  Throws Error(DRPRG_EINVAL) on a file
+// that does not parse or names an unknown locus.
+void read_denovo_paths(const std::string& path, const std::vector<std::string>& names, GenotypeResult& gr, std::vector<NovelVariant>& variants);
 
 } // namespace drprg

@@ -1331,6 +1331,9 @@ void Mapper::map_host_async(const HostBatch& hb)
         drop_kept();
         kept_cap_ = cap;
         kept_broken_ = true;
+        // (said once per context, always: the run takes a different, slower route from here -- results are the same)
+        std::fprintf(stderr, "[drprg-hip] the sample is larger than the %.1f GB of device memory set aside for resident reads (device %d): reads are "
+                             "not kept, later passes read the file again (DRPRG_HIP_KEEP_READS_GB raises the limit)\n", (double)cap / 1e9, device_);
     }
     if (!use_filter_ || max_lanes_ > 1) { // no deferred form of this sequence
         map_host(hb);

@@ -224,6 +224,12 @@ class Context:
         _check(lib.drprg_hip_update_prg(self._h, os.fsencode(out_prg), C.byref(n)), self._h)
         return int(n.value)
 
+    def update_prg_from_paths(self, denovo_paths, out_prg):
+        """MakePrg::update (/root/reference/src/lib.rs:279-456) on a denovo_paths.txt -- this library's or pandora discover's own"""
+        n = C.c_uint32()
+        _check(lib.drprg_hip_update_prg_from_paths(self._h, os.fsencode(denovo_paths), os.fsencode(out_prg), C.byref(n)), self._h)
+        return int(n.value)
+
     def save_coverage(self, path, tag):
         _check(lib.drprg_hip_save_coverage(self._h, os.fsencode(path), tag.encode()), self._h)
 

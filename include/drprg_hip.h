@@ -207,10 +207,18 @@ int drprg_hip_keep_reads(drprg_hip_ctx* ctx, uint64_t max_bytes);
 int drprg_hip_map_resident(drprg_hip_ctx* ctx, drprg_hip_ctx* from);
 int drprg_hip_resident_info(drprg_hip_ctx* ctx, uint64_t out[4]);
 
-/* What MakePrg::update does in the reference (/root/reference/src/lib.rs:279-456) for a host without make_prg / mafft: writes the
- * context's PRG file again with every novel variant of the last drprg_hip_discover_reads that lies inside one local node of its
- * locus' called path added as a new site (index it with drprg_hip_index, open it, map again).  *n_applied: sites added. */
+/* What MakePrg::update does in the reference (/root/reference/src/lib.rs:279-456: mafft --add of the consensus with the novel
+ * variants, then make_prg from_msa) for a host without make_prg / mafft: writes the context's PRG file again with every novel variant
+ * added as a new site -- first allele: the stretch of the PRG string the variant touches, whole sites it runs into included; second
+ * allele: the called path over that stretch with the variant applied; markers numbered again in pandora's parse order -- so that the
+ * PRG spells everything it spelled before and the sample's sequence (index it with drprg_hip_index, open it, map again).
+ *   drprg_hip_update_prg: the variants of the last drprg_hip_discover_reads.
+ *   drprg_hip_update_prg_from_paths: the loci, called paths and variants of a denovo_paths.txt -- this library's or pandora discover's own
+ *     (layout: /root/reference/src/lib.rs:3010-3038; the file MakePrg::update is handed, src/predict.rs:260-279).  -EINVAL if the file
+ *     does not parse, names a locus the PRG file does not hold, or its node intervals are not intervals of this context's PRG.  Host only.
+ * *n_applied: variants placed. */
 int drprg_hip_update_prg(drprg_hip_ctx* ctx, const char* out_prg, uint32_t* n_applied);
+int drprg_hip_update_prg_from_paths(drprg_hip_ctx* ctx, const char* denovo_paths, const char* out_prg, uint32_t* n_applied);
 
 /* Coverage hand-over between `discover` and the `map` that follows it on the same reads and PRG
  * (/root/reference/src/predict.rs:248-255, :296-302): save writes vector + counters under `tag`; load returns 0 and installs

@@ -764,13 +764,21 @@ def test_discover_lists_several_loci_several_variants_and_a_variant_inside_a_nes
         assert got == [(str(p), r, a) for p, r, a in by_locus[name]]
     g1_nodes = "".join(m.group(4) for m in [re.fullmatch(r"\((\d+) \[(\d+), (\d+)\) ([ACGT]*)\)", l) for l in blocks[2].split("\n")[2:]] if m)
     assert g1_nodes == g1_hap  # the called path runs through the long (nested) allele
-    # ---- the update: four placed, the one across the existing site reported and left out ----
+    # ---- the update: all placed -- the one across the existing site takes that site along as the first allele of a new site (round 4;
+    # rounds 2-3 reported it and left it out) ----
     new_prg = str(tmp_path / "updated.dr.prg")
     n_sites_before = [len(re.findall(r" \d+ ", p)) for p in panel.prgs]
     applied = ctx.update_prg(new_prg)
     placed = sum(len(v) for v in by_locus.values())
-    assert applied in (placed, placed - 1) and applied >= 4
+    assert applied == placed and applied >= 5
     prgs = [l.rstrip("\n") for l in open(new_prg) if not l.startswith(">")]
+    # every updated PRG parses the way pandora parses (markers numbered in the order its parser meets the sites), spells everything the
+    # old one spelled, and spells the sample's haplotype
+    from util import prg_language
+    for old, new, hap in zip(panel.prgs, prgs, (h0, h1, h2)):
+        lang = prg_language(new)
+        assert prg_language(old) <= lang and hap in lang and hap not in prg_language(old)
+    assert re.search(r" 7 [ACGT]* ?9 T 10 G 9  8 [ACGT]+ 7 ", prgs[2]), prgs[2][200:320]  # the T/G site inside the new site's first allele
     # g1: the new site sits inside the long allele, i.e. between the inner site's close and the outer site's close
     m = re.search(r" 7 (?P<tail>[ACGT]+ \d+ [ACGT] \d+ [ACGT] \d+ [ACGT]+) 5 ", prgs[1])
     assert m, prgs[1][240:420]
@@ -785,6 +793,7 @@ def test_discover_lists_several_loci_several_variants_and_a_variant_inside_a_nes
     alt_calls = {(t[0], int(t[1])) for t, fmt in _parse_vcf(vcf) if fmt["GT"] not in ("0", ".")}
     assert ("g0", 101) in alt_calls and ("g0", 401) in alt_calls and ("g2", 121) in alt_calls
     assert any(c == "g1" for c, _ in alt_calls)
+    assert any(c == "g2" and 238 <= p <= 242 for c, p in alt_calls), alt_calls  # the allele across the old site
 
 
 def test_named_index_with_foreign_files_is_an_error_unless_rebuild_is_asked_for(tmp_path):

@@ -422,3 +422,38 @@ def oracle_denovo(discover_dir, consensus, bases, offs, noisy=False):
     text = np.asarray(bases, np.uint8).tobytes().decode()
     reads = [text[int(offs[i]):int(offs[i + 1])] for i in range(len(offs) - 1)]
     return (mod.column_vote if noisy else mod.pile_up)(consensus, regions, reads)
+
+
+def prg_language(prg):
+    """Every sequence a PRG string spells, parsed the way pandora's LocalPRG::build_graph does [UPSTREAM-MEMORY]: an interval that holds a
+    marker is split at the NEXT site number (5, 7, 9 ... in the order the parser meets the sites: a site before the sites inside it, then
+    the sites behind it), what stands before that site must be plain sequence, the alleles are parsed in turn, then what stands behind the
+    site.  Raises AssertionError on a string pandora would refuse (markers out of that order, unbalanced sites).  Small PRGs only."""
+    import re
+    next_site = [5]
+
+    def build(s):
+        if not re.search(r"\d", s):
+            assert re.fullmatch(r"[ACGT ]*", s), s
+            return {s.replace(" ", "")}
+        m = next_site[0]
+        tok, sep = " %d " % m, " %d " % (m + 1)
+        i = s.find(tok)
+        assert i >= 0, "site %d is not the next site of %r" % (m, s[:60])
+        first = s[:i]
+        assert not re.search(r"\d", first), "a site before site %d in %r" % (m, s[:60])
+        j = s.find(tok, i + len(tok) - 1)  # (the closing marker may share the space of an empty last allele: " 6  5 ")
+        assert j >= 0, "site %d does not close" % m
+        middle, rest = s[i + len(tok):j] if j >= i + len(tok) else "", s[j + len(tok):]
+        next_site[0] += 2
+        alleles = middle.split(sep)
+        assert len(alleles) >= 2, "site %d has one allele" % m
+        mids = set()
+        for a in alleles:
+            mids |= build(a)
+        tails = build(rest)
+        first = first.replace(" ", "")
+        return {first + a + t for a in mids for t in tails}
+
+    out = build(prg)
+    return out
