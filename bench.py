@@ -446,6 +446,7 @@ def main():
     comm_mode = args.comm if args.comm != "auto" else ("native" if backend == "nccl" else "torch")
     native = None
     cstream = None
+    comm_fallback = None
     if world > 1 and comm_mode == "native":
         from drprg_amd.distributed import NativeComm
 
@@ -454,11 +455,27 @@ def main():
             dist.broadcast_object_list(box, src=0)
             return box[0]
 
-        if backend == "nccl":
-            native = NativeComm(rank, world, local_rank, exchange)
+        native_error = None
+        try:
+            if backend == "nccl":
+                native = NativeComm(rank, world, local_rank, exchange)
+            else:
+                native = NativeComm(0, 1, local_rank, lambda ident: ident)
+        except Exception as e:  # (e.g. no RCCL library the binding can open)
+            native_error = str(e)
+        # every rank must take the same path: one that could not make its communicator sends all of them to torch.distributed
+        flag = torch.tensor([0 if native is None else 1], dtype=torch.int32, device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if native is not None:
+                native.close()
+                native = None
+            comm_mode = "torch"
+            comm_fallback = native_error or "another rank could not make its native communicator"
+            if rank == 0:
+                print("[bench] --comm native is not available (%s): reducing through torch.distributed" % comm_fallback, file=sys.stderr)
         else:
-            native = NativeComm(0, 1, local_rank, lambda ident: ident)
-        cstream = torch.cuda.Stream(device)
+            cstream = torch.cuda.Stream(device)
 
     class _Done:  # what the stream of the hot path waits for before it reuses a buffer
         def __init__(self, event=None, work=None):
@@ -652,7 +669,8 @@ def main():
                          ("native: drprg_hip_comm_unique_id / comm_init_rank / drprg_hip_allreduce (C ABI, RCCL bound at run time), id broadcast "
                           "over the torch.distributed group" + ("" if backend == "nccl" else "; ONE-GPU TEST HOOK: one-rank native communicators, "
                                                                  "the sum over the ranks by gloo"))
-                         if native is not None else f"torch.distributed.all_reduce ({backend})"),
+                         if native is not None else f"torch.distributed.all_reduce ({backend})"
+                         + (f" -- the native communicator could not be made: {comm_fallback}" if comm_fallback else "")),
                 "reduced_words": n_acc,
                 "all_ranks_hold_the_sum_of_the_ranks_vectors": reduce_consistent,
                 "bases_per_s": n_bases * world * args.steps / elapsed,

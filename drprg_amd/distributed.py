@@ -62,11 +62,15 @@ class NativeComm:
         from ._lib import lib
         self._lib = lib
         ident = (C.c_uint8 * 128)()
+        err = None
         if rank == 0:
             rc = lib.drprg_hip_comm_unique_id(ident)
             if rc != 0:
-                raise RuntimeError(f"drprg_hip_comm_unique_id: {lib.drprg_hip_last_error(None).decode()} ({rc})")
-        raw = exchange(bytes(ident) if rank == 0 else None)
+                err = f"drprg_hip_comm_unique_id: {lib.drprg_hip_last_error(None).decode()} ({rc})"
+        # (rank 0 takes part in the exchange even when it has no id to give: the other ranks are waiting in it)
+        raw = exchange(bytes(ident) if rank == 0 and err is None else None)
+        if raw is None:
+            raise RuntimeError(err or "rank 0 could not make a communicator id")
         ident = (C.c_uint8 * 128).from_buffer_copy(raw)
         comm = C.c_void_p()
         rc = lib.drprg_hip_comm_init_rank(C.byref(comm), world, ident, rank, device)
