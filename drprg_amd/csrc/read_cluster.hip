@@ -34,9 +34,11 @@ constexpr int RC_THREADS = 1024;
 constexpr int RC_WAVES = RC_THREADS / 64;
 constexpr int RC_PER = 2;
 constexpr int RC_SLOTS = RC_THREADS * RC_PER; // staged candidates
-constexpr int RC_AHEAD = 512;                 // look-ahead: a read belongs to the chunk that owns its first candidate
-constexpr int RC_OWN = RC_SLOTS - RC_AHEAD;
-static_assert(RC_OWN == (int)RC_CHUNK_OWN, "kernels.h RC_CHUNK_OWN");
+// Look-ahead (template parameter AHEAD; RC_AHEAD / RC_OWN are defined at the top of the kernel): a read belongs to the chunk that owns its
+// first candidate, so the last AHEAD of the staged slots are there for reads that begin in the owned range and run on.  512 slots serve
+// a 4 kb Nanopore read (~250 candidates); a 150-base read has a few dozen at most, and every slot not spent on look-ahead is owned:
+// 128 slots of look-ahead mean 1920 owned candidates per chunk instead of 1536, a fifth fewer chunks -- and a chunk costs ~21 us whatever
+// is in it (round 4).  A read that does not fit its chunk's look-ahead goes through the generic pipeline as before.
 constexpr int RC_HCAP = 3072;                 // staged hits
 constexpr int RC_POOL = 512;                  // reads per chunk that may take the wave path (sketch_wave_kernel clusters the plain reads itself: what is left is rich in these)
 constexpr uint32_t RC_IRREGULAR = 2u, RC_COMPLEX = 1u;
@@ -57,9 +59,13 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 __device__ __forceinline__ void lds_barrier(int& t) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+v"(t) : : "memory"); }
 
 // SLICES: the candidates are read from the tile slices of the direct sketch kernel (rc.slice_prefix), not from a gathered list
-template <bool SLICES>
+template <bool SLICES, int AHEAD>
 __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs a, FilterWork fw, ReadClusterArgs rc)
 {
+    constexpr int RC_AHEAD = AHEAD, RC_OWN = RC_SLOTS - AHEAD;
+    static_assert(AHEAD != 512 || RC_OWN == (int)RC_CHUNK_OWN, "kernels.h RC_CHUNK_OWN: the chunk numbering the wave form's flags use");
+    static_assert(RC_OWN % 64 == 0, "the slices form locates 64 entries from a multiple of 64 per wave");
+    (void)RC_AHEAD;
     extern __shared__ uint32_t s_hist[]; // clusters kept per PRG
     __shared__ uint32_t s_read[RC_SLOTS + 1], s_hstart[RC_SLOTS + 1];
     __shared__ uint16_t s_pos1[RC_SLOTS]; // read position + 1 of a minimizer (0xFFFF: too far for this kernel), 0 = not a minimizer
@@ -651,15 +657,30 @@ hipError_t launch_read_cluster(const SketchArgs& a, const FilterWork& fw, const 
         HIP_TRY(hipMemsetAsync(d_phase, 0, 14 * sizeof(unsigned long long), stream));
         rcd.phase_clock = d_phase;
     }
-    const size_t dyn = (size_t)rc.n_prgs * sizeof(uint32_t); // the per-PRG histogram, behind ~70 KB of static LDS
-    static size_t configured[MAX_HIP_DEVICES] = {};
+    const size_t dyn = (size_t)rc.n_prgs * sizeof(uint32_t); // the per-PRG histogram, behind ~77 KB of static LDS
+    // look-ahead by the batch's mean read length (DRPRG_RC_AHEAD=128 / 256 / 512 forces one; the second pass behind the wave form shares
+    // that form's chunk numbering: 512)
+    const uint64_t mean_len = a.n_bases / (a.n_reads ? a.n_reads : 1u);
+    int ahead = mean_len <= 300 ? 128 : mean_len <= 600 ? 256 : 512;
+    if (const char* e = std::getenv("DRPRG_RC_AHEAD")) {
+        const int v = std::atoi(e);
+        if (v == 128 || v == 256 || v == 512) ahead = v;
+    }
+    if (rcd.second_pass) ahead = 512;
+    static size_t configured[6][MAX_HIP_DEVICES] = {};
+    auto launch = [&](auto kernel, size_t (&conf)[MAX_HIP_DEVICES]) -> hipError_t {
+        HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), dyn, conf));
+        hipLaunchKernelGGL(kernel, dim3((uint32_t)n_cus * 2), dim3(RC_THREADS), dyn, stream, a, fw, rcd);
+        return hipGetLastError();
+    };
     if (rcd.slice_prefix) {
-        static size_t configured_slices[MAX_HIP_DEVICES] = {};
-        HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&read_cluster_kernel<true>), dyn, configured_slices));
-        hipLaunchKernelGGL(read_cluster_kernel<true>, dim3((uint32_t)n_cus * 2), dim3(RC_THREADS), dyn, stream, a, fw, rcd);
+        if (ahead == 128) HIP_TRY(launch(&read_cluster_kernel<true, 128>, configured[0]));
+        else if (ahead == 256) HIP_TRY(launch(&read_cluster_kernel<true, 256>, configured[1]));
+        else HIP_TRY(launch(&read_cluster_kernel<true, 512>, configured[2]));
     } else {
-        HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&read_cluster_kernel<false>), dyn, configured));
-        hipLaunchKernelGGL(read_cluster_kernel<false>, dim3((uint32_t)n_cus * 2), dim3(RC_THREADS), dyn, stream, a, fw, rcd);
+        if (ahead == 128) HIP_TRY(launch(&read_cluster_kernel<false, 128>, configured[3]));
+        else if (ahead == 256) HIP_TRY(launch(&read_cluster_kernel<false, 256>, configured[4]));
+        else HIP_TRY(launch(&read_cluster_kernel<false, 512>, configured[5]));
     }
     if (debug) { // cycles of thread 0, summed over the workgroups, per phase (the marks follow the barriers of the chunk loop)
         unsigned long long h[14];

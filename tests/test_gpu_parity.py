@@ -88,7 +88,10 @@ def _compare(ctx, oracle, bases, offsets, w, k, illumina, kernel, min_cluster_si
     pcov, pprg = ctx.coverage()
     pcnt = ctx.counters()
     assert np.array_equal(pcov, ocov) and np.array_equal(pprg, oprg)
-    for key in ("reads", "bases", "minimizers", "hits", "clusters_kept", "hits_kept", "leftover_reads"):
+    # (not leftover_reads: a non-ACGT byte reads as a letter in the words, so the packed filter can pass a position the ASCII filter
+    # does not; verify_count_kernel rejects it, but it holds a slot of the ordered candidate list, the chunks of read_cluster_kernel shift
+    # by it, and WHICH reads straddle a chunk's look-ahead and go through the generic pipeline instead can differ -- the results cannot)
+    for key in ("reads", "bases", "minimizers", "hits", "clusters_kept", "hits_kept"):
         assert pcnt[key] == gcnt[key], key
     # ... and through the opt-in wave form of the last filtered stage (read_cluster_wave.hip; the switch is read at every launch)
     if len(offsets) > 1 and int(offsets[-1]) // (len(offsets) - 1) <= 600:
