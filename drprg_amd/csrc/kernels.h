@@ -237,6 +237,8 @@ struct ReadClusterArgs {
                            // candidate lies in read_cluster_kernel's chunk c; the second pass takes only those chunks
     unsigned long long* phase_clock; // DRPRG_RC_DEBUG=1: 12 counters, clock cycles thread 0 of every workgroup spent per phase (else null)
 };
+// DRPRG_RC_FORM=wave (read at every call): launch_read_cluster runs the wave form first; its flag words must be zero before the launch
+bool read_cluster_wave_form_requested();
 size_t filter_small_words();
 // the fields of fw that the consumers of a dense candidate list use (candidates.hip, read_cluster.hip)
 void init_candidate_work(FilterWork& fw, const FilterBuffers& b, int n_cus);

@@ -409,7 +409,8 @@ void Mapper::launch_lane(Lane& lane, hipStream_t stream, const uint8_t* d_bases,
     rc.chunk_flags = lane.rc_flags;
     rc.wg_partials = lane.rc_partials;
     rc.wg_done = lane.rc_flags + (lane.raw_capacity / dev::RC_CHUNK_OWN + 2); // (one word behind the flags, cleared with them)
-    HIPCHK(hipMemsetAsync(lane.rc_flags, 0, (lane.raw_capacity / dev::RC_CHUNK_OWN + 3) * sizeof(uint32_t), stream));
+    if (dev::read_cluster_wave_form_requested()) // (only the opt-in wave form reads them)
+        HIPCHK(hipMemsetAsync(lane.rc_flags, 0, (lane.raw_capacity / dev::RC_CHUNK_OWN + 3) * sizeof(uint32_t), stream));
     rc.chunk_counter = reinterpret_cast<uint32_t*>(&lane.d_scratch[L_CHUNK]);
     dev::KernelTimer timer;
     if (timing_) { // events bracket the dominant kernel only
@@ -674,7 +675,8 @@ void Mapper::direct_launch(int set, const uint8_t* d_bases, const uint64_t* d_of
     rc.chunk_flags = lane.rc_flags;
     rc.wg_partials = lane.rc_partials;
     rc.wg_done = lane.rc_flags + (lane.raw_capacity / dev::RC_CHUNK_OWN + 2); // (one word behind the flags, cleared with them)
-    HIPCHK(hipMemsetAsync(lane.rc_flags, 0, (lane.raw_capacity / dev::RC_CHUNK_OWN + 3) * sizeof(uint32_t), stream));
+    if (dev::read_cluster_wave_form_requested()) // (only the opt-in wave form reads them)
+        HIPCHK(hipMemsetAsync(lane.rc_flags, 0, (lane.raw_capacity / dev::RC_CHUNK_OWN + 3) * sizeof(uint32_t), stream));
     rc.chunk_counter = reinterpret_cast<uint32_t*>(&lane.d_scratch[L_CHUNK]);
     lane.fw = dev::FilterWork {};
     lane.fw.read_begin = 0;

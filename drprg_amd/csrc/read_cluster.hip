@@ -631,6 +631,12 @@ __global__ void flag_complex_kernel(const unsigned long long* n_hits, unsigned l
     if (*n_hits) *n_complex = 1;
 }
 
+bool read_cluster_wave_form_requested()
+{
+    const char* form = std::getenv("DRPRG_RC_FORM");
+    return form && std::string(form) == "wave";
+}
+
 hipError_t launch_read_cluster(const SketchArgs& a, const FilterWork& fw, const ReadClusterArgs& rc, int n_cus, bool skip, hipStream_t stream)
 {
     if (skip) {
@@ -642,8 +648,7 @@ hipError_t launch_read_cluster(const SketchArgs& a, const FilterWork& fw, const 
     // everything a 150-base read needs) and this kernel behind it for what that leaves.  NOT the default: measured on MI355X
     // (profiles/r04/rc_forms.txt) the wave form takes 61 us where this kernel takes 68 us on configs[1], and then still needs this
     // kernel for the reads it left (37 us) and a 8 us kernel for the totals; on configs[4] 2.2 ms against 1.3 ms.  DESIGN.md section 6.
-    const char* form = std::getenv("DRPRG_RC_FORM");
-    const bool wave_first = form && std::string(form) == "wave";
+    const bool wave_first = read_cluster_wave_form_requested();
     rcd.second_pass = 0;
     // (long reads do not fit a wave's 128 staged candidates: a batch of them goes straight to the workgroup form)
     if (wave_first && rc.n_unfit && rc.chunk_flags && a.n_bases / (a.n_reads ? a.n_reads : 1u) <= 600) {
