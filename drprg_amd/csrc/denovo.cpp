@@ -11,6 +11,15 @@
 // a novel variant.  Noisy long reads (no -I) spell the allele with their own errors: their strings are aligned to the consensus
 // slice and the majority is taken column by column instead (column_consensus).
 //
+// Round 4: LOCAL ASSEMBLY beside the pile-up, for accurate reads (assemble_region below): every read that shares a k-mer with a region's
+// slice of the consensus (anchors included) joins the region's pile, oriented like the consensus; the pile's k-mers (k = anchor_len = 15,
+// pandora's --discover-k default [UPSTREAM-MEMORY]) seen at least min_dbg_dp = 2 times [UPSTREAM-MEMORY: --min-dbg-dp] are the nodes of a
+// de Bruijn graph; paths are searched depth first from a k-mer of the left flank to a k-mer of the right flank (outermost first, as
+// pandora's start / end k-mer lists), no longer than the consensus between them + max_len_change, at most 25 of them; every path that
+// is not the consensus is an allele.  It finds what the pile-up cannot see -- reads too short to hold both anchors, minor alleles of a
+// mixed sample -- and it is the method family of the reference; the pile-up stays the source of the majority allele's read counts.
+// DRPRG_HIP_DENOVO=pileup | dbg | both (default both: the pile-up's variant, then every assembled allele that is not that variant).
+//
 // Outputs: denovo_paths.txt in the layout the reference's parser and make_prg read (/root/reference/src/lib.rs:648-697 and
 // the example at :3010-3038: locus, "<n> nodes", one "(id [start, end) seq)" line per local node of the called path,
 // "<m> denovo variants for this locus", "pos<TAB>ref<TAB>alt" lines -- positions 1-based on the path sequence
@@ -181,6 +190,115 @@ std::string column_consensus(const CandidateRegion& cr, const std::string& core,
     return out;
 }
 
+// ---- local assembly of one region (accurate reads) ---------------------------------------------------------------------------------
+struct AssembledAllele {
+    std::string slice;   // the region's slice of the consensus (left anchor + region + right anchor) as this path spells it
+    uint32_t support;    // smallest count among the path's k-mers that the consensus slice does not hold
+};
+constexpr uint32_t DBG_MIN_DP = 2, DBG_MAX_PATHS = 25, DBG_MAX_STEPS = 200000;
+
+// slice: left anchor + region + right anchor; flank_l / flank_r: how many bases on either side are anchor + padding (start / end k-mers
+// lie inside them); pile: the reads that share a k-mer with the slice, oriented like it.  Returns the alleles, best supported first; `depth`:
+// the largest count of a consensus k-mer of the flanks (what "spanning" is for an assembled allele).
+std::vector<AssembledAllele> assemble_region(const std::string& slice, uint32_t flank_l, uint32_t flank_r, const std::vector<std::string>& pile, uint32_t K,
+    uint32_t max_len_change, uint32_t* depth)
+{
+    std::vector<AssembledAllele> out;
+    *depth = 0;
+    if (K == 0 || K > 15 || slice.size() < 2 * (size_t)K) return out;
+    const uint32_t mask = K == 16 ? ~0u : ((1u << (2 * K)) - 1);
+    std::unordered_map<uint32_t, uint32_t> count;
+    for (const std::string& r : pile) {
+        uint32_t v = 0, run = 0;
+        for (size_t p = 0; p < r.size(); ++p) {
+            const int c = nt4((unsigned char)r[p]);
+            v = ((v << 2) | (uint32_t)(c & 3)) & mask;
+            run = c > 3 ? 0 : run + 1;
+            if (run >= K) ++count[v];
+        }
+    }
+    auto code_at = [&](const std::string& t, size_t i, uint32_t& v) -> bool {
+        uint64_t w;
+        if (i + K > t.size() || !pack_kmer(t.data() + i, K, w)) return false;
+        v = (uint32_t)w;
+        return true;
+    };
+    auto cnt = [&](uint32_t v) -> uint32_t {
+        const auto it = count.find(v);
+        return it == count.end() ? 0u : it->second;
+    };
+    std::unordered_map<uint32_t, char> on_consensus; // the slice's own k-mers
+    for (size_t i = 0; i + K <= slice.size(); ++i) {
+        uint32_t v;
+        if (code_at(slice, i, v)) on_consensus[v] = 1;
+    }
+    const size_t n_starts = flank_l >= K ? (size_t)(flank_l - K + 1) : 0, n_ends = flank_r >= K ? (size_t)(flank_r - K + 1) : 0;
+    for (size_t i = 0; i < n_starts; ++i) {
+        uint32_t v;
+        if (code_at(slice, i, v)) *depth = std::max(*depth, cnt(v));
+    }
+    for (size_t i = 0; i < n_ends; ++i) {
+        uint32_t v;
+        if (code_at(slice, slice.size() - K - i, v)) *depth = std::max(*depth, cnt(v));
+    }
+    for (size_t si = 0; si < n_starts && out.empty(); ++si) {
+        uint32_t sv;
+        if (!code_at(slice, si, sv) || cnt(sv) < DBG_MIN_DP) continue;
+        for (size_t ei = 0; ei < n_ends; ++ei) {
+            const size_t eo = slice.size() - K - ei; // the end k-mer's offset in the slice
+            uint32_t ev;
+            if (eo <= si || !code_at(slice, eo, ev) || cnt(ev) < DBG_MIN_DP) continue;
+            const size_t want = eo + K - si, max_len = want + max_len_change; // bases from the start k-mer's first to the end k-mer's last
+            // depth-first over the graph; a path is the bases appended to the start k-mer
+            std::vector<std::string> paths;
+            std::string cur;
+            struct Frame {
+                uint32_t v;
+                int next; // next base to try
+            };
+            std::vector<Frame> st { { sv, 0 } };
+            uint32_t steps = 0;
+            bool too_many = false;
+            while (!st.empty() && !too_many) {
+                Frame& f = st.back();
+                if (f.next == 0 && f.v == ev && K + cur.size() >= (want > max_len_change ? want - max_len_change : K)) {
+                    paths.push_back(cur);
+                    if (paths.size() > DBG_MAX_PATHS) too_many = true;
+                }
+                if (f.next > 3 || K + cur.size() >= max_len) {
+                    st.pop_back();
+                    if (!cur.empty()) cur.pop_back();
+                    continue;
+                }
+                const int b = f.next++;
+                const uint32_t nv = ((f.v << 2) | (uint32_t)b) & mask;
+                if (++steps > DBG_MAX_STEPS) too_many = true;
+                if (cnt(nv) < DBG_MIN_DP) continue;
+                cur.push_back("ACGT"[b]);
+                st.push_back({ nv, 0 });
+            }
+            if (too_many) continue; // (a repeat: this pair of k-mers does not delimit the region)
+            std::map<std::string, uint32_t> found;
+            for (const std::string& tail : paths) {
+                const std::string spelled = slice.substr(si, K) + tail;
+                std::string whole = slice.substr(0, si) + spelled + slice.substr(eo + K);
+                if (whole == slice) continue;
+                uint32_t support = ~0u, v;
+                for (size_t i = 0; i + K <= spelled.size(); ++i)
+                    if (code_at(spelled, i, v) && !on_consensus.count(v)) support = std::min(support, cnt(v));
+                if (support == ~0u) continue; // (only consensus k-mers in another order: a repeat, not a variant)
+                auto it = found.find(whole);
+                if (it == found.end() || it->second < support) found[whole] = support;
+            }
+            if (paths.empty()) continue;
+            for (auto& kv : found) out.push_back({ kv.first, kv.second });
+            break; // the first pair of k-mers that is connected decides (pandora does the same [UPSTREAM-MEMORY])
+        }
+    }
+    std::sort(out.begin(), out.end(), [](const AssembledAllele& a, const AssembledAllele& b) { return a.support != b.support ? a.support > b.support : a.slice < b.slice; });
+    return out;
+}
+
 } // namespace
 
 std::vector<NovelVariant> assemble_candidate_regions(const GenotypeResult& gr, const std::string& reads_path, int threads, const DiscoverParams& dp,
@@ -209,9 +327,43 @@ std::vector<NovelVariant> assemble_candidate_regions(const GenotypeResult& gr, c
             }
     }
     if (anchors.empty()) return out;
+    // local assembly (accurate reads): every k-mer of a region's slice of the consensus, either orientation -> (region, orientation); a read
+    // that holds one joins the region's pile
+    enum { MODE_PILEUP = 1, MODE_DBG = 2 };
+    int mode = accurate_reads ? (MODE_PILEUP | MODE_DBG) : MODE_PILEUP;
+    if (const char* e = std::getenv("DRPRG_HIP_DENOVO")) {
+        if (!std::strcmp(e, "pileup")) mode = MODE_PILEUP;
+        else if (!std::strcmp(e, "dbg") && accurate_reads) mode = MODE_DBG;
+    }
+    struct SliceRef {
+        uint32_t region;
+        uint8_t reverse;
+    };
+    std::unordered_multimap<uint64_t, SliceRef> slice_kmers;
+    std::vector<std::string> slices(gr.candidates.size());
+    if (mode & MODE_DBG)
+        for (uint32_t r = 0; r < gr.candidates.size(); ++r) {
+            const CandidateRegion& c = gr.candidates[r];
+            if (c.left_anchor.size() != A || c.right_anchor.size() != A) continue;
+            slices[r] = c.left_anchor + c.seq + c.right_anchor;
+            const std::string rc_slice = revcomp(slices[r]);
+            for (int rev = 0; rev < 2; ++rev) {
+                const std::string& t = rev ? rc_slice : slices[r];
+                for (size_t i = 0; i + A <= t.size(); ++i) {
+                    uint64_t v;
+                    if (pack_kmer(t.data() + i, A, v)) slice_kmers.insert({ v, SliceRef { r, (uint8_t)rev } });
+                }
+            }
+        }
+    struct RegionPile {
+        std::mutex mu;
+        std::vector<std::string> reads;
+    };
+    std::vector<RegionPile> piles(gr.candidates.size());
     // low 16 bits of the packed k-mer, one BIT each (8 KB: stays in the L1 of every parser thread): most read k-mers stop here
     std::vector<uint64_t> prefilter(1u << 10, 0);
     for (auto& kv : anchors) prefilter[(kv.first & 0xFFFF) >> 6] |= 1ull << (kv.first & 63);
+    for (auto& kv : slice_kmers) prefilter[(kv.first & 0xFFFF) >> 6] |= 1ull << (kv.first & 63);
     uint8_t code_of[256]; // the scan below is the whole cost of this pass (every base of every read): table, no branches per base
     for (int ch = 0; ch < 256; ++ch) code_of[ch] = (uint8_t)nt4((unsigned char)ch);
     std::vector<RegionVotes> votes(gr.candidates.size());
@@ -228,11 +380,13 @@ std::vector<NovelVariant> assemble_candidate_regions(const GenotypeResult& gr, c
     auto scan_batch = [&](const PinnedBatch& b) {
         std::vector<Hit> hits;
         std::vector<Span> spans;
+        std::vector<SliceRef> touched;
         for (uint64_t i = 0; i < b.n_reads; ++i) {
             const char* s = (const char*)b.bases + b.offsets[i];
             const uint64_t len = b.offsets[i + 1] - b.offsets[i];
-            if (len < 2 * (uint64_t)A) continue;
+            if (len < (uint64_t)A || (len < 2 * (uint64_t)A && !(mode & MODE_DBG))) continue;
             hits.clear();
+            touched.clear();
             uint64_t v = 0;
             uint32_t run = 0;
             for (uint64_t p = 0; p < len; ++p) {
@@ -243,8 +397,23 @@ std::vector<NovelVariant> assemble_candidate_regions(const GenotypeResult& gr, c
                 auto range = anchors.equal_range(v);
                 for (auto it = range.first; it != range.second; ++it)
                     hits.push_back(Hit { it->second.region, (uint32_t)(p + 1 - A), it->second.right, it->second.reverse, it->second.j });
+                if (mode & MODE_DBG) {
+                    auto sr = slice_kmers.equal_range(v);
+                    for (auto it = sr.first; it != sr.second; ++it) {
+                        bool seen = false;
+                        for (const SliceRef& t : touched) seen |= t.region == it->second.region && t.reverse == it->second.reverse;
+                        if (!seen) touched.push_back(it->second);
+                    }
+                }
             }
-            if (hits.size() < 2) continue;
+            for (const SliceRef& t : touched) { // the read joins the region's pile, oriented like the consensus
+                std::string r(s, len);
+                for (char& ch : r) ch = (char)std::toupper((unsigned char)ch);
+                if (t.reverse) r = revcomp(r);
+                std::lock_guard<std::mutex> g(piles[t.region].mu);
+                piles[t.region].reads.push_back(std::move(r));
+            }
+            if (hits.size() < 2 || !(mode & MODE_PILEUP)) continue;
             // forward read: left anchor, allele, right anchor; reverse read: rc(right anchor), rc(allele), rc(left anchor)
             spans.clear();
             for (const Hit& x : hits)
@@ -280,6 +449,9 @@ std::vector<NovelVariant> assemble_candidate_regions(const GenotypeResult& gr, c
         // the reads are in HBM: the device picks those that hold an anchor, the scan above runs on them alone
         std::vector<uint64_t> kmers;
         for (auto& kv : anchors) kmers.push_back(kv.first);
+        for (auto& kv : slice_kmers) kmers.push_back(kv.first);
+        std::sort(kmers.begin(), kmers.end());
+        kmers.erase(std::unique(kmers.begin(), kmers.end()), kmers.end());
         std::vector<uint8_t> sel_bases;
         std::vector<uint64_t> sel_offsets;
         resident(kmers, A, sel_bases, sel_offsets);
@@ -299,8 +471,26 @@ std::vector<NovelVariant> assemble_candidate_regions(const GenotypeResult& gr, c
             throw Error(DRPRG_EFORMAT, "discover: multi-line FASTQ is not supported by the region pile-up");
         }
     }
+    // a variant from two spellings of the same stretch of the consensus (which starts at consensus position `origin`)
+    auto make_variant = [&](const CandidateRegion& c, uint32_t origin, const std::string& ref, const std::string& alt, uint32_t support, uint32_t spanning) {
+        size_t pre = 0;
+        while (pre < ref.size() && pre < alt.size() && ref[pre] == alt[pre]) ++pre;
+        size_t suf = 0;
+        while (suf < ref.size() - pre && suf < alt.size() - pre && ref[ref.size() - 1 - suf] == alt[alt.size() - 1 - suf]) ++suf;
+        NovelVariant v;
+        v.chrom = c.chrom;
+        v.prg = c.prg;
+        v.pos = origin + (uint32_t)pre;
+        v.ref = ref.substr(pre, ref.size() - pre - suf);
+        v.alt = alt.substr(pre, alt.size() - pre - suf);
+        v.support = support;
+        v.spanning = spanning;
+        v.group = (uint32_t)(&c - gr.candidates.data());
+        return v;
+    };
     for (uint32_t r = 0; r < gr.candidates.size(); ++r) {
         const CandidateRegion& c = gr.candidates[r];
+        const size_t first_of_region = out.size();
         uint32_t spanning = 0, best_n = 0;
         const std::string* best_key = nullptr;
         for (auto& kv : votes[r].alleles) {
@@ -310,46 +500,43 @@ std::vector<NovelVariant> assemble_candidate_regions(const GenotypeResult& gr, c
                 best_key = &kv.first;
             }
         }
-        std::string allele;
+        std::string allele = c.seq;
         if (!accurate_reads) { // noisy reads: the allele is the column-wise majority of the aligned strings
-            if (spanning < dp.min_support) continue;
-            // a change the first alignment spreads over neighbouring columns (a deletion inside a repeat) is gathered by aligning again,
-            // to the result: at most three rounds, normally the second one changes nothing
-            allele = c.seq;
-            for (int round = 0; round < 3; ++round) {
-                std::string next = column_consensus(c, allele, A, votes[r].alleles, spanning, dp);
-                if (next == allele) break;
-                allele.swap(next);
+            if (spanning >= dp.min_support) {
+                // a change the first alignment spreads over neighbouring columns (a deletion inside a repeat) is gathered by aligning again,
+                // to the result: at most three rounds, normally the second one changes nothing
+                for (int round = 0; round < 3; ++round) {
+                    std::string next = column_consensus(c, allele, A, votes[r].alleles, spanning, dp);
+                    if (next == allele) break;
+                    allele.swap(next);
+                }
+                if (allele != c.seq) {
+                    best_n = 0;
+                    for (auto& kv : votes[r].alleles) { // reported support: reads that are closer to the new allele than to the consensus
+                        const uint32_t jl = (uint32_t)(kv.first[0] - '0'), jr = (uint32_t)(kv.first[1] - '0');
+                        const std::string s = kv.first.substr(2);
+                        best_n += kv.second * (edit_distance(s, extended(c, A, jl, jr, allele)) < edit_distance(s, extended(c, A, jl, jr, c.seq)));
+                    }
+                }
             }
-            if (allele == c.seq) continue;
-            best_n = 0;
-            for (auto& kv : votes[r].alleles) { // reported support: reads that are closer to the new allele than to the consensus
-                const uint32_t jl = (uint32_t)(kv.first[0] - '0'), jr = (uint32_t)(kv.first[1] - '0');
-                const std::string s = kv.first.substr(2);
-                best_n += kv.second * (edit_distance(s, extended(c, A, jl, jr, allele)) < edit_distance(s, extended(c, A, jl, jr, c.seq)));
-            }
-        } else {
-            if (!best_key || best_n < dp.min_support || (double)best_n < dp.min_fraction * (double)spanning) continue;
+        } else if ((mode & MODE_PILEUP) && best_key && best_n >= dp.min_support && (double)best_n >= dp.min_fraction * (double)spanning) {
             allele = best_key->substr(2); // one anchor per side: the key is "00" + the string
-            if (allele == c.seq) continue;
         }
-        const std::string* best = &allele;
-        // trim what the allele shares with the consensus on both sides
-        const std::string& ref = c.seq;
-        const std::string& alt = *best;
-        size_t pre = 0;
-        while (pre < ref.size() && pre < alt.size() && ref[pre] == alt[pre]) ++pre;
-        size_t suf = 0;
-        while (suf < ref.size() - pre && suf < alt.size() - pre && ref[ref.size() - 1 - suf] == alt[alt.size() - 1 - suf]) ++suf;
-        NovelVariant v;
-        v.chrom = c.chrom;
-        v.prg = c.prg;
-        v.pos = c.start + (uint32_t)pre;
-        v.ref = ref.substr(pre, ref.size() - pre - suf);
-        v.alt = alt.substr(pre, alt.size() - pre - suf);
-        v.support = best_n;
-        v.spanning = spanning;
-        out.push_back(std::move(v));
+        if (allele != c.seq) out.push_back(make_variant(c, c.start, c.seq, allele, best_n, spanning));
+        // local assembly: every assembled allele with enough support that the pile-up has not reported already
+        if ((mode & MODE_DBG) && !slices[r].empty()) {
+            uint32_t depth = 0;
+            const uint32_t flank_l = A + (c.low_start - c.start), flank_r = A + (c.end - c.low_end);
+            const std::vector<AssembledAllele> found = assemble_region(slices[r], flank_l, flank_r, piles[r].reads, A, dp.max_len_change, &depth);
+            const uint32_t need = found.empty() ? 0 : std::max<uint32_t>(dp.min_support, (found[0].support + 9) / 10); // a tenth of the best one
+            for (const AssembledAllele& f : found) {
+                if (f.support < need) break;
+                NovelVariant v = make_variant(c, c.start - A, slices[r], f.slice, f.support, depth);
+                bool dup = false;
+                for (size_t i = first_of_region; i < out.size(); ++i) dup |= out[i].pos == v.pos && out[i].ref == v.ref && out[i].alt == v.alt;
+                if (!dup) out.push_back(std::move(v));
+            }
+        }
     }
     std::sort(out.begin(), out.end(), [](const NovelVariant& a, const NovelVariant& b) {
         if (a.chrom != b.chrom) return a.chrom < b.chrom;
@@ -382,9 +569,18 @@ void write_denovo_paths(const std::string& dir, const std::string& sample, const
             o << kv.first << "\n" << lc->nodes.size() << " nodes\n";
             for (const ConsensusNode& n : lc->nodes) o << "(" << n.id << " [" << n.start << ", " << n.end << ") " << n.seq << ")\n";
             o << kv.second.size() << " denovo variants for this locus\n";
+            // the locus' sequence with the variants applied; of variants that overlap (alleles of one region) the best supported one
             std::string updated = lc->seq;
-            for (auto it = kv.second.rbegin(); it != kv.second.rend(); ++it) // (right to left: earlier positions stay valid)
-                updated.replace((*it)->pos, (*it)->ref.size(), (*it)->alt);
+            std::vector<const NovelVariant*> by_support = kv.second, chosen;
+            std::stable_sort(by_support.begin(), by_support.end(), [](const NovelVariant* x, const NovelVariant* y) { return x->support > y->support; });
+            for (const NovelVariant* v : by_support) {
+                bool clash = false;
+                for (const NovelVariant* u : chosen)
+                    clash |= (v->pos <= u->pos + u->ref.size() && u->pos <= v->pos + v->ref.size()) || (u->group != ~0u && u->group == v->group);
+                if (!clash) chosen.push_back(v);
+            }
+            std::sort(chosen.begin(), chosen.end(), [](const NovelVariant* x, const NovelVariant* y) { return x->pos > y->pos; });
+            for (const NovelVariant* v : chosen) updated.replace(v->pos, v->ref.size(), v->alt); // (right to left: earlier positions stay valid)
             for (const NovelVariant* v : kv.second) o << v->pos + 1 << "\t" << v->ref << "\t" << v->alt << "\n";
             fa << ">" << kv.first << "\n" << updated << "\n";
         }
@@ -532,10 +728,20 @@ uint32_t update_prgs(std::vector<std::pair<std::string, std::string>>& prgs, con
             std::vector<const NovelVariant*> vs;
         };
         std::vector<Edit> edits;
-        for (const NovelVariant* v : kv.second) {
+        // the alleles of one candidate region (same group) share ONE stretch: the span from the first to the last of them
+        std::map<uint32_t, std::vector<const NovelVariant*>> units;
+        uint32_t solo = 0;
+        for (const NovelVariant* v : kv.second) units[v->group != ~0u ? v->group : 0x80000000u + solo++].push_back(v);
+        for (auto& unit : units) {
+            const std::vector<const NovelVariant*>& members = unit.second;
+            const NovelVariant* v = members[0];
             uint32_t p = v->pos, q = v->pos + (uint32_t)v->ref.size();
+            for (const NovelVariant* m : members) {
+                p = std::min(p, m->pos);
+                q = std::max(q, m->pos + (uint32_t)m->ref.size());
+            }
             if (q > cons.size() || cum.back() != cons.size() || cons.empty()) {
-                skip(v);
+                for (const NovelVariant* m : members) skip(m);
                 continue;
             }
             if (p == q) { // an insertion takes the base before it along (the one behind it at the very start)
@@ -544,7 +750,7 @@ uint32_t update_prgs(std::vector<std::pair<std::string, std::string>>& prgs, con
             }
             const size_t xa = offset_of(p), xb = offset_of(q - 1);
             if (xa >= prg.size() || xb >= prg.size() || ctx_of[xa] < 0 || ctx_of[xb] < 0) {
-                skip(v);
+                for (const NovelVariant* m : members) skip(m);
                 continue;
             }
             // the deepest context both ends lie in; an end that lies deeper takes the whole site it is in at the next level
@@ -560,7 +766,7 @@ uint32_t update_prgs(std::vector<std::pair<std::string, std::string>>& prgs, con
             e.b = sb >= 0 ? sites[(size_t)sb].close_off : xb + 1;
             e.p = sa >= 0 ? first_path_base_at_or_after(e.a) : p;
             e.q = sb >= 0 ? first_path_base_at_or_after(e.b) : q;
-            e.vs.push_back(v);
+            e.vs = members;
             edits.push_back(std::move(e));
         }
         // overlapping stretches lie in one context (each holds whole sites only), so their union is a stretch of the same kind
@@ -586,22 +792,45 @@ uint32_t update_prgs(std::vector<std::pair<std::string, std::string>>& prgs, con
         }
         int next_marker = marker + 1 + ((marker + 1) % 2 == 0 ? 1 : 0); // the next odd number (renumbered below)
         for (auto it = merged.rbegin(); it != merged.rend(); ++it) { // right to left: the offsets further left stay valid
-            std::string alt = cons.substr(it->p, it->q - it->p);
+            const std::string base = cons.substr(it->p, it->q - it->p);
             std::vector<const NovelVariant*> vs = it->vs;
             std::sort(vs.begin(), vs.end(), [](const NovelVariant* x, const NovelVariant* y) { return x->pos > y->pos; });
+            // Variants of one candidate region (same group) and variants that overlap each other (the overlapping lines of a
+            // denovo_paths.txt) are alternatives: each becomes an allele of its own; the others are in every allele.
+            auto overlap = [](const NovelVariant* x, const NovelVariant* y) {
+                const uint32_t xe = x->pos + (uint32_t)std::max<size_t>(x->ref.size(), 1), ye = y->pos + (uint32_t)std::max<size_t>(y->ref.size(), 1);
+                return x->pos < ye && y->pos < xe;
+            };
+            std::vector<const NovelVariant*> common, alternatives;
             bool ok = true;
-            uint32_t last = it->q;
-            for (const NovelVariant* v : vs) { // (variants of one locus never overlap: one per candidate region)
-                if (v->pos < it->p || v->pos + v->ref.size() > last) ok = false;
-                else alt.replace(v->pos - it->p, v->ref.size(), v->alt);
-                last = v->pos;
+            for (const NovelVariant* v : vs) {
+                if (v->pos < it->p || v->pos + v->ref.size() > it->q) ok = false;
+                bool clashes = false;
+                for (const NovelVariant* u : vs) clashes |= u != v && (overlap(u, v) || (u->group != ~0u && u->group == v->group));
+                (clashes ? alternatives : common).push_back(v);
             }
             if (!ok) {
                 for (const NovelVariant* v : vs) skip(v);
                 continue;
             }
+            auto spelled = [&](const NovelVariant* extra) { // `common` (+ one alternative) applied right to left
+                std::vector<const NovelVariant*> use = common;
+                if (extra) use.push_back(extra);
+                std::sort(use.begin(), use.end(), [](const NovelVariant* x, const NovelVariant* y) { return x->pos > y->pos; });
+                std::string t = base;
+                for (const NovelVariant* v : use) t.replace(v->pos - it->p, v->ref.size(), v->alt);
+                return t;
+            };
+            std::vector<std::string> alts;
+            if (alternatives.empty()) alts.push_back(spelled(nullptr));
+            for (const NovelVariant* v : alternatives) {
+                const std::string t = spelled(v);
+                if (std::find(alts.begin(), alts.end(), t) == alts.end()) alts.push_back(t);
+            }
             const std::string m = std::to_string(next_marker), sep = std::to_string(next_marker + 1);
-            prg = prg.substr(0, it->a) + " " + m + " " + prg.substr(it->a, it->b - it->a) + " " + sep + " " + alt + " " + m + " " + prg.substr(it->b);
+            std::string site = " " + m + " " + prg.substr(it->a, it->b - it->a);
+            for (const std::string& t : alts) site += " " + sep + " " + t;
+            prg = prg.substr(0, it->a) + site + " " + m + " " + prg.substr(it->b);
             next_marker += 2;
             applied += (uint32_t)vs.size();
         }

@@ -10,7 +10,8 @@ struct NovelVariant {
     uint32_t prg = 0;
     uint32_t pos = 0; // 0-based on the locus' called consensus
     std::string ref, alt; // either may be empty (insertion / deletion)
-    uint32_t support = 0, spanning = 0; // reads that spell alt between the anchors / reads that hold both anchors
+    uint32_t support = 0, spanning = 0; // reads that spell alt between the anchors / reads that hold both anchors (assembled alleles: k-mer counts)
+    uint32_t group = ~0u; // variants with the same group (the candidate region they come from) are ALTERNATIVE alleles, never one haplotype
 };
 
 // second pass over the reads file (host threads): exact-anchor pile-up over every candidate region of `gr`; accurate_reads:

@@ -246,3 +246,122 @@ def column_vote(consensus, regions, reads, anchor=15, min_support=4, min_fractio
             suf += 1
         out.append((locus, start + pre, core0[pre:len(core0) - suf], allele[pre:len(allele) - suf], support, spanning))
     return sorted(out, key=lambda v: (v[0], v[1]))
+
+
+# ---- local assembly (round 4; accurate reads) ---------------------------------------------------------------------------------------------
+# A second statement of the product's de Bruijn assembly of a candidate region (drprg_amd/csrc/denovo.cpp assemble_region +
+# assemble_candidate_regions with DRPRG_HIP_DENOVO=dbg), in plain Python: str.find-free set / dict code over whole reads, recursion instead
+# of the product's explicit stack.  It follows what pandora discover does as far as remembered [UPSTREAM-MEMORY: de Bruijn graph over the
+# reads of a region, k = 15, nodes seen at least twice, depth-first paths from a start k-mer to an end k-mer taken from the region's
+# flanks, outermost pair first] -- pandora's source is not in the reference tree, so like everything else in this file it checks the
+# IMPLEMENTATION of this build's rules.
+# Rules: slice = the `anchor` consensus bases before the padded region + the region + the `anchor` bases behind it.  A read (>= anchor
+# bases) joins the region's pile once per orientation in which it shares an anchor-mer with the slice (the reverse complement of the read
+# joins when it shares one with the slice's reverse complement, i.e. reads are piled in the consensus' orientation).  Nodes: the
+# anchor-mers of the piled reads (no N) seen >= min_dp times.  Start k-mers: slice offsets 0 .. flank_l - k, end k-mers: offsets
+# len - k - (0 .. flank_r - k), flank = anchor + padding on that side (region start -> first low-coverage base).  For the start k-mers in
+# that order and, per start, the end k-mers in that order (a k-mer must be a node, the end must lie behind the start): all paths from
+# start to end of total length within max_len_change of the consensus stretch between them; more than max_paths paths, or more than
+# 200000 extension attempts: this pair is skipped; the first pair with at least one path decides.  A path that spells the consensus is
+# dropped, as is one whose k-mers are all consensus k-mers; support = the smallest count among its non-consensus k-mers.  Alleles with
+# support >= max(min_support, ceil(best / 10)) are reported, trimmed against the slice, best supported first (ties: by sequence);
+# spanning = the largest count among the start / end k-mers.
+def local_assembly(consensus, regions, reads, anchor=15, min_dp=2, min_support=3, max_len_change=30, max_paths=25, max_steps=200000):
+    """regions: [(locus, start, end, low_start, low_end)].  Returns [(locus, pos0, ref, alt, support, spanning)] in region order, the
+    alleles of a region best supported first."""
+    K = anchor
+    out = []
+    for locus, start, end, low_start, low_end in regions:
+        cons = consensus[locus]
+        if start < K or end + K > len(cons):
+            continue
+        sl = cons[start - K:end + K]
+        rc_sl = revcomp(sl)
+        fwd_k = {sl[i:i + K] for i in range(len(sl) - K + 1)}
+        rev_k = {rc_sl[i:i + K] for i in range(len(rc_sl) - K + 1)}
+        pile = []
+        for read in reads:
+            read = read.upper()
+            if len(read) < K:
+                continue
+            ks = {read[i:i + K] for i in range(len(read) - K + 1)}
+            ks = {k for k in ks if all(c in "ACGT" for c in k)}
+            if ks & fwd_k:
+                pile.append(read)
+            if ks & rev_k:
+                pile.append(revcomp(read))
+        count = {}
+        for r in pile:
+            for i in range(len(r) - K + 1):
+                k = r[i:i + K]
+                if all(c in "ACGT" for c in k):
+                    count[k] = count.get(k, 0) + 1
+        node = lambda k: count.get(k, 0) >= min_dp
+        flank_l, flank_r = K + (low_start - start), K + (end - low_end)
+        starts = list(range(0, max(0, flank_l - K + 1)))
+        ends = [len(sl) - K - i for i in range(0, max(0, flank_r - K + 1))]
+        depth = max([count.get(sl[i:i + K], 0) for i in starts + ends] or [0])
+        found = None
+        for si in starts:
+            if found is not None:
+                break
+            if not node(sl[si:si + K]):
+                continue
+            for eo in ends:
+                if eo <= si or not node(sl[eo:eo + K]):
+                    continue
+                want = eo + K - si
+                target, paths, steps = sl[eo:eo + K], [], [0]
+
+                class TooMany(Exception):
+                    pass
+
+                def walk(kmer, tail):
+                    if kmer == target and K + len(tail) >= max(K, want - max_len_change):
+                        paths.append(tail)
+                        if len(paths) > max_paths:
+                            raise TooMany()
+                    if K + len(tail) >= want + max_len_change:
+                        return
+                    for b in "ACGT":
+                        steps[0] += 1
+                        if steps[0] > max_steps:
+                            raise TooMany()
+                        nxt = kmer[1:] + b
+                        if node(nxt):
+                            walk(nxt, tail + b)
+
+                try:
+                    import sys
+                    sys.setrecursionlimit(max(sys.getrecursionlimit(), 4 * (want + max_len_change) + 200))
+                    walk(sl[si:si + K], "")
+                except TooMany:
+                    continue
+                if not paths:
+                    continue
+                found = {}
+                for tail in paths:
+                    spelled = sl[si:si + K] + tail
+                    whole = sl[:si] + spelled + sl[eo + K:]
+                    if whole == sl:
+                        continue
+                    novel = [count.get(spelled[i:i + K], 0) for i in range(len(spelled) - K + 1) if spelled[i:i + K] not in fwd_k]
+                    if not novel:
+                        continue
+                    found[whole] = max(found.get(whole, 0), min(novel))
+                break
+        if not found:
+            continue
+        ranked = sorted(found.items(), key=lambda kv: (-kv[1], kv[0]))
+        need = max(min_support, (ranked[0][1] + 9) // 10)
+        for whole, support in ranked:
+            if support < need:
+                break
+            pre = 0
+            while pre < len(sl) and pre < len(whole) and sl[pre] == whole[pre]:
+                pre += 1
+            suf = 0
+            while suf < len(sl) - pre and suf < len(whole) - pre and sl[len(sl) - 1 - suf] == whole[len(whole) - 1 - suf]:
+                suf += 1
+            out.append((locus, start - K + pre, sl[pre:len(sl) - suf], whole[pre:len(whole) - suf], support, depth))
+    return out

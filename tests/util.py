@@ -407,6 +407,23 @@ def vcf_without_date(path):
 
 
 # ---- discover: the oracle's two pile-ups (oracle/oracle_denovo.py) on the candidate regions a discover run wrote -------------------
+def oracle_local_assembly(discover_dir, consensus, bases, offs):
+    """[(locus, pos0, ref, alt, support, spanning)] by the oracle's own statement of the local (de Bruijn) assembly of every candidate region
+    in <discover_dir>/candidate_regions.tsv: region order, the alleles of a region best supported first"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("oracle_denovo", os.path.join(ROOT, "oracle", "oracle_denovo.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    regions = []
+    for line in open(os.path.join(str(discover_dir), "candidate_regions.tsv")):
+        if not line.startswith("#"):
+            f = line.split("\t")
+            regions.append((f[0], int(f[1]), int(f[2]), int(f[3]), int(f[4])))
+    text = np.asarray(bases, np.uint8).tobytes().decode()
+    reads = [text[int(offs[i]):int(offs[i + 1])] for i in range(len(offs) - 1)]
+    return mod.local_assembly(consensus, regions, reads)
+
+
 def oracle_denovo(discover_dir, consensus, bases, offs, noisy=False):
     """[(locus, pos0, ref, alt, support, spanning)] by the oracle's separate statement of the accurate-read pile-up (noisy = False) or of the
     noisy-read column vote, over the regions in <discover_dir>/candidate_regions.tsv and the consensus {locus: sequence} the test knows"""
@@ -424,18 +441,19 @@ def oracle_denovo(discover_dir, consensus, bases, offs, noisy=False):
     return (mod.column_vote if noisy else mod.pile_up)(consensus, regions, reads)
 
 
-def prg_language(prg):
-    """Every sequence a PRG string spells, parsed the way pandora's LocalPRG::build_graph does [UPSTREAM-MEMORY]: an interval that holds a
-    marker is split at the NEXT site number (5, 7, 9 ... in the order the parser meets the sites: a site before the sites inside it, then
-    the sites behind it), what stands before that site must be plain sequence, the alleles are parsed in turn, then what stands behind the
-    site.  Raises AssertionError on a string pandora would refuse (markers out of that order, unbalanced sites).  Small PRGs only."""
+def prg_tree(prg):
+    """A PRG string as a tree -- [plain sequence | [allele, allele, ...]] with every allele such a list again --, parsed the way pandora's
+    LocalPRG::build_graph does [UPSTREAM-MEMORY]: an interval that holds a marker is split at the NEXT site number (5, 7, 9 ... in the order
+    the parser meets the sites: a site before the sites inside it, then the sites behind it), what stands before that site must be plain
+    sequence, the alleles are parsed in turn, then what stands behind the site.  Raises AssertionError on a string pandora would refuse
+    (markers out of that order, unbalanced sites)."""
     import re
     next_site = [5]
 
     def build(s):
         if not re.search(r"\d", s):
             assert re.fullmatch(r"[ACGT ]*", s), s
-            return {s.replace(" ", "")}
+            return [s.replace(" ", "")]
         m = next_site[0]
         tok, sep = " %d " % m, " %d " % (m + 1)
         i = s.find(tok)
@@ -448,12 +466,52 @@ def prg_language(prg):
         next_site[0] += 2
         alleles = middle.split(sep)
         assert len(alleles) >= 2, "site %d has one allele" % m
-        mids = set()
-        for a in alleles:
-            mids |= build(a)
-        tails = build(rest)
-        first = first.replace(" ", "")
-        return {first + a + t for a in mids for t in tails}
+        return [first.replace(" ", ""), [build(a) for a in alleles]] + build(rest)
 
-    out = build(prg)
-    return out
+    return build(prg)
+
+
+def prg_language(prg):
+    """Every sequence a PRG string spells (prg_tree's rules).  Small PRGs only: the number of sequences is the product over the sites."""
+    def spell(items):
+        out = {""}
+        for it in items:
+            if isinstance(it, str):
+                out = {x + it for x in out}
+            else:
+                alts = set()
+                for allele in it:
+                    alts |= spell(allele)
+                out = {x + a for x in out for a in alts}
+        return out
+
+    return spell(prg_tree(prg))
+
+
+def prg_spells(prg, seq):
+    """does the PRG string (prg_tree's rules) spell `seq`?  Sets of reachable positions: fine for PRGs of any size"""
+    def step(items, starts):
+        for it in items:
+            if not starts:
+                return starts
+            if isinstance(it, str):
+                starts = {p + len(it) for p in starts if seq.startswith(it, p)}
+            else:
+                ends = set()
+                for allele in it:
+                    ends |= step(allele, starts)
+                starts = ends
+        return starts
+
+    return len(seq) in step(prg_tree(prg), {0})
+
+
+def prg_walks(prg, n, seed=0):
+    """n random sequences of the PRG string (a random allele at every site)"""
+    rng = np.random.default_rng(seed)
+
+    def walk(items):
+        return "".join(it if isinstance(it, str) else walk(it[int(rng.integers(len(it)))]) for it in items)
+
+    tree = prg_tree(prg)
+    return [walk(tree) for _ in range(n)]
