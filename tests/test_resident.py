@@ -133,6 +133,28 @@ def test_discover_from_resident_reads_writes_what_discover_from_the_file_writes(
     assert fa == fc
 
 
+def test_local_assembly_from_resident_reads(tmp_path, oracle):
+    """round 4: the local (de Bruijn) assembly piles up every read that shares a k-mer with a region's slice of the consensus; with the reads
+    in HBM the device selects them (all the slice's k-mers go to anchor_scan_kernel, not two anchors per region).  100-base reads and a
+    24-base insertion: no read holds both anchors, the pile-up finds nothing, the assembly does -- the same from the file, from HBM, from
+    packed blocks in HBM, and by the oracle's own statement of the assembly (oracle/oracle_denovo.py local_assembly)"""
+    from drprg_amd import Context
+    from test_local_assembly import _sample as assembly_sample
+    from util import oracle_local_assembly
+    host, panel, genes, fq, bases, offs, hs, pos = assembly_sample(tmp_path, oracle, lambda ref, pos: [(1.0, ref[:pos] + "TCGGATACCGTTAGCAATGCCTAG" + ref[pos + 2:])],
+                                                                 read_len=100, n_reads=1400)
+    prg = str(tmp_path / "dr.prg")
+    a, va = _discover(prg, genes, fq, tmp_path / "file", 0)
+    b, vb = _discover(prg, genes, fq, tmp_path / "hbm", 1 << 30)
+    c, vc = _discover(prg, genes, fq, tmp_path / "hbm_packed", 1 << 30, packed=True)
+    assert b.resident_info()["last_discover_from_hbm"] and c.resident_info()["last_discover_from_hbm"] and not a.resident_info()["last_discover_from_hbm"]
+    assert len(va) == 1 and va == vb == vc and va[0][0] == "g1"
+    mutated = panel.refs[1][:va[0][1] - 1] + va[0][3] + panel.refs[1][va[0][1] - 1 + len(va[0][2]):]
+    assert mutated == hs[0][1]
+    assert oracle_local_assembly(tmp_path / "hbm", dict(zip(panel.names, panel.refs)), bases, offs) == [(l, p - 1, r, alt, s, n) for l, p, r, alt, s, n in vb]
+    assert _files(tmp_path / "file") == _files(tmp_path / "hbm")
+
+
 def test_many_blocks_and_reads_without_anchors(tmp_path):
     """300 k reads, most of them from an unrelated genome, eight parser threads -> several blocks in HBM; anchors that run over the
     end of a read into the next read of the block select a read too many at worst"""
