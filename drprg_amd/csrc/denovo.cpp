@@ -360,10 +360,11 @@ std::vector<NovelVariant> assemble_candidate_regions(const GenotypeResult& gr, c
         std::vector<std::string> reads;
     };
     std::vector<RegionPile> piles(gr.candidates.size());
-    // low 16 bits of the packed k-mer, one BIT each (8 KB: stays in the L1 of every parser thread): most read k-mers stop here
-    std::vector<uint64_t> prefilter(1u << 10, 0);
-    for (auto& kv : anchors) prefilter[(kv.first & 0xFFFF) >> 6] |= 1ull << (kv.first & 63);
-    for (auto& kv : slice_kmers) prefilter[(kv.first & 0xFFFF) >> 6] |= 1ull << (kv.first & 63);
+    // low 20 bits of the packed k-mer, one BIT each (128 KB: stays in the L2 of every parser thread; with the slices' k-mers in it -- a
+    // few hundred per region -- the 8 KB table of round 3 let one read k-mer in eight through to the hash maps): most read k-mers stop here
+    std::vector<uint64_t> prefilter(1u << 14, 0);
+    for (auto& kv : anchors) prefilter[(kv.first & 0xFFFFF) >> 6] |= 1ull << (kv.first & 63);
+    for (auto& kv : slice_kmers) prefilter[(kv.first & 0xFFFFF) >> 6] |= 1ull << (kv.first & 63);
     uint8_t code_of[256]; // the scan below is the whole cost of this pass (every base of every read): table, no branches per base
     for (int ch = 0; ch < 256; ++ch) code_of[ch] = (uint8_t)nt4((unsigned char)ch);
     std::vector<RegionVotes> votes(gr.candidates.size());
@@ -393,7 +394,7 @@ std::vector<NovelVariant> assemble_candidate_regions(const GenotypeResult& gr, c
                 const uint32_t c = code_of[(unsigned char)s[p]];
                 v = ((v << 2) | (uint64_t)(c & 3)) & mask;
                 run = c > 3 ? 0 : run + 1; // (a k-mer over a non-ACGT base never counts: the run restarts after it)
-                if (!((prefilter[(v & 0xFFFF) >> 6] >> (v & 63)) & 1) || run < A) continue;
+                if (!((prefilter[(v & 0xFFFFF) >> 6] >> (v & 63)) & 1) || run < A) continue;
                 auto range = anchors.equal_range(v);
                 for (auto it = range.first; it != range.second; ++it)
                     hits.push_back(Hit { it->second.region, (uint32_t)(p + 1 - A), it->second.right, it->second.reverse, it->second.j });
