@@ -754,7 +754,7 @@ def main():
             ho = offsets[:ns + 1].cpu().numpy().astype(np.uint64)
 
             def cpu_map(lo, hi):
-                return orc.map_reads(hb[int(ho[lo]):int(ho[hi])], ho[lo:hi + 1] - ho[lo], idx, W, K, md, frac, 10)[0]
+                return orc.map_reads(hb[int(ho[lo]):int(ho[hi])], ho[lo:hi + 1] - ho[lo], idx, W, K, md, frac, 10)[:2]
 
             t1 = time.perf_counter()
             cpu_map(0, ns1)
@@ -764,18 +764,36 @@ def main():
             with ThreadPoolExecutor(threads) as pool:
                 parts = list(pool.map(lambda i: cpu_map(cuts[i], cuts[i + 1]), range(threads)))
             cpu_s = time.perf_counter() - t1
-            ocov = np.sum(np.stack(parts).astype(np.uint64), axis=0).astype(np.uint32)
+            ocov = np.sum(np.stack([p[0] for p in parts]).astype(np.uint64), axis=0).astype(np.uint32)
+            oprg = np.sum(np.stack([p[1] for p in parts]).astype(np.uint64), axis=0).astype(np.uint32)
             # the same sample through the HIP path must give the identical vector
             c2 = torch.zeros_like(covg)
             p2 = torch.zeros_like(prg_reads)
             torch.cuda.synchronize()
             map_range(ctx, bases, offsets, 0, ns, c2, p2, stream, torch)
             parity = bool(np.array_equal(c2.cpu().numpy().view(np.uint32), ocov))
+            # ... and the genotyped VCF of that vector (SURVEY 8d "parity gates run with every benchmark"): the product's genotyper on the
+            # coverage the DEVICE accumulated against the oracle's own model / site enumeration / statistics / likelihoods on the
+            # oracle's vector (tests/util.py oracle_vcf_text), byte for byte minus ##fileDate
+            vcf_parity = None
+            try:
+                from util import oracle_vcf_text, vcf_without_date
+                host = Context(prg, W, K, device=-1, from_files=False)
+                host.set_opts(illumina=illumina, genome_size=opts["genome_size"])
+                host.set_coverage(c2.cpu().numpy().view(np.uint32), p2.cpu().numpy().view(np.uint32), nb)
+                vcf_path = os.path.join(tmp, "pandora_genotyped.vcf")
+                host.genotype(os.path.join(tmp, "genes.fa"), vcf_path)
+                want, _ = oracle_vcf_text(orc, panel.names, panel.prgs, dict(zip(panel.names, panel.refs)), ocov, oprg, nb, W, K, opts["genome_size"], er)
+                vcf_parity = bool(vcf_without_date(vcf_path) == want)
+                host.close()
+            except Exception as exc:  # (the bench line must not depend on this gate)
+                vcf_parity = f"not run: {type(exc).__name__}: {exc}"
             out["cpu_baseline"] = {"value": ns / cpu_s, "unit": "reads/s", "cores": threads, "kind": "port",
                                    "sample": f"first {ns} reads ({nb} bases) of rank 0's shard, oracle/oracle.c on {threads} threads "
                                              f"(disjoint read ranges), {cpu_s:.1f}s",
                                    "single_thread_value": ns1 / cpu1_s, "single_thread_sample": f"first {ns1} reads, {cpu1_s:.1f}s",
-                                   "host_cores_available": os.cpu_count(), "cpu_model": cpu_model(), "parity_vs_hip_on_sample": parity}
+                                   "host_cores_available": os.cpu_count(), "cpu_model": cpu_model(), "parity_vs_hip_on_sample": parity,
+                                   "genotyped_vcf_identical_to_oracle_on_sample": vcf_parity}
         if args.e2e and world == 1 and args.workload != "nanopore" and not args.no_checks:
             try:
                 out["e2e"] = e2e_leg(torch, ctx, synth, bases, n_reads, args.read_len, covg)
