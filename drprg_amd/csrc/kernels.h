@@ -45,11 +45,13 @@ struct SketchArgs {
     // [2 (i & 15) + 1 : 2 (i & 15)] of word i >> 4, letter = bits 2:1 of its ASCII code (A 0, C 1, T 2, G 3 -- the alphabet of the
     // filter's k-mer codes, sketch_filter.hip pack16le -- for ANY byte, so that both formats give the filter the same codes);
     // npos: the ascending positions of the bases that are not one of ACGTacgt (they poison every k-mer that holds them, exactly
-    // as in the ASCII form).  Only the kernels of the filtered sequence read this form; every other consumer of bases gets an
-    // ASCII copy made on the device (launch_unpack).
+    // as in the ASCII form).  The kernels of the filtered sequence and sketch_wave_kernel read this form; every other consumer of
+    // bases gets an ASCII copy made on the device (launch_unpack).
     int packed;
     const uint64_t* npos;
     uint64_t n_npos;
+    const uint16_t* nbits; // packed batches in sketch_wave_kernel: bit j of word i = base 16 i + j is in npos (null when n_npos == 0):
+                           // launch_mark_npos sets them before the kernel (the list itself would cost a search per tile)
     // index
     const void* slot_key; // u32[2^bits] (k <= 15) or u64[2^bits]
     const uint2* slot_rec; // {record offset, record count}; count 0 = empty slot
@@ -280,6 +282,8 @@ hipError_t launch_vector_add_u32(uint32_t* dst, const uint32_t* src, uint64_t n,
 // packed.hip: 2-bit packed reads -> ASCII (A C G T, 'N' at the positions in npos and in the 64 bytes behind the last base): what the
 // direct sketch kernels and the anchor scan read.  out: n_bases + 64 bytes, 16-byte aligned.
 hipError_t launch_unpack(const uint32_t* words, uint64_t n_bases, const uint64_t* npos, uint64_t n_npos, uint8_t* out, hipStream_t stream);
+// bits[i >> 4] |= 1 << (i & 15) for every position i of npos below n_bases (bits: zeroed u16[ceil(n_bases / 16)], 4-byte aligned)
+hipError_t launch_mark_npos(const uint64_t* npos, uint64_t n_npos, uint64_t n_bases, uint16_t* bits, hipStream_t stream);
 // ... and ASCII -> packed on the device (harnesses: bench.py packs its synthetic batch with it).  words: ceil(n_bases / 16); npos: room
 // for npos_cap positions, *n_npos (zeroed by the caller) counts all of them (more than npos_cap: overflow); positions come out
 // unordered: sort them before use.

@@ -567,6 +567,8 @@ void Mapper::leftovers(Lane& lane, const uint8_t* d_bases, const uint64_t* d_off
 void Mapper::free_tile_set(TileSet& t)
 {
     dfree(t.d_tile_info); dfree(t.d_tile_pos1); dfree(t.d_tile_count); dfree(t.d_tile_hits); dfree(t.d_tile_nmin); dfree(t.d_tile_prefix); dfree(t.d_tile_fast);
+    dfree(t.d_nbits);
+    t.nbits_cap = 0;
     dfree(t.d_tile_rec); dfree(t.d_tile_first);
     if (t.d_tile_temp) (void)hipFree(t.d_tile_temp);
     t.d_tile_temp = nullptr;
@@ -632,8 +634,24 @@ void Mapper::direct_launch(int set, const uint8_t* d_bases, const uint64_t* d_of
     if (!lane.scratch_zero) HIPCHK(hipMemsetAsync(lane.d_scratch, 0, L_N * sizeof(unsigned long long), stream));
     lane.scratch_zero = false;
     HIPCHK(hipMemsetAsync(t.d_tile_count + n_tiles, 0, sizeof(uint32_t), stream)); // the scan's closing zero
-    // (a packed batch: the direct sketch kernels read its ASCII expansion, made here on the same stream -- packed.hip)
-    dev::SketchArgs a = sketch_args(ascii_view(set, d_bases, n_bases, stream), d_offsets, n_reads, n_bases);
+    // a packed batch: sketch_wave_kernel reads the words themselves (round 4; the positions of its npos as one bit per base, set here);
+    // the general direct kernel reads an ASCII expansion made on the same stream (packed.hip)
+    const bool native_packed = packed_.count(d_bases) != 0 && dev::direct_uses_wave_form(params_.k, params_.w, wide_hash_);
+    dev::SketchArgs a = sketch_args(native_packed ? d_bases : ascii_view(set, d_bases, n_bases, stream), d_offsets, n_reads, n_bases);
+    if (native_packed && a.n_npos) {
+        const uint64_t words16 = ((n_bases + 15) / 16 + 1) & ~1ull; // (an even number of u16 words: the marks are 32-bit atomics)
+        if (words16 > t.nbits_cap) {
+            dfree(t.d_nbits);
+            t.nbits_cap = words16 + words16 / 4;
+            t.nbits_cap += t.nbits_cap & 1;
+            dmalloc(t.d_nbits, (size_t)t.nbits_cap);
+            t.nbits_dirty = true; // (fresh memory)
+        }
+        if (t.nbits_dirty) HIPCHK(hipMemsetAsync(t.d_nbits, 0, (size_t)t.nbits_cap * sizeof(uint16_t), stream));
+        HIPCHK(dev::launch_mark_npos(a.npos, a.n_npos, n_bases, t.d_nbits, stream));
+        t.nbits_dirty = true;
+        a.nbits = t.d_nbits;
+    }
     a.n_hits = &lane.d_scratch[L_HITS];
     a.n_minimizers = &lane.d_scratch[L_MINIMIZERS];
     a.overflow = reinterpret_cast<uint32_t*>(&lane.d_scratch[L_OVERFLOW]);

@@ -271,6 +271,11 @@ private:
         void* d_tile_temp = nullptr;
         size_t tile_temp_bytes = 0;
         uint32_t* d_tile_first = nullptr; // first read of every tile
+        // packed batches through sketch_wave_kernel: one bit per base, set for the positions in the batch's npos (allocated with the first
+        // batch that has any; all zero except between a launch and the next launch on this set)
+        uint16_t* d_nbits = nullptr;
+        uint64_t nbits_cap = 0; // u16 words
+        bool nbits_dirty = false;
         hipEvent_t done = nullptr, t0 = nullptr, t1 = nullptr;
         uint32_t mark = 0, n_tiles = 0;   // of the batch in flight
         dev::SketchArgs a_done {};

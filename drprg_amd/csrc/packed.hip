@@ -78,6 +78,20 @@ __global__ __launch_bounds__(PK_THREADS) void pack_kernel(const uint8_t* __restr
     }
 }
 
+__global__ __launch_bounds__(PK_THREADS) void mark_npos_kernel(const uint64_t* __restrict__ npos, uint64_t n_npos, uint64_t n_bases, uint32_t* __restrict__ bits32)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * PK_THREADS + threadIdx.x; i < n_npos; i += (uint64_t)gridDim.x * PK_THREADS)
+        if (npos[i] < n_bases) atomicOr(&bits32[npos[i] >> 5], 1u << (npos[i] & 31)); // (u16 words i >> 4, little endian: the same bits)
+}
+
+hipError_t launch_mark_npos(const uint64_t* npos, uint64_t n_npos, uint64_t n_bases, uint16_t* bits, hipStream_t stream)
+{
+    if (!n_npos) return hipSuccess;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((n_npos + PK_THREADS - 1) / PK_THREADS, 1u << 14);
+    hipLaunchKernelGGL(mark_npos_kernel, dim3(grid), dim3(PK_THREADS), 0, stream, npos, n_npos, n_bases, reinterpret_cast<uint32_t*>(bits));
+    return hipGetLastError();
+}
+
 hipError_t launch_unpack(const uint32_t* words, uint64_t n_bases, const uint64_t* npos, uint64_t n_npos, uint8_t* out, hipStream_t stream)
 {
     const uint64_t n_out = ((n_bases + 15) >> 4) + 4;

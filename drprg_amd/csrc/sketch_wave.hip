@@ -97,7 +97,7 @@ struct alignas(16) WaveLds {
     uint32_t rcnt[64];      // per lane: reads that start in its 16 positions; later the read before its first position
 };
 
-template <int K, int W, bool FUSE>
+template <int K, int W, bool FUSE, bool PACKED>
 __device__ __forceinline__ void sketch_wave_tile(const SketchArgs& a, uint32_t tile, bool active, WaveLds& lds, uint32_t* s_nb, uint32_t* s_sum, int lane, int wave)
 {
     if (!active) { // a wave past the last tile still meets the workgroup's two barriers
@@ -112,31 +112,51 @@ __device__ __forceinline__ void sketch_wave_tile(const SketchArgs& a, uint32_t t
     const int64_t g0 = origin + (int64_t)lane * SW_G;
 
     // ---- bases -> 2-bit words, low-first (le) and high-first (be) ----
-    uint4 in;
-    if (g0 >= 0 && g0 + SW_G <= n_bases) {
-        in = load_once_16(a.bases + g0);
-    } else { // the ends of the buffer: what lies outside is 'N'
-        uint32_t tmp[4];
-        for (int q = 0; q < 4; ++q) {
-            uint32_t wd = 0;
-            for (int b = 0; b < 4; ++b) {
-                const int64_t gg = g0 + q * 4 + b;
-                wd |= (uint32_t)((gg >= 0 && gg < n_bases) ? a.bases[gg] : (uint8_t)'N') << (8 * b);
-            }
-            tmp[q] = wd;
-        }
-        in = make_uint4(tmp[0], tmp[1], tmp[2], tmp[3]);
-    }
     lds.inv[lane] = 0;
     lds.rbits[lane] = 0;
     lds.rcnt[lane] = 0;
-    uint32_t diff = 0;
-    const uint32_t s0 = select4(in.x, diff), s1 = select4(in.y, diff), s2 = select4(in.z, diff), s3 = select4(in.w, diff);
-    // v_dot4_u32_u8 packs four selectors into a byte: weights 1,4,16,64 (first base lowest) / 64,16,4,1 (first base highest)
-    uint32_t le = __builtin_amdgcn_udot4(s0, 0x40100401u, 0u, false) | (__builtin_amdgcn_udot4(s1, 0x40100401u, 0u, false) << 8)
-        | (__builtin_amdgcn_udot4(s2, 0x40100401u, 0u, false) << 16) | (__builtin_amdgcn_udot4(s3, 0x40100401u, 0u, false) << 24);
-    uint32_t be = (__builtin_amdgcn_udot4(s0, 0x01041040u, 0u, false) << 24) | (__builtin_amdgcn_udot4(s1, 0x01041040u, 0u, false) << 16)
-        | (__builtin_amdgcn_udot4(s2, 0x01041040u, 0u, false) << 8) | __builtin_amdgcn_udot4(s3, 0x01041040u, 0u, false);
+    uint32_t le, be, diff = 0;
+    uint4 in = make_uint4(0, 0, 0, 0);
+    uint32_t bad16 = 0; // PACKED: bit i = my base i is not ACGT (listed in npos) or lies outside the batch
+    (void)in; (void)bad16;
+    if constexpr (PACKED) {
+        // a lane's 16 bases are one word of the batch (g0 is a multiple of 16); the letters are the low-first stream as they are, the
+        // high-first stream is the word with its sixteen fields in reverse order (v_bfrev + the two bits of every field swapped back)
+        const uint32_t* const words = reinterpret_cast<const uint32_t*>(a.bases);
+        uint32_t wd = 0;
+        if (g0 >= 0 && g0 < n_bases) {
+            wd = words[g0 >> 4];
+            if (a.nbits) bad16 = a.nbits[g0 >> 4];
+            if (g0 + SW_G > n_bases) bad16 |= (0xFFFFu << (uint32_t)(n_bases - g0)) & 0xFFFFu;
+        } else {
+            bad16 = 0xFFFFu;
+        }
+        const uint32_t r = __brev(wd);
+        le = wd;
+        be = ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);
+        diff = bad16;
+    } else {
+        if (g0 >= 0 && g0 + SW_G <= n_bases) {
+            in = load_once_16(a.bases + g0);
+        } else { // the ends of the buffer: what lies outside is 'N'
+            uint32_t tmp[4];
+            for (int q = 0; q < 4; ++q) {
+                uint32_t wd = 0;
+                for (int b = 0; b < 4; ++b) {
+                    const int64_t gg = g0 + q * 4 + b;
+                    wd |= (uint32_t)((gg >= 0 && gg < n_bases) ? a.bases[gg] : (uint8_t)'N') << (8 * b);
+                }
+                tmp[q] = wd;
+            }
+            in = make_uint4(tmp[0], tmp[1], tmp[2], tmp[3]);
+        }
+        const uint32_t s0 = select4(in.x, diff), s1 = select4(in.y, diff), s2 = select4(in.z, diff), s3 = select4(in.w, diff);
+        // v_dot4_u32_u8 packs four selectors into a byte: weights 1,4,16,64 (first base lowest) / 64,16,4,1 (first base highest)
+        le = __builtin_amdgcn_udot4(s0, 0x40100401u, 0u, false) | (__builtin_amdgcn_udot4(s1, 0x40100401u, 0u, false) << 8)
+            | (__builtin_amdgcn_udot4(s2, 0x40100401u, 0u, false) << 16) | (__builtin_amdgcn_udot4(s3, 0x40100401u, 0u, false) << 24);
+        be = (__builtin_amdgcn_udot4(s0, 0x01041040u, 0u, false) << 24) | (__builtin_amdgcn_udot4(s1, 0x01041040u, 0u, false) << 16)
+            | (__builtin_amdgcn_udot4(s2, 0x01041040u, 0u, false) << 8) | __builtin_amdgcn_udot4(s3, 0x01041040u, 0u, false);
+    }
     le ^= (le >> 1) & 0x55555555u; // A0 C1 T2 G3 -> A0 C1 G2 T3 in every 2-bit field
     be ^= (be >> 1) & 0x55555555u;
     const uint32_t le_next = from_next_lane(le), be_next = from_next_lane(be);
@@ -165,9 +185,14 @@ __device__ __forceinline__ void sketch_wave_tile(const SketchArgs& a, uint32_t t
     // ---- ... and bases that are not ACGT (rare: the exact per-base test only runs when some lane saw one) ----
     uint32_t inv = 0;
     if (__any(diff != 0)) {
-        uint32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0;
-        (void)select4(in.x, d0); (void)select4(in.y, d1); (void)select4(in.z, d2); (void)select4(in.w, d3);
-        const uint32_t bad = nonzero_bytes4(d0) | (nonzero_bytes4(d1) << 4) | (nonzero_bytes4(d2) << 8) | (nonzero_bytes4(d3) << 12);
+        uint32_t bad;
+        if constexpr (PACKED) {
+            bad = bad16;
+        } else {
+            uint32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+            (void)select4(in.x, d0); (void)select4(in.y, d1); (void)select4(in.z, d2); (void)select4(in.w, d3);
+            bad = nonzero_bytes4(d0) | (nonzero_bytes4(d1) << 4) | (nonzero_bytes4(d2) << 8) | (nonzero_bytes4(d3) << 12);
+        }
         const uint32_t win = bad | (from_next_lane(bad) << 16); // my 16 bases and the 16 after them
         for (int d = 0; d < K; ++d) inv |= win >> d;           // k-mer j holds bases j .. j + K - 1
     }
@@ -536,7 +561,7 @@ __device__ __forceinline__ void sketch_wave_tile(const SketchArgs& a, uint32_t t
 // A ticket per workgroup of 16 waves / 112 KB of LDS: 10 ms, 5.3 ms even without the scan (4 waves per SIMD).  No tickets,
 // tile = blockIdx order, two-level scan (64 tiles per group, look-back over groups): 13 ms against 3.8 ms without the scan --
 // a tile waited 48 us for its 63 group neighbours and 40 us for the previous group, four times its own 12 us.
-template <int K, int W, bool FUSE>
+template <int K, int W, bool FUSE, bool PACKED>
 __global__ __launch_bounds__(SW_WAVES * 64) void sketch_wave_kernel(SketchArgs a, uint32_t n_tiles)
 {
     __shared__ WaveLds s_lds[SW_WAVES];
@@ -544,7 +569,7 @@ __global__ __launch_bounds__(SW_WAVES * 64) void sketch_wave_kernel(SketchArgs a
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x < 4) s_sum[threadIdx.x] = 0; // (added to after the first barrier at the earliest)
     const uint32_t tile = blockIdx.x * SW_WAVES + (uint32_t)wave;
-    sketch_wave_tile<K, W, FUSE>(a, tile, tile < n_tiles, s_lds[wave], s_nb, s_sum, lane, wave);
+    sketch_wave_tile<K, W, FUSE, PACKED>(a, tile, tile < n_tiles, s_lds[wave], s_nb, s_sum, lane, wave);
 }
 
 hipError_t launch_sketch_wave(const SketchArgs& a, hipStream_t stream, KernelTimer timer)
@@ -554,10 +579,18 @@ hipError_t launch_sketch_wave(const SketchArgs& a, hipStream_t stream, KernelTim
     HIP_TRY(launch_tile_first_read(a.offsets, a.n_reads, SW_EVAL, SW_G, n_tiles, a.tile_first_read, stream));
     const dim3 g(wave_n_slices(a.n_bases)), b(SW_WAVES * 64);
     if (timer.begin) HIP_TRY(hipEventRecord(timer.begin, stream));
-    if (a.w == 11 && !a.fuse) hipLaunchKernelGGL((sketch_wave_kernel<15, 11, false>), g, b, 0, stream, a, n_tiles);
-    else if (a.w == 11) hipLaunchKernelGGL((sketch_wave_kernel<15, 11, true>), g, b, 0, stream, a, n_tiles);
-    else if (!a.fuse) hipLaunchKernelGGL((sketch_wave_kernel<15, 14, false>), g, b, 0, stream, a, n_tiles);
-    else hipLaunchKernelGGL((sketch_wave_kernel<15, 14, true>), g, b, 0, stream, a, n_tiles);
+    auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, g, b, 0, stream, a, n_tiles); };
+    const int which = (a.w == 11 ? 0 : 4) | (a.fuse ? 2 : 0) | (a.packed ? 1 : 0);
+    switch (which) {
+    case 0: go(sketch_wave_kernel<15, 11, false, false>); break;
+    case 1: go(sketch_wave_kernel<15, 11, false, true>); break;
+    case 2: go(sketch_wave_kernel<15, 11, true, false>); break;
+    case 3: go(sketch_wave_kernel<15, 11, true, true>); break;
+    case 4: go(sketch_wave_kernel<15, 14, false, false>); break;
+    case 5: go(sketch_wave_kernel<15, 14, false, true>); break;
+    case 6: go(sketch_wave_kernel<15, 14, true, false>); break;
+    default: go(sketch_wave_kernel<15, 14, true, true>); break;
+    }
     HIP_TRY(hipGetLastError());
     if (timer.end) HIP_TRY(hipEventRecord(timer.end, stream));
     return hipSuccess;
