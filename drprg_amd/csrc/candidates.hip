@@ -19,15 +19,24 @@ __global__ __launch_bounds__(SCAN_THREADS) void cand_scan_kernel(FilterWork fw)
     __shared__ uint32_t s_w[SCAN_THREADS / 64 + 1];
     constexpr int PER = MAX_SLICES / SCAN_THREADS;
     const int tid = threadIdx.x;
-    uint32_t v[PER], run = 0;
+    uint32_t v[PER], cnt[PER], run = 0;
+    // (all the loads before the first use, without a branch -- an entry past the end reads entry 0 and drops it --: one after the other
+    // behind their own conditions they were PER memory round trips in a row, most of this kernel's 10 us)
+#pragma unroll
     for (int i = 0; i < PER; ++i) {
         const uint32_t s = (uint32_t)tid * PER + i;
-        const uint32_t n = s < fw.n_slices ? fw.slice_count[s] : 0u;
+        cnt[i] = fw.slice_count[s < fw.n_slices ? s : 0u];
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const uint32_t s = (uint32_t)tid * PER + i;
+        const uint32_t n = s < fw.n_slices ? cnt[i] : 0u;
         v[i] = run;
         run += n < fw.raw_slice ? n : fw.raw_slice;
     }
     uint32_t total;
     const uint32_t before = block_exclusive_scan<SCAN_THREADS / 64>(run, s_w, &total);
+#pragma unroll
     for (int i = 0; i < PER; ++i) {
         const uint32_t s = (uint32_t)tid * PER + i;
         if (s < fw.n_slices) fw.cand_prefix[s] = before + v[i];
@@ -376,19 +385,27 @@ __global__ __launch_bounds__(SCAN_THREADS) void hit_scan_kernel(SketchArgs a, Fi
     __shared__ uint32_t s_n[SCAN_THREADS / 64], s_m[SCAN_THREADS / 64];
     constexpr int PER = MAX_EX_WG / SCAN_THREADS;
     const int tid = threadIdx.x;
-    uint32_t v[PER], run = 0, nmin = 0, mx = 0;
+    uint32_t v[PER], h[PER], nm[PER], ml[PER], run = 0, nmin = 0, mx = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) { // (all twelve loads together, as in cand_scan_kernel)
+        const uint32_t g = (uint32_t)tid * PER + i, gc = g < fw.ex_grid ? g : 0u;
+        h[i] = fw.wg_hits[gc];
+        nm[i] = fw.wg_nmin[gc];
+        ml[i] = fw.wg_maxlen[gc];
+    }
+#pragma unroll
     for (int i = 0; i < PER; ++i) {
         const uint32_t g = (uint32_t)tid * PER + i;
         v[i] = run;
         if (g < fw.ex_grid) {
-            run += fw.wg_hits[g];
-            nmin += fw.wg_nmin[g];
-            const uint32_t m = fw.wg_maxlen[g];
-            mx = m > mx ? m : mx;
+            run += h[i];
+            nmin += nm[i];
+            mx = ml[i] > mx ? ml[i] : mx;
         }
     }
     uint32_t total;
     const uint32_t before = block_exclusive_scan<SCAN_THREADS / 64>(run, s_w, &total);
+#pragma unroll
     for (int i = 0; i < PER; ++i) {
         const uint32_t g = (uint32_t)tid * PER + i;
         if (g < fw.ex_grid) fw.wg_base[g] = before + v[i];
