@@ -660,7 +660,7 @@ __global__ __launch_bounds__(TG_THREADS) void tile_gather_kernel(SketchArgs a, F
 // every workgroup of cand_gather_kernel summing the slice counts before its own, and every workgroup of verify_count_kernel adding
 // its totals to the batch counters with three atomics.  Measured: cand_gather 11 -> 38 us (8192 workgroups x up to 8192 loads),
 // verify_count 116 -> 231 us (12 k atomics on one 64-byte line take their turn in the L2), step 0.59 -> 0.72 ms.  The scans stay.)
-hipError_t launch_candidate_stage(const SketchArgs& a, const FilterWork& fw, const ReadClusterArgs& rc, hipStream_t stream)
+hipError_t launch_candidate_stage(const SketchArgs& a, const FilterWork& fw, const ReadClusterArgs& rc, hipStream_t stream, bool with_totals)
 {
     hipLaunchKernelGGL(cand_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, fw);
     hipLaunchKernelGGL(cand_gather_kernel, dim3(fw.n_slices), dim3(64), 0, stream, fw);
@@ -669,7 +669,7 @@ hipError_t launch_candidate_stage(const SketchArgs& a, const FilterWork& fw, con
         else hipLaunchKernelGGL((verify_count_kernel<0, true>), dim3(fw.ex_grid), dim3(EX_THREADS), 0, stream, a, fw, rc);
     } else if (a.k == 15) hipLaunchKernelGGL((verify_count_kernel<15, false>), dim3(fw.ex_grid), dim3(EX_THREADS), 0, stream, a, fw, rc);
     else hipLaunchKernelGGL((verify_count_kernel<0, false>), dim3(fw.ex_grid), dim3(EX_THREADS), 0, stream, a, fw, rc);
-    hipLaunchKernelGGL(hit_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, a, fw, 0);
+    if (with_totals) hipLaunchKernelGGL(hit_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, a, fw, 0); // (else: read_cluster_kernel's workgroup 0)
     return hipGetLastError();
 }
 

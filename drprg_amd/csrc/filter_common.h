@@ -33,7 +33,7 @@ __device__ inline void candidate_range(const FilterWork& fw, uint32_t wg, uint32
 
 // stages of the filtered sequence that live in the other translation units (all asynchronous on `stream`)
 // candidates.hip: slices -> dense ordered candidate list -> verified candidates + per-candidate records + batch totals
-hipError_t launch_candidate_stage(const SketchArgs& a, const FilterWork& fw, const ReadClusterArgs& rc, hipStream_t stream);
+hipError_t launch_candidate_stage(const SketchArgs& a, const FilterWork& fw, const ReadClusterArgs& rc, hipStream_t stream, bool with_totals = true);
 // read_cluster.hip: per-read clustering straight from the candidate list (skip: mark the batch as left over instead)
 hipError_t launch_read_cluster(const SketchArgs& a, const FilterWork& fw, const ReadClusterArgs& rc, int n_cus, bool skip, hipStream_t stream);
 // read_cluster_wave.hip: the same for the reads that fit a wave's 128 staged candidates (one wave per 64 candidates, no workgroup barrier)

@@ -237,6 +237,13 @@ struct ReadClusterArgs {
     uint32_t* wg_done;     // zero before the launch: workgroups of the wave form that have finished
     uint32_t* chunk_flags; // [candidate capacity / RC_CHUNK_OWN + 2], zero before the launch: the wave form sets word c when it leaves a read whose first
                            // candidate lies in read_cluster_kernel's chunk c; the second pass takes only those chunks
+    // the batch totals of the candidate stage (hits, minimizers, longest read with a hit) summed by workgroup 0 of read_cluster_kernel
+    // from verify_count_kernel's per-workgroup words instead of by a kernel of their own (hit_scan_kernel: 6 us of launch + one round
+    // trip; it still runs when the hits are counted again for the generic pipeline, which also needs its prefix sums)
+    const uint32_t *wg_hits, *wg_nmin, *wg_maxlen;
+    uint32_t n_wg;                 // 0: the totals are somebody else's business
+    unsigned long long *tot_hits, *tot_minimizers, *tot_max_len;
+    const uint32_t* overflow_word; // bit 2: a candidate slice overflowed (the host runs the batch again: minimizers must not count twice)
     unsigned long long* phase_clock; // DRPRG_RC_DEBUG=1: 12 counters, clock cycles thread 0 of every workgroup spent per phase (else null)
 };
 // DRPRG_RC_FORM=wave (read at every call): launch_read_cluster runs the wave form first; its flag words must be zero before the launch

@@ -97,6 +97,35 @@ __global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs 
             pc_last = pc_now;                                        \
         }                                                            \
     } while (0)
+    if (rc.n_wg && blockIdx.x == 0) { // the candidate stage's totals (kernels.h): before any of the early returns below
+        uint32_t h = 0, nm = 0, ml = 0;
+        for (uint32_t g = (uint32_t)tid; g < rc.n_wg; g += RC_THREADS) {
+            h += rc.wg_hits[g];
+            nm += rc.wg_nmin[g];
+            const uint32_t m = rc.wg_maxlen[g];
+            ml = m > ml ? m : ml;
+        }
+        const uint32_t wh = wave_inclusive_scan(h), wn = wave_inclusive_scan(nm), wm = wave_max(ml);
+        if (lane == 63) {
+            s_w[0][wave] = wh;
+            s_w[1][wave] = wn;
+            s_irr[wave] = wm;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long th = 0, tn = 0;
+            uint32_t tm = 0;
+            for (int i = 0; i < RC_WAVES; ++i) {
+                th += s_w[0][i];
+                tn += s_w[1][i];
+                tm = s_irr[i] > tm ? s_irr[i] : tm;
+            }
+            *rc.tot_hits = th;
+            if (tn && !(*reinterpret_cast<volatile const uint32_t*>(rc.overflow_word) & 4u)) atomicAdd(rc.tot_minimizers, tn);
+            *rc.tot_max_len = (unsigned long long)tm;
+        }
+        __syncthreads();
+    }
     if (*reinterpret_cast<volatile uint32_t*>(a.overflow) & 4u) return; // a candidate slice overflowed: the host re-runs the batch
     // second pass behind read_cluster_wave_kernel: only if that kernel left reads untouched (long reads, mostly)
     if (rc.second_pass && *reinterpret_cast<volatile unsigned long long*>(rc.n_unfit) == 0ull) return;

@@ -692,8 +692,20 @@ hipError_t launch_sketch_filter(const SketchArgs& a, uint32_t read_begin, uint32
         hipLaunchKernelGGL(refine_kernel, dim3(std::min<uint32_t>((fw.n_slices + RF_THREADS / 64 - 1) / (RF_THREADS / 64), (uint32_t)n_cus * 2)), dim3(RF_THREADS), dyn, stream, a, fw);
         HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(launch_candidate_stage(a, fw, rc, stream));
-    return launch_read_cluster(a, fw, rc, n_cus, (fw.debug & 8u) != 0, stream); // debug 8: every read with a hit goes the generic way
+    const bool skip_rc = (fw.debug & 8u) != 0; // debug 8: every read with a hit goes the generic way
+    HIP_TRY(launch_candidate_stage(a, fw, rc, stream, skip_rc));
+    ReadClusterArgs rct = rc;
+    if (!skip_rc) { // the batch totals come out of read_cluster_kernel's workgroup 0
+        rct.wg_hits = fw.wg_hits;
+        rct.wg_nmin = fw.wg_nmin;
+        rct.wg_maxlen = fw.wg_maxlen;
+        rct.n_wg = fw.ex_grid;
+        rct.tot_hits = a.n_hits;
+        rct.tot_minimizers = a.n_minimizers;
+        rct.tot_max_len = fw.max_len;
+        rct.overflow_word = a.overflow;
+    }
+    return launch_read_cluster(a, fw, rct, n_cus, skip_rc, stream);
 }
 
 } // namespace dev
