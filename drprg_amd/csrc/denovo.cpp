@@ -26,6 +26,7 @@
 // [UPSTREAM-MEMORY]); and, for hosts without make_prg / mafft, the PRG updated in place: a variant that lies inside ONE local
 // node becomes a new site of that PRG (MakePrg::update's job in the reference, /root/reference/src/lib.rs:279-456).
 #include "denovo.h"
+#include "fastx.h"
 #include "ingest.h"
 #include <algorithm>
 #include <array>
@@ -469,7 +470,17 @@ std::vector<NovelVariant> assemble_candidate_regions(const GenotypeResult& gr, c
             ingest_fastx(reads_path, threads, hooks);
         } catch (const Error& e) {
             if (e.code != DRPRG_EAGAIN_SERIAL) throw;
-            throw Error(DRPRG_EFORMAT, "discover: multi-line FASTQ is not supported by the region pile-up");
+            // multi-line FASTQ: the serial reader (fastx.cpp), batch by batch through the same scan
+            for (RegionVotes& v : votes) v.alleles.clear();
+            for (RegionPile& pl : piles) pl.reads.clear();
+            FastxReader reader(reads_path);
+            ReadBatch rb;
+            while (reader.next_batch(rb, 1u << 18, 64ull << 20)) {
+                if (!rb.n_reads()) continue;
+                rb.bases.resize(rb.bases.size() + 64); // (what an ingest block has after its last base)
+                PinnedBatch b { rb.bases.data(), rb.offsets.data(), rb.n_reads(), rb.offsets.back() };
+                scan_batch(b);
+            }
         }
     }
     // a variant from two spellings of the same stretch of the consensus (which starts at consensus position `origin`)

@@ -165,3 +165,18 @@ def test_a_mixed_sample_gives_two_alleles_of_one_new_site(tmp_path, oracle, layo
     if layout == "five bases apart":  # the haplotype with both changes is in neither read set and not in the PRG
         assert not prg_spells(prgs[1], _flip(hs[0][1], pos + 5, 1))
     assert [c for c in calls if c[0] == "g1"] and all(_apply(panel.refs[1], p - 1, r, a) == hs[0][1] for c, p, r, a in calls if c == "g1")
+
+
+def test_discover_reads_a_multi_line_fastq_through_the_serial_reader(tmp_path, oracle):
+    """a FASTQ whose sequence and quality run over several lines is not for the parallel ingest (it hands the file to the serial reader);
+    discover's file pass does the same and finds what it finds in the one-line file"""
+    ctx, panel, genes, fq, bases, offs, hs, pos = _sample(tmp_path, oracle, lambda ref, pos: [(1.0, _flip(ref, pos))])
+    want = _discover(ctx, fq, genes, tmp_path / "one_line")
+    assert len(want) == 1
+    multi = str(tmp_path / "multi.fq")
+    with open(fq) as src, open(multi, "w") as dst:
+        lines = src.read().split("\n")
+        for i in range(0, len(lines) - 3, 4):
+            h, s, p, q = lines[i:i + 4]
+            dst.write("%s\n%s\n%s\n%s\n%s\n%s\n" % (h, s[:70], s[70:], p, q[:70], q[70:]))
+    assert _discover(ctx, multi, genes, tmp_path / "multi_line") == want
