@@ -10,7 +10,7 @@ HIPFLAGS := $(CXXFLAGS) --offload-arch=$(ARCH)
 SRC  := drprg_amd/csrc
 OBJD := build/obj
 HOST_SRCS := prg.cpp kmergraph.cpp index.cpp fastx.cpp genotype.cpp params.cpp denovo.cpp mapper.cpp capi.cpp vcfio.cpp bcfout.cpp annotate.cpp report_json.cpp ingest.cpp pgunzip.cpp rccl_dyn.cpp pack.cpp
-HIP_SRCS := sketch_probe.hip sketch_wave.hip sketch_filter.hip candidates.hip read_cluster.hip read_cluster_wave.hip cluster.hip anchor_scan.hip packed.hip
+HIP_SRCS := sketch_probe.hip sketch_wave.hip sketch_filter.hip candidates.hip read_verify.hip read_cluster.hip read_cluster_wave.hip cluster.hip anchor_scan.hip packed.hip
 OBJS := $(addprefix $(OBJD)/,$(HOST_SRCS:.cpp=.o)) $(addprefix $(OBJD)/,$(HIP_SRCS:.hip=.o))
 LIB  := drprg_amd/lib/libdrprg_hip.so
 BIN  := drprg_amd/bin/pandora

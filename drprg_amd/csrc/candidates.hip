@@ -3,6 +3,8 @@
 // window-minimizer test per candidate (verify_count_kernel) -> batch totals; and, for the reads that
 // read_cluster_kernel leaves over, the hit list for the generic cluster pipeline (recount / expand / per-read reorder).
 #include "filter_common.h"
+#include "verify_lane.h"
+#include <algorithm>
 #include <cstdlib>
 #include <string>
 #include <cstdint>
@@ -45,283 +47,18 @@ __global__ __launch_bounds__(SCAN_THREADS) void cand_scan_kernel(FilterWork fw)
 }
 
 // ---------------------------------------------------------------------------------------------
-// verification
+// verification (the per-candidate device functions: verify_lane.h)
 // ---------------------------------------------------------------------------------------------
-// 16 ASCII bases -> packed codes (A0 C1 G2 T3, first base highest) + 16-bit "not ACGT" mask (bit i = base i)
-__device__ inline void pack16n(const uint4& in, uint32_t& packed, uint32_t& nmask)
-{
-    const uint32_t e0 = encode4(in.x), e1 = encode4(in.y), e2 = encode4(in.z), e3 = encode4(in.w);
-    // v_dot4_u32_u8 with the byte weights 64, 16, 4, 1: the four codes of a dword in one byte, first base highest (full rate;
-    // the 32 x 32 multiply that gathers them is quarter rate)
-    constexpr uint32_t W = 0x01041040u;
-    packed = (__builtin_amdgcn_udot4(e0 & 0x03030303u, W, 0u, false) << 24) | (__builtin_amdgcn_udot4(e1 & 0x03030303u, W, 0u, false) << 16)
-        | (__builtin_amdgcn_udot4(e2 & 0x03030303u, W, 0u, false) << 8) | __builtin_amdgcn_udot4(e3 & 0x03030303u, W, 0u, false);
-    nmask = 0;
-    if ((e0 | e1 | e2 | e3) & 0x04040404u) { // rare; (flags * 0x01020408) >> 24 gathers the flag of byte i into bit i
-        auto m4 = [](uint32_t e) { return ((((e >> 2) & 0x01010101u) * 0x01020408u) >> 24) & 0xFu; };
-        nmask = m4(e0) | (m4(e1) << 4) | (m4(e2) << 8) | (m4(e3) << 12);
-    }
-}
-
-// reverse complement of a k-mer code (2 bits per base, k <= 16)
-__device__ inline uint32_t revcomp_code(uint32_t f, int k)
-{
-    uint32_t x = __brev(f);                                    // bit reversal also swaps the two bits of every base
-    x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);   // swap them back
-    return (~x) >> (32 - 2 * k);                               // complement, right-align
-}
-
-// 16 bases at global position g (a multiple of 16); bytes past the end of the buffer read as 'N'
-__device__ inline uint4 load16_guarded(const uint8_t* __restrict__ bases, int64_t n_bases, int64_t g)
-{
-    if (g + 16 <= n_bases) return *reinterpret_cast<const uint4*>(bases + g);
-    uint32_t t4[4];
-    for (int q = 0; q < 4; ++q) {
-        uint32_t wd = 0;
-        for (int b = 0; b < 4; ++b) {
-            const int64_t gg = g + q * 4 + b;
-            wd |= (uint32_t)(gg < n_bases ? bases[gg] : (uint8_t)'N') << (8 * b);
-        }
-        t4[q] = wd;
-    }
-    return make_uint4(t4[0], t4[1], t4[2], t4[3]);
-}
-
-// 16 bases of a packed batch (SketchArgs::packed: letters A0 C1 T2 G3, first base in the lowest bits) -> the form pack16n makes of 16
-// ASCII bases: A0 C1 G2 T3, first base highest.  letter ^ (letter >> 1) swaps T and G; v_bfrev reverses the order of the sixteen
-// 2-bit fields and the two bits of each, which are then swapped back.
-__device__ __forceinline__ uint32_t packed_to_hash_order(uint32_t x)
-{
-    const uint32_t y = x ^ ((x >> 1) & 0x55555555u);
-    const uint32_t r = __brev(y);
-    return ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);
-}
-
-// bit i: base a0 + i of a packed batch is not one of ACGTacgt (npos: ascending positions; most batches have none)
-__device__ inline uint64_t packed_bad_bases(const uint64_t* __restrict__ npos, uint64_t n_npos, int64_t a0)
-{
-    uint64_t lo = 0, hi = n_npos;
-    while (lo < hi) { // first position >= a0
-        const uint64_t mid = (lo + hi) >> 1;
-        if ((int64_t)npos[mid] < a0) lo = mid + 1; else hi = mid;
-    }
-    uint64_t bad = 0;
-    for (; lo < n_npos && (int64_t)npos[lo] < a0 + 64; ++lo) bad |= 1ull << ((int64_t)npos[lo] - a0);
-    return bad;
-}
-
-// slices -> one dense, ordered candidate list (cand_info[t] holds the position until verify_count_kernel replaces it)
+// slices -> one dense, ordered list of candidate positions (cand_gp; the verification kernel writes cand_info / cand_pos1 / cand_rec
+// at the same indices.  Until round 5 the positions went to cand_info and were replaced there: read_verify_kernel's workgroups read
+// positions their neighbours own, so the list has to stay as it is)
 __global__ __launch_bounds__(64) void cand_gather_kernel(FilterWork fw)
 {
     const uint32_t s = blockIdx.x;
     const uint32_t n = fw.cand_prefix[s + 1] - fw.cand_prefix[s];
     const uint64_t* __restrict__ src = fw.raw_pos + (size_t)s * fw.raw_slice;
-    uint64_t* __restrict__ dst = fw.cand_info + fw.cand_prefix[s];
+    uint64_t* __restrict__ dst = fw.cand_gp + fw.cand_prefix[s];
     for (uint32_t i = threadIdx.x; i < n; i += 64) dst[i] = src[i];
-}
-
-// One lane per candidate, start to finish: the 64 bases around it are packed into registers once (2 bits per base,
-// first base highest), the candidate's canonical hash goes to the exact table lookup (Bloom false positives end there),
-// then the 2w-1 neighbouring k-mers are hashed one after the other out of a 96-bit shift register -- a third of the
-// instructions of giving every neighbour its own lane, each of which had to load and pack its own bases.  It is a read
-// minimizer iff the run of neighbours with hash >= its own (inside the read, no N) reaches w-1 across both sides.
-// KC: compile-time k (15: the mask-free 12-instruction hash mix_k) or 0 (any k <= 15)
-template <int KC> __device__ __forceinline__ uint32_t verify_mix(uint32_t x, uint32_t kmask)
-{
-    if constexpr (KC > 0) return mix_k<KC>(x);
-    else return HashTraits<uint32_t>::mix(x, kmask);
-}
-
-// what the kernels below derive once from their arguments
-struct VerifyConsts {
-    const uint32_t* __restrict__ slot_key;
-    uint32_t tmask, kmask, w1_magic;
-    int k, w, sh_k;
-    int64_t n_bases, win_lo, win_hi;
-    double reads_per_base;
-    __device__ VerifyConsts(const SketchArgs& a, const FilterWork& fw)
-        : slot_key(reinterpret_cast<const uint32_t*>(a.slot_key)), tmask((1u << a.table_bits) - 1), kmask((1u << (2 * a.k)) - 1), w1_magic(w1_reciprocal(a.w)),
-          k(a.k), w(a.w), sh_k(32 - 2 * a.k), n_bases((int64_t)a.n_bases), win_lo((int64_t)a.offsets[fw.read_begin]), win_hi((int64_t)a.offsets[fw.read_end]),
-          reads_per_base((double)a.n_reads / (double)(a.n_bases ? a.n_bases : 1))
-    {
-    }
-};
-// everything one candidate leaves behind
-struct VerifyOut {
-    uint32_t pos1 = 0, slot = 0, read = READ_NONE, strand = 0;
-    uint4 crec = make_uint4(0, 0, 0, 0);
-};
-
-// the record of a candidate that is a minimizer of its read: what read_cluster_kernel needs of it (and the lane's totals)
-__device__ __forceinline__ void verify_emit(const SketchArgs& a, const ReadClusterArgs& rc, const VerifyConsts& c, int64_t gp, int64_t r0, int64_t r1, uint32_t strand,
-    const uint4& sf, VerifyOut& o, uint32_t& my_hits, uint32_t& my_nmin, uint32_t& my_maxlen)
-{
-    const uint64_t pos = (uint64_t)(gp - r0);
-    if (pos >= (1ull << HIT_POS_BITS)) {
-        atomicOr(a.overflow, 2u);
-        return;
-    }
-    o.pos1 = (uint32_t)pos + 1;
-    my_hits += sf.y;
-    my_nmin += 1;
-    const uint32_t len = (uint32_t)((r1 - r0) > 0xFFFFFFFFll ? 0xFFFFFFFFll : (r1 - r0));
-    my_maxlen = len > my_maxlen ? len : my_maxlen;
-    // for read_cluster_kernel: the first hit of this minimizer and the size threshold of a cluster of this read on that hit's PRG
-    // (cluster_eval_kernel)
-    const uint32_t kn = sf.z, prg = sf.w & 0xFFFu;
-    const uint32_t rev = ((kn & 1u) == strand) ? 0u : 1u;
-    const uint64_t expected = expected_minimizers((uint64_t)(r1 - r0), c.w, c.w1_magic);
-    uint64_t m = sf.w >> 12;
-    if (expected < m) m = expected;
-    const uint32_t length_based = (uint32_t)((double)m * rc.fraction);
-    uint32_t thr = length_based > rc.min_cluster_size ? length_based : rc.min_cluster_size;
-    if (thr > 0xFFFFu) thr = 0xFFFFu; // read_cluster_kernel stages at most RC_HCAP hits: no difference
-    o.crec = make_uint4(sf.x, sf.y, (strand << 31) | (((prg << 1) | rev) << 16) | thr, (kn >> 1) * 2u + rev);
-}
-
-// One candidate, start to finish, by one lane (the whole algorithm described above verify_count_kernel)
-template <int KC, bool PACKED>
-__device__ __forceinline__ void verify_one_lane(const SketchArgs& a, const FilterWork& fw, const ReadClusterArgs& rc, const VerifyConsts& c, int64_t gp, VerifyOut& o,
-    uint32_t& my_hits, uint32_t& my_nmin, uint32_t& my_maxlen)
-{
-    using Tr = HashTraits<uint32_t>;
-    const uint32_t* __restrict__ slot_key = c.slot_key;
-    const uint32_t tmask = c.tmask, kmask = c.kmask;
-    const int k = c.k, w = c.w, sh_k = c.sh_k;
-    const int64_t n_bases = c.n_bases, win_lo = c.win_lo, win_hi = c.win_hi;
-    const double reads_per_base = c.reads_per_base;
-    uint32_t &pos1 = o.pos1, &slot = o.slot, &read = o.read, &strand = o.strand;
-    (void)pos1;
-    if (gp >= win_lo && gp < win_hi && gp + k <= n_bases) { // (the boundary tiles of a read range reach past it)
-        // Everything the candidate needs from memory that does not depend on other loads is requested before anything is
-        // waited for: the two read offsets around the interpolated read index and the four 16-byte words of the 64 bases
-        // [a0, a0+64) that hold the candidate and all its neighbours (w <= 16, k <= 15).  (One guarded load after the other,
-        // each behind its own branch, was four round trips in a row, and the read lookup two more.)
-        uint32_t guess = (uint32_t)((double)gp * reads_per_base);
-        if (guess >= a.n_reads) guess = a.n_reads - 1;
-        const uint64_t o0 = a.offsets[guess], o1 = a.offsets[guess + 1];
-        const int64_t a0 = (gp > 15 ? gp - 15 : 0) & ~(int64_t)15;
-        uint4 b0, b1, b2, b3;
-        uint32_t x0 = 0, x1 = 0, x2 = 0, x3 = 0; // packed input: the four words of [a0, a0 + 64)
-        (void)b0; (void)b1; (void)b2; (void)b3; (void)x0; (void)x1; (void)x2; (void)x3;
-        if constexpr (PACKED) {
-            const uint32_t* __restrict__ wp = reinterpret_cast<const uint32_t*>(a.bases) + (a0 >> 4);
-            const int64_t left = ((n_bases + 15) >> 4) - (a0 >> 4); // words from a0 on: >= 1 (gp + k <= n_bases)
-            x0 = wp[0];
-            if (left >= 4) {
-                x1 = wp[1];
-                x2 = wp[2];
-                x3 = wp[3];
-            } else {
-                if (left > 1) x1 = wp[1];
-                if (left > 2) x2 = wp[2];
-            }
-        } else if (a0 + 64 <= n_bases) {
-            const uint4* __restrict__ bp = reinterpret_cast<const uint4*>(a.bases + a0);
-            b0 = bp[0];
-            b1 = bp[1];
-            b2 = bp[2];
-            b3 = bp[3];
-        } else { // the last bytes of the buffer
-            b0 = load16_guarded(a.bases, n_bases, a0);
-            b1 = load16_guarded(a.bases, n_bases, a0 + 16);
-            b2 = load16_guarded(a.bases, n_bases, a0 + 32);
-            b3 = load16_guarded(a.bases, n_bases, a0 + 48);
-        }
-        // the read of every candidate, index k-mer or not: read_cluster_kernel finds the first candidate of a read by
-        // comparing neighbours (the interpolated index is exact for fixed-length reads; a short gallop otherwise)
-        int64_t r0 = (int64_t)o0, r1 = (int64_t)o1;
-        if (o0 <= (uint64_t)gp && (uint64_t)gp < o1) read = guess;
-        else {
-            read = find_read_near(a.offsets, a.n_reads, guess, (uint64_t)gp);
-            r0 = (int64_t)a.offsets[read];
-            r1 = (int64_t)a.offsets[read + 1];
-        }
-        uint32_t r0w, r1w, r2w, r3w;
-        uint64_t bad; // bit i: base a0+i is not ACGT (or lies behind the last base of the batch)
-        if constexpr (PACKED) {
-            r0w = packed_to_hash_order(x0);
-            r1w = packed_to_hash_order(x1);
-            r2w = packed_to_hash_order(x2);
-            r3w = packed_to_hash_order(x3);
-            bad = a.n_npos ? packed_bad_bases(a.npos, a.n_npos, a0) : 0ull;
-            if (a0 + 64 > n_bases) bad |= ~0ull << (n_bases - a0);
-        } else {
-            uint32_t n0, n1, n2, n3;
-            pack16n(b0, r0w, n0);
-            pack16n(b1, r1w, n1);
-            pack16n(b2, r2w, n2);
-            pack16n(b3, r3w, n3);
-            bad = (uint64_t)(n0 | (n1 << 16)) | ((uint64_t)(n2 | (n3 << 16)) << 32);
-        }
-        if (bad) { // -> bit i: the k-mer starting at a0+i holds such a base
-            uint64_t m = bad;
-            for (int i = 1; i < k; ++i) m |= bad >> i;
-            bad = m;
-        }
-        // ---- the candidate's own canonical hash, exact lookup ----
-        const int oc = (int)(gp - a0); // 0..30
-        uint32_t g = 0;
-        if (!((bad >> oc) & 1u)) {
-            const uint32_t h0 = (oc & 16) ? r1w : r0w, h1 = (oc & 16) ? r2w : r1w;
-            const uint32_t f = __funnelshift_l(h1, h0, 2 * (oc & 15)) >> sh_k;
-            const uint32_t hf = verify_mix<KC>(f, kmask), hr = verify_mix<KC>(revcomp_code(f, k), kmask);
-            strand = hf <= hr ? 1u : 0u;
-            g = (hf < hr ? hf : hr) + 1;
-        }
-        bool found = false;
-        if (g && !(fw.debug & 32u)) { // (DRPRG_FT_DEBUG=32: timing only, no table probe and nothing after it)
-            const uint32_t h = g - 1;
-            uint32_t sl = table_slot_dev(h, a.table_bits);
-            while (true) {
-                const uint32_t key = slot_key[sl];
-                if (key == h) { found = true; break; }
-                if (key == Tr::EMPTY) break;
-                sl = (sl + 1) & tmask;
-            }
-            slot = sl;
-        }
-        if (found) {
-            if (gp + k <= r1) { // the k-mer lies inside one read
-                // (requested before the window scan that decides whether it is needed: the scan hides the round trip)
-                const uint4 sf = a.slot_first[slot]; // record offset, count, first record's node, its prg and that prg's shortest path
-                // ---- scan q = q_first .. q_first + 2w-2; steps outside [gp-(w-1), gp+(w-1)] or the read are invalid ----
-                const int64_t q_lo = gp - (w - 1);
-                const int64_t q_first = q_lo > a0 ? q_lo : a0; // a0 <= max(q_lo, 0)
-                const int of = (int)(q_first - a0);            // 0..30
-                const int64_t v_lo = r0 > q_first ? r0 : q_first;
-                const int64_t v_hi = (r1 - k) < (gp + w - 1) ? (r1 - k) : (gp + w - 1);
-                const int i_lo = (int)(v_lo - q_first), i_hi = (int)(v_hi - q_first), ic = (int)(gp - q_first);
-                // align the shift register on q_first: 48 bases in three words cover 2w-1 + k-1 <= 45
-                if (of & 16) { r0w = r1w; r1w = r2w; r2w = r3w; r3w = 0; }
-                const int s2 = 2 * (of & 15);
-                r0w = __funnelshift_l(r1w, r0w, s2);
-                r1w = __funnelshift_l(r2w, r1w, s2);
-                r2w = __funnelshift_l(r3w, r2w, s2);
-                // steps that can count at all: inside the read and the window, no N in the k-mer (bit i = step i)
-                const uint32_t valid = ((2u << i_hi) - 1u) & ~((1u << i_lo) - 1u) & ~(uint32_t)(bad >> of);
-                uint32_t streak = 0, right = 0, alive = 1;
-                uint32_t rcw = revcomp_code(r0w >> sh_k, k) << 2; // the reverse complement rolls along: one base in, one out
-                const int n_steps = (fw.debug & 16u) ? 0 : 2 * w - 1; // (DRPRG_FT_DEBUG=16: measurement only, no window test)
-                for (int i = 0; i < n_steps; ++i) {
-                    const uint32_t f = r0w >> sh_k;
-                    rcw = (rcw >> 2) | ((~f & 3u) << (2 * k - 2));
-                    r0w = __funnelshift_l(r1w, r0w, 2);
-                    r1w = __funnelshift_l(r2w, r1w, 2);
-                    r2w <<= 2;
-                    const uint32_t hf = verify_mix<KC>(f, kmask), hr = verify_mix<KC>(rcw, kmask);
-                    const uint32_t x = (hf < hr ? hf : hr) + 1;
-                    const bool ok = ((valid >> i) & 1u) && x >= g;
-                    if (i < ic) streak = ok ? streak + 1 : 0;
-                    else if (i > ic) {
-                        alive = ok ? alive : 0u;
-                        right += alive;
-                    }
-                }
-                if ((int)(streak + right) >= w - 1) verify_emit(a, rc, c, gp, r0, r1, strand, sf, o, my_hits, my_nmin, my_maxlen);
-            }
-        }
-    }
 }
 
 template <int KC, bool PACKED>
@@ -334,10 +71,10 @@ __global__ __launch_bounds__(EX_THREADS) void verify_count_kernel(SketchArgs a, 
     const VerifyConsts c(a, fw);
     uint32_t my_hits = 0, my_nmin = 0, my_maxlen = 0;
     // (the position of this thread's next candidate is requested one round early: one round trip less in the chain of each)
-    int64_t gp_next = t_begin + tid < t_end ? (int64_t)fw.cand_info[t_begin + tid] : 0;
+    int64_t gp_next = t_begin + tid < t_end ? (int64_t)fw.cand_gp[t_begin + tid] : 0;
     for (uint32_t t = t_begin + tid; t < t_end; t += EX_THREADS) {
-        const int64_t gp = gp_next; // position now, (slot, strand, read) when this lane is done
-        if (t + EX_THREADS < t_end) gp_next = (int64_t)fw.cand_info[t + EX_THREADS];
+        const int64_t gp = gp_next;
+        if (t + EX_THREADS < t_end) gp_next = (int64_t)fw.cand_gp[t + EX_THREADS];
         VerifyOut o;
         verify_one_lane<KC, PACKED>(a, fw, rc, c, gp, o, my_hits, my_nmin, my_maxlen);
         fw.cand_pos1[t] = o.pos1;
@@ -379,7 +116,8 @@ __global__ __launch_bounds__(EX_THREADS) void verify_count_kernel(SketchArgs a, 
 // on the 8-fold one.  Not kept.)
 
 // one workgroup: wg_base = exclusive scan of wg_hits; batch totals
-__global__ __launch_bounds__(SCAN_THREADS) void hit_scan_kernel(SketchArgs a, FilterWork fw, int recount)
+// n_wg: the workgroups whose totals wg_hits / wg_nmin / wg_maxlen hold (the verification kernel's grid, or recount_kernel's)
+__global__ __launch_bounds__(SCAN_THREADS) void hit_scan_kernel(SketchArgs a, FilterWork fw, int recount, uint32_t n_wg)
 {
     __shared__ uint32_t s_w[SCAN_THREADS / 64 + 1];
     __shared__ uint32_t s_n[SCAN_THREADS / 64], s_m[SCAN_THREADS / 64];
@@ -388,7 +126,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void hit_scan_kernel(SketchArgs a, Fi
     uint32_t v[PER], h[PER], nm[PER], ml[PER], run = 0, nmin = 0, mx = 0;
 #pragma unroll
     for (int i = 0; i < PER; ++i) { // (all twelve loads together, as in cand_scan_kernel)
-        const uint32_t g = (uint32_t)tid * PER + i, gc = g < fw.ex_grid ? g : 0u;
+        const uint32_t g = (uint32_t)tid * PER + i, gc = g < n_wg ? g : 0u;
         h[i] = fw.wg_hits[gc];
         nm[i] = fw.wg_nmin[gc];
         ml[i] = fw.wg_maxlen[gc];
@@ -397,7 +135,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void hit_scan_kernel(SketchArgs a, Fi
     for (int i = 0; i < PER; ++i) {
         const uint32_t g = (uint32_t)tid * PER + i;
         v[i] = run;
-        if (g < fw.ex_grid) {
+        if (g < n_wg) {
             run += h[i];
             nmin += nm[i];
             mx = ml[i] > mx ? ml[i] : mx;
@@ -408,7 +146,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void hit_scan_kernel(SketchArgs a, Fi
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const uint32_t g = (uint32_t)tid * PER + i;
-        if (g < fw.ex_grid) fw.wg_base[g] = before + v[i];
+        if (g < n_wg) fw.wg_base[g] = before + v[i];
     }
     const uint32_t wn = wave_inclusive_scan(nmin), wm = wave_max(mx);
     if ((tid & 63) == 63) {
@@ -662,16 +400,22 @@ __global__ __launch_bounds__(TG_THREADS) void tile_gather_kernel(SketchArgs a, F
 // verify_count 116 -> 231 us (12 k atomics on one 64-byte line take their turn in the L2), step 0.59 -> 0.72 ms.  Round 4: the totals of
 // hit_scan_kernel are summed by workgroup 0 of read_cluster_kernel when that kernel follows (with_totals = false); scan + gather in one
 // launch -- a workgroup summing what lies before its 64 slices -- took 19.4 us against 9.1 + 11.8: cand_scan_kernel stays.)
-hipError_t launch_candidate_stage(const SketchArgs& a, const FilterWork& fw, const ReadClusterArgs& rc, hipStream_t stream, bool with_totals)
+hipError_t launch_candidate_stage(const SketchArgs& a, FilterWork& fw, const ReadClusterArgs& rc, int n_cus, hipStream_t stream, bool with_totals)
 {
     hipLaunchKernelGGL(cand_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, fw);
     hipLaunchKernelGGL(cand_gather_kernel, dim3(fw.n_slices), dim3(64), 0, stream, fw);
-    if (a.packed) {
+    // Short-read batches at k = 15, w in {11, 14} are verified read by read (read_verify.hip, round 5); everything else -- long reads, other
+    // (w, k), DRPRG_VERIFY_FORM=lane -- one lane per candidate
+    fw.verify_grid = fw.ex_grid;
+    if (read_verify_applies(a, fw)) {
+        fw.verify_grid = std::min<uint32_t>(read_verify_grid(n_cus), MAX_EX_WG);
+        HIP_TRY(launch_read_verify(a, fw, rc, fw.verify_grid, stream));
+    } else if (a.packed) {
         if (a.k == 15) hipLaunchKernelGGL((verify_count_kernel<15, true>), dim3(fw.ex_grid), dim3(EX_THREADS), 0, stream, a, fw, rc);
         else hipLaunchKernelGGL((verify_count_kernel<0, true>), dim3(fw.ex_grid), dim3(EX_THREADS), 0, stream, a, fw, rc);
     } else if (a.k == 15) hipLaunchKernelGGL((verify_count_kernel<15, false>), dim3(fw.ex_grid), dim3(EX_THREADS), 0, stream, a, fw, rc);
     else hipLaunchKernelGGL((verify_count_kernel<0, false>), dim3(fw.ex_grid), dim3(EX_THREADS), 0, stream, a, fw, rc);
-    if (with_totals) hipLaunchKernelGGL(hit_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, a, fw, 0); // (else: read_cluster_kernel's workgroup 0)
+    if (with_totals) hipLaunchKernelGGL(hit_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, a, fw, 0, fw.verify_grid); // (else: read_cluster_kernel's workgroup 0)
     return hipGetLastError();
 }
 
@@ -740,7 +484,7 @@ hipError_t launch_filter_recount(const SketchArgs& a, const FilterWork& fw, hipS
 {
     hipLaunchKernelGGL(recount_kernel, dim3(fw.ex_grid), dim3(EX_THREADS), 0, stream, a, fw);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(hit_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, a, fw, 1);
+    hipLaunchKernelGGL(hit_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, a, fw, 1, fw.ex_grid);
     return hipGetLastError();
 }
 

@@ -33,7 +33,13 @@ __device__ inline void candidate_range(const FilterWork& fw, uint32_t wg, uint32
 
 // stages of the filtered sequence that live in the other translation units (all asynchronous on `stream`)
 // candidates.hip: slices -> dense ordered candidate list -> verified candidates + per-candidate records + batch totals
-hipError_t launch_candidate_stage(const SketchArgs& a, const FilterWork& fw, const ReadClusterArgs& rc, hipStream_t stream, bool with_totals = true);
+// (fw.verify_grid receives the number of workgroups whose totals the stage left in fw.wg_hits / wg_nmin / wg_maxlen)
+hipError_t launch_candidate_stage(const SketchArgs& a, FilterWork& fw, const ReadClusterArgs& rc, int n_cus, hipStream_t stream, bool with_totals = true);
+// read_verify.hip: the verification of a short-read batch read by read (k = 15, w in {11, 14}): every read that holds several candidates is
+// sketched ONCE by a wave (sketch_block.h) instead of once per candidate; same outputs as verify_count_kernel
+bool read_verify_applies(const SketchArgs& a, const FilterWork& fw);
+uint32_t read_verify_grid(int n_cus);
+hipError_t launch_read_verify(const SketchArgs& a, const FilterWork& fw, const ReadClusterArgs& rc, uint32_t grid, hipStream_t stream);
 // read_cluster.hip: per-read clustering straight from the candidate list (skip: mark the batch as left over instead)
 hipError_t launch_read_cluster(const SketchArgs& a, const FilterWork& fw, const ReadClusterArgs& rc, int n_cus, bool skip, hipStream_t stream);
 // read_cluster_wave.hip: the same for the reads that fit a wave's 128 staged candidates (one wave per 64 candidates, no workgroup barrier)

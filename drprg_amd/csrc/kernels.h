@@ -162,6 +162,7 @@ struct BloomTables {
 struct FilterBuffers {
     uint64_t* raw_pos;
     uint4* raw_grp; // raw_capacity entries: level-0 survivors (groups of four positions) on their way to refine_kernel
+    uint64_t* cand_gp; // raw_capacity entries: the dense, ordered list of candidate positions (cand_gather_kernel)
     uint64_t* cand_info;
     uint32_t* cand_pos1;
     uint4* cand_rec; // raw_capacity entries
@@ -193,11 +194,15 @@ struct FilterWork {
     uint32_t* grp_count;     // [n_slices] (may exceed raw_slice: overflow)
     uint32_t* cand_prefix;   // [n_slices + 1]: exclusive scan of the clamped counts
     const uint32_t* cand_total; // the number of candidates (filtered sequence: &cand_prefix[n_slices])
+    uint64_t* cand_gp;       // [candidates]: global base position of the candidate k-mer, ascending (the slices gathered; nothing writes
+                             // it after cand_gather_kernel: read_verify_kernel's workgroups read their neighbours' entries)
     uint64_t* cand_info;     // [candidates]: slot << 32 | strand << 31 | read
     uint32_t* cand_pos1;     // [candidates]: read position + 1 of a minimizer, 0 = not a minimizer
     uint4* cand_rec;         // [candidates]: what read_cluster_kernel needs of a minimizer: first index record, number of
                              // records, group << 16 | size threshold, coverage index of the first record (0,0,.. = not a minimizer)
     uint32_t ex_grid;        // workgroups of verify_count_kernel / expand_kernel
+    uint32_t verify_grid;    // workgroups of the verification kernel of this batch (verify_count_kernel: ex_grid; read_verify_kernel: its
+                             // persistent grid): as many words of wg_hits / wg_nmin / wg_maxlen hold its totals
     uint32_t *wg_hits, *wg_nmin, *wg_maxlen, *wg_base; // [ex_grid]
     unsigned long long* max_len; // longest read that holds a minimizer hit (this batch)
     uint32_t debug;          // ablation switches for profiling (DRPRG_FT_DEBUG): 1 = skip the Bloom test, 8 = every read through the

@@ -327,7 +327,7 @@ void Mapper::ensure_workspace(uint64_t cap)
 
 void Mapper::free_lane(Lane& lane)
 {
-    dfree(lane.raw_pos); dfree(lane.raw_grp); dfree(lane.cand_info); dfree(lane.cand_pos1); dfree(lane.cand_rec); dfree(lane.small); dfree(lane.rc_flags); dfree(lane.rc_partials);
+    dfree(lane.raw_pos); dfree(lane.raw_grp); dfree(lane.cand_gp); dfree(lane.cand_info); dfree(lane.cand_pos1); dfree(lane.cand_rec); dfree(lane.small); dfree(lane.rc_flags); dfree(lane.rc_partials);
     dfree(lane.d_scratch);
     if (lane.h_scratch) (void)hipHostFree(lane.h_scratch);
     lane.h_scratch = nullptr;
@@ -341,10 +341,10 @@ void Mapper::grow_lane(Lane& lane, uint64_t cap)
 {
     if (cap <= lane.raw_capacity) return;
     if (cap >= (1ull << 31)) throw Error(DRPRG_EOVERFLOW, "more than 2^31 candidate k-mers in one read range; map smaller batches");
-    dfree(lane.raw_pos); dfree(lane.raw_grp); dfree(lane.cand_info); dfree(lane.cand_pos1); dfree(lane.cand_rec); dfree(lane.rc_flags);
+    dfree(lane.raw_pos); dfree(lane.raw_grp); dfree(lane.cand_gp); dfree(lane.cand_info); dfree(lane.cand_pos1); dfree(lane.cand_rec); dfree(lane.rc_flags);
     lane.raw_capacity = cap;
     if (bloom0_wbits_) dmalloc(lane.raw_grp, cap);
-    dmalloc(lane.raw_pos, cap); dmalloc(lane.cand_info, cap); dmalloc(lane.cand_pos1, cap); dmalloc(lane.cand_rec, cap);
+    dmalloc(lane.raw_pos, cap); dmalloc(lane.cand_gp, cap); dmalloc(lane.cand_info, cap); dmalloc(lane.cand_pos1, cap); dmalloc(lane.cand_rec, cap);
     dmalloc(lane.rc_flags, (size_t)(cap / dev::RC_CHUNK_OWN + 3));
     if (!lane.rc_partials) dmalloc(lane.rc_partials, (size_t)dev::RC_WAVE_MAX_WG * ((size_t)n_prgs_ + 4));
     // the slices form of the direct sequence uses cand_pos1 as an array of "handled" marks (mark = a batch's epoch): fresh device
@@ -383,7 +383,7 @@ void Mapper::launch_lane(Lane& lane, hipStream_t stream, const uint8_t* d_bases,
     a.n_hits = &lane.d_scratch[L_HITS];
     a.n_minimizers = &lane.d_scratch[L_MINIMIZERS];
     a.overflow = reinterpret_cast<uint32_t*>(&lane.d_scratch[L_OVERFLOW]);
-    dev::FilterBuffers fb { lane.raw_pos, lane.raw_grp, lane.cand_info, lane.cand_pos1, lane.cand_rec, lane.raw_capacity, lane.small,
+    dev::FilterBuffers fb { lane.raw_pos, lane.raw_grp, lane.cand_gp, lane.cand_info, lane.cand_pos1, lane.cand_rec, lane.raw_capacity, lane.small,
         &lane.d_scratch[L_MAXLEN] };
     fb.stat = d_ft_stat_;
     dev::BloomTables bt { d_bloom_, bloom_wbits_, d_bloom0_, bloom0_wbits_, d_bloomr_, d_bloom0f_ };
@@ -676,7 +676,7 @@ void Mapper::direct_launch(int set, const uint8_t* d_bases, const uint64_t* d_of
     a.dbg = std::getenv("DRPRG_WAVE_DEBUG") ? &d_counters_[C_CHUNK] : nullptr; // (words C_CHUNK.. are unused by this sequence)
     a.fraction = params_.cluster_fraction();
     a.min_cluster_size = params_.min_cluster_size;
-    dev::FilterBuffers fb { lane.raw_pos, lane.raw_grp, lane.cand_info, lane.cand_pos1, lane.cand_rec, lane.raw_capacity, lane.small,
+    dev::FilterBuffers fb { lane.raw_pos, lane.raw_grp, lane.cand_gp, lane.cand_info, lane.cand_pos1, lane.cand_rec, lane.raw_capacity, lane.small,
         &lane.d_scratch[L_MAXLEN] };
     dev::ReadClusterArgs rc {};
     rc.prg_min_path_len = d_min_path_len_;

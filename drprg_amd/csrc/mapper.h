@@ -138,7 +138,7 @@ private:
         hipStream_t stream = nullptr; // lanes >= 1 (lane 0 uses the stream of the call)
         hipEvent_t done = nullptr, t0 = nullptr, t1 = nullptr;
         uint64_t raw_capacity = 0;
-        uint64_t *raw_pos = nullptr, *cand_info = nullptr;
+        uint64_t *raw_pos = nullptr, *cand_gp = nullptr, *cand_info = nullptr;
         uint4 *raw_grp = nullptr, *cand_rec = nullptr;
         uint32_t *cand_pos1 = nullptr, *small = nullptr;
         uint32_t* rc_partials = nullptr; // RC_WAVE_MAX_WG x (n_prgs + 4) words: per-workgroup sums of read_cluster_wave_kernel

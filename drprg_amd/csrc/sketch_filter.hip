@@ -608,6 +608,7 @@ size_t filter_small_words() { return (size_t)MAX_SLICES * 3 + 1 + 4 * (size_t)MA
 
 void init_candidate_work(FilterWork& fw, const FilterBuffers& b, int n_cus)
 {
+    fw.cand_gp = b.cand_gp;
     fw.cand_info = b.cand_info;
     fw.cand_pos1 = b.cand_pos1;
     fw.cand_rec = b.cand_rec;
@@ -616,6 +617,7 @@ void init_candidate_work(FilterWork& fw, const FilterBuffers& b, int n_cus)
     fw.wg_maxlen = fw.wg_nmin + MAX_EX_WG;
     fw.wg_base = fw.wg_maxlen + MAX_EX_WG;
     fw.ex_grid = std::min<uint32_t>((uint32_t)n_cus * 8, MAX_EX_WG);
+    fw.verify_grid = fw.ex_grid;
     fw.max_len = b.max_len;
 }
 
@@ -693,13 +695,13 @@ hipError_t launch_sketch_filter(const SketchArgs& a, uint32_t read_begin, uint32
         HIP_TRY(hipGetLastError());
     }
     const bool skip_rc = (fw.debug & 8u) != 0; // debug 8: every read with a hit goes the generic way
-    HIP_TRY(launch_candidate_stage(a, fw, rc, stream, skip_rc));
+    HIP_TRY(launch_candidate_stage(a, fw, rc, n_cus, stream, skip_rc));
     ReadClusterArgs rct = rc;
     if (!skip_rc) { // the batch totals come out of read_cluster_kernel's workgroup 0
         rct.wg_hits = fw.wg_hits;
         rct.wg_nmin = fw.wg_nmin;
         rct.wg_maxlen = fw.wg_maxlen;
-        rct.n_wg = fw.ex_grid;
+        rct.n_wg = fw.verify_grid;
         rct.tot_hits = a.n_hits;
         rct.tot_minimizers = a.n_minimizers;
         rct.tot_max_len = fw.max_len;

@@ -21,12 +21,12 @@
 //   * the minimizers of the tile are compacted per wave (prefix over lanes with wave scans) and thinned in passes with all
 //     lanes busy: Bloom tier -> exact table lookup -> reads that lie inside the tile are clustered on the spot and their
 //     coverage added (stage C1) -> a record for what is left; the four tiles of a workgroup share one slice.
-#include "device_common.h"
+#include "sketch_block.h"
 
 namespace drprg {
 namespace dev {
 
-constexpr int SW_G = 16;                    // k-mer positions (= bytes loaded) per lane
+constexpr int SW_G = SB_G;                  // k-mer positions (= bytes loaded) per lane (sketch_block.h)
 constexpr int SW_LOAD = 64 * SW_G;          // bases staged per wave tile
 constexpr int SW_FIRST = 1, SW_LAST = 61;   // lanes that evaluate their positions
 constexpr int SW_EVAL = (SW_LAST - SW_FIRST + 1) * SW_G; // 976 positions per tile
@@ -36,35 +36,6 @@ uint32_t wave_tile_eval() { return SW_EVAL; }
 uint32_t wave_n_tiles(uint64_t n_bases) { return (uint32_t)((n_bases + SW_EVAL - 1) / SW_EVAL); }
 bool wave_kernel_applies(int k, int w) { return k == 15 && (w == 11 || w == 14); }
 uint32_t wave_n_slices(uint64_t n_bases) { return (wave_n_tiles(n_bases) + SW_WAVES - 1) / SW_WAVES; } // one slice per workgroup
-
-__device__ __forceinline__ uint32_t from_next_lane(uint32_t v) // lane i <- lane i + 1 (lane 63 <- 0)
-{
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
-}
-__device__ __forceinline__ uint32_t from_prev_lane(uint32_t v) // lane i <- lane i - 1 (lane 0 <- 0)
-{
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
-}
-__device__ __forceinline__ uint32_t lanes_below(uint64_t m)
-{
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-}
-
-// four ASCII bases -> selector bytes (A0 C1 T2 G3 = bits 2:1 of the letter); *diff receives a non-zero byte for every base
-// that is not ACGT / acgt
-__device__ __forceinline__ uint32_t select4(uint32_t word, uint32_t& diff_acc)
-{
-    const uint32_t sel = (word >> 1) & 0x03030303u;
-    const uint32_t expect = __builtin_amdgcn_perm(0u, 0x47544341u, sel); // the upper-case letter each selector stands for
-    diff_acc |= (word & 0xDFDFDFDFu) ^ expect;
-    return sel;
-}
-// bit i set iff byte i of x is non-zero
-__device__ __forceinline__ uint32_t nonzero_bytes4(uint32_t x)
-{
-    const uint32_t t = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
-    return ((t >> 7) | (t >> 14) | (t >> 21) | (t >> 28)) & 0xFu;
-}
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 {
@@ -131,9 +102,7 @@ __device__ __forceinline__ void sketch_wave_tile(const SketchArgs& a, uint32_t t
         } else {
             bad16 = 0xFFFFu;
         }
-        const uint32_t r = __brev(wd);
-        le = wd;
-        be = ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);
+        sketch_pack_word(wd, le, be);
         diff = bad16;
     } else {
         if (g0 >= 0 && g0 + SW_G <= n_bases) {
@@ -150,15 +119,10 @@ __device__ __forceinline__ void sketch_wave_tile(const SketchArgs& a, uint32_t t
             }
             in = make_uint4(tmp[0], tmp[1], tmp[2], tmp[3]);
         }
-        const uint32_t s0 = select4(in.x, diff), s1 = select4(in.y, diff), s2 = select4(in.z, diff), s3 = select4(in.w, diff);
-        // v_dot4_u32_u8 packs four selectors into a byte: weights 1,4,16,64 (first base lowest) / 64,16,4,1 (first base highest)
-        le = __builtin_amdgcn_udot4(s0, 0x40100401u, 0u, false) | (__builtin_amdgcn_udot4(s1, 0x40100401u, 0u, false) << 8)
-            | (__builtin_amdgcn_udot4(s2, 0x40100401u, 0u, false) << 16) | (__builtin_amdgcn_udot4(s3, 0x40100401u, 0u, false) << 24);
-        be = (__builtin_amdgcn_udot4(s0, 0x01041040u, 0u, false) << 24) | (__builtin_amdgcn_udot4(s1, 0x01041040u, 0u, false) << 16)
-            | (__builtin_amdgcn_udot4(s2, 0x01041040u, 0u, false) << 8) | __builtin_amdgcn_udot4(s3, 0x01041040u, 0u, false);
+        sketch_pack_ascii(in, le, be, diff);
     }
-    le ^= (le >> 1) & 0x55555555u; // A0 C1 T2 G3 -> A0 C1 G2 T3 in every 2-bit field
-    be ^= (be >> 1) & 0x55555555u;
+    le = sketch_letters_to_hash_order(le); // A0 C1 T2 G3 -> A0 C1 G2 T3 in every 2-bit field
+    be = sketch_letters_to_hash_order(be);
     const uint32_t le_next = from_next_lane(le), be_next = from_next_lane(be);
 
     // ---- read boundaries: a k-mer must not straddle two reads (invalid k-mer starts), and where reads start (read lookup) ----
@@ -189,9 +153,7 @@ __device__ __forceinline__ void sketch_wave_tile(const SketchArgs& a, uint32_t t
         if constexpr (PACKED) {
             bad = bad16;
         } else {
-            uint32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0;
-            (void)select4(in.x, d0); (void)select4(in.y, d1); (void)select4(in.z, d2); (void)select4(in.w, d3);
-            bad = nonzero_bytes4(d0) | (nonzero_bytes4(d1) << 4) | (nonzero_bytes4(d2) << 8) | (nonzero_bytes4(d3) << 12);
+            bad = sketch_bad16(in);
         }
         const uint32_t win = bad | (from_next_lane(bad) << 16); // my 16 bases and the 16 after them
         for (int d = 0; d < K; ++d) inv |= win >> d;           // k-mer j holds bases j .. j + K - 1
@@ -209,78 +171,12 @@ __device__ __forceinline__ void sketch_wave_tile(const SketchArgs& a, uint32_t t
 
     // ---- canonical hash + 1 of my 16 k-mers (0 = invalid), strand bits ----
     uint32_t hv[SW_G];
-    uint32_t strandbits = 0;
-#pragma unroll
-    for (int j = 0; j < SW_G; ++j) {
-        // low-first stream: bits [2j, 2j + 2K) = the k-mer read backwards; its complement is the reverse-complement k-mer
-        const uint32_t e = __builtin_amdgcn_alignbit(le_next, le, 2 * j);
-        // high-first stream (be : be_next): the forward k-mer sits at bits [64 - 2j - 2K, 64 - 2j)
-        constexpr int TOP = 64 - 2 * K;
-        const int sh = TOP - 2 * j;
-        const uint32_t f = sh >= 32 ? be >> (sh - 32) : __builtin_amdgcn_alignbit(be, be_next, sh);
-        const uint32_t hf = mix_k<K>(f), hr = mix_k<K>(~e);
-        strandbits |= (uint32_t)(hf <= hr) << j;
-        const uint32_t h1 = (hf < hr ? hf : hr) + 1u;
-        hv[j] = h1 & (uint32_t)__builtin_amdgcn_sbfe((int)validbits, j, 1);
-    }
+    uint32_t strandbits;
+    sketch_hashes16<K>(le, be, le_next, be_next, validbits, hv, strandbits);
 
-    // ---- window minimizers: position j is one iff some window of W consecutive valid k-mers containing it has no smaller
-    //      value (an invalid k-mer is 0: a window holding one has minimum 0, which no valid value equals) ----
-    uint32_t minbits = 0;
-    {
-        constexpr int N = SW_G + 2 * (W - 1);
-        uint32_t g[N];
-#pragma unroll
-        for (int i = 0; i < W - 1; ++i) g[i] = from_prev_lane(hv[SW_G - (W - 1) + i]);
-#pragma unroll
-        for (int j = 0; j < SW_G; ++j) g[W - 1 + j] = hv[j];
-#pragma unroll
-        for (int i = 0; i < W - 1; ++i) g[W - 1 + SW_G + i] = from_next_lane(hv[i]);
-        constexpr int NW = SW_G + W - 1; // window starts that matter: 0 .. NW - 1
-        uint32_t wm[NW];                  // wm[i] = min g[i .. i + W - 1]
-        if constexpr (W == 11 || W == 14) {
-            // three-input minima: runs of 3, of 9, then the window (11 = 9 + a run of 3 that overlaps it, 14 = 9 + two runs of 3)
-            uint32_t m3[N - 2], m9[N - 8];
-#pragma unroll
-            for (int i = 0; i < N - 2; ++i) m3[i] = min(min(g[i], g[i + 1]), g[i + 2]);
-#pragma unroll
-            for (int i = 0; i < N - 8; ++i) m9[i] = min(min(m3[i], m3[i + 3]), m3[i + 6]);
-#pragma unroll
-            for (int i = 0; i < NW; ++i) wm[i] = W == 11 ? min(m9[i], m3[i + 8]) : min(min(m9[i], m3[i + 9]), m3[i + 11]);
-            // the same shape with maxima over the W windows that hold position j: windows j .. j + W - 1
-            uint32_t x3[NW - 2], x9[NW - 8];
-#pragma unroll
-            for (int i = 0; i < NW - 2; ++i) x3[i] = max(max(wm[i], wm[i + 1]), wm[i + 2]);
-#pragma unroll
-            for (int i = 0; i < NW - 8; ++i) x9[i] = max(max(x3[i], x3[i + 3]), x3[i + 6]);
-#pragma unroll
-            for (int j = 0; j < SW_G; ++j) {
-                const uint32_t best = W == 11 ? max(x9[j], x3[j + 8]) : max(max(x9[j], x3[j + 9]), x3[j + 11]);
-                minbits |= (uint32_t)(best == hv[j]) << j;
-            }
-        } else {
-            constexpr int P = (W >= 16) ? 16 : (W >= 8) ? 8 : (W >= 4) ? 4 : 2; // largest power of two <= W
-#pragma unroll
-            for (int sp = 1; sp < P; sp *= 2) {
-#pragma unroll
-                for (int i = 0; i + sp < N; ++i) g[i] = g[i] < g[i + sp] ? g[i] : g[i + sp];
-            }
-#pragma unroll
-            for (int i = 0; i < NW; ++i) wm[i] = g[i] < g[i + W - P] ? g[i] : g[i + W - P];
-#pragma unroll
-            for (int sp = 1; sp < P; sp *= 2) {
-#pragma unroll
-                for (int i = 0; i + sp < NW; ++i) wm[i] = wm[i] > wm[i + sp] ? wm[i] : wm[i + sp];
-            }
-#pragma unroll
-            for (int j = 0; j < SW_G; ++j) {
-                const uint32_t best = wm[j] > wm[j + W - P] ? wm[j] : wm[j + W - P];
-                minbits |= (uint32_t)(best == hv[j]) << j;
-            }
-        }
-        minbits &= validbits;
-        if (lane < SW_FIRST || lane > SW_LAST) minbits = 0;
-    }
+    // ---- window minimizers (sketch_block.h); lanes 0, 62 and 63 only supply neighbours ----
+    uint32_t minbits = sketch_minimizers16<W>(hv) & validbits;
+    if (lane < SW_FIRST || lane > SW_LAST) minbits = 0;
 
     // ---- the tile's minimizers, compacted in position order; hashes and strands parked in LDS for the probe loops ----
     {

@@ -223,6 +223,56 @@ def _reads_from(rng, seqs, n, length, sub_rate=0.002):
     return np.concatenate(reads), offs
 
 
+@pytest.mark.parametrize("w", [11, 14])
+def test_read_by_read_verification(tmp_path, oracle, w):
+    """read_verify_kernel (short-read batches at k = 15: every read with several candidates is sketched once) on everything its
+    chunk logic distinguishes: 150-base panel reads (sketched), genome reads with a stray index k-mer (the lane path's queue), panel
+    reads of 280 / 900 bases (more candidates than a chunk's look-ahead: the overhang goes through the queue of another chunk),
+    reads over 1024 bases (never sketched), reads shorter than k, empty reads, N runs, lower case -- mean length below 300, so the
+    kernel is the one that runs; and the lane form (DRPRG_VERIFY_FORM=lane) must count the same"""
+    from drprg_amd import synth
+    rng = np.random.default_rng(40 + w)
+    loci = [synth.make_locus(rng, 2500, site_every=45) for _ in range(3)]
+    panel = synth.Panel(["a", "b", "c"], loci)
+    haps = [synth.sample_haplotype(rng, t).encode() for t in loci for _ in range(3)]
+    genome = synth.random_seq(rng, 60000).encode()
+    parts = [_reads_from(rng, haps, 5000, 150), _reads_from(rng, [genome], 9000, 150), _reads_from(rng, haps, 600, 280),
+             _reads_from(rng, haps, 60, 900, sub_rate=0.01), _reads_from(rng, haps, 12, 1500), _reads_from(rng, haps + [genome], 800, 40),
+             _reads_from(rng, haps, 300, 14), _reads_from(rng, haps, 300, 15), _reads_from(rng, haps, 300, 16)]
+    reads = []
+    for b, o in parts:
+        reads += [b[int(o[i]):int(o[i + 1])].copy() for i in range(len(o) - 1)]
+    reads += [np.zeros(0, np.uint8)] * 200
+    order = rng.permutation(len(reads))
+    reads = [reads[i] for i in order]
+    for r in reads:
+        if len(r) and rng.random() < 0.05:
+            r[rng.integers(0, len(r), size=max(1, len(r) // 60))] = ord("N")
+    reads = [np.frombuffer(r.tobytes().lower(), np.uint8) if len(r) and rng.random() < 0.1 else r for r in reads]
+    offs = np.zeros(len(reads) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(r) for r in reads])
+    bases = np.concatenate(reads)
+    assert int(offs[-1]) // len(reads) <= 300
+    ctx = _ctx(tmp_path, panel, w, 15, True, genome_size=60000, kernel=2)
+    cnt = _compare(ctx, oracle, bases, offs, w, 15, True, 2)
+    assert cnt["clusters_kept"] > 4000
+    got = ctx.counters()
+    os.environ["DRPRG_VERIFY_FORM"] = "lane"
+    try:
+        ctx.reset()
+        ctx.map_host(bases, offs)
+        lane = ctx.counters()
+        lcov, lprg = ctx.coverage()
+    finally:
+        del os.environ["DRPRG_VERIFY_FORM"]
+    ctx.reset()
+    ctx.map_host(bases, offs)
+    cov, prg = ctx.coverage()
+    assert np.array_equal(cov, lcov) and np.array_equal(prg, lprg)
+    for key in ("reads", "bases", "minimizers", "hits", "clusters_kept", "hits_kept", "leftover_reads"):
+        assert lane[key] == got[key], key
+
+
 @pytest.mark.parametrize("illumina", [True, False])
 def test_reads_with_hits_in_several_groups(tmp_path, oracle, illumina):
     """duplicated loci, a reverse-complemented copy and an inverted repeat: every read has hits in several
