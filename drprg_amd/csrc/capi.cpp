@@ -646,8 +646,10 @@ int drprg_hip_allreduce(drprg_hip_ctx* ctx, void* comm, void* d_covg, void* d_pr
     // The context's own accumulators: a batch queued by map_device_async may still need the host (leftover reads) before its
     // vector is final, so it is completed first.  A caller's own buffers: the caller orders the reduce behind the batch that
     // filled them (the contract of drprg_hip_map_device_async says when that batch is done) -- waiting here for the batch in
-    // flight would serialise the reduce of batch i with the mapping of batch i+1.
-    if (!d_covg) m.sync();
+    // flight would serialise the reduce of batch i with the mapping of batch i+1.  But if the batch in flight is the one that fills
+    // the very buffers being reduced, the reduce completes it, as it did before round 4 (its vector may still be waiting for an
+    // overflow re-run or the leftover pipeline): the caller cannot have meant to sum an unfinished vector.
+    if (!d_covg || m.pending_writes_to((const uint32_t*)d_covg, (const uint32_t*)d_prg_reads)) m.sync();
     if (hipSetDevice(m.device()) != hipSuccess) throw Error(DRPRG_EIO, "hipSetDevice failed");
     uint32_t* c = d_covg ? (uint32_t*)d_covg : m.d_covg();
     uint32_t* p = d_prg_reads ? (uint32_t*)d_prg_reads : m.d_prg_reads();

@@ -184,6 +184,7 @@ Mapper::~Mapper()
     if (d_slot_key_) (void)hipFree(d_slot_key_);
     dfree(d_covg_); d_prg_reads_ = nullptr; dfree(d_counters_);
     for (int i = 0; i < 3; ++i) dfree(d_unpacked_[i]);
+    dfree(d_pack_count_);
     dfree(d_npos_);
     dfree(d_key_a_); dfree(d_key_b_); dfree(d_val_a_); dfree(d_val_b_);
     dfree(d_head_); dfree(d_scan_); dfree(d_cstart_); dfree(d_order_); dfree(d_clusters_);
@@ -522,7 +523,11 @@ const uint8_t* Mapper::ascii_view(int slot, const uint8_t* d_bases, uint64_t n_b
         unpacked_cap_[slot] = need + need / 4;
         dmalloc(d_unpacked_[slot], unpacked_cap_[slot]);
     }
-    HIPCHK(dev::launch_unpack(reinterpret_cast<const uint32_t*>(d_bases), n_bases, it->second.d_npos, it->second.n_npos, d_unpacked_[slot], stream));
+    const PackedInfo info = it->second;
+    // (the expansion is ASCII whatever lived at its address before: a freed packed batch whose memory the allocator handed back here
+    // must not make sketch_args() call it packed -- ADVICE r04)
+    packed_.erase(d_unpacked_[slot]);
+    HIPCHK(dev::launch_unpack(reinterpret_cast<const uint32_t*>(d_bases), n_bases, info.d_npos, info.n_npos, d_unpacked_[slot], stream));
     return d_unpacked_[slot];
 }
 
@@ -1048,10 +1053,19 @@ void Mapper::map_device_packed(const uint32_t* d_words, const uint64_t* d_offset
     uint32_t* covg, uint32_t* prg_reads, hipStream_t stream, bool deferred)
 {
     if (n_npos && !d_npos) throw Error(DRPRG_EINVAL, "n_npos > 0 without the positions");
+    if (n_reads == 0) return;
+    // (everything that can refuse the batch is checked before the batch is known as packed; a batch that fails later is forgotten again)
+    if (!d_words || !d_offsets) throw Error(DRPRG_EINVAL, "null device pointer");
+    if ((reinterpret_cast<uintptr_t>(d_words) & 15u) != 0) throw Error(DRPRG_EINVAL, "d_words must be 16-byte aligned");
     const uint8_t* key = reinterpret_cast<const uint8_t*>(d_words);
     packed_[key] = PackedInfo { d_npos, n_npos };
-    if (deferred) map_device_async_impl(key, d_offsets, n_reads, n_bases, covg, prg_reads, stream);
-    else map_device_impl(key, d_offsets, n_reads, n_bases, covg, prg_reads, stream);
+    try {
+        if (deferred) map_device_async_impl(key, d_offsets, n_reads, n_bases, covg, prg_reads, stream);
+        else map_device_impl(key, d_offsets, n_reads, n_bases, covg, prg_reads, stream);
+    } catch (...) {
+        packed_.erase(key);
+        throw;
+    }
 }
 
 void Mapper::map_device_impl(const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n_reads, uint64_t n_bases,
@@ -1089,6 +1103,7 @@ void Mapper::map_host(const HostBatch& b)
     if (b.offsets[0] != 0) throw Error(DRPRG_EINVAL, "offsets[0] must be 0");
     const uint64_t n_bases = b.n_bases(), bytes = b.payload_bytes();
     if (bytes + 64 > stage_bases_cap_) {
+        packed_.erase(d_bases_); // (the address goes back to the allocator)
         dfree(d_bases_);
         stage_bases_cap_ = bytes + bytes / 4 + 64;
         dmalloc(d_bases_, stage_bases_cap_);
@@ -1121,16 +1136,14 @@ uint64_t Mapper::pack_on_device(const uint8_t* d_bases, uint64_t n_bases, uint32
     if (!stream) stream = stream_;
     if (n_bases == 0) return 0;
     if (!d_bases || !d_words) throw Error(DRPRG_EINVAL, "null device pointer");
-    unsigned long long* d_n = nullptr;
-    HIPCHK(hipMalloc((void**)&d_n, sizeof(unsigned long long)));
+    if (!d_pack_count_) dmalloc(d_pack_count_, (size_t)1); // (one counter word per Mapper: a hipMalloc / hipFree per call synchronises the device)
     unsigned long long n = 0;
-    hipError_t e = hipMemsetAsync(d_n, 0, sizeof(unsigned long long), stream);
-    if (e == hipSuccess) e = dev::launch_pack(d_bases, n_bases, d_words, d_npos, d_npos ? npos_cap : 0, d_n, stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(&n, d_n, sizeof n, hipMemcpyDeviceToHost, stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(stream);
-    (void)hipFree(d_n);
-    HIPCHK(e);
-    if (n > 1 && n <= npos_cap) { // the positions come out in any order: sorted on the host (few; the harness path)
+    HIPCHK(hipMemsetAsync(d_pack_count_, 0, sizeof(unsigned long long), stream));
+    HIPCHK(dev::launch_pack(d_bases, n_bases, d_words, d_npos, d_npos ? npos_cap : 0, d_pack_count_, stream));
+    HIPCHK(hipMemcpyAsync(&n, d_pack_count_, sizeof n, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    if (n && !d_npos) throw Error(DRPRG_EINVAL, "the batch holds bases that are not ACGT and no buffer for their positions was given");
+    if (d_npos && n > 1 && n <= npos_cap) { // the positions come out in any order: sorted on the host (few; the harness path)
         std::vector<uint64_t> h(n);
         HIPCHK(hipMemcpy(h.data(), d_npos, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
         std::sort(h.begin(), h.end());
@@ -1178,6 +1191,7 @@ void Mapper::drop_kept()
         HIPCHK(hipStreamSynchronize(stream_));
         for (auto& a : kept_arenas_) (void)hipFree(a.first);
     }
+    for (const KeptBatch& b : kept_) packed_.erase(b.d_bases); // (their memory goes back to the allocator)
     kept_arenas_.clear();
     kept_.clear();
     arena_at_ = nullptr;
@@ -1374,6 +1388,7 @@ void Mapper::map_host_async(const HostBatch& hb)
     if (!st.copied) HIPCHK(hipEventCreateWithFlags(&st.copied, hipEventDisableTiming));
     if (bytes + 64 > st.bases_cap) {
         sync(); // (freeing device memory waits for the device; be explicit about the batch in flight)
+        packed_.erase(st.d_bases); // (the address goes back to the allocator)
         dfree(st.d_bases);
         st.bases_cap = bytes + bytes / 4 + 64;
         dmalloc(st.d_bases, st.bases_cap);

@@ -123,6 +123,11 @@ public:
     void device_tables(uint64_t out[6]) const;
 
     // timing of the dominant kernel (HIP events on the launch stream), for bench.py
+    // is the batch queued by map_device_async (not yet completed) accumulating into these buffers?
+    bool pending_writes_to(const uint32_t* covg, const uint32_t* prg_reads) const
+    {
+        return pending_.active && ((covg && pending_.covg == covg) || (prg_reads && pending_.prg_reads == prg_reads));
+    }
     void enable_kernel_timing(bool on) { timing_ = on; }
     double sketch_ms_total() const { return sketch_ms_; }
     uint64_t sketch_launches() const { return sketch_launches_; }
@@ -177,6 +182,7 @@ private:
     // sequence's candidate form, 2: the generic sequence), made on `stream`
     const uint8_t* ascii_view(int slot, const uint8_t* d_bases, uint64_t n_bases, hipStream_t stream);
     uint8_t* d_unpacked_[3] = { nullptr, nullptr, nullptr };
+    unsigned long long* d_pack_count_ = nullptr; // pack_on_device's counter word
     uint64_t unpacked_cap_[3] = { 0, 0, 0 };
     void map_device_impl(const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n_reads, uint64_t n_bases, uint32_t* d_covg, uint32_t* d_prg_reads,
         hipStream_t stream);

@@ -130,6 +130,60 @@ __device__ __forceinline__ void verify_emit(const SketchArgs& a, const ReadClust
     o.crec = make_uint4(sf.x, sf.y, (strand << 31) | (((prg << 1) | rev) << 16) | thr, (kn >> 1) * 2u + rev);
 }
 
+// The first half of verify_one_lane on its own: the read of a candidate, its canonical hash, the exact lookup -- and nothing of the window
+// scan.  true: the k-mer is an index k-mer that lies inside its read (verify_one_lane then decides whether it is a minimizer); false: o
+// is what verify_one_lane would leave (no minimizer; the read).  read_verify_kernel sends the candidates of sparsely hit reads through
+// this first: most of them are false positives of the Bloom filter, which end here at a sixth of the cost.
+// gp: a candidate position of this launch's read range (win_lo <= gp < win_hi, gp + k <= n_bases)
+template <int KC, bool PACKED>
+__device__ __forceinline__ bool probe_one_lane(const SketchArgs& a, const VerifyConsts& c, int64_t gp, VerifyOut& o)
+{
+    using Tr = HashTraits<uint32_t>;
+    const int k = c.k;
+    const int64_t n_bases = c.n_bases;
+    uint32_t guess = (uint32_t)((double)gp * c.reads_per_base);
+    if (guess >= a.n_reads) guess = a.n_reads - 1;
+    const uint64_t o0 = a.offsets[guess], o1 = a.offsets[guess + 1];
+    const int64_t a0 = gp & ~(int64_t)15; // the k-mer lies in the 32 bases from here
+    uint32_t r0w, r1w, bad;
+    if constexpr (PACKED) {
+        const uint32_t* __restrict__ wp = reinterpret_cast<const uint32_t*>(a.bases) + (a0 >> 4);
+        const uint32_t x0 = wp[0], x1 = a0 + 16 < n_bases ? wp[1] : 0u;
+        r0w = packed_to_hash_order(x0);
+        r1w = packed_to_hash_order(x1);
+        bad = a.n_npos ? (uint32_t)packed_bad_bases(a.npos, a.n_npos, a0) : 0u;
+    } else {
+        const uint4 b0 = a0 + 16 <= n_bases ? *reinterpret_cast<const uint4*>(a.bases + a0) : load16_guarded(a.bases, n_bases, a0);
+        const uint4 b1 = a0 + 32 <= n_bases ? *reinterpret_cast<const uint4*>(a.bases + a0 + 16) : load16_guarded(a.bases, n_bases, a0 + 16);
+        uint32_t n0, n1;
+        pack16n(b0, r0w, n0);
+        pack16n(b1, r1w, n1);
+        bad = n0 | (n1 << 16);
+    }
+    int64_t r1 = (int64_t)o1;
+    if (o0 <= (uint64_t)gp && (uint64_t)gp < o1) o.read = guess;
+    else {
+        o.read = find_read_near(a.offsets, a.n_reads, guess, (uint64_t)gp);
+        r1 = (int64_t)a.offsets[o.read + 1];
+    }
+    const int oc = (int)(gp - a0); // 0..15: the k-mer is bases oc .. oc + k - 1 <= 29 of the 32
+    if ((bad >> oc) & ((1u << k) - 1u)) return false; // a base that is not ACGT
+    const uint32_t f = __funnelshift_l(r1w, r0w, 2 * oc) >> c.sh_k;
+    const uint32_t hf = verify_mix<KC>(f, c.kmask), hr = verify_mix<KC>(revcomp_code(f, k), c.kmask);
+    o.strand = hf <= hr ? 1u : 0u;
+    const uint32_t h = hf < hr ? hf : hr;
+    uint32_t sl = table_slot_dev(h, a.table_bits);
+    bool found = false;
+    while (true) {
+        const uint32_t key = c.slot_key[sl];
+        if (key == h) { found = true; break; }
+        if (key == Tr::EMPTY) break;
+        sl = (sl + 1) & c.tmask;
+    }
+    o.slot = sl;
+    return found && gp + k <= r1;
+}
+
 // One candidate, start to finish, by one lane (the whole algorithm described above verify_count_kernel)
 template <int KC, bool PACKED>
 __device__ __forceinline__ void verify_one_lane(const SketchArgs& a, const FilterWork& fw, const ReadClusterArgs& rc, const VerifyConsts& c, int64_t gp, VerifyOut& o,

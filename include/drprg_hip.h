@@ -86,7 +86,8 @@ int drprg_hip_reduce_info(const drprg_hip_ctx* ctx, char* out, size_t cap);
  * drprg_hip_coverage_size) on `hip_stream` (NULL: the context's stream), asynchronous on that stream -- every rank then holds the
  * sample's vectors and rank 0 genotypes.  d_covg NULL: the context's own accumulators (which are laid out that way; a batch
  * still queued by drprg_hip_map_device_async is completed first).  d_covg given: d_prg_reads == d_covg + n_covg takes the same
- * single call, anything else two calls in one group; the CALLER orders the reduce behind the batch that filled the buffers.  `comm` is an ncclComm_t: a host that already has one (its own RCCL binding) may pass it. */
+ * single call, anything else two calls in one group; the CALLER orders the reduce behind the batch that filled the buffers -- except the batch
+ * still queued by drprg_hip_map_device_async INTO these buffers, which the reduce completes first (it may still need the host).  `comm` is an ncclComm_t: a host that already has one (its own RCCL binding) may pass it. */
 int drprg_hip_comm_unique_id(uint8_t id[128]);
 int drprg_hip_comm_init_rank(void** comm, int nranks, const uint8_t id[128], int rank, int device);
 int drprg_hip_comm_destroy(void* comm);
@@ -141,9 +142,9 @@ int drprg_hip_sync(drprg_hip_ctx* ctx); /* completes the batch in flight and wai
  *   drprg_hip_pack_reads: host helper, bases[n_bases] -> words[ceil(n_bases / 16)] + npos (-EOVERFLOW, *n_npos set, when npos_cap is
  *     too small).
  *   drprg_hip_map_host_packed / drprg_hip_map_device_packed(_async): the packed counterparts of map_host / map_device(_async); d_words
- *     8-byte aligned, d_npos may be NULL when n_npos == 0.
+ *     16-byte aligned like d_bases (the kernels read them with 16-byte loads; -EINVAL otherwise), d_npos may be NULL when n_npos == 0.
  *   drprg_hip_pack_device: the same conversion for a batch that is already on the device (harnesses); d_npos: room for npos_cap
- *     positions, *n_npos receives their number (positions ascending). */
+ *     positions, *n_npos receives their number (positions ascending); d_npos NULL: -EINVAL if the batch holds a base that is not ACGT. */
 int drprg_hip_set_input_format(drprg_hip_ctx* ctx, int packed);
 int drprg_hip_pack_reads(const uint8_t* bases, uint64_t n_bases, uint32_t* words, uint64_t* npos, uint64_t npos_cap, uint64_t* n_npos);
 int drprg_hip_map_host_packed(drprg_hip_ctx* ctx, const uint32_t* words, const uint64_t* offsets, uint64_t n_reads, const uint64_t* npos, uint64_t n_npos);

@@ -228,8 +228,8 @@ def test_read_by_read_verification(tmp_path, oracle, w):
     """read_verify_kernel (short-read batches at k = 15: every read with several candidates is sketched once) on everything its
     chunk logic distinguishes: 150-base panel reads (sketched), genome reads with a stray index k-mer (the lane path's queue), panel
     reads of 280 / 900 bases (more candidates than a chunk's look-ahead: the overhang goes through the queue of another chunk),
-    reads over 1024 bases (never sketched), reads shorter than k, empty reads, N runs, lower case -- mean length below 300, so the
-    kernel is the one that runs; and the lane form (DRPRG_VERIFY_FORM=lane) must count the same"""
+    reads over 1024 bases (never sketched), reads shorter than k, empty reads, N runs, lower case -- mean length below 300, the batches
+    the kernel serves when DRPRG_VERIFY_FORM=read asks for it; and the default lane form must count the same"""
     from drprg_amd import synth
     rng = np.random.default_rng(40 + w)
     loci = [synth.make_locus(rng, 2500, site_every=45) for _ in range(3)]
@@ -254,20 +254,20 @@ def test_read_by_read_verification(tmp_path, oracle, w):
     bases = np.concatenate(reads)
     assert int(offs[-1]) // len(reads) <= 300
     ctx = _ctx(tmp_path, panel, w, 15, True, genome_size=60000, kernel=2)
-    cnt = _compare(ctx, oracle, bases, offs, w, 15, True, 2)
-    assert cnt["clusters_kept"] > 4000
-    got = ctx.counters()
-    os.environ["DRPRG_VERIFY_FORM"] = "lane"
+    os.environ["DRPRG_VERIFY_FORM"] = "read"
     try:
+        cnt = _compare(ctx, oracle, bases, offs, w, 15, True, 2)
+        assert cnt["clusters_kept"] > 4000
         ctx.reset()
         ctx.map_host(bases, offs)
-        lane = ctx.counters()
-        lcov, lprg = ctx.coverage()
+        got = ctx.counters()
+        cov, prg = ctx.coverage()
     finally:
         del os.environ["DRPRG_VERIFY_FORM"]
     ctx.reset()
     ctx.map_host(bases, offs)
-    cov, prg = ctx.coverage()
+    lane = ctx.counters()
+    lcov, lprg = ctx.coverage()
     assert np.array_equal(cov, lcov) and np.array_equal(prg, lprg)
     for key in ("reads", "bases", "minimizers", "hits", "clusters_kept", "hits_kept", "leftover_reads"):
         assert lane[key] == got[key], key
