@@ -10,15 +10,34 @@ HIPFLAGS := $(CXXFLAGS) --offload-arch=$(ARCH)
 SRC  := drprg_amd/csrc
 OBJD := build/obj
 HOST_SRCS := prg.cpp kmergraph.cpp index.cpp fastx.cpp genotype.cpp params.cpp denovo.cpp mapper.cpp capi.cpp vcfio.cpp bcfout.cpp annotate.cpp report_json.cpp ingest.cpp pgunzip.cpp rccl_dyn.cpp pack.cpp
-HIP_SRCS := sketch_probe.hip sketch_wave.hip sketch_filter.hip candidates.hip read_verify.hip read_cluster.hip read_cluster_wave.hip cluster.hip anchor_scan.hip packed.hip
-OBJS := $(addprefix $(OBJD)/,$(HOST_SRCS:.cpp=.o)) $(addprefix $(OBJD)/,$(HIP_SRCS:.hip=.o))
+HIP_SRCS := sketch_probe.hip sketch_wave.hip sketch_filter.hip candidates.hip read_cluster.hip cluster.hip anchor_scan.hip packed.hip
 LIB  := drprg_amd/lib/libdrprg_hip.so
+# make EXPERIMENTAL=1: the kernel forms that were built, are bit-exact and lost their measurement -- the wave form of
+# read_cluster, refine_kernel, the in-kernel clustering of sketch_wave_kernel, the read-by-read verification -- compiled in behind their
+# environment switches, into a library of its own (build/exp/libdrprg_hip.so; DRPRG_HIP_LIB=... selects it, pytest -m "gpu and
+# experimental" runs their parity cases).  The default build does not contain them.
+EXPERIMENTAL ?= 0
+ifeq ($(EXPERIMENTAL),1)
+CXXFLAGS += -DDRPRG_EXPERIMENTAL=1
+HIPFLAGS += -DDRPRG_EXPERIMENTAL=1
+HIP_SRCS += read_cluster_wave.hip read_verify.hip
+OBJD := build/obj_exp
+LIB  := build/exp/libdrprg_hip.so
+endif
+OBJS := $(addprefix $(OBJD)/,$(HOST_SRCS:.cpp=.o)) $(addprefix $(OBJD)/,$(HIP_SRCS:.hip=.o))
 BIN  := drprg_amd/bin/pandora
 ORACLE := oracle/liboracle.so
 
 DRPRG := drprg_amd/bin/drprg
 
+ifeq ($(EXPERIMENTAL),1)
+all: $(LIB)
+else
 all: $(LIB) $(BIN) $(DRPRG) $(ORACLE)
+endif
+
+experimental:
+	$(MAKE) EXPERIMENTAL=1
 
 $(DRPRG): $(SRC)/drprg_main.cpp $(LIB)
 	@mkdir -p $(dir $@)
@@ -46,7 +65,8 @@ $(ORACLE): oracle/oracle.c oracle/oracle_index.c oracle/oracle_params.c oracle/o
 clean:
 	rm -rf build $(LIB) $(BIN) $(ORACLE)
 
-.PHONY: all clean
+
+.PHONY: all clean experimental
 
 # host code under AddressSanitizer + UBSan (CPU build only: GPU sanitizers are not available on the pool):
 #   make asan && LD_PRELOAD=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so) \

@@ -151,6 +151,38 @@ for _s in (2, 4, 8, 16, 32):
                                f"({18 * _s} loci)", 10_000_000, True, f"mtb_x{_s}")
 
 
+# the source files of the dominant kernels: profiles/traffic.json and profiles/valu.json say which state of them their numbers were
+# measured on (tools/make_profile_json.py holds the same table)
+KERNEL_SOURCES = {
+    "sketch_filter_kernel": ["sketch_filter.hip", "filter_common.h", "device_common.h"],
+    "sketch_wave_kernel": ["sketch_wave.hip", "sketch_block.h", "device_common.h"],
+    "sketch_probe_kernel": ["sketch_probe.hip", "device_common.h"],
+}
+
+
+def kernel_source_sha16(kernel):
+    import hashlib
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES.get(kernel, []):
+        h.update(open(os.path.join(ROOT, "drprg_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def profile_entry_stale(entry, kernel):
+    """None if the replayed profile entry was measured on the kernel sources of this tree, else the reason it is dropped"""
+    if not entry:
+        return None
+    if kernel not in KERNEL_SOURCES:
+        return f"no source table for {kernel}"
+    was = entry.get("source_sha16")
+    now = kernel_source_sha16(kernel)
+    if was is None:
+        return f"the profile entry does not name the kernel sources it was measured on ({', '.join(KERNEL_SOURCES[kernel])} are now {now})"
+    if was != now:
+        return f"{', '.join(KERNEL_SOURCES[kernel])} changed since the profile was taken (sha256 {was} then, {now} now): run tools/run_profiles_r05.sh + tools/make_profile_json.py"
+    return None
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -650,12 +682,20 @@ def main():
             kernel_name = "sketch_wave_kernel"  # the register-resident form of the direct kernel (csrc/sketch_wave.hip)
         # HBM bytes per launch of that kernel from rocprofv3 PMC counters (separate --pmc passes, FETCH_SIZE doubled as
         # the microarch guide prescribes for wide coalesced loads on gfx950): measured offline, committed under profiles/
-        traffic = None
+        # (the replayed numbers belong to the kernel source they were measured on: an entry whose sources have changed since -- or that
+        # does not say what it was measured on -- is dropped, with the reason; tools/make_profile_json.py writes the entries)
+        traffic, traffic_source = None, None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
+        wkey = args.workload + ("-packed" if packed else "")
         if n_reads == default_reads and os.path.exists(tfile):
-            traffic = json.load(open(tfile)).get(args.workload + ("-packed" if packed else ""), {}).get(kernel_name, {}).get("hbm_bytes_per_launch")
-            if traffic is not None:
-                traffic = traffic / launches_per_step  # (measured per batch)
+            entry = json.load(open(tfile)).get(wkey, {}).get(kernel_name, {})
+            stale = profile_entry_stale(entry, kernel_name)
+            if entry.get("hbm_bytes_per_launch") is not None and not stale:
+                traffic = entry["hbm_bytes_per_launch"] / launches_per_step  # (measured per batch)
+                traffic_source = (f"profiles/traffic.json, rows {entry.get('rows')}, kernel sources sha256 {entry.get('source_sha16')} = the build's "
+                                  "(offline rocprofv3 PMC passes of this workload, FETCH_SIZE doubled + WRITE_SIZE)")
+            elif stale:
+                traffic_source = "dropped: " + stale
         # secondary bound (SURVEY 8d "report honestly"): the dominant kernel's VALU issue slots.  Wave instructions per launch come
         # from offline rocprofv3 SQ-counter passes of this workload (profiles/valu.json, SQ_INSTS_VALU); the duration is the live one.
         # One wave64 VALU instruction of the kinds the sketch kernels are made of occupies its SIMD for 4 cycles, however many waves
@@ -665,14 +705,18 @@ def main():
         secondary = None
         vfile = os.path.join(ROOT, "profiles", "valu.json")
         if n_reads == default_reads and os.path.exists(vfile) and avg_ms > 0:
-            vkey = args.workload + ("-packed" if packed else "")
-            v = json.load(open(vfile)).get(vkey, {}).get(kernel_name, {}).get("valu_wave_insts_per_launch")
-            if v:
+            entry = json.load(open(vfile)).get(wkey, {}).get(kernel_name, {})
+            v = entry.get("valu_wave_insts_per_launch")
+            stale = profile_entry_stale(entry, kernel_name)
+            if v and stale:
+                secondary = {"bound": "valu_issue", "wave_insts": None, "frac": None, "source": "dropped: " + stale}
+            elif v:
                 v = v / launches_per_step
                 peak = 1024 * 2.4e9 / 4
                 secondary = {"bound": "valu_issue", "wave_insts": v, "achieved": v / (avg_ms * 1e-3), "peak": peak, "unit": "wave-instructions/s",
                              "frac": v / (avg_ms * 1e-3) / peak,
-                             "source": "wave_insts: profiles/valu.json (offline rocprofv3 --pmc SQ_INSTS_VALU of this workload) over the live kernel "
+                             "source": f"wave_insts: profiles/valu.json, rows {entry.get('rows')}, kernel sources sha256 {entry.get('source_sha16')} = the "
+                                       "build's (offline rocprofv3 --pmc SQ_INSTS_VALU of this workload) over the live kernel "
                                        "duration; peak: 4 cycles per wave64 integer VALU instruction per SIMD, measured at 1/2/4/8 waves per SIMD in "
                                        "profiles/r04/mb_issue.txt (tools/mb_issue.hip)"}
         out = {
@@ -721,8 +765,7 @@ def main():
                 "bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "frac_of_achievable": achieved / HBM_ACHIEVABLE_GBS,
                 "achievable": HBM_ACHIEVABLE_GBS, "traffic": traffic,
-                "traffic_source": "profiles/traffic.json (offline rocprofv3 PMC passes of this workload, FETCH_SIZE doubled + WRITE_SIZE)"
-                                  if traffic is not None else None,
+                "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "bytes_of_the_batch_as_stored": ((n_bases + 15) // 16 * 4 if packed else n_bases) + 8 * (n_reads + 1),
                 "avg_launch_ms": avg_ms, "launches_timed": k_launches, "launches_per_step": launches_per_step,
@@ -732,6 +775,12 @@ def main():
         if packed_leg is not None:
             packed_leg["roofline_frac_priced_on_L_plus_8"] = (alg_bytes / (packed_leg["dominant_kernel_avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
                                                               if packed_leg["dominant_kernel_avg_launch_ms"] > 0 else None)
+            # ... and on the bytes the packed kernel really reads (the batch as stored + index table + coverage vector): SURVEY 8d allows the
+            # L + 8 pricing ("packing is an optimisation, not a change of work"); this is the fraction of the memory system it uses
+            packed_read = packed_leg["bytes_of_the_batch_as_stored"] + table_bytes + 8 * ctx.n_knodes
+            packed_leg["bytes_read_per_launch"] = packed_read
+            packed_leg["frac_of_bytes_read"] = (packed_read / (packed_leg["dominant_kernel_avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+                                                if packed_leg["dominant_kernel_avg_launch_ms"] > 0 else None)
             out["packed_input"] = packed_leg
         # CPU baseline: the oracle (a scalar port of the same path, oracle/oracle.c) on a bounded sample of rank 0's shard,
         # once on one thread and once with the reads split over the host's cores (threads calling the same C function on

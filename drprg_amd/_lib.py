@@ -57,6 +57,7 @@ SIGNATURES = {
     "drprg_hip_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "drprg_hip_close": (None, [C.c_void_p]),
     "drprg_hip_last_error": (C.c_char_p, [C.c_void_p]),
+    "drprg_hip_experimental": (C.c_int, []),
     "drprg_hip_set_opts": (C.c_int, [C.c_void_p, C.POINTER(MapOpts)]),
     "drprg_hip_set_opts_sized": (C.c_int, [C.c_void_p, C.POINTER(MapOpts), C.c_size_t]),
     "drprg_hip_map_fastx": (C.c_int, [C.c_void_p, C.c_char_p]),

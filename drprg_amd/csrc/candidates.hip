@@ -404,13 +404,17 @@ hipError_t launch_candidate_stage(const SketchArgs& a, FilterWork& fw, const Rea
 {
     hipLaunchKernelGGL(cand_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, fw);
     hipLaunchKernelGGL(cand_gather_kernel, dim3(fw.n_slices), dim3(64), 0, stream, fw);
-    // Short-read batches at k = 15, w in {11, 14} are verified read by read (read_verify.hip, round 5); everything else -- long reads, other
-    // (w, k), DRPRG_VERIFY_FORM=lane -- one lane per candidate
+    // One lane per candidate.  (make EXPERIMENTAL=1 + DRPRG_VERIFY_FORM=read: short-read batches at k = 15, w in {11, 14} read by read --
+    // read_verify.hip, round 5: bit-exact and 8 % slower, profiles/r05/read_verify.txt)
     fw.verify_grid = fw.ex_grid;
+    (void)n_cus;
+#ifdef DRPRG_EXPERIMENTAL
     if (read_verify_applies(a, fw)) {
         fw.verify_grid = std::min<uint32_t>(read_verify_grid(n_cus), MAX_EX_WG);
         HIP_TRY(launch_read_verify(a, fw, rc, fw.verify_grid, stream));
-    } else if (a.packed) {
+    } else
+#endif
+    if (a.packed) {
         if (a.k == 15) hipLaunchKernelGGL((verify_count_kernel<15, true>), dim3(fw.ex_grid), dim3(EX_THREADS), 0, stream, a, fw, rc);
         else hipLaunchKernelGGL((verify_count_kernel<0, true>), dim3(fw.ex_grid), dim3(EX_THREADS), 0, stream, a, fw, rc);
     } else if (a.k == 15) hipLaunchKernelGGL((verify_count_kernel<15, false>), dim3(fw.ex_grid), dim3(EX_THREADS), 0, stream, a, fw, rc);

@@ -635,6 +635,15 @@ int drprg_hip_comm_destroy(void* comm)
     return r->CommDestroy(comm) == Rccl::Success ? DRPRG_OK : DRPRG_EIO;
 }
 
+int drprg_hip_experimental(void)
+{
+#ifdef DRPRG_EXPERIMENTAL
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 int drprg_hip_allreduce(drprg_hip_ctx* ctx, void* comm, void* d_covg, void* d_prg_reads, void* hip_stream)
 {
     API_BEGIN(ctx)

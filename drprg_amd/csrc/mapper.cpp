@@ -148,6 +148,7 @@ Mapper::Mapper(const FlatIndex& idx, const MapParams& p, int device) : device_(d
     HIPCHK(hipDeviceGetAttribute(&n_cus_, hipDeviceAttributeMultiprocessorCount, device_));
     HIPCHK(hipStreamSynchronize(nullptr)); // every table is on the device before a kernel of a non-blocking stream can ask for it
     set_params(p); // again: the kernel choice depends on the filter being available
+#ifdef DRPRG_EXPERIMENTAL // (make EXPERIMENTAL=1; the default build has no such instantiation of sketch_wave_kernel)
     {
         const char* f = std::getenv("DRPRG_WAVE_FUSE");
         const char* d = std::getenv("DRPRG_FT_DEBUG");
@@ -157,6 +158,7 @@ Mapper::Mapper(const FlatIndex& idx, const MapParams& p, int device) : device_(d
         fuse_in_kernel_ = f && std::atoi(f) != 0 && !(d && (std::atoi(d) & 8));
         fuse_mode_ = f && std::atoi(f) == 2 ? 2 : 1;
     }
+#endif
     if (const char* e = std::getenv("DRPRG_HIP_LANES")) max_lanes_ = std::min(4, std::max(1, std::atoi(e)));
     if (const char* e = std::getenv("DRPRG_HIP_LANES_MIN_BASES")) lanes_min_bases_ = std::strtoull(e, nullptr, 10); // (tests: 0)
     // ONE allocation [coverage | reads per PRG]: the sample's whole additive state is one contiguous u32 vector, so the

@@ -662,8 +662,12 @@ __global__ void flag_complex_kernel(const unsigned long long* n_hits, unsigned l
 
 bool read_cluster_wave_form_requested()
 {
+#ifdef DRPRG_EXPERIMENTAL
     const char* form = std::getenv("DRPRG_RC_FORM");
     return form && std::string(form) == "wave";
+#else
+    return false; // (the wave form is part of `make EXPERIMENTAL=1` only)
+#endif
 }
 
 hipError_t launch_read_cluster(const SketchArgs& a, const FilterWork& fw, const ReadClusterArgs& rc, int n_cus, bool skip, hipStream_t stream)
@@ -673,17 +677,21 @@ hipError_t launch_read_cluster(const SketchArgs& a, const FilterWork& fw, const 
         return hipGetLastError();
     }
     ReadClusterArgs rcd = rc;
-    // DRPRG_RC_FORM=wave (read per launch; tests switch it): the wave form first (read_cluster_wave.hip: no workgroup barriers;
+    // make EXPERIMENTAL=1 + DRPRG_RC_FORM=wave (read per launch; tests switch it): the wave form first (read_cluster_wave.hip: no workgroup barriers;
     // everything a 150-base read needs) and this kernel behind it for what that leaves.  NOT the default: measured on MI355X
     // (profiles/r04/rc_forms.txt) the wave form takes 61 us where this kernel takes 68 us on configs[1], and then still needs this
     // kernel for the reads it left (37 us) and a 8 us kernel for the totals; on configs[4] 2.2 ms against 1.3 ms.  DESIGN.md section 6.
     const bool wave_first = read_cluster_wave_form_requested();
     rcd.second_pass = 0;
     // (long reads do not fit a wave's 128 staged candidates: a batch of them goes straight to the workgroup form)
+#ifdef DRPRG_EXPERIMENTAL
     if (wave_first && rc.n_unfit && rc.chunk_flags && a.n_bases / (a.n_reads ? a.n_reads : 1u) <= 600) {
         HIP_TRY(launch_read_cluster_wave(a, fw, rc, n_cus, stream));
         rcd.second_pass = 1;
     }
+#else
+    (void)wave_first;
+#endif
     static unsigned long long* d_phase = nullptr;
     const bool debug = std::getenv("DRPRG_RC_DEBUG") != nullptr;
     if (debug) {

@@ -528,6 +528,7 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
 #undef DRPRG_BLOCK_TEST
 #undef DRPRG_STAGE2_APPEND
 
+#ifdef DRPRG_EXPERIMENTAL
 // Second stage of the filter for the groups that passed level 0 (level-0 form of sketch_filter_kernel): one lane per
 // group tests its four k-mer codes against a 64 KB LDS-resident filter (four bits per code, < 15 % full); every wave
 // works through whole slices and compacts the surviving positions, in order, into the slice of raw_pos that
@@ -583,6 +584,7 @@ __global__ __launch_bounds__(RF_THREADS) void refine_kernel(SketchArgs a, Filter
         }
     }
 }
+#endif // DRPRG_EXPERIMENTAL
 
 // ---------------------------------------------------------------------------------------------
 // host side
@@ -639,8 +641,12 @@ hipError_t launch_sketch_filter(const SketchArgs& a, uint32_t read_begin, uint32
         && !(fw.debug & 4u));
     // the second stage inside the streaming kernel (default; its bits share the level-0 array) or as refine_kernel behind it
     // (DRPRG_FILTER_FORM=refine): 0.64 against 0.69 ms per 10 M reads, DESIGN.md section 6
+#ifdef DRPRG_EXPERIMENTAL
     const char* form = std::getenv("DRPRG_FILTER_FORM");
     const bool fused = mid || (level0 && !(form && std::string(form) == "refine"));
+#else
+    const bool fused = mid || level0; // (the two-kernel form is part of `make EXPERIMENTAL=1` only)
+#endif
     fw.bloom = bt.bloom;
     fw.bloom_wbits = bt.bloom_wbits;
     fw.bloomr = bt.bloomr;
@@ -687,6 +693,7 @@ hipError_t launch_sketch_filter(const SketchArgs& a, uint32_t read_begin, uint32
     }
     HIP_TRY(hipGetLastError());
     if (timer.end) HIP_TRY(hipEventRecord(timer.end, stream));
+#ifdef DRPRG_EXPERIMENTAL
     if (level0 && !fused) {
         static size_t refine_configured[MAX_HIP_DEVICES] = {};
         const size_t dyn = (size_t)4 << BLOOMR_WBITS;
@@ -694,6 +701,7 @@ hipError_t launch_sketch_filter(const SketchArgs& a, uint32_t read_begin, uint32
         hipLaunchKernelGGL(refine_kernel, dim3(std::min<uint32_t>((fw.n_slices + RF_THREADS / 64 - 1) / (RF_THREADS / 64), (uint32_t)n_cus * 2)), dim3(RF_THREADS), dyn, stream, a, fw);
         HIP_TRY(hipGetLastError());
     }
+#endif
     const bool skip_rc = (fw.debug & 8u) != 0; // debug 8: every read with a hit goes the generic way
     HIP_TRY(launch_candidate_stage(a, fw, rc, n_cus, stream, skip_rc));
     ReadClusterArgs rct = rc;

@@ -480,12 +480,15 @@ hipError_t launch_sketch_wave(const SketchArgs& a, hipStream_t stream, KernelTim
     switch (which) {
     case 0: go(sketch_wave_kernel<15, 11, false, false>); break;
     case 1: go(sketch_wave_kernel<15, 11, false, true>); break;
-    case 2: go(sketch_wave_kernel<15, 11, true, false>); break;
-    case 3: go(sketch_wave_kernel<15, 11, true, true>); break;
     case 4: go(sketch_wave_kernel<15, 14, false, false>); break;
     case 5: go(sketch_wave_kernel<15, 14, false, true>); break;
+#ifdef DRPRG_EXPERIMENTAL // stage C1 (a.fuse != 0: DRPRG_WAVE_FUSE) exists in `make EXPERIMENTAL=1` only
+    case 2: go(sketch_wave_kernel<15, 11, true, false>); break;
+    case 3: go(sketch_wave_kernel<15, 11, true, true>); break;
     case 6: go(sketch_wave_kernel<15, 14, true, false>); break;
-    default: go(sketch_wave_kernel<15, 14, true, true>); break;
+    case 7: go(sketch_wave_kernel<15, 14, true, true>); break;
+#endif
+    default: return hipErrorInvalidValue;
     }
     HIP_TRY(hipGetLastError());
     if (timer.end) HIP_TRY(hipEventRecord(timer.end, stream));

@@ -95,6 +95,11 @@ int drprg_hip_allreduce(drprg_hip_ctx* ctx, void* comm, void* d_covg, void* d_pr
 
 void drprg_hip_close(drprg_hip_ctx* ctx);
 const char* drprg_hip_last_error(const drprg_hip_ctx* ctx);
+/* 1: the library was built with `make EXPERIMENTAL=1` -- it also holds the kernel forms that are bit-exact but measured slower than the
+ * defaults (the wave form of read_cluster, refine_kernel, in-kernel clustering of sketch_wave_kernel, read-by-read verification), each
+ * behind its environment switch (DRPRG_RC_FORM=wave, DRPRG_FILTER_FORM=refine, DRPRG_WAVE_FUSE=1, DRPRG_VERIFY_FORM=read).  0: the
+ * default build; those switches do nothing.  Nothing of the reference corresponds to it (test and measurement infrastructure). */
+int drprg_hip_experimental(void);
 
 int drprg_hip_set_opts(drprg_hip_ctx* ctx, const drprg_hip_map_opts* opts);
 /* The same with the caller's sizeof(drprg_hip_map_opts): -EINVAL when it differs from this library's (header / library mismatch). */

@@ -11,6 +11,8 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "experimental: parity cases of the kernel forms of `make EXPERIMENTAL=1` (bit-exact, measured slower than "
+                            "the defaults); run them with DRPRG_HIP_LIB=build/exp/libdrprg_hip.so pytest -m 'gpu and experimental'")
     from util import ensure_built
     ensure_built()
 
@@ -19,3 +21,14 @@ def pytest_configure(config):
 def oracle():
     from util import Oracle
     return Oracle()
+
+
+def pytest_collection_modifyitems(config, items):
+    """the experimental cases need the library of `make EXPERIMENTAL=1` (DRPRG_HIP_LIB=build/exp/libdrprg_hip.so): skipped on the default one"""
+    from drprg_amd import _lib
+    if _lib.lib.drprg_hip_experimental():
+        return
+    skip = pytest.mark.skip(reason="library built without EXPERIMENTAL=1")
+    for item in items:
+        if "experimental" in item.keywords:
+            item.add_marker(skip)
