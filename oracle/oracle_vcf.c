@@ -51,6 +51,24 @@
  * allele), kept only so that tests/test_kmer_count_kat.py can show that the fixture VCFs reject it. */
 static int g_overlap_rule = 0;
 ORC_API void orc_vcf_set_overlap_rule(int rule) { g_overlap_rule = rule; }
+/* Hypothesis scoring for the records that are printed with a padding base (tests/test_kmer_count_kat.py, tools/indel_rule_scan.py):
+ * rule 2 = for such records the k-mers at bases s with  R0 - k + dl <= s < R1 + dr,  [R0, R1) = the allele as printed (bare = 0) or
+ * without its padding base (bare = 1), R1 one further for an allele that is empty without it (empty_ext = 1); records without a
+ * padding base keep the default rule.  Test infrastructure only. */
+static int g_pad_bare = 0, g_pad_dl = 0, g_pad_dr = 0, g_pad_empty_ext = 0, g_all_dl = 0, g_all_dr = 0;
+/* ... and rule 3 = the same two offsets for EVERY record (the allele as printed) */
+ORC_API void orc_vcf_set_all_rule(int dl, int dr)
+{
+    g_all_dl = dl;
+    g_all_dr = dr;
+}
+ORC_API void orc_vcf_set_padded_rule(int bare, int dl, int dr, int empty_ext)
+{
+    g_pad_bare = bare;
+    g_pad_dl = dl;
+    g_pad_dr = dr;
+    g_pad_empty_ext = empty_ext;
+}
 
 typedef struct {
     int marker, level;
@@ -264,7 +282,7 @@ static int u32_cmp(const void* a, const void* b)
 
 /* ids (1..n) of the k-mer nodes on walk[0..n_walk) that count for the allele at bases [A, B) of the walk; sorted */
 static uint32_t allele_kmers(const orc_kgraph* g, const uint32_t* sorted_kn, const uint32_t* walk, uint32_t n_walk, uint32_t A, uint32_t B,
-    uint32_t* out, uint32_t cap)
+    uint32_t* out, uint32_t cap, int dl, int dr)
 {
     /* the walk written out: one item per base and per crossed empty node */
     uint32_t n_items = 0;
@@ -295,9 +313,9 @@ static uint32_t allele_kmers(const orc_kgraph* g, const uint32_t* sorted_kn, con
     if (g_overlap_rule == 1) { /* the rule of rounds 1-3: strict overlap with the unpadded allele (kept so that the test can show the fixtures reject it) */
         lo = (int64_t)A - k + 1;
         hi = (A == B) ? (int64_t)A : (int64_t)B;
-    } else { /* s < B and s + k >= A */
-        lo = (int64_t)A - k;
-        hi = (int64_t)B;
+    } else { /* s < B and s + k >= A (dl = dr = 0; rule 2 moves the ends for records with a padding base) */
+        lo = (int64_t)A - k + dl;
+        hi = (int64_t)B + dr;
     }
     if (lo < 0) lo = 0;
     for (int64_t s = lo; s < hi && s + k <= (int64_t)n_bases; ++s) {
@@ -531,11 +549,24 @@ ORC_API char* orc_vcf_sites(const orc_kgraph* g, const char* refseq)
                 for (uint32_t i = iq; i < n_path; ++i) walk[nw++] = path[i];
                 /* the range is the allele as printed: the padding base belongs to it (rule 1: the bare allele) */
                 uint32_t PA = A, PB = B;
+                int dl = 0, dr = 0;
                 if (g_overlap_rule != 1) {
                     if (pad_l[0]) PA = A - 1;
                     if (pad_r[0]) PB = B + 1;
                 }
-                const uint32_t n = allele_kmers(g, sorted_kn, walk, nw, PA, PB, ids, g->n_kn);
+                if (g_overlap_rule == 2 && (pad_l[0] || pad_r[0])) {
+                    if (g_pad_bare) {
+                        PA = A;
+                        PB = B;
+                    }
+                    dl = g_pad_dl;
+                    dr = g_pad_dr + (g_pad_empty_ext && A == B ? 1 : 0);
+                }
+                if (g_overlap_rule == 3) {
+                    dl = g_all_dl;
+                    dr = g_all_dr;
+                }
+                const uint32_t n = allele_kmers(g, sorted_kn, walk, nw, PA, PB, ids, g->n_kn, dl, dr);
                 sb_str(&body, head.buf);
                 sb_str(&body, "\t");
                 sb_u(&body, al);

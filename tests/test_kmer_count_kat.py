@@ -7,7 +7,8 @@ the PRG sketch (which k-mers are k-mer-graph nodes) and the rule that assigns k-
 (tools/make_golden.py) holds, per allele, the set of n its statistics admit.  Here the oracle (oracle_index.c + oracle_vcf.c) and the
 product index a PRG made of each fixture's own sites (genes.fa + that VCF's REF / ALT records) and their n is held against that set:
 
-  * with minimap's hash64, k = 15 and the window size the fixture was made with, 316 of the 322 informative alleles agree (3 of the 6
+  * with minimap's hash64, k = 15 and the window size the fixture was made with, 318 of the 324 informative alleles agree (round 5: the
+    MED_* fields joined SUM / MEAN / GAPS in the feasibility filter and made two more alleles informative; both agree) (3 of the 6
     that do not are the records SURVEY.md section 8a lists as hand-assembled); four control hashes reach a quarter to a third;
   * the fixtures come from two index generations: in*.vcf (fileDate 11/2022) agree at w = 14 (pandora's default), the three 2023 files
     at w = 11 (the w of tests/cases/predict/.config.toml, mtb-20230308) -- a scan over w peaks exactly there, a scan over k at 15;
@@ -33,8 +34,12 @@ KNOWN_MISMATCHES = {
     ("in.vcf", "ddn", 627, 1): "hand-edited record (SURVEY 8a: GAPS edited, no n fits SUM / MEAN / GAPS)",
     ("in.vcf", "katG", 1044, 0): "hand-edited record (SURVEY 8a: MEAN edited, SUM is 0)",
     ("in4.vcf", "fabG1", 92, 1): "hand-assembled record (SURVEY 8a: spliced from another sample; VC=SNP on a two-base REF)",
-    ("in.vcf", "embA", 69, 1): "unexplained: deletion GC -> G, oracle 3, fixture 4",
-    ("in.vcf", "gid", 160, 0): "unexplained: deletion GC -> G, oracle 4, fixture 3",
+    # (round 5, test_the_two_deletions below: no rule for padded records does better than the default one, every uniform shift of the rule
+    # loses 40+ alleles, and all three records lie within w + k - 1 bases of catalogue sites the fixture does not list)
+    ("in.vcf", "embA", 69, 1): "unseen neighbours (panel.bcf embA 85, 89): deletion GC -> G inside a run of C, oracle 3 (one of them covered by REF "
+                               "reads: it spells a REF k-mer), fixture 4 (one covered, three not): one uncovered k-mer node short",
+    ("in.vcf", "gid", 160, 0): "unseen neighbours (panel.bcf gid 155-157, 176-178): deletion GC -> G, oracle 4, fixture 3: the k-mer that ends on the "
+                               "padding base is a node here (a minimizer on the deletion's walk only) and is not among pandora's",
     ("in.vcf", "gyrA", 362, 0): "unseen neighbours: codon 88-91 of gyrA holds seven catalogue sites (panel.bcf 362-371) that in.vcf does not list; oracle 3, fixture 4",
 }
 
@@ -85,7 +90,7 @@ def _score(counts):
 def test_golden_file_shape():
     assert set(KAT) == set(FILE_W)
     n_inf = sum(f is not None and f != [] for recs in KAT.values() for r in recs for f in r["feasible"])
-    assert n_inf == 321
+    assert n_inf == 323  # (321 from SUM / MEAN / GAPS; the medians make two more alleles informative: round 5)
     # the integer-mean rule itself: ahpC:19 allele 2 of in.vcf (SUM 29 over 3 k-mers -> MEAN 9) admits exactly n = 3
     r = next(r for r in KAT["in.vcf"] if (r["chrom"], r["pos"]) == ("ahpC", 19))
     assert r["feasible"][0] == [5] and r["feasible"][2] == [3]
@@ -107,8 +112,8 @@ def test_hash64_explains_the_fixture_counts_and_control_hashes_do_not(oracle):
     finally:
         oracle.set_hash_mode(0)
     ok, tot, per = rates["hash64"]
-    assert (ok, tot) == (316, 322), rates["hash64"]
-    assert per["in.vcf"] == (259, 264) and per["SRR6824468.vcf"] == (16, 16) and per["ERR2510634.drprg.vcf"] == (9, 9) and per["in2.vcf"] == (13, 13)
+    assert (ok, tot) == (318, 324), rates["hash64"]
+    assert per["in.vcf"] == (261, 266) and per["SRR6824468.vcf"] == (16, 16) and per["ERR2510634.drprg.vcf"] == (9, 9) and per["in2.vcf"] == (13, 13)
     best_control = max(v[0] for k, v in rates.items() if k != "hash64")
     assert ok >= 2 * best_control and best_control <= 0.4 * tot, {k: v[:2] for k, v in rates.items()}
 
@@ -144,7 +149,7 @@ def test_fixtures_reject_the_strict_overlap_rule(oracle):
     finally:
         oracle.lib.orc_vcf_set_overlap_rule(0)
     new = _score(_oracle_counts(oracle, "in.vcf", 14))
-    assert old == (204, 264) and new == (259, 264)
+    assert old == (206, 266) and new == (261, 266)
     # every allele the old rule got wrong and the new one gets right has one k-mer MORE in the fixture than the old rule counted
     oracle.lib.orc_vcf_set_overlap_rule(1)
     try:
@@ -203,3 +208,80 @@ def test_product_counts_equal_oracle_counts(tmp_path, oracle):
                 assert n == want[(r["chrom"], r["pos"], a)][0]
                 got_ok += n in feas
         assert got_ok == _score(want)[0]
+
+
+def _padded(r):
+    alls = [r["ref"]] + r["alts"]
+    return len({len(a) for a in alls}) > 1 and all(a[:1] == r["ref"][:1] for a in alls) and min(len(a) for a in alls) == 1
+
+
+def _score_all(oracle):
+    ok = tot = 0
+    for f, w in FILE_W.items():
+        a, b = _score(_oracle_counts(oracle, f, w))
+        ok += a
+        tot += b
+    return ok, tot
+
+
+def test_the_two_deletions(oracle):
+    """in.vcf embA:69 ALT (oracle 3, fixture 4) and gid:160 REF (oracle 4, fixture 3), both GC -> G.  What the fixtures
+    say about them (tools/indel_rule_scan.py prints the whole table, DESIGN.md section 5 quotes it):
+      * the allele -> k-mer rule is a sharp optimum: moving either end of the range by one base for EVERY record loses 42 alleles or more,
+        and no rule for the records with a padding base -- printed or bare range, either end moved by -1 .. +2, an empty allele made one
+        base wide -- explains more than the default's 15 of their 18 informative alleles; none explains the two deletions together;
+      * embA:69: the deleted C lies in a run (GCCCT): the ALT k-mer that crosses the deletion by one base spells the REF k-mer at the same
+        place (same hash), so REF reads cover it -- the fixture's ALT has exactly one covered k-mer (35 / 36 against the REF k-mers' 40)
+        and three bare ones; this build has the covered one and two bare ones: ONE uncovered node short;
+      * all three genuine mismatches (with gyrA:362) lie within w + k - 1 bases of a catalogue site (panel.bcf) that in.vcf does not list,
+        and the three mismatches that do not are the hand-edited records: the counts there depend on PRG structure the fixture does not show
+        (126 of the 129 alleles with such a neighbour agree all the same)."""
+    L = oracle.lib
+    base = _score_all(oracle)
+    assert base == (318, 324)
+    try:
+        L.orc_vcf_set_overlap_rule(3)
+        for dl, dr in ((-1, 0), (1, 0), (0, -1), (0, 1)):
+            L.orc_vcf_set_all_rule(dl, dr)
+            assert _score_all(oracle)[0] <= 276, (dl, dr)
+        L.orc_vcf_set_overlap_rule(2)
+        best = 0
+        for bare in (0, 1):
+            for dl in (-1, 0, 1, 2):
+                for dr in (-1, 0, 1):
+                    for ext in (0, 1):
+                        L.orc_vcf_set_padded_rule(bare, dl, dr, ext)
+                        c = _oracle_counts(oracle, "in.vcf", 14)
+                        both = c[("embA", 69, 1)][0] in c[("embA", 69, 1)][1] and c[("gid", 160, 0)][0] in c[("gid", 160, 0)][1]
+                        assert not both, (bare, dl, dr, ext)
+                        best = max(best, _score_all(oracle)[0])
+        assert best == 318
+    finally:
+        L.orc_vcf_set_overlap_rule(0)
+        L.orc_vcf_set_padded_rule(0, 0, 0, 0)
+        L.orc_vcf_set_all_rule(0, 0)
+    # embA:69: the ALT k-mer that crosses the deletion by one base and the REF k-mer over the deleted base share their hash
+    names, prgs, _ = flat_prgs_from_sites(GENES, KAT["in.vcf"])
+    prg = dict(zip(names, prgs))["embA"]
+    sk = oracle.sketch_prg(prg, 14, K, paths=True)
+    rec = next(r for r in oracle.vcf_sites(prg, 14, K, GENES["embA"])[0] if r["pos"] == 69)
+    ref_h = {int(sk["hash"][i - 1]) for i in rec["knodes"][0]}
+    alt_h = [int(sk["hash"][i - 1]) for i in rec["knodes"][1]]
+    assert len(alt_h) == 3 and sum(h in ref_h for h in alt_h) == 1
+    # every mismatch that is not a hand-edited record has a catalogue site within w + k - 1 bases that the fixture does not list
+    from drprg_amd import bcf_lite
+    sites = {}
+    for r in bcf_lite.read_bcf(os.path.join(GOLDEN, "downstream", "panel.bcf")):
+        sites.setdefault(r["chrom"], set()).add(r["pos"] + 1)  # (bcf_lite positions are 0-based)
+    near = {True: [0, 0], False: [0, 0]}
+    for f, w in FILE_W.items():
+        listed = {}
+        for r in KAT[f]:
+            listed.setdefault(r["chrom"], set()).update(range(r["pos"], r["pos"] + len(r["ref"])))
+        for (chrom, pos, a), (n, feas) in _oracle_counts(oracle, f, w).items():
+            unseen = any(abs(p - pos) <= w + K - 1 and not any(q in listed.get(chrom, ()) for q in range(p, p + 3)) for p in sites.get(chrom, ()))
+            near[unseen][0] += n in feas
+            near[unseen][1] += 1
+            if n not in feas:
+                assert unseen == ("hand" not in KNOWN_MISMATCHES[(f, chrom, pos, a)]), (f, chrom, pos, a)
+    assert near == {True: [126, 129], False: [192, 195]}
