@@ -146,7 +146,8 @@ def test_short_reads_bit_exact(tmp_path, oracle, w, k, kernel):
     bases, offs = synth.sample_short_reads(gen, 20000, seed=5)
     cnt = _compare(ctx, oracle, bases, offs, w, k, True, kernel)
     assert cnt["clusters_kept"] > 0
-    if k >= 13 and not FORCED_GENERIC:  # (a 9-mer index matches everywhere: dozens of one-hit clusters per read)
+    if k >= 13 and w > 1 and not FORCED_GENERIC:  # (a 9-mer index matches everywhere: dozens of one-hit clusters per read; with w = 1
+        # every k-mer is a minimizer: a read inside a locus carries 136 candidates, more than the look-ahead of a short-read chunk holds)
         assert ctx.counters()["leftover_reads"] == 0  # ordinary short reads never need the generic pipeline
 
 
