@@ -1257,16 +1257,29 @@ void Mapper::select_reads_with_anchors(std::vector<uint64_t> anchors, uint32_t A
     HIPCHK(hipMemcpyAsync(d_anchors, anchors.data(), anchors.size() * sizeof(uint64_t), hipMemcpyHostToDevice, stream_));
     HIPCHK(hipMemcpyAsync(d_pf, pf.data(), pf.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
     HIPCHK(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), stream_));
-    // batches kept in the packed form: the scan and the gather read an ASCII expansion, made here for the duration of this call
-    // (all of them at once: the selected reads are gathered after the last scan)
-    std::vector<const uint8_t*> ascii(kept_.size(), nullptr);
-    {
+    // Batches kept in the packed form: the scan and the gather read an ASCII expansion.  It is made a WINDOW of batches at a time -- as
+    // many consecutive batches as expand into <= 1 GB (a larger batch alone) --, scanned, and its selected reads gathered before the next
+    // window's expansion takes the scratch: the scratch is the largest window, not the sample (up to 128 Gbases can stay
+    // resident packed; expanding all of them at once needed that much memory again, with no way back to the file pass).
+    auto expanded = [](const KeptBatch& kb) -> uint64_t { return kb.packed ? (kb.n_bases + 15) / 16 * 16 + 64 : 0; };
+    constexpr uint64_t WINDOW_BYTES = 1ull << 30;
+    std::vector<std::pair<size_t, size_t>> windows; // [first batch, one past the last)
+    uint64_t scratch_need = 0;
+    for (size_t b = 0; b < kept_.size();) {
+        size_t e = b;
         uint64_t need = 0;
-        for (const KeptBatch& kb : kept_)
-            if (kb.packed) need += (kb.n_bases + 15) / 16 * 16 + 64;
-        uint8_t* d_ascii = need ? static_cast<uint8_t*>(scratch.get(need)) : nullptr;
+        do need += expanded(kept_[e++]);
+        while (e < kept_.size() && need + expanded(kept_[e]) <= WINDOW_BYTES);
+        windows.emplace_back(b, e);
+        scratch_need = std::max(scratch_need, need);
+        b = e;
+    }
+    uint8_t* d_ascii = scratch_need ? static_cast<uint8_t*>(scratch.get(scratch_need)) : nullptr;
+    std::vector<const uint8_t*> ascii(kept_.size(), nullptr);
+    unsigned long long done = 0; // entries of d_list the windows before this one left
+    for (const auto& win : windows) {
         uint64_t at = 0;
-        for (size_t b = 0; b < kept_.size(); ++b) {
+        for (size_t b = win.first; b < win.second; ++b) {
             const KeptBatch& kb = kept_[b];
             if (!kb.packed) {
                 ascii[b] = kb.d_bases;
@@ -1274,41 +1287,50 @@ void Mapper::select_reads_with_anchors(std::vector<uint64_t> anchors, uint32_t A
             }
             HIPCHK(dev::launch_unpack(reinterpret_cast<const uint32_t*>(kb.d_bases), kb.n_bases, kb.d_npos, kb.n_npos, d_ascii + at, stream_));
             ascii[b] = d_ascii + at;
-            at += (kb.n_bases + 15) / 16 * 16 + 64;
+            at += expanded(kb);
         }
+        for (size_t b = win.first; b < win.second; ++b) {
+            const KeptBatch& kb = kept_[b];
+            HIPCHK(hipMemsetAsync(d_flags, 0, kb.n_reads * sizeof(uint32_t), stream_));
+            HIPCHK(dev::launch_anchor_scan(ascii[b], kb.d_offsets, (uint32_t)kb.n_reads, kb.n_bases, d_anchors, (uint32_t)anchors.size(), A, d_pf, (uint32_t)b,
+                d_flags, d_count, d_list, total_reads, n_cus_, stream_));
+        }
+        unsigned long long count = 0;
+        HIPCHK(hipMemcpyAsync(&count, d_count, sizeof count, hipMemcpyDeviceToHost, stream_));
+        HIPCHK(hipStreamSynchronize(stream_));
+        if (count > total_reads) throw Error(DRPRG_EIO, "read selection: more reads than the batches hold"); // (each read is appended once)
+        if (count == done) continue;
+        std::vector<dev::SelectedRead> list(count - done);
+        HIPCHK(hipMemcpy(list.data(), d_list + done, (count - done) * sizeof(dev::SelectedRead), hipMemcpyDeviceToHost));
+        done = count;
+        std::sort(list.begin(), list.end(), [](const dev::SelectedRead& x, const dev::SelectedRead& y) { return x.batch != y.batch ? x.batch < y.batch : x.read < y.read; });
+        std::vector<dev::GatherEntry> table(list.size());
+        uint64_t out_bytes = 0;
+        for (size_t i = 0; i < list.size(); ++i) {
+            table[i].src = ascii[list[i].batch] + list[i].offset;
+            table[i].dst = out_bytes;
+            table[i].len = list[i].len;
+            table[i].pad = 0;
+            out_bytes += list[i].len;
+        }
+        // (device memory of this window only: freed before the next one)
+        dev::GatherEntry* d_table = nullptr;
+        uint8_t* d_out = nullptr;
+        if (hipMalloc((void**)&d_table, list.size() * sizeof(dev::GatherEntry)) != hipSuccess || hipMalloc((void**)&d_out, out_bytes ? out_bytes : 16) != hipSuccess) {
+            if (d_table) (void)hipFree(d_table);
+            throw Error(DRPRG_ENOMEM, "out of device memory (read selection)");
+        }
+        const size_t base0 = bases.size();
+        bases.resize(base0 + out_bytes);
+        hipError_t e = hipMemcpyAsync(d_table, table.data(), list.size() * sizeof(dev::GatherEntry), hipMemcpyHostToDevice, stream_);
+        if (e == hipSuccess) e = dev::launch_gather_reads(d_table, (uint32_t)list.size(), d_out, stream_);
+        if (e == hipSuccess && out_bytes) e = hipMemcpyAsync(bases.data() + base0, d_out, out_bytes, hipMemcpyDeviceToHost, stream_);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream_);
+        (void)hipFree(d_table);
+        (void)hipFree(d_out);
+        HIPCHK(e);
+        for (size_t i = 0; i < list.size(); ++i) offsets.push_back(offsets.back() + list[i].len);
     }
-    for (size_t b = 0; b < kept_.size(); ++b) {
-        const KeptBatch& kb = kept_[b];
-        HIPCHK(hipMemsetAsync(d_flags, 0, kb.n_reads * sizeof(uint32_t), stream_));
-        HIPCHK(dev::launch_anchor_scan(ascii[b], kb.d_offsets, (uint32_t)kb.n_reads, kb.n_bases, d_anchors, (uint32_t)anchors.size(), A, d_pf, (uint32_t)b,
-            d_flags, d_count, d_list, total_reads, n_cus_, stream_));
-    }
-    unsigned long long count = 0;
-    HIPCHK(hipMemcpyAsync(&count, d_count, sizeof count, hipMemcpyDeviceToHost, stream_));
-    HIPCHK(hipStreamSynchronize(stream_));
-    if (count > total_reads) throw Error(DRPRG_EIO, "read selection: more reads than the batches hold"); // (each read is appended once)
-    if (count == 0) return;
-    std::vector<dev::SelectedRead> list(count);
-    HIPCHK(hipMemcpy(list.data(), d_list, count * sizeof(dev::SelectedRead), hipMemcpyDeviceToHost));
-    std::sort(list.begin(), list.end(), [](const dev::SelectedRead& x, const dev::SelectedRead& y) { return x.batch != y.batch ? x.batch < y.batch : x.read < y.read; });
-    std::vector<dev::GatherEntry> table(count);
-    uint64_t at = 0;
-    for (size_t i = 0; i < count; ++i) {
-        table[i].src = ascii[list[i].batch] + list[i].offset;
-        table[i].dst = at;
-        table[i].len = list[i].len;
-        table[i].pad = 0;
-        at += list[i].len;
-    }
-    dev::GatherEntry* d_table = static_cast<dev::GatherEntry*>(scratch.get(count * sizeof(dev::GatherEntry)));
-    uint8_t* d_out = static_cast<uint8_t*>(scratch.get(at));
-    HIPCHK(hipMemcpyAsync(d_table, table.data(), count * sizeof(dev::GatherEntry), hipMemcpyHostToDevice, stream_));
-    HIPCHK(dev::launch_gather_reads(d_table, (uint32_t)count, d_out, stream_));
-    const size_t base0 = bases.size();
-    bases.resize(base0 + at);
-    if (at) HIPCHK(hipMemcpyAsync(bases.data() + base0, d_out, at, hipMemcpyDeviceToHost, stream_));
-    HIPCHK(hipStreamSynchronize(stream_));
-    for (size_t i = 0; i < count; ++i) offsets.push_back(offsets.back() + list[i].len);
 }
 
 void Mapper::map_host_async(const uint8_t* bases, const uint64_t* offsets, uint64_t n_reads)
