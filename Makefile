@@ -17,6 +17,10 @@ LIB  := drprg_amd/lib/libdrprg_hip.so
 # environment switches, into a library of its own (build/exp/libdrprg_hip.so; DRPRG_HIP_LIB=... selects it, pytest -m "gpu and
 # experimental" runs their parity cases).  The default build does not contain them.
 EXPERIMENTAL ?= 0
+# EXTRA_DEFS: build-time knobs for measurement builds (tools/rc_variants.sh), e.g. make OBJD=build/obj_x LIB=build/x/libdrprg_hip.so EXTRA_DEFS=-DDRPRG_RC_PER=4
+EXTRA_DEFS ?=
+CXXFLAGS += $(EXTRA_DEFS)
+HIPFLAGS += $(EXTRA_DEFS)
 ifeq ($(EXPERIMENTAL),1)
 CXXFLAGS += -DDRPRG_EXPERIMENTAL=1
 HIPFLAGS += -DDRPRG_EXPERIMENTAL=1

@@ -32,14 +32,19 @@ namespace dev {
 // nothing else.)  Chunks are handed out through a global counter.
 constexpr int RC_THREADS = 1024;
 constexpr int RC_WAVES = RC_THREADS / 64;
-constexpr int RC_PER = 2;
+#ifndef DRPRG_RC_PER // (build-time knobs of tools/rc_variants.sh: slots per thread, staged hits, workgroups per CU)
+#define DRPRG_RC_PER 2
+#define DRPRG_RC_HCAP 3072
+#define DRPRG_RC_WG_PER_CU 2
+#endif
+constexpr int RC_PER = DRPRG_RC_PER;
 constexpr int RC_SLOTS = RC_THREADS * RC_PER; // staged candidates
 // Look-ahead (template parameter AHEAD; RC_AHEAD / RC_OWN are defined at the top of the kernel): a read belongs to the chunk that owns its
 // first candidate, so the last AHEAD of the staged slots are there for reads that begin in the owned range and run on.  512 slots serve
 // a 4 kb Nanopore read (~250 candidates); a 150-base read has a few dozen at most, and every slot not spent on look-ahead is owned:
 // 128 slots of look-ahead mean 1920 owned candidates per chunk instead of 1536, a fifth fewer chunks -- and a chunk costs ~21 us whatever
 // is in it (round 4).  A read that does not fit its chunk's look-ahead goes through the generic pipeline as before.
-constexpr int RC_HCAP = 3072;                 // staged hits
+constexpr int RC_HCAP = DRPRG_RC_HCAP;         // staged hits
 constexpr int RC_POOL = 512;                  // reads per chunk that may take the wave path (sketch_wave_kernel clusters the plain reads itself: what is left is rich in these)
 constexpr uint32_t RC_IRREGULAR = 2u, RC_COMPLEX = 1u;
 
@@ -60,10 +65,10 @@ __device__ __forceinline__ void lds_barrier(int& t) { asm volatile("s_waitcnt lg
 
 // SLICES: the candidates are read from the tile slices of the direct sketch kernel (rc.slice_prefix), not from a gathered list
 template <bool SLICES, int AHEAD>
-__global__ __launch_bounds__(RC_THREADS, 8) void read_cluster_kernel(SketchArgs a, FilterWork fw, ReadClusterArgs rc)
+__global__ __launch_bounds__(RC_THREADS, 4 * DRPRG_RC_WG_PER_CU) void read_cluster_kernel(SketchArgs a, FilterWork fw, ReadClusterArgs rc)
 {
     constexpr int RC_AHEAD = AHEAD, RC_OWN = RC_SLOTS - AHEAD;
-    static_assert(AHEAD != 512 || RC_OWN == (int)RC_CHUNK_OWN, "kernels.h RC_CHUNK_OWN: the chunk numbering the wave form's flags use");
+    static_assert(RC_PER != 2 || AHEAD != 512 || RC_OWN == (int)RC_CHUNK_OWN, "kernels.h RC_CHUNK_OWN: the chunk numbering the wave form's flags use");
     static_assert(RC_OWN % 64 == 0, "the slices form locates 64 entries from a multiple of 64 per wave");
     (void)RC_AHEAD;
     extern __shared__ uint32_t s_hist[]; // clusters kept per PRG
@@ -712,7 +717,7 @@ hipError_t launch_read_cluster(const SketchArgs& a, const FilterWork& fw, const 
     static size_t configured[6][MAX_HIP_DEVICES] = {};
     auto launch = [&](auto kernel, size_t (&conf)[MAX_HIP_DEVICES]) -> hipError_t {
         HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), dyn, conf));
-        hipLaunchKernelGGL(kernel, dim3((uint32_t)n_cus * 2), dim3(RC_THREADS), dyn, stream, a, fw, rcd);
+        hipLaunchKernelGGL(kernel, dim3((uint32_t)n_cus * DRPRG_RC_WG_PER_CU), dim3(RC_THREADS), dyn, stream, a, fw, rcd);
         return hipGetLastError();
     };
     if (rcd.slice_prefix) {
