@@ -102,6 +102,110 @@ __global__ __launch_bounds__(EX_THREADS) void verify_count_kernel(SketchArgs a, 
     }
 }
 
+// The same kernel WITHOUT cand_scan_kernel and cand_gather_kernel in front of it (round 5: 10 + 12 us of a 0.59 ms step, one workgroup's
+// latency and a copy of 14 MB).  Every workgroup scans the slice counts itself -- 8192 words, 32 per thread, one coalesced round trip and
+// a block scan: 64 MB of L2 reads over the whole grid -- takes its share [t_begin, t_end) of the ordered list from the total, and reads
+// the positions of its candidates straight from the filter kernel's slices: entry t lives in the slice s with prefix[s] <= t <
+// prefix[s + 1], at raw_pos[s * raw_slice + t - prefix[s]].  The prefixes of the 64 slices from the one that holds the workgroup's next
+// candidate sit in LDS (a workgroup's share is four or five slices of a full batch; a sparse batch takes several such windows), every
+// candidate bisects them.  Workgroup 0 leaves the total where read_cluster_kernel and the generic pipeline look for it (*fw.cand_total).
+// The dense list of positions (fw.cand_gp) is not made: only the experimental read-by-read form wants it, and gets the old sequence.
+constexpr int VS_PER = MAX_SLICES / EX_THREADS; // slices per thread of the scan
+constexpr int VS_WINDOW = 64;                   // slices whose prefixes a window holds
+template <int KC, bool PACKED>
+__global__ __launch_bounds__(EX_THREADS) void verify_scan_kernel(SketchArgs a, FilterWork fw, ReadClusterArgs rc)
+{
+    __shared__ uint32_t s_red[3][EX_THREADS / 64];
+    __shared__ uint32_t s_w[EX_THREADS / 64 + 1];
+    __shared__ uint32_t s_fine[VS_WINDOW + 1]; // exclusive prefix of slices s_first .. s_first + VS_WINDOW
+    __shared__ uint32_t s_first;
+    const int tid = threadIdx.x;
+    // ---- the scan: my VS_PER consecutive slices (clamped counts, as cand_scan_kernel: an overflowing slice holds raw_slice entries).
+    //      Only their sum stays in a register: 32 counts kept across the kernel cost half the occupancy (135 VGPRs against 55) ----
+    auto my_count = [&](int i4) -> uint4 { // counts 4 i4 .. 4 i4 + 3 of this thread's slices
+        const uint4* __restrict__ c4 = reinterpret_cast<const uint4*>(fw.slice_count + (size_t)tid * VS_PER); // (b.small is 16-byte aligned; VS_PER is a multiple of 4)
+        uint4 v = (uint32_t)tid * VS_PER + 4u * (uint32_t)i4 < fw.n_slices ? c4[i4] : make_uint4(0, 0, 0, 0); // (n_slices is a multiple of 32)
+        v.x = v.x < fw.raw_slice ? v.x : fw.raw_slice;
+        v.y = v.y < fw.raw_slice ? v.y : fw.raw_slice;
+        v.z = v.z < fw.raw_slice ? v.z : fw.raw_slice;
+        v.w = v.w < fw.raw_slice ? v.w : fw.raw_slice;
+        return v;
+    };
+    uint32_t run = 0;
+    {
+        uint4 v[VS_PER / 4];
+#pragma unroll
+        for (int i = 0; i < VS_PER / 4; ++i) v[i] = my_count(i); // (all eight loads before the first sum)
+#pragma unroll
+        for (int i = 0; i < VS_PER / 4; ++i) run += v[i].x + v[i].y + v[i].z + v[i].w;
+    }
+    uint32_t total;
+    const uint32_t before = block_exclusive_scan<EX_THREADS / 64>(run, s_w, &total);
+    if (blockIdx.x == 0 && tid == 0) fw.cand_prefix[fw.n_slices] = total; // = *fw.cand_total
+    const uint32_t per_wg = (total + gridDim.x - 1) / gridDim.x;
+    const uint64_t b64 = (uint64_t)blockIdx.x * per_wg;
+    const uint32_t t_begin = b64 < total ? (uint32_t)b64 : total, t_end = b64 + per_wg < total ? (uint32_t)(b64 + per_wg) : total;
+    const VerifyConsts c(a, fw);
+    uint32_t my_hits = 0, my_nmin = 0, my_maxlen = 0;
+    for (uint32_t cur = t_begin; cur < t_end;) { // (wave-uniform: one window of VS_WINDOW slices per round)
+        // entry `cur` lies in the slices of exactly one thread of the scan: the window starts at that thread's first slice
+        if (before <= cur && cur < before + run) {
+            s_first = (uint32_t)tid * VS_PER;
+            s_fine[0] = before;
+        }
+        __syncthreads();
+        const uint32_t sf = s_first;
+        if (tid < 64) { // the prefixes of slices sf + 1 .. sf + VS_WINDOW (a slice past the last one: nothing in it): one load, one wave scan
+            const uint32_t sl = sf + (uint32_t)tid;
+            uint32_t n = sl < fw.n_slices ? fw.slice_count[sl] : 0u;
+            n = n < fw.raw_slice ? n : fw.raw_slice;
+            const uint32_t incl = wave_inclusive_scan(n);
+            s_fine[tid + 1] = s_fine[0] + incl; // (s_fine[0] was written before the barrier; nobody writes it here)
+        }
+        __syncthreads();
+        const uint32_t w_end = t_end < s_fine[VS_WINDOW] ? t_end : s_fine[VS_WINDOW]; // (> cur: entry cur lies in the window's first VS_PER slices)
+        auto position_of = [&](uint32_t t) -> int64_t { // entry t of the ordered list, cur <= t < w_end
+            uint32_t lo = 0;
+#pragma unroll
+            for (int step = VS_WINDOW / 2; step >= 1; step >>= 1)
+                if (s_fine[lo + step] <= t) lo += step; // largest j with s_fine[j] <= t
+            return (int64_t)fw.raw_pos[(size_t)(sf + lo) * fw.raw_slice + (t - s_fine[lo])];
+        };
+        // (the position of this thread's next candidate is requested one round early: one round trip less in the chain of each)
+        int64_t gp_next = cur + tid < w_end ? position_of(cur + (uint32_t)tid) : 0;
+        for (uint32_t t = cur + (uint32_t)tid; t < w_end; t += EX_THREADS) {
+            const int64_t gp = gp_next;
+            if (t + EX_THREADS < w_end) gp_next = position_of(t + EX_THREADS);
+            VerifyOut o;
+            verify_one_lane<KC, PACKED>(a, fw, rc, c, gp, o, my_hits, my_nmin, my_maxlen);
+            fw.cand_pos1[t] = o.pos1;
+            fw.cand_info[t] = ((uint64_t)o.slot << 32) | ((uint64_t)o.strand << 31) | (uint64_t)o.read;
+            fw.cand_rec[t] = o.crec;
+        }
+        cur = w_end;
+        __syncthreads(); // (s_first and s_fine are written again)
+    }
+    // ---- per-workgroup totals ----
+    const uint32_t wh = wave_inclusive_scan(my_hits), wn = wave_inclusive_scan(my_nmin), wm = wave_max(my_maxlen);
+    if ((tid & 63) == 63) {
+        s_red[0][tid >> 6] = wh;
+        s_red[1][tid >> 6] = wn;
+        s_red[2][tid >> 6] = wm;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t h = 0, n = 0, mx = 0;
+        for (int i = 0; i < EX_THREADS / 64; ++i) {
+            h += s_red[0][i];
+            n += s_red[1][i];
+            mx = s_red[2][i] > mx ? s_red[2][i] : mx;
+        }
+        fw.wg_hits[blockIdx.x] = h;
+        fw.wg_nmin[blockIdx.x] = n;
+        fw.wg_maxlen[blockIdx.x] = mx;
+    }
+}
+
 // (Round 3 built a wave-cooperative form of this kernel -- the 64 consecutive candidates of a wave work out which k-mer positions
 // their windows need, hash each ONCE, four per lane, into LDS, and read their neighbours from there -- and measured it slower than
 // one lane per candidate on every index size: 151 against 118-132 us on the 8d index, 1.06 against 0.82 ms on the 8-fold one.  The
@@ -402,23 +506,38 @@ __global__ __launch_bounds__(TG_THREADS) void tile_gather_kernel(SketchArgs a, F
 // launch -- a workgroup summing what lies before its 64 slices -- took 19.4 us against 9.1 + 11.8: cand_scan_kernel stays.)
 hipError_t launch_candidate_stage(const SketchArgs& a, FilterWork& fw, const ReadClusterArgs& rc, int n_cus, hipStream_t stream, bool with_totals)
 {
-    hipLaunchKernelGGL(cand_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, fw);
-    hipLaunchKernelGGL(cand_gather_kernel, dim3(fw.n_slices), dim3(64), 0, stream, fw);
-    // One lane per candidate.  (make EXPERIMENTAL=1 + DRPRG_VERIFY_FORM=read: short-read batches at k = 15, w in {11, 14} read by read --
-    // read_verify.hip, round 5: bit-exact and 8 % slower, profiles/r05/read_verify.txt)
     fw.verify_grid = fw.ex_grid;
     (void)n_cus;
+    // DRPRG_VERIFY_FORM=gather keeps the three-kernel sequence of rounds 1-4 (A/B runs, a second way through the parity tests); the
+    // experimental read-by-read form (make EXPERIMENTAL=1 + DRPRG_VERIFY_FORM=read: read_verify.hip, bit-exact and 8 % slower,
+    // profiles/r05/read_verify.txt) needs the gathered list of positions as well
+    const char* form = std::getenv("DRPRG_VERIFY_FORM");
+    bool gathered = form && std::string(form) == "gather";
 #ifdef DRPRG_EXPERIMENTAL
-    if (read_verify_applies(a, fw)) {
-        fw.verify_grid = std::min<uint32_t>(read_verify_grid(n_cus), MAX_EX_WG);
-        HIP_TRY(launch_read_verify(a, fw, rc, fw.verify_grid, stream));
-    } else
+    const bool by_read = read_verify_applies(a, fw);
+    gathered = gathered || by_read;
 #endif
-    if (a.packed) {
-        if (a.k == 15) hipLaunchKernelGGL((verify_count_kernel<15, true>), dim3(fw.ex_grid), dim3(EX_THREADS), 0, stream, a, fw, rc);
-        else hipLaunchKernelGGL((verify_count_kernel<0, true>), dim3(fw.ex_grid), dim3(EX_THREADS), 0, stream, a, fw, rc);
-    } else if (a.k == 15) hipLaunchKernelGGL((verify_count_kernel<15, false>), dim3(fw.ex_grid), dim3(EX_THREADS), 0, stream, a, fw, rc);
-    else hipLaunchKernelGGL((verify_count_kernel<0, false>), dim3(fw.ex_grid), dim3(EX_THREADS), 0, stream, a, fw, rc);
+    if (!gathered) { // one launch: verify_scan_kernel scans the slice counts itself and reads the slices
+        if (a.packed) {
+            if (a.k == 15) hipLaunchKernelGGL((verify_scan_kernel<15, true>), dim3(fw.ex_grid), dim3(EX_THREADS), 0, stream, a, fw, rc);
+            else hipLaunchKernelGGL((verify_scan_kernel<0, true>), dim3(fw.ex_grid), dim3(EX_THREADS), 0, stream, a, fw, rc);
+        } else if (a.k == 15) hipLaunchKernelGGL((verify_scan_kernel<15, false>), dim3(fw.ex_grid), dim3(EX_THREADS), 0, stream, a, fw, rc);
+        else hipLaunchKernelGGL((verify_scan_kernel<0, false>), dim3(fw.ex_grid), dim3(EX_THREADS), 0, stream, a, fw, rc);
+    } else {
+        hipLaunchKernelGGL(cand_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, fw);
+        hipLaunchKernelGGL(cand_gather_kernel, dim3(fw.n_slices), dim3(64), 0, stream, fw);
+#ifdef DRPRG_EXPERIMENTAL
+        if (by_read) {
+            fw.verify_grid = std::min<uint32_t>(read_verify_grid(n_cus), MAX_EX_WG);
+            HIP_TRY(launch_read_verify(a, fw, rc, fw.verify_grid, stream));
+        } else
+#endif
+        if (a.packed) {
+            if (a.k == 15) hipLaunchKernelGGL((verify_count_kernel<15, true>), dim3(fw.ex_grid), dim3(EX_THREADS), 0, stream, a, fw, rc);
+            else hipLaunchKernelGGL((verify_count_kernel<0, true>), dim3(fw.ex_grid), dim3(EX_THREADS), 0, stream, a, fw, rc);
+        } else if (a.k == 15) hipLaunchKernelGGL((verify_count_kernel<15, false>), dim3(fw.ex_grid), dim3(EX_THREADS), 0, stream, a, fw, rc);
+        else hipLaunchKernelGGL((verify_count_kernel<0, false>), dim3(fw.ex_grid), dim3(EX_THREADS), 0, stream, a, fw, rc);
+    }
     if (with_totals) hipLaunchKernelGGL(hit_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, a, fw, 0, fw.verify_grid); // (else: read_cluster_kernel's workgroup 0)
     return hipGetLastError();
 }

@@ -17,7 +17,7 @@ constexpr int FT_BLOOM_WORDS = 1 << 14; // levels 1+2 of the filter, at most (64
 constexpr int FT_L0_WORDS = 1 << 15;    // level 0 (128 KB; levels 1+2 then get 32 KB: all 160 KB of a CU)
 constexpr int EX_THREADS = 256;
 constexpr int SCAN_THREADS = 1024;
-constexpr int FT_SUB = 2;                    // slices per filter wave
+constexpr int FT_SUB = 1;                    // slices per filter wave (two until round 5: more, shorter slices for cand_gather_kernel, which the default sequence no longer runs; every workgroup of verify_scan_kernel reads all the counts)
 constexpr int MAX_SLICES = SCAN_THREADS * 8;
 constexpr int MAX_EX_WG = SCAN_THREADS * 4;  // workgroups of verify_count_kernel / expand_kernel
 

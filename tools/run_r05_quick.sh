@@ -9,10 +9,10 @@ if [ -n "$sel" ] && [ "$sel" != "none" ]; then
   timeout 1500 python -m pytest tests -x -q -m gpu -k "$sel" > $O/gputests.txt 2>&1; tail -4 $O/gputests.txt
   grep -q " passed" $O/gputests.txt && ! grep -q "failed\|error" $O/gputests.txt || { tail -60 $O/gputests.txt; exit 1; }
 fi
-forms="default"
+forms="default"; [ -n "$VERIFY_AB" ] && forms="default gather"   # gather: cand_scan + cand_gather + verify_count_kernel (rounds 1-4)
 for wl in $wls; do for form in $forms; do for inp in ascii packed; do
   [ "$wl" != "mtb" ] && [ "$inp" = "packed" ] && continue
-  :
+  unset DRPRG_VERIFY_FORM; [ "$form" = gather ] && export DRPRG_VERIFY_FORM=gather
   timeout 400 python bench.py --workload $wl --steps 20 --warmup 5 --input $inp --cpu-sample 0 --e2e 0 > $O/bench_${wl}_${form}_$inp.json 2> $O/bench_${wl}_${form}_$inp.err
   ( cd /tmp && export TMPDIR=/tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof -o k -- python3 $R/bench.py --workload $wl --input $inp --steps 5 --warmup 2 --cpu-sample 0 --e2e 0 --no-checks > /dev/null 2>&1 )
   echo "== $wl $form $inp"; python tools/kstats.py $O/prof/k_kernel_stats.csv | grep -v rocclr
