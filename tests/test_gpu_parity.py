@@ -284,6 +284,41 @@ def test_read_by_read_verification(tmp_path, oracle, w):
         assert lane[key] == got[key], key
 
 
+def test_candidates_at_both_ends_of_the_batch(tmp_path, oracle):
+    """verify_scan_kernel reads the candidates from the filter kernel's slices through a window of 64 slice prefixes: a batch whose
+    candidates sit in its first and its last slices, with half a million reads that leave no candidate between them, makes the
+    workgroup whose share straddles the gap take several windows -- and the three-kernel sequence (DRPRG_VERIFY_FORM=gather) must
+    count the same"""
+    from drprg_amd import synth
+    rng = np.random.default_rng(77)
+    panel = synth.small_panel(seed=31, n_loci=3, length=900)
+    haps = [synth.sample_haplotype(rng, t).encode() for t in panel.trees]
+    head, ho = _reads_from(rng, haps, 180, 150)
+    tail, to = _reads_from(rng, haps, 120, 150)
+    n_mid = 500_000
+    mid = np.full(n_mid * 150, ord("A"), np.uint8)
+    bases = np.concatenate([head, mid, tail])
+    offs = np.concatenate([ho, ho[-1] + np.arange(1, n_mid + 1, dtype=np.uint64) * np.uint64(150), ho[-1] + np.uint64(n_mid * 150) + to[1:]])
+    ctx = _ctx(tmp_path, panel, 11, 15, True, kernel=2)
+    cnt = _compare(ctx, oracle, bases, offs, 11, 15, True, 2, threads=ORACLE_THREADS)
+    assert cnt["clusters_kept"] > 200
+    got = ctx.counters()
+    os.environ["DRPRG_VERIFY_FORM"] = "gather"
+    try:
+        ctx.reset()
+        ctx.map_host(bases, offs)
+        old = ctx.counters()
+        ocov, oprg = ctx.coverage()
+    finally:
+        del os.environ["DRPRG_VERIFY_FORM"]
+    ctx.reset()
+    ctx.map_host(bases, offs)
+    cov, prg = ctx.coverage()
+    assert np.array_equal(cov, ocov) and np.array_equal(prg, oprg)
+    for key in ("reads", "bases", "minimizers", "hits", "clusters_kept", "hits_kept", "leftover_reads"):
+        assert old[key] == got[key] or key == "leftover_reads", key
+
+
 @pytest.mark.parametrize("illumina", [True, False])
 def test_reads_with_hits_in_several_groups(tmp_path, oracle, illumina):
     """duplicated loci, a reverse-complemented copy and an inverted repeat: every read has hits in several
