@@ -59,7 +59,11 @@ namespace dev {
 
 constexpr int RV_THREADS = 256;
 constexpr int RV_WAVES = RV_THREADS / 64;     // four autonomous waves per workgroup: they only meet for the workgroup's totals
-constexpr int RV_ROUNDS = 3;                  // owned slots per lane of a full chunk: slot s = 64 r + lane
+#ifndef DRPRG_RV_ROUNDS // (build-time knobs of measurement builds: Makefile EXTRA_DEFS)
+#define DRPRG_RV_ROUNDS 3
+#define DRPRG_RV_WAVES_PER_SIMD 4
+#endif
+constexpr int RV_ROUNDS = DRPRG_RV_ROUNDS;    // owned slots per lane of a full chunk: slot s = 64 r + lane
 constexpr int RV_OWN = 64 * RV_ROUNDS;        // candidates a full chunk owns; one more round of 64 is look-ahead
 constexpr int RV_EVAL = 61;                   // pieces a pass evaluates (lanes 1..61)
 constexpr int RV_DENSE_MIN = 5;               // candidates a read must hold in the chunk to be sketched: a sketch costs a read of 150
@@ -171,7 +175,7 @@ __device__ __forceinline__ void rv_sketch_pass(const SketchArgs& a, uint32_t pas
 __device__ __forceinline__ uint32_t rv_state(uint32_t didx, uint32_t pos, uint32_t vj) { return 0x80000000u | (didx << 25) | (pos << 14) | vj; }
 
 template <int W, bool PACKED>
-__global__ __launch_bounds__(RV_THREADS, 4) void read_verify_kernel(SketchArgs a, FilterWork fw, ReadClusterArgs rc)
+__global__ __launch_bounds__(RV_THREADS, DRPRG_RV_WAVES_PER_SIMD) void read_verify_kernel(SketchArgs a, FilterWork fw, ReadClusterArgs rc)
 {
     constexpr int K = 15;
     __shared__ RvWave s_wave[RV_WAVES];
@@ -538,7 +542,7 @@ bool read_verify_applies(const SketchArgs& a, const FilterWork& fw)
     return true;
 }
 
-uint32_t read_verify_grid(int n_cus) { return (uint32_t)n_cus * 4u; } // persistent: the workgroups of four waves that stay resident at 128 VGPRs
+uint32_t read_verify_grid(int n_cus) { return (uint32_t)n_cus * (uint32_t)DRPRG_RV_WAVES_PER_SIMD; } // persistent: the workgroups of four waves that stay resident at 128 VGPRs
 
 hipError_t launch_read_verify(const SketchArgs& a, const FilterWork& fw, const ReadClusterArgs& rc, uint32_t grid, hipStream_t stream)
 {
