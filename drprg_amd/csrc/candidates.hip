@@ -177,7 +177,7 @@ __global__ __launch_bounds__(EX_THREADS) void verify_scan_kernel(SketchArgs a, F
             const int64_t gp = gp_next;
             if (t + EX_THREADS < w_end) gp_next = position_of(t + EX_THREADS);
             VerifyOut o;
-            verify_one_lane<KC, PACKED>(a, fw, rc, c, gp, o, my_hits, my_nmin, my_maxlen);
+            if (!(fw.debug & 512u)) verify_one_lane<KC, PACKED>(a, fw, rc, c, gp, o, my_hits, my_nmin, my_maxlen); // (DRPRG_FT_DEBUG=512: measurement only, the scan and the positions alone)
             fw.cand_pos1[t] = o.pos1;
             fw.cand_info[t] = ((uint64_t)o.slot << 32) | ((uint64_t)o.strand << 31) | (uint64_t)o.read;
             fw.cand_rec[t] = o.crec;
@@ -507,7 +507,6 @@ __global__ __launch_bounds__(TG_THREADS) void tile_gather_kernel(SketchArgs a, F
 hipError_t launch_candidate_stage(const SketchArgs& a, FilterWork& fw, const ReadClusterArgs& rc, int n_cus, hipStream_t stream, bool with_totals)
 {
     fw.verify_grid = fw.ex_grid;
-    (void)n_cus;
     // DRPRG_VERIFY_FORM=gather keeps the three-kernel sequence of rounds 1-4 (A/B runs, a second way through the parity tests); the
     // experimental read-by-read form (make EXPERIMENTAL=1 + DRPRG_VERIFY_FORM=read: read_verify.hip, bit-exact and 8 % slower,
     // profiles/r05/read_verify.txt) needs the gathered list of positions as well
@@ -518,11 +517,16 @@ hipError_t launch_candidate_stage(const SketchArgs& a, FilterWork& fw, const Rea
     gathered = gathered || by_read;
 #endif
     if (!gathered) { // one launch: verify_scan_kernel scans the slice counts itself and reads the slices
+        // (DRPRG_VERIFY_WG_PER_CU: measurements.  8 per CU where the ASCII form holds 7 resident (72 VGPRs) leaves no tail worth having:
+        // 7 per CU measured 111 against 107 us on the 8d index, 766 against 741 on the 8-fold one; profiles/r05/verify_scan.txt)
+        static const int per_cu = [] { const char* e = std::getenv("DRPRG_VERIFY_WG_PER_CU"); return e ? std::max(1, std::atoi(e)) : 0; }();
+        if (per_cu) fw.verify_grid = std::min<uint32_t>((uint32_t)n_cus * (uint32_t)per_cu, MAX_EX_WG);
+        const dim3 grid(fw.verify_grid);
         if (a.packed) {
-            if (a.k == 15) hipLaunchKernelGGL((verify_scan_kernel<15, true>), dim3(fw.ex_grid), dim3(EX_THREADS), 0, stream, a, fw, rc);
-            else hipLaunchKernelGGL((verify_scan_kernel<0, true>), dim3(fw.ex_grid), dim3(EX_THREADS), 0, stream, a, fw, rc);
-        } else if (a.k == 15) hipLaunchKernelGGL((verify_scan_kernel<15, false>), dim3(fw.ex_grid), dim3(EX_THREADS), 0, stream, a, fw, rc);
-        else hipLaunchKernelGGL((verify_scan_kernel<0, false>), dim3(fw.ex_grid), dim3(EX_THREADS), 0, stream, a, fw, rc);
+            if (a.k == 15) hipLaunchKernelGGL((verify_scan_kernel<15, true>), grid, dim3(EX_THREADS), 0, stream, a, fw, rc);
+            else hipLaunchKernelGGL((verify_scan_kernel<0, true>), grid, dim3(EX_THREADS), 0, stream, a, fw, rc);
+        } else if (a.k == 15) hipLaunchKernelGGL((verify_scan_kernel<15, false>), grid, dim3(EX_THREADS), 0, stream, a, fw, rc);
+        else hipLaunchKernelGGL((verify_scan_kernel<0, false>), grid, dim3(EX_THREADS), 0, stream, a, fw, rc);
     } else {
         hipLaunchKernelGGL(cand_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, fw);
         hipLaunchKernelGGL(cand_gather_kernel, dim3(fw.n_slices), dim3(64), 0, stream, fw);

@@ -4,6 +4,9 @@
 // inside the external `pandora map` process of /root/reference/src/lib.rs:580-642.
 #pragma once
 #include "filter_common.h"
+#ifndef DRPRG_VERIFY_OUTWARD
+#define DRPRG_VERIFY_OUTWARD 1
+#endif
 
 namespace drprg {
 namespace dev {
@@ -83,6 +86,37 @@ template <int KC> __device__ __forceinline__ uint32_t verify_mix(uint32_t x, uin
     else return HashTraits<uint32_t>::mix(x, kmask);
 }
 
+// The exact table of 32-bit hashes, searched four slots per round trip: the aligned group of four that holds slot `sl`, then the groups
+// after it.  Same answer as one slot after the other (the first slot in probe order that holds the hash or is empty; the table is a
+// power of two >= 16 slots at <= 50 % load, index.cpp), in 1.1 dependent loads on average where linear probing takes 1.3 for a hit and
+// 1.9 for a miss -- and what a wave waits for is its slowest lane.  true: found, sl = its slot; false: sl = the empty slot.
+__device__ __forceinline__ bool table_find4(const uint32_t* __restrict__ slot_key, uint32_t tmask, uint32_t h, uint32_t& sl)
+{
+    constexpr uint32_t EMPTY = HashTraits<uint32_t>::EMPTY;
+#ifdef DRPRG_PROBE_LINEAR // (measurement builds: one slot per round trip, rounds 1-4)
+    while (true) {
+        const uint32_t key = slot_key[sl];
+        if (key == h) return true;
+        if (key == EMPTY) return false;
+        sl = (sl + 1) & tmask;
+    }
+#endif
+    uint32_t base = sl & ~3u, from = 0xFu << (sl & 3u);
+    while (true) {
+        const uint4 q = *reinterpret_cast<const uint4*>(slot_key + base);
+        const uint32_t hit = (q.x == h ? 1u : 0u) | (q.y == h ? 2u : 0u) | (q.z == h ? 4u : 0u) | (q.w == h ? 8u : 0u);
+        const uint32_t end = hit | (q.x == EMPTY ? 1u : 0u) | (q.y == EMPTY ? 2u : 0u) | (q.z == EMPTY ? 4u : 0u) | (q.w == EMPTY ? 8u : 0u);
+        const uint32_t m = end & from;
+        if (m) {
+            const uint32_t i = (uint32_t)__builtin_ctz(m);
+            sl = base + i;
+            return (hit >> i) & 1u;
+        }
+        base = (base + 4u) & tmask;
+        from = 0xFu;
+    }
+}
+
 // what the kernels below derive once from their arguments
 struct VerifyConsts {
     const uint32_t* __restrict__ slot_key;
@@ -138,7 +172,6 @@ __device__ __forceinline__ void verify_emit(const SketchArgs& a, const ReadClust
 template <int KC, bool PACKED>
 __device__ __forceinline__ bool probe_one_lane(const SketchArgs& a, const VerifyConsts& c, int64_t gp, VerifyOut& o)
 {
-    using Tr = HashTraits<uint32_t>;
     const int k = c.k;
     const int64_t n_bases = c.n_bases;
     uint32_t guess = (uint32_t)((double)gp * c.reads_per_base);
@@ -173,13 +206,7 @@ __device__ __forceinline__ bool probe_one_lane(const SketchArgs& a, const Verify
     o.strand = hf <= hr ? 1u : 0u;
     const uint32_t h = hf < hr ? hf : hr;
     uint32_t sl = table_slot_dev(h, a.table_bits);
-    bool found = false;
-    while (true) {
-        const uint32_t key = c.slot_key[sl];
-        if (key == h) { found = true; break; }
-        if (key == Tr::EMPTY) break;
-        sl = (sl + 1) & c.tmask;
-    }
+    const bool found = table_find4(c.slot_key, c.tmask, h, sl);
     o.slot = sl;
     return found && gp + k <= r1;
 }
@@ -189,7 +216,6 @@ template <int KC, bool PACKED>
 __device__ __forceinline__ void verify_one_lane(const SketchArgs& a, const FilterWork& fw, const ReadClusterArgs& rc, const VerifyConsts& c, int64_t gp, VerifyOut& o,
     uint32_t& my_hits, uint32_t& my_nmin, uint32_t& my_maxlen)
 {
-    using Tr = HashTraits<uint32_t>;
     const uint32_t* __restrict__ slot_key = c.slot_key;
     const uint32_t tmask = c.tmask, kmask = c.kmask;
     const int k = c.k, w = c.w, sh_k = c.sh_k;
@@ -278,12 +304,7 @@ __device__ __forceinline__ void verify_one_lane(const SketchArgs& a, const Filte
         if (g && !(fw.debug & 32u)) { // (DRPRG_FT_DEBUG=32: timing only, no table probe and nothing after it)
             const uint32_t h = g - 1;
             uint32_t sl = table_slot_dev(h, a.table_bits);
-            while (true) {
-                const uint32_t key = slot_key[sl];
-                if (key == h) { found = true; break; }
-                if (key == Tr::EMPTY) break;
-                sl = (sl + 1) & tmask;
-            }
+            found = table_find4(slot_key, tmask, h, sl);
             slot = sl;
         }
         if (found) {
@@ -305,6 +326,37 @@ __device__ __forceinline__ void verify_one_lane(const SketchArgs& a, const Filte
                 r2w = __funnelshift_l(r3w, r2w, s2);
                 // steps that can count at all: inside the read and the window, no N in the k-mer (bit i = step i)
                 const uint32_t valid = ((2u << i_hi) - 1u) & ~((1u << i_lo) - 1u) & ~(uint32_t)(bad >> of);
+#if DRPRG_VERIFY_OUTWARD
+                // The candidate is a minimizer iff the neighbours with hash >= its own form a run of w-1 around it: L on its left, then
+                // w-1-L on its right.  Walked outward from the candidate -- left until the first smaller hash (or enough), then right
+                // exactly as far as still needed -- that is at most w hashes per lane, whatever L is, where every step q_first ..
+                // q_first + 2w-2 in turn is 2w-1.  (Each lane extracts the k-mer of ITS step from the three words; the reverse
+                // complement is formed per step instead of rolled.)  What bounds the runs before any hash: the steps that can count.
+                const uint32_t below = ic ? (valid << (32 - ic)) : 0u;         // bit 31 = step ic-1
+                const int l_cap = (int)__builtin_clz(~below | (ic ? 0u : 0x80000000u)); // ones from bit 31 down (ic = 0: none)
+                const uint32_t above = valid >> (ic + 1);                     // bit 0 = step ic+1
+                const int r_cap = (int)__builtin_ctz(~above);                 // (bits 30.. of `above` are clear)
+                const int need = w - 1;
+                const int l_lim = l_cap < need ? l_cap : need;
+                int dir = l_lim > 0 ? -1 : 1, j = ic + dir, remaining = need; // remaining: neighbours still to be shown >= the candidate
+                bool going = l_cap + r_cap >= need && need > 0 && (dir < 0 || need <= r_cap) && !(fw.debug & 16u);
+                bool is_min = need == 0 || (fw.debug & 16u) != 0; // (DRPRG_FT_DEBUG=16: measurement only, no window test)
+                while (__builtin_amdgcn_ballot_w64(going)) { // (lanes that are through compute along: nothing of theirs is kept)
+                    const uint32_t hi = (j & 16) ? r1w : r0w, lo = (j & 16) ? r2w : r1w;
+                    const uint32_t f = __funnelshift_l(lo, hi, 2 * (j & 15)) >> sh_k;
+                    const uint32_t hf = verify_mix<KC>(f, kmask), hr = verify_mix<KC>(revcomp_code(f, k), kmask);
+                    const bool ok = (hf < hr ? hf : hr) + 1 >= g;
+                    remaining -= ok ? 1 : 0;
+                    const bool was_left = dir < 0;
+                    const bool turn = was_left && (!ok || ic - j == l_lim); // the left run ends here: the right one has to bring the rest
+                    const bool dead = was_left ? (turn && remaining > r_cap) : !ok;
+                    is_min = is_min || (going && remaining == 0);
+                    going = going && remaining != 0 && !dead;
+                    dir = turn ? 1 : dir;
+                    j = turn ? ic + 1 : j + dir;
+                }
+                const uint32_t streak = is_min ? (uint32_t)need : 0u, right = 0;
+#else
                 uint32_t streak = 0, right = 0, alive = 1;
                 uint32_t rcw = revcomp_code(r0w >> sh_k, k) << 2; // the reverse complement rolls along: one base in, one out
                 const int n_steps = (fw.debug & 16u) ? 0 : 2 * w - 1; // (DRPRG_FT_DEBUG=16: measurement only, no window test)
@@ -323,6 +375,7 @@ __device__ __forceinline__ void verify_one_lane(const SketchArgs& a, const Filte
                         right += alive;
                     }
                 }
+#endif
                 if ((int)(streak + right) >= w - 1) verify_emit(a, rc, c, gp, r0, r1, strand, sf, o, my_hits, my_nmin, my_maxlen);
             }
         }
