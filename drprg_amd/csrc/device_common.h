@@ -2,6 +2,7 @@
 #pragma once
 #include "kernels.h"
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 namespace drprg {
 namespace dev {
@@ -24,6 +25,16 @@ inline hipError_t ensure_dynamic_lds(const void* kernel, size_t bytes, size_t (&
     e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e == hipSuccess && dev >= 0 && dev < MAX_HIP_DEVICES) cache[dev] = bytes;
     return e;
+}
+
+// One launch, timed or not.  With a KernelTimer the two events ride on the kernel's own dispatch (hipExtLaunchKernelGGL: its start and
+// end timestamps) instead of being recorded on the stream before and after it -- two barrier packets that cost a 0.56 ms step 5.7 us of
+// idle GPU each (rocprofv3 --kernel-trace timeline, round 5).  hipEventElapsedTime(begin, end) is the kernel's duration either way.
+template <typename... Args, typename... Given>
+inline void launch_timed(const KernelTimer& timer, void (*kernel)(Args...), dim3 grid, dim3 block, size_t dyn_lds, hipStream_t stream, Given&&... args)
+{
+    if (timer.begin && timer.end) hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)dyn_lds, stream, timer.begin, timer.end, 0, Args(args)...);
+    else hipLaunchKernelGGL(kernel, grid, block, dyn_lds, stream, Args(args)...);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -108,6 +119,37 @@ __device__ inline uint32_t table_slot_dev(uint32_t key, uint32_t bits) { return 
 __device__ inline uint32_t table_slot_dev(uint64_t key, uint32_t bits)
 {
     return (uint32_t)((key * 0x9E3779B97F4A7C15ULL) >> (64 - bits));
+}
+
+// The exact table of 32-bit hashes, searched four slots per round trip: the aligned group of four that holds slot `sl`, then the groups
+// after it.  Same answer as one slot after the other (the first slot in probe order that holds the hash or is empty; the table is a
+// power of two >= 16 slots at <= 50 % load, index.cpp), in 1.1 dependent loads on average where linear probing takes 1.3 for a hit and
+// 1.9 for a miss -- and what a wave waits for is its slowest lane.  true: found, sl = its slot; false: sl = the empty slot.
+__device__ __forceinline__ bool table_find4(const uint32_t* __restrict__ slot_key, uint32_t tmask, uint32_t h, uint32_t& sl)
+{
+    constexpr uint32_t EMPTY = HashTraits<uint32_t>::EMPTY;
+#ifdef DRPRG_PROBE_LINEAR // (measurement builds: one slot per round trip, rounds 1-4)
+    while (true) {
+        const uint32_t key = slot_key[sl];
+        if (key == h) return true;
+        if (key == EMPTY) return false;
+        sl = (sl + 1) & tmask;
+    }
+#endif
+    uint32_t base = sl & ~3u, from = 0xFu << (sl & 3u);
+    while (true) {
+        const uint4 q = *reinterpret_cast<const uint4*>(slot_key + base);
+        const uint32_t hit = (q.x == h ? 1u : 0u) | (q.y == h ? 2u : 0u) | (q.z == h ? 4u : 0u) | (q.w == h ? 8u : 0u);
+        const uint32_t end = hit | (q.x == EMPTY ? 1u : 0u) | (q.y == EMPTY ? 2u : 0u) | (q.z == EMPTY ? 4u : 0u) | (q.w == EMPTY ? 8u : 0u);
+        const uint32_t m = end & from;
+        if (m) {
+            const uint32_t i = (uint32_t)__builtin_ctz(m);
+            sl = base + i;
+            return (hit >> i) & 1u;
+        }
+        base = (base + 4u) & tmask;
+        from = 0xFu;
+    }
 }
 
 // ASCII -> code byte: bits 0-1 base (A0 C1 G2 T3), bit 2 = not ACGT

@@ -669,7 +669,6 @@ hipError_t launch_sketch_filter(const SketchArgs& a, uint32_t read_begin, uint32
     fw.cand_total = fw.cand_prefix + grid * FT_WAVES * FT_SUB;
     fw.grp_count = b.small + 2 * MAX_SLICES + 1;
     fw.raw_grp = b.raw_grp;
-    if (timer.begin) HIP_TRY(hipEventRecord(timer.begin, stream));
     {
         using Kernel = void (*)(SketchArgs, FilterWork);
         const int which = mid ? (bt.mid0_bits == 3 ? 4 : 5) : level0 ? (fused ? 3 : 2) : (a.k < 12 ? 1 : 0);
@@ -689,10 +688,9 @@ hipError_t launch_sketch_filter(const SketchArgs& a, uint32_t read_begin, uint32
         const size_t dyn = level0 ? (size_t)FT_L0_WORDS * 4 + (fused ? (size_t)FT_WAVES * 2048 : 0) : ((size_t)4 << bt.bloom_wbits);
         static size_t configured[12][MAX_HIP_DEVICES] = {};
         HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), dyn, configured[which + (a.packed ? 6 : 0)]));
-        hipLaunchKernelGGL(kernel, dim3(grid), dim3(FT_THREADS), dyn, stream, a, fw);
+        launch_timed(timer, kernel, dim3(grid), dim3(FT_THREADS), dyn, stream, a, fw);
     }
     HIP_TRY(hipGetLastError());
-    if (timer.end) HIP_TRY(hipEventRecord(timer.end, stream));
 #ifdef DRPRG_EXPERIMENTAL
     if (level0 && !fused) {
         static size_t refine_configured[MAX_HIP_DEVICES] = {};

@@ -401,17 +401,15 @@ hipError_t launch_sketch_probe(const SketchArgs& a, bool wide_hash, hipStream_t 
     const uint32_t grid = sketch_n_tiles(a.n_bases, a.halo); // positions past n_bases-k are invalid inside the kernel
     HIP_TRY(launch_tile_first_read(a.offsets, a.n_reads, (int)sketch_tile_eval(a.halo), a.halo, grid, a.tile_first_read, stream));
     const dim3 g(grid), b(SK_THREADS);
-    if (timer.begin) HIP_TRY(hipEventRecord(timer.begin, stream));
     if (wide_hash)
-        hipLaunchKernelGGL((sketch_probe_kernel<uint64_t, 0, 0>), g, b, 0, stream, a);
+        launch_timed(timer, sketch_probe_kernel<uint64_t, 0, 0>, g, b, 0, stream, a);
     else if (a.k == 15 && a.w == 11)
-        hipLaunchKernelGGL((sketch_probe_kernel<uint32_t, 15, 11>), g, b, 0, stream, a);
+        launch_timed(timer, sketch_probe_kernel<uint32_t, 15, 11>, g, b, 0, stream, a);
     else if (a.k == 15 && a.w == 14)
-        hipLaunchKernelGGL((sketch_probe_kernel<uint32_t, 15, 14>), g, b, 0, stream, a);
+        launch_timed(timer, sketch_probe_kernel<uint32_t, 15, 14>, g, b, 0, stream, a);
     else
-        hipLaunchKernelGGL((sketch_probe_kernel<uint32_t, 0, 0>), g, b, 0, stream, a);
+        launch_timed(timer, sketch_probe_kernel<uint32_t, 0, 0>, g, b, 0, stream, a);
     HIP_TRY(hipGetLastError());
-    if (timer.end) HIP_TRY(hipEventRecord(timer.end, stream));
     return hipSuccess;
 }
 

@@ -242,12 +242,7 @@ __device__ __forceinline__ void sketch_wave_tile(const SketchArgs& a, uint32_t t
             p = list[i];
             const uint32_t h = hvs[p] - 1u;
             s = table_slot_dev(h, a.table_bits);
-            while (true) {
-                const uint32_t key = slot_key[s];
-                if (key == h) { found = true; break; }
-                if (key == 0xFFFFFFFFu) break;
-                s = (s + 1) & tmask;
-            }
+            found = table_find4(slot_key, tmask, h, s); // (four slots per round trip)
         }
         const uint64_t fm = __ballot(found);
         if (found) {
@@ -474,8 +469,7 @@ hipError_t launch_sketch_wave(const SketchArgs& a, hipStream_t stream, KernelTim
     const uint32_t n_tiles = wave_n_tiles(a.n_bases);
     HIP_TRY(launch_tile_first_read(a.offsets, a.n_reads, SW_EVAL, SW_G, n_tiles, a.tile_first_read, stream));
     const dim3 g(wave_n_slices(a.n_bases)), b(SW_WAVES * 64);
-    if (timer.begin) HIP_TRY(hipEventRecord(timer.begin, stream));
-    auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, g, b, 0, stream, a, n_tiles); };
+    auto go = [&](auto kernel) { launch_timed(timer, kernel, g, b, 0, stream, a, n_tiles); };
     const int which = (a.w == 11 ? 0 : 4) | (a.fuse ? 2 : 0) | (a.packed ? 1 : 0);
     switch (which) {
     case 0: go(sketch_wave_kernel<15, 11, false, false>); break;
@@ -491,7 +485,6 @@ hipError_t launch_sketch_wave(const SketchArgs& a, hipStream_t stream, KernelTim
     default: return hipErrorInvalidValue;
     }
     HIP_TRY(hipGetLastError());
-    if (timer.end) HIP_TRY(hipEventRecord(timer.end, stream));
     return hipSuccess;
 }
 

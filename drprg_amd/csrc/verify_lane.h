@@ -86,37 +86,6 @@ template <int KC> __device__ __forceinline__ uint32_t verify_mix(uint32_t x, uin
     else return HashTraits<uint32_t>::mix(x, kmask);
 }
 
-// The exact table of 32-bit hashes, searched four slots per round trip: the aligned group of four that holds slot `sl`, then the groups
-// after it.  Same answer as one slot after the other (the first slot in probe order that holds the hash or is empty; the table is a
-// power of two >= 16 slots at <= 50 % load, index.cpp), in 1.1 dependent loads on average where linear probing takes 1.3 for a hit and
-// 1.9 for a miss -- and what a wave waits for is its slowest lane.  true: found, sl = its slot; false: sl = the empty slot.
-__device__ __forceinline__ bool table_find4(const uint32_t* __restrict__ slot_key, uint32_t tmask, uint32_t h, uint32_t& sl)
-{
-    constexpr uint32_t EMPTY = HashTraits<uint32_t>::EMPTY;
-#ifdef DRPRG_PROBE_LINEAR // (measurement builds: one slot per round trip, rounds 1-4)
-    while (true) {
-        const uint32_t key = slot_key[sl];
-        if (key == h) return true;
-        if (key == EMPTY) return false;
-        sl = (sl + 1) & tmask;
-    }
-#endif
-    uint32_t base = sl & ~3u, from = 0xFu << (sl & 3u);
-    while (true) {
-        const uint4 q = *reinterpret_cast<const uint4*>(slot_key + base);
-        const uint32_t hit = (q.x == h ? 1u : 0u) | (q.y == h ? 2u : 0u) | (q.z == h ? 4u : 0u) | (q.w == h ? 8u : 0u);
-        const uint32_t end = hit | (q.x == EMPTY ? 1u : 0u) | (q.y == EMPTY ? 2u : 0u) | (q.z == EMPTY ? 4u : 0u) | (q.w == EMPTY ? 8u : 0u);
-        const uint32_t m = end & from;
-        if (m) {
-            const uint32_t i = (uint32_t)__builtin_ctz(m);
-            sl = base + i;
-            return (hit >> i) & 1u;
-        }
-        base = (base + 4u) & tmask;
-        from = 0xFu;
-    }
-}
-
 // what the kernels below derive once from their arguments
 struct VerifyConsts {
     const uint32_t* __restrict__ slot_key;
