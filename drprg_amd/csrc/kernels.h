@@ -250,6 +250,7 @@ struct ReadClusterArgs {
     unsigned long long *tot_hits, *tot_minimizers, *tot_max_len;
     const uint32_t* overflow_word; // bit 2: a candidate slice overflowed (the host runs the batch again: minimizers must not count twice)
     unsigned long long* phase_clock; // DRPRG_RC_DEBUG=1: 12 counters, clock cycles thread 0 of every workgroup spent per phase (else null)
+    uint32_t minpath_in_lds;         // set by launch_read_cluster: the dynamic LDS holds [n_prgs] u16 shortest paths behind the histogram
 };
 // DRPRG_RC_FORM=wave (read at every call): launch_read_cluster runs the wave form first; its flag words must be zero before the launch
 bool read_cluster_wave_form_requested();

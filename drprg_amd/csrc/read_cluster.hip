@@ -1,6 +1,7 @@
 // read_cluster.hip -- the last stage of the filtered launch sequence (see the overview at the top of
 // sketch_filter.hip): clusters, size / overlap filters and coverage straight from the ordered candidate list.
 #include "filter_common.h"
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -136,7 +137,17 @@ __global__ __launch_bounds__(RC_THREADS, 4 * DRPRG_RC_WG_PER_CU) void read_clust
     if (rc.second_pass && *reinterpret_cast<volatile unsigned long long*>(rc.n_unfit) == 0ull) return;
     const uint32_t total = SLICES ? rc.slice_prefix[rc.n_slices] : *fw.cand_total;
     const uint32_t handled_mark = SLICES ? rc.mark_epoch : 0u; // what a handled candidate's cand_pos1 becomes
-    for (uint32_t i = tid; i < rc.n_prgs; i += RC_THREADS) s_hist[i] = 0;
+    // (the shortest path of every PRG sits behind the histogram when two workgroups per CU still fit with it -- launch_read_cluster decides:
+    // the wave path reads it per cluster, and a global load there is a round trip on one wave with the rest of the workgroup waiting at
+    // the next barrier.  16 bits each; 0xFFFF = look it up)
+    uint16_t* const s_minpath = reinterpret_cast<uint16_t*>(s_hist + rc.n_prgs);
+    for (uint32_t i = tid; i < rc.n_prgs; i += RC_THREADS) {
+        s_hist[i] = 0;
+        if (rc.minpath_in_lds) {
+            const uint32_t m = rc.prg_min_path_len[i];
+            s_minpath[i] = (uint16_t)(m < 0xFFFFu ? m : 0xFFFFu);
+        }
+    }
     if (tid < 3) s_tot[tid] = 0;
     unsigned long long my_kept_hits = 0;
     uint32_t my_kept = 0, my_complex = 0;
@@ -583,7 +594,8 @@ __global__ __launch_bounds__(RC_THREADS, 4 * DRPRG_RC_WG_PER_CU) void read_clust
             const uint64_t expected = expected_minimizers(len, a.w, w1_magic); // (2 len / (w + 1) without a 64-bit division)
             bool kept = false;
             if (lane < nc) {
-                uint64_t m = rc.prg_min_path_len[cl_g >> 1];
+                uint64_t m = rc.minpath_in_lds ? s_minpath[cl_g >> 1] : 0xFFFFu;
+                if (m == 0xFFFFu) m = rc.prg_min_path_len[cl_g >> 1];
                 if (expected < m) m = expected;
                 const uint32_t length_based = (uint32_t)((double)m * rc.fraction);
                 const uint32_t thr = length_based > rc.min_cluster_size ? length_based : rc.min_cluster_size;
@@ -704,7 +716,25 @@ hipError_t launch_read_cluster(const SketchArgs& a, const FilterWork& fw, const 
         HIP_TRY(hipMemsetAsync(d_phase, 0, 14 * sizeof(unsigned long long), stream));
         rcd.phase_clock = d_phase;
     }
-    const size_t dyn = (size_t)rc.n_prgs * sizeof(uint32_t); // the per-PRG histogram, behind ~77 KB of static LDS
+    size_t dyn = (size_t)rc.n_prgs * sizeof(uint32_t); // the per-PRG histogram, behind ~77 KB of static LDS
+    {   // + the shortest paths, 16 bits each, if the same number of workgroups per CU still fits (configs[4]: 500 PRGs, 88 bytes to spare)
+        static size_t static_lds = 0;
+        if (!static_lds) {
+            size_t most = 0;
+            for (const void* k : { reinterpret_cast<const void*>(&read_cluster_kernel<false, 128>), reinterpret_cast<const void*>(&read_cluster_kernel<false, 256>),
+                     reinterpret_cast<const void*>(&read_cluster_kernel<false, 512>), reinterpret_cast<const void*>(&read_cluster_kernel<true, 128>),
+                     reinterpret_cast<const void*>(&read_cluster_kernel<true, 256>), reinterpret_cast<const void*>(&read_cluster_kernel<true, 512>) }) {
+                hipFuncAttributes at {};
+                HIP_TRY(hipFuncGetAttributes(&at, k));
+                most = std::max<size_t>(most, at.sharedSizeBytes);
+            }
+            static_lds = most;
+        }
+        const size_t lds_cu = 160 * 1024, with = dyn + (size_t)rc.n_prgs * sizeof(uint16_t);
+        const size_t fit_without = std::min<size_t>(lds_cu / (static_lds + dyn), DRPRG_RC_WG_PER_CU), fit_with = std::min<size_t>(lds_cu / (static_lds + with), DRPRG_RC_WG_PER_CU);
+        rcd.minpath_in_lds = fit_with == fit_without ? 1u : 0u;
+        if (rcd.minpath_in_lds) dyn = with;
+    }
     // look-ahead by the batch's mean read length (DRPRG_RC_AHEAD=128 / 256 / 512 forces one; the second pass behind the wave form shares
     // that form's chunk numbering: 512)
     const uint64_t mean_len = a.n_bases / (a.n_reads ? a.n_reads : 1u);
