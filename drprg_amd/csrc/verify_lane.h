@@ -310,17 +310,21 @@ __device__ __forceinline__ void verify_one_lane(const SketchArgs& a, const Filte
                 int dir = l_lim > 0 ? -1 : 1, j = ic + dir, remaining = need; // remaining: neighbours still to be shown >= the candidate
                 bool going = l_cap + r_cap >= need && need > 0 && (dir < 0 || need <= r_cap) && !(fw.debug & 16u);
                 bool is_min = need == 0 || (fw.debug & 16u) != 0; // (DRPRG_FT_DEBUG=16: measurement only, no window test)
+                // (the three words one bit to the right: step j then starts at the odd bit 2j + 1, and the funnel shift that extracts it is
+                // never one by zero -- which v_alignbit_b32 cannot do and the compiler guards with a branch)
+                const uint32_t q0 = r0w >> 1, q1 = __builtin_amdgcn_alignbit(r0w, r1w, 1), q2 = __builtin_amdgcn_alignbit(r1w, r2w, 1);
                 while (__builtin_amdgcn_ballot_w64(going)) { // (lanes that are through compute along: nothing of theirs is kept)
-                    const uint32_t hi = (j & 16) ? r1w : r0w, lo = (j & 16) ? r2w : r1w;
-                    const uint32_t f = __funnelshift_l(lo, hi, 2 * (j & 15)) >> sh_k;
+                    const uint32_t bo = 2u * (uint32_t)j + 1u;
+                    const uint32_t hi = (bo & 32u) ? q1 : q0, lo = (bo & 32u) ? q2 : q1;
+                    const uint32_t f = __builtin_amdgcn_alignbit(hi, lo, 0u - bo) >> sh_k; // ((hi:lo) << (bo & 31)) >> 32: the shift count is taken mod 32
                     const uint32_t hf = verify_mix<KC>(f, kmask), hr = verify_mix<KC>(revcomp_code(f, k), kmask);
                     const bool ok = (hf < hr ? hf : hr) + 1 >= g;
                     remaining -= ok ? 1 : 0;
                     const bool was_left = dir < 0;
-                    const bool turn = was_left && (!ok || ic - j == l_lim); // the left run ends here: the right one has to bring the rest
-                    const bool dead = was_left ? (turn && remaining > r_cap) : !ok;
-                    is_min = is_min || (going && remaining == 0);
-                    going = going && remaining != 0 && !dead;
+                    const bool turn = was_left & (!ok | (ic - j == l_lim)); // the left run ends here: the right one has to bring the rest
+                    const bool dead = (turn & (remaining > r_cap)) | (!was_left & !ok); // (plain & and |: lane masks, no selects)
+                    is_min = is_min | (going & (remaining == 0));
+                    going = going & (remaining != 0) & !dead;
                     dir = turn ? 1 : dir;
                     j = turn ? ic + 1 : j + dir;
                 }
