@@ -14,16 +14,34 @@ namespace dev {
 // 16 ASCII bases -> packed codes (A0 C1 G2 T3, first base highest) + 16-bit "not ACGT" mask (bit i = base i)
 __device__ inline void pack16n(const uint4& in, uint32_t& packed, uint32_t& nmask)
 {
-    const uint32_t e0 = encode4(in.x), e1 = encode4(in.y), e2 = encode4(in.z), e3 = encode4(in.w);
+    // four bases: their codes (encode4's v_perm_b32 look-up), and what tells a byte that is no base -- it differs from the letter its index
+    // stands for.  The per-byte flags encode4 makes of that difference (six more instructions per dword) are left to the rare case below
+    auto diff_of = [](uint32_t word, uint32_t& sel) {
+        const uint32_t u = word & 0xDFDFDFDFu; // upper case
+        sel = (u >> 1) & 0x03030303u;          // A0 C1 T2 G3
+        return u ^ __builtin_amdgcn_perm(0u, 0x47544341u, sel);
+    };
+    uint32_t any = 0;
+    auto enc = [&](uint32_t word) {
+        uint32_t sel;
+        any |= diff_of(word, sel);
+        return __builtin_amdgcn_perm(0u, 0x02030100u, sel); // -> A0 C1 G2 T3
+    };
+    const uint32_t c0 = enc(in.x), c1 = enc(in.y), c2 = enc(in.z), c3 = enc(in.w);
     // v_dot4_u32_u8 with the byte weights 64, 16, 4, 1: the four codes of a dword in one byte, first base highest (full rate;
     // the 32 x 32 multiply that gathers them is quarter rate)
     constexpr uint32_t W = 0x01041040u;
-    packed = (__builtin_amdgcn_udot4(e0 & 0x03030303u, W, 0u, false) << 24) | (__builtin_amdgcn_udot4(e1 & 0x03030303u, W, 0u, false) << 16)
-        | (__builtin_amdgcn_udot4(e2 & 0x03030303u, W, 0u, false) << 8) | __builtin_amdgcn_udot4(e3 & 0x03030303u, W, 0u, false);
+    packed = (__builtin_amdgcn_udot4(c0, W, 0u, false) << 24) | (__builtin_amdgcn_udot4(c1, W, 0u, false) << 16) | (__builtin_amdgcn_udot4(c2, W, 0u, false) << 8)
+        | __builtin_amdgcn_udot4(c3, W, 0u, false);
     nmask = 0;
-    if ((e0 | e1 | e2 | e3) & 0x04040404u) { // rare; (flags * 0x01020408) >> 24 gathers the flag of byte i into bit i
-        auto m4 = [](uint32_t e) { return ((((e >> 2) & 0x01010101u) * 0x01020408u) >> 24) & 0xFu; };
-        nmask = m4(e0) | (m4(e1) << 4) | (m4(e2) << 8) | (m4(e3) << 12);
+    if (any) { // rare; bit 7 of every non-zero byte, then (flags * 0x01020408) >> 24 gathers the flag of byte i into bit i
+        auto m4 = [&](uint32_t word) {
+            uint32_t sel;
+            const uint32_t diff = diff_of(word, sel);
+            const uint32_t bad = (((diff & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | diff) & 0x80808080u;
+            return (((bad >> 7) * 0x01020408u) >> 24) & 0xFu;
+        };
+        nmask = m4(in.x) | (m4(in.y) << 4) | (m4(in.z) << 8) | (m4(in.w) << 12);
     }
 }
 
