@@ -142,6 +142,7 @@ __global__ __launch_bounds__(EX_THREADS, 7) void verify_scan_kernel(SketchArgs a
     uint32_t total;
     const uint32_t before = block_exclusive_scan<EX_THREADS / 64>(run, s_w, &total);
     if (blockIdx.x == 0 && tid == 0) fw.cand_prefix[fw.n_slices] = total; // = *fw.cand_total
+    if (fw.debug & 2048u) return; // (DRPRG_FT_DEBUG=2048: measurement only, the slice scan alone)
     const uint32_t per_wg = (total + gridDim.x - 1) / gridDim.x;
     const uint64_t b64 = (uint64_t)blockIdx.x * per_wg;
     const uint32_t t_begin = b64 < total ? (uint32_t)b64 : total, t_end = b64 + per_wg < total ? (uint32_t)(b64 + per_wg) : total;
