@@ -17,13 +17,14 @@
 //   refine_kernel          level-0 form with DRPRG_FILTER_FORM=refine: the groups leave sketch_filter_kernel as 16-byte
 //                          records; one lane per group, second-stage filter in LDS, ordered compaction per slice.
 //   candidates.hip
-//   cand_scan_kernel       one workgroup: exclusive scan of the slice counts; cand_gather_kernel copies the slices into
-//                          one dense, ordered candidate list.
-//   verify_count_kernel    one lane per candidate, start to finish, no barrier and no atomic: canonical hash from the
-//                          raw bases -> exact table lookup (false positives end here) -> read lookup -> window-minimizer
-//                          test over the 2w-1 neighbouring k-mers inside the read, hashed one by one out of a register
-//                          shift register.  Leaves one record per candidate and the totals per workgroup.
-//   hit_scan_kernel        one workgroup: batch totals.
+//   verify_scan_kernel     (round 5) every workgroup scans the slice counts itself, takes its share of the ordered candidate
+//                          list and reads the positions from the slices; then one lane per candidate, start to finish, no
+//                          atomic: canonical hash from the raw bases -> exact table lookup, four slots per load (false
+//                          positives end here) -> read lookup -> window-minimizer test, walked outward from the candidate
+//                          (verify_lane.h).  Leaves one record per candidate and the totals per workgroup, which workgroup 0
+//                          of read_cluster_kernel sums.
+//   cand_scan_kernel, cand_gather_kernel, verify_count_kernel, hit_scan_kernel: the same stage as four launches over a gathered
+//                          list (rounds 1-4; DRPRG_VERIFY_FORM=gather, and the generic pipeline's recount).
 //   read_cluster.hip
 //   read_cluster_kernel    clusters, size / overlap filters and coverage per read, out of LDS-staged chunks of the
 //                          candidate list: no hit list, no sort.

@@ -94,9 +94,10 @@ __device__ inline uint64_t packed_bad_bases(const uint64_t* __restrict__ npos, u
 
 // One lane per candidate, start to finish: the 64 bases around it are packed into registers once (2 bits per base,
 // first base highest), the candidate's canonical hash goes to the exact table lookup (Bloom false positives end there),
-// then the 2w-1 neighbouring k-mers are hashed one after the other out of a 96-bit shift register -- a third of the
-// instructions of giving every neighbour its own lane, each of which had to load and pack its own bases.  It is a read
-// minimizer iff the run of neighbours with hash >= its own (inside the read, no N) reaches w-1 across both sides.
+// then its neighbours are hashed out of three of those words by the same lane -- a third of the instructions of giving every
+// neighbour its own lane, each of which had to load and pack its own bases.  It is a read minimizer iff the run of neighbours
+// with hash >= its own (inside the read, no N) reaches w-1 across both sides: the lane walks outward from the candidate, left
+// until the first smaller hash, then right as far as still needed -- at most w hashes (rounds 1-4: all 2w-1 in turn).
 // KC: compile-time k (15: the mask-free 12-instruction hash mix_k) or 0 (any k <= 15)
 template <int KC> __device__ __forceinline__ uint32_t verify_mix(uint32_t x, uint32_t kmask)
 {
