@@ -113,7 +113,7 @@ __global__ __launch_bounds__(EX_THREADS) void verify_count_kernel(SketchArgs a, 
 constexpr int VS_PER = MAX_SLICES / EX_THREADS; // slices per thread of the scan
 constexpr int VS_WINDOW = 64;                   // slices whose prefixes a window holds
 template <int KC, bool PACKED>
-__global__ __launch_bounds__(EX_THREADS, 7) void verify_scan_kernel(SketchArgs a, FilterWork fw, ReadClusterArgs rc) // (7 waves per SIMD = 72 VGPRs: the ASCII form came out at 74 without the bound, no scratch with it)
+__global__ __launch_bounds__(EX_THREADS, 8) void verify_scan_kernel(SketchArgs a, FilterWork fw, ReadClusterArgs rc) // (8 waves per SIMD = 64 VGPRs: the ASCII form wants 74 and spills 28 bytes per lane, and is still faster for the eighth wave: 102 -> 97 us, nanopore 424 -> 383 us)
 {
     __shared__ uint32_t s_red[3][EX_THREADS / 64];
     __shared__ uint32_t s_w[EX_THREADS / 64 + 1];
