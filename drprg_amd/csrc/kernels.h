@@ -254,6 +254,8 @@ struct ReadClusterArgs {
 };
 // DRPRG_RC_FORM=wave (read at every call): launch_read_cluster runs the wave form first; its flag words must be zero before the launch
 bool read_cluster_wave_form_requested();
+// from[0 .. n) -> to[0 .. n) (the device address of pinned host memory), then from[0 .. n) = 0; n <= 64
+hipError_t launch_counters_home(unsigned long long* from, unsigned long long* to, uint32_t n, hipStream_t stream);
 size_t filter_small_words();
 // the fields of fw that the consumers of a dense candidate list use (candidates.hip, read_cluster.hip)
 void init_candidate_work(FilterWork& fw, const FilterBuffers& b, int n_cus);

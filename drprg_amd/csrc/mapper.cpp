@@ -334,6 +334,7 @@ void Mapper::free_lane(Lane& lane)
     dfree(lane.d_scratch);
     if (lane.h_scratch) (void)hipHostFree(lane.h_scratch);
     lane.h_scratch = nullptr;
+    lane.h_scratch_dev = nullptr;
     if (lane.stream) (void)hipStreamDestroy(lane.stream);
     for (hipEvent_t* e : { &lane.done, &lane.t0, &lane.t1 })
         if (*e) (void)hipEventDestroy(*e);
@@ -421,8 +422,15 @@ void Mapper::launch_lane(Lane& lane, hipStream_t stream, const uint8_t* d_bases,
         timer.end = lane.t1;
     }
     HIPCHK(dev::launch_sketch_filter(a, lane.r0, lane.r1, bt, n_cus_, fb, rc, lane.fw, stream, timer));
-    HIPCHK(hipMemcpyAsync(lane.h_scratch, lane.d_scratch, L_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-    HIPCHK(hipMemsetAsync(lane.d_scratch, 0, L_N * sizeof(unsigned long long), stream));
+    // the counters to the pinned mirror and zero again behind it: one small kernel (DRPRG_HIP_COUNTERS_HOME=0: a copy and a memset, rounds 1-4)
+    static const bool one_launch = [] { const char* e = std::getenv("DRPRG_HIP_COUNTERS_HOME"); return !e || std::atoi(e) != 0; }();
+    if (one_launch) {
+        if (!lane.h_scratch_dev) HIPCHK(hipHostGetDevicePointer((void**)&lane.h_scratch_dev, lane.h_scratch, 0));
+        HIPCHK(dev::launch_counters_home(lane.d_scratch, lane.h_scratch_dev, L_N, stream));
+    } else {
+        HIPCHK(hipMemcpyAsync(lane.h_scratch, lane.d_scratch, L_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipMemsetAsync(lane.d_scratch, 0, L_N * sizeof(unsigned long long), stream));
+    }
     lane.scratch_zero = true;
 }
 

@@ -150,6 +150,7 @@ private:
         uint32_t* rc_flags = nullptr; // raw_capacity / RC_CHUNK_OWN + 2 words: chunks in which read_cluster_wave_kernel left a read (zeroed per batch)
         unsigned long long* d_scratch = nullptr; // L_N x u64 per-sequence counters (below)
         unsigned long long* h_scratch = nullptr; // pinned mirror
+        unsigned long long* h_scratch_dev = nullptr; // its device address
         bool scratch_zero = false;               // d_scratch is known to be zero on the device
         dev::FilterWork fw {};
         uint32_t r0 = 0, r1 = 0;                 // read range of the current batch

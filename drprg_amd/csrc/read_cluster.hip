@@ -671,6 +671,22 @@ __global__ __launch_bounds__(RC_THREADS, 4 * DRPRG_RC_WG_PER_CU) void read_clust
 #undef wave
 #undef RC_MARK
 
+// The counters of a launch sequence to their pinned mirror on the host, and zero again on the device for the next batch: one small launch
+// where a copy and a memset were two (mapper.cpp launch_lane; to: the device address of the mirror)
+__global__ void counters_home_kernel(unsigned long long* from, unsigned long long* to, uint32_t n)
+{
+    const uint32_t i = threadIdx.x;
+    if (i < n) {
+        to[i] = from[i];
+        from[i] = 0;
+    }
+}
+hipError_t launch_counters_home(unsigned long long* from, unsigned long long* to, uint32_t n, hipStream_t stream)
+{
+    hipLaunchKernelGGL(counters_home_kernel, dim3(1), dim3(64), 0, stream, from, to, n);
+    return hipGetLastError();
+}
+
 // DRPRG_FT_DEBUG=8: no read_cluster_kernel; the generic pipeline runs iff there is a hit
 __global__ void flag_complex_kernel(const unsigned long long* n_hits, unsigned long long* n_complex)
 {
