@@ -110,13 +110,20 @@ __global__ __launch_bounds__(EX_THREADS) void verify_count_kernel(SketchArgs a, 
 // candidate sit in LDS (a workgroup's share is four or five slices of a full batch; a sparse batch takes several such windows), every
 // candidate bisects them.  Workgroup 0 leaves the total where read_cluster_kernel and the generic pipeline look for it (*fw.cand_total).
 // The dense list of positions (fw.cand_gp) is not made: only the experimental read-by-read form wants it, and gets the old sequence.
-constexpr int VS_PER = MAX_SLICES / EX_THREADS; // slices per thread of the scan
+#ifndef DRPRG_VS_THREADS // (measurement builds)
+#define DRPRG_VS_THREADS 512
+#endif
+// threads per workgroup: every workgroup pays the slice scan once, so fewer and larger ones pay less of it -- 256 (as verify_count_kernel, 8 per
+// CU) measured 0.516 ms per step on the 8d index (packed 0.452), 512 (4 per CU) 0.503-0.512 (0.445), 1024 (2 per CU) 0.507-0.514 (0.447);
+// the larger indexes do not care (profiles/r05/verify_scan.txt)
+constexpr int VS_THREADS = DRPRG_VS_THREADS;
+constexpr int VS_PER = MAX_SLICES / VS_THREADS; // slices per thread of the scan
 constexpr int VS_WINDOW = 64;                   // slices whose prefixes a window holds
 template <int KC, bool PACKED>
-__global__ __launch_bounds__(EX_THREADS, 8) void verify_scan_kernel(SketchArgs a, FilterWork fw, ReadClusterArgs rc) // (8 waves per SIMD = 64 VGPRs: the ASCII form wants 74 and spills 28 bytes per lane, and is still faster for the eighth wave: 102 -> 97 us, nanopore 424 -> 383 us)
+__global__ __launch_bounds__(VS_THREADS, 8) void verify_scan_kernel(SketchArgs a, FilterWork fw, ReadClusterArgs rc) // (8 waves per SIMD = 64 VGPRs: the ASCII form wants 74 and spills 28 bytes per lane, and is still faster for the eighth wave: 102 -> 97 us, nanopore 424 -> 383 us)
 {
-    __shared__ uint32_t s_red[3][EX_THREADS / 64];
-    __shared__ uint32_t s_w[EX_THREADS / 64 + 1];
+    __shared__ uint32_t s_red[3][VS_THREADS / 64];
+    __shared__ uint32_t s_w[VS_THREADS / 64 + 1];
     __shared__ uint32_t s_fine[VS_WINDOW + 1]; // exclusive prefix of slices s_first .. s_first + VS_WINDOW
     __shared__ uint32_t s_first;
     const int tid = threadIdx.x;
@@ -140,7 +147,7 @@ __global__ __launch_bounds__(EX_THREADS, 8) void verify_scan_kernel(SketchArgs a
         for (int i = 0; i < VS_PER / 4; ++i) run += v[i].x + v[i].y + v[i].z + v[i].w;
     }
     uint32_t total;
-    const uint32_t before = block_exclusive_scan<EX_THREADS / 64>(run, s_w, &total);
+    const uint32_t before = block_exclusive_scan<VS_THREADS / 64>(run, s_w, &total);
     if (blockIdx.x == 0 && tid == 0) fw.cand_prefix[fw.n_slices] = total; // = *fw.cand_total
     if (fw.debug & 2048u) return; // (DRPRG_FT_DEBUG=2048: measurement only, the slice scan alone)
     const uint32_t per_wg = (total + gridDim.x - 1) / gridDim.x;
@@ -174,9 +181,9 @@ __global__ __launch_bounds__(EX_THREADS, 8) void verify_scan_kernel(SketchArgs a
         };
         // (the position of this thread's next candidate is requested one round early: one round trip less in the chain of each)
         int64_t gp_next = cur + tid < w_end ? position_of(cur + (uint32_t)tid) : 0;
-        for (uint32_t t = cur + (uint32_t)tid; t < w_end; t += EX_THREADS) {
+        for (uint32_t t = cur + (uint32_t)tid; t < w_end; t += VS_THREADS) {
             const int64_t gp = gp_next;
-            if (t + EX_THREADS < w_end) gp_next = position_of(t + EX_THREADS);
+            if (t + VS_THREADS < w_end) gp_next = position_of(t + VS_THREADS);
             VerifyOut o;
             if (!(fw.debug & 512u)) verify_one_lane<KC, PACKED>(a, fw, rc, c, gp, o, my_hits, my_nmin, my_maxlen); // (DRPRG_FT_DEBUG=512: measurement only, the scan and the positions alone)
             fw.cand_pos1[t] = o.pos1;
@@ -196,7 +203,7 @@ __global__ __launch_bounds__(EX_THREADS, 8) void verify_scan_kernel(SketchArgs a
     __syncthreads();
     if (tid == 0) {
         uint32_t h = 0, n = 0, mx = 0;
-        for (int i = 0; i < EX_THREADS / 64; ++i) {
+        for (int i = 0; i < VS_THREADS / 64; ++i) {
             h += s_red[0][i];
             n += s_red[1][i];
             mx = s_red[2][i] > mx ? s_red[2][i] : mx;
@@ -518,16 +525,16 @@ hipError_t launch_candidate_stage(const SketchArgs& a, FilterWork& fw, const Rea
     gathered = gathered || by_read;
 #endif
     if (!gathered) { // one launch: verify_scan_kernel scans the slice counts itself and reads the slices
-        // (DRPRG_VERIFY_WG_PER_CU: measurements.  8 per CU where the ASCII form holds 7 resident (72 VGPRs) leaves no tail worth having:
-        // 7 per CU measured 111 against 107 us on the 8d index, 766 against 741 on the 8-fold one; profiles/r05/verify_scan.txt)
+        // (DRPRG_VERIFY_WG_PER_CU: measurements.  The grid is what fills the CUs' 2048 thread slots: fewer or more workgroups per CU measured
+        // within the noise or worse; profiles/r05/verify_scan.txt)
         static const int per_cu = [] { const char* e = std::getenv("DRPRG_VERIFY_WG_PER_CU"); return e ? std::max(1, std::atoi(e)) : 0; }();
-        if (per_cu) fw.verify_grid = std::min<uint32_t>((uint32_t)n_cus * (uint32_t)per_cu, MAX_EX_WG);
+        fw.verify_grid = std::min<uint32_t>((uint32_t)n_cus * (uint32_t)(per_cu ? per_cu : 2048 / VS_THREADS), MAX_EX_WG); // (2048 threads per CU)
         const dim3 grid(fw.verify_grid);
         if (a.packed) {
-            if (a.k == 15) hipLaunchKernelGGL((verify_scan_kernel<15, true>), grid, dim3(EX_THREADS), 0, stream, a, fw, rc);
-            else hipLaunchKernelGGL((verify_scan_kernel<0, true>), grid, dim3(EX_THREADS), 0, stream, a, fw, rc);
-        } else if (a.k == 15) hipLaunchKernelGGL((verify_scan_kernel<15, false>), grid, dim3(EX_THREADS), 0, stream, a, fw, rc);
-        else hipLaunchKernelGGL((verify_scan_kernel<0, false>), grid, dim3(EX_THREADS), 0, stream, a, fw, rc);
+            if (a.k == 15) hipLaunchKernelGGL((verify_scan_kernel<15, true>), grid, dim3(VS_THREADS), 0, stream, a, fw, rc);
+            else hipLaunchKernelGGL((verify_scan_kernel<0, true>), grid, dim3(VS_THREADS), 0, stream, a, fw, rc);
+        } else if (a.k == 15) hipLaunchKernelGGL((verify_scan_kernel<15, false>), grid, dim3(VS_THREADS), 0, stream, a, fw, rc);
+        else hipLaunchKernelGGL((verify_scan_kernel<0, false>), grid, dim3(VS_THREADS), 0, stream, a, fw, rc);
     } else {
         hipLaunchKernelGGL(cand_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, fw);
         hipLaunchKernelGGL(cand_gather_kernel, dim3(fw.n_slices), dim3(64), 0, stream, fw);
