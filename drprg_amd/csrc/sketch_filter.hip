@@ -136,11 +136,15 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
     uint32_t st_a = 0, st_b = 0, st_c = 0; // DRPRG_FT_STATS (middle tier): groups past level 0 / past the bitmap, candidate positions, per lane
     (void)st_a; (void)st_b; (void)st_c;
 
-    if (LEVEL0) // (FUSED: fw.bloom0 is the array that also holds the second-stage bits)
-        for (uint32_t i = tid; i < (1u << fw.bloom0_wbits); i += FT_THREADS) s_dyn[i] = fw.bloom0[i];
-
-    if (!LEVEL0) // (the level-0 form leaves levels 1+2 to refine_kernel)
-        for (uint32_t i = tid; i < n_words; i += FT_THREADS) s_dyn[L12_BASE / 4 + i] = fw.bloom[i];
+    // The filter arrays into LDS, 16 bytes per load and store (all of them powers of two >= 256 words, 16-byte aligned on both sides): 8 rounds
+    // for the 128 KB of level 0 where word by word it was 32 -- and 8 us of every launch (round 5: step 0.511 -> 0.503 ms, packed 0.444 -> 0.437)
+    auto fill = [&](uint32_t lds_word0, const uint32_t* __restrict__ from, uint32_t n) {
+        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(from);
+        uint4* dst = reinterpret_cast<uint4*>(s_dyn + lds_word0);
+        for (uint32_t i = tid; i < n / 4; i += FT_THREADS) dst[i] = src[i];
+    };
+    if (LEVEL0) fill(0, fw.bloom0, 1u << fw.bloom0_wbits); // (FUSED: fw.bloom0 is the array that also holds the second-stage bits)
+    if (!LEVEL0) fill(L12_BASE / 4, fw.bloom, n_words);    // (the level-0 form leaves levels 1+2 to refine_kernel)
     if (tid == 0 && (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)s_dyn != 0u) atomicOr(a.overflow, 8u);
 
     // every wave owns a contiguous range of tiles and FT_SUB consecutive slices of the candidate buffers: it moves on to its
