@@ -265,15 +265,21 @@ __global__ __launch_bounds__(RC_THREADS, 4 * DRPRG_RC_WG_PER_CU) void read_clust
         return st;
     };
     // (second pass: only the chunks in which the wave form left a read)
+    // Chunks 0 .. gridDim.x - 1 belong to the workgroups by number, the counter hands out the ones after them: every workgroup's first
+    // ticket used to be a returning atomic on one address, 512 of them at the same moment -- microseconds in which nothing else of the
+    // workgroup could start (round 5; the fixed cost of a launch went from 21 to 17 us)
     auto take_ticket = [&]() -> uint32_t {
         uint32_t t;
-        do t = atomicAdd(rc.chunk_counter, 1u);
+        do t = atomicAdd(rc.chunk_counter, 1u) + gridDim.x;
         while (rc.second_pass && (uint64_t)t * RC_OWN < total && !rc.chunk_flags[t]);
         return t;
     };
-    if (tid == 0) s_chunk = take_ticket();
-    lds_barrier(tid);
-    uint32_t cur = s_chunk;
+    uint32_t cur = blockIdx.x;
+    if (rc.second_pass) { // (experimental wave form first: a chunk of its own only if that form left a read in it)
+        if (tid == 0) s_chunk = ((uint64_t)cur * RC_OWN < total && !rc.chunk_flags[cur]) ? take_ticket() : cur;
+        lds_barrier(tid);
+        cur = s_chunk;
+    }
     Staged nx = request(cur);
     for (;;) {
         RC_MARK(9); // (what ran since mark 8: the wave path of thread 0's wave)
