@@ -143,7 +143,17 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
         uint4* dst = reinterpret_cast<uint4*>(s_dyn + lds_word0);
         for (uint32_t i = tid; i < n / 4; i += FT_THREADS) dst[i] = src[i];
     };
-    if (LEVEL0) fill(0, fw.bloom0, 1u << fw.bloom0_wbits); // (FUSED: fw.bloom0 is the array that also holds the second-stage bits)
+    if constexpr (LEVEL0) { // (FUSED: fw.bloom0 is the array that also holds the second-stage bits; always FT_L0_WORDS words: launch_sketch_filter checks)
+        // all eight loads of a thread in flight before the first store: one round trip instead of eight in a row
+        constexpr int ROUNDS = FT_L0_WORDS / 4 / FT_THREADS;
+        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(fw.bloom0);
+        uint4* dst = reinterpret_cast<uint4*>(s_dyn);
+        uint4 v[ROUNDS];
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) v[r] = src[tid + r * FT_THREADS];
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) dst[tid + r * FT_THREADS] = v[r];
+    }
     if (!LEVEL0) fill(L12_BASE / 4, fw.bloom, n_words);    // (the level-0 form leaves levels 1+2 to refine_kernel)
     if (tid == 0 && (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)s_dyn != 0u) atomicOr(a.overflow, 8u);
 
