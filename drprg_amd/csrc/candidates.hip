@@ -103,13 +103,13 @@ __global__ __launch_bounds__(EX_THREADS) void verify_count_kernel(SketchArgs a, 
 }
 
 // The same kernel WITHOUT cand_scan_kernel and cand_gather_kernel in front of it (round 5: 10 + 12 us of a 0.59 ms step, one workgroup's
-// latency and a copy of 14 MB).  Every workgroup scans the slice counts itself -- 8192 words, 32 per thread, one coalesced round trip and
-// a block scan: 64 MB of L2 reads over the whole grid -- takes its share [t_begin, t_end) of the ordered list from the total, and reads
-// the positions of its candidates straight from the filter kernel's slices: entry t lives in the slice s with prefix[s] <= t <
-// prefix[s + 1], at raw_pos[s * raw_slice + t - prefix[s]].  The prefixes of the 64 slices from the one that holds the workgroup's next
-// candidate sit in LDS (a workgroup's share is four or five slices of a full batch; a sparse batch takes several such windows), every
-// candidate bisects them.  Workgroup 0 leaves the total where read_cluster_kernel and the generic pipeline look for it (*fw.cand_total).
-// The dense list of positions (fw.cand_gp) is not made: only the experimental read-by-read form wants it, and gets the old sequence.
+// latency and a copy of 14 MB).  Every workgroup scans the slice counts itself -- 8192 words at most, 16 per thread, one coalesced round trip
+// and a block scan: 16 MB of L2 reads over the whole grid --, leaves the exclusive prefix of every slice in LDS (32 KB), takes its share
+// [t_begin, t_end) of the ordered list from the total, and reads the positions of its candidates straight from the filter kernel's slices:
+// entry t lives in the slice s with prefix[s] <= t < prefix[s + 1], at raw_pos[s * raw_slice + t - prefix[s]]; a candidate bisects the
+// slices of its workgroup's share (four or five of a full batch).  Workgroup 0 leaves the total where read_cluster_kernel and the generic
+// pipeline look for it (*fw.cand_total).  The dense list of positions (fw.cand_gp) is not made: only the experimental read-by-read form
+// wants it, and gets the old sequence.
 #ifndef DRPRG_VS_THREADS // (measurement builds)
 #define DRPRG_VS_THREADS 512
 #endif
@@ -118,17 +118,15 @@ __global__ __launch_bounds__(EX_THREADS) void verify_count_kernel(SketchArgs a, 
 // the larger indexes do not care (profiles/r05/verify_scan.txt)
 constexpr int VS_THREADS = DRPRG_VS_THREADS;
 constexpr int VS_PER = MAX_SLICES / VS_THREADS; // slices per thread of the scan
-constexpr int VS_WINDOW = 64;                   // slices whose prefixes a window holds
 template <int KC, bool PACKED>
 __global__ __launch_bounds__(VS_THREADS, 8) void verify_scan_kernel(SketchArgs a, FilterWork fw, ReadClusterArgs rc) // (8 waves per SIMD = 64 VGPRs: the ASCII form wants 74 and spills 28 bytes per lane, and is still faster for the eighth wave: 102 -> 97 us, nanopore 424 -> 383 us)
 {
     __shared__ uint32_t s_red[3][VS_THREADS / 64];
     __shared__ uint32_t s_w[VS_THREADS / 64 + 1];
-    __shared__ uint32_t s_fine[VS_WINDOW + 1]; // exclusive prefix of slices s_first .. s_first + VS_WINDOW
-    __shared__ uint32_t s_first;
+    __shared__ uint32_t s_share[2];
+    __shared__ __attribute__((aligned(16))) uint32_t s_pre[MAX_SLICES + 4]; // exclusive prefix of ALL slices (32 KB; a slice past the last one: the total)
     const int tid = threadIdx.x;
-    // ---- the scan: my VS_PER consecutive slices (clamped counts, as cand_scan_kernel: an overflowing slice holds raw_slice entries).
-    //      Only their sum stays in a register: 32 counts kept across the kernel cost half the occupancy (135 VGPRs against 55) ----
+    // ---- the scan: my VS_PER consecutive slices (clamped counts, as cand_scan_kernel: an overflowing slice holds raw_slice entries) ----
     auto my_count = [&](int i4) -> uint4 { // counts 4 i4 .. 4 i4 + 3 of this thread's slices
         const uint4* __restrict__ c4 = reinterpret_cast<const uint4*>(fw.slice_count + (size_t)tid * VS_PER); // (b.small is 16-byte aligned; VS_PER is a multiple of 4)
         uint4 v = (uint32_t)tid * VS_PER + 4u * (uint32_t)i4 < fw.n_slices ? c4[i4] : make_uint4(0, 0, 0, 0); // (n_slices is a multiple of 32)
@@ -139,59 +137,70 @@ __global__ __launch_bounds__(VS_THREADS, 8) void verify_scan_kernel(SketchArgs a
         return v;
     };
     uint32_t run = 0;
-    {
-        uint4 v[VS_PER / 4];
+    uint4 v[VS_PER / 4];
 #pragma unroll
-        for (int i = 0; i < VS_PER / 4; ++i) v[i] = my_count(i); // (all eight loads before the first sum)
+    for (int i = 0; i < VS_PER / 4; ++i) v[i] = my_count(i); // (all loads before the first sum)
 #pragma unroll
-        for (int i = 0; i < VS_PER / 4; ++i) run += v[i].x + v[i].y + v[i].z + v[i].w;
-    }
+    for (int i = 0; i < VS_PER / 4; ++i) run += v[i].x + v[i].y + v[i].z + v[i].w;
     uint32_t total;
     const uint32_t before = block_exclusive_scan<VS_THREADS / 64>(run, s_w, &total);
     if (blockIdx.x == 0 && tid == 0) fw.cand_prefix[fw.n_slices] = total; // = *fw.cand_total
     if (fw.debug & 2048u) return; // (DRPRG_FT_DEBUG=2048: measurement only, the slice scan alone)
+    // Every thread leaves the prefixes of its own slices in LDS, out of the counts it still holds: entry t of the list then lives in the
+    // slice s with s_pre[s] <= t < s_pre[s + 1], for every t, and no workgroup reads a count twice.  (Until late in round 5 a window of 64
+    // prefixes was rebuilt -- one more dependent load, a wave scan and two barriers: 3-4.5 us per workgroup -- every 64 slices of its share.)
     const uint32_t per_wg = (total + gridDim.x - 1) / gridDim.x;
     const uint64_t b64 = (uint64_t)blockIdx.x * per_wg;
     const uint32_t t_begin = b64 < total ? (uint32_t)b64 : total, t_end = b64 + per_wg < total ? (uint32_t)(b64 + per_wg) : total;
+    {
+        // (... and the two slices that bound this workgroup's share come from the threads that hold them: the number of a thread's prefixes
+        // that do not exceed the entry, counted in registers -- instead of two 13-step searches of dependent LDS reads in every lane)
+        const uint32_t x0 = t_begin, x1 = t_end - 1u; // (x1 only used when t_begin < t_end)
+        const bool own0 = t_begin < t_end && before <= x0 && x0 < before + run, own1 = t_begin < t_end && before <= x1 && x1 < before + run;
+        uint32_t acc = before, n0 = 0, n1 = 0;
+        uint4* dst = reinterpret_cast<uint4*>(s_pre + (size_t)tid * VS_PER);
+#pragma unroll
+        for (int i = 0; i < VS_PER / 4; ++i) {
+            uint4 p;
+            p.x = acc;
+            p.y = p.x + v[i].x;
+            p.z = p.y + v[i].y;
+            p.w = p.z + v[i].z;
+            acc = p.w + v[i].w;
+            dst[i] = p;
+            // prefixes of my slices 4 i + 1 .. 4 i + 4 (the last one: the next thread's first, > any entry I own)
+            n0 += (p.y <= x0 ? 1u : 0u) + (p.z <= x0 ? 1u : 0u) + (p.w <= x0 ? 1u : 0u) + (acc <= x0 ? 1u : 0u);
+            n1 += (p.y <= x1 ? 1u : 0u) + (p.z <= x1 ? 1u : 0u) + (p.w <= x1 ? 1u : 0u) + (acc <= x1 ? 1u : 0u);
+        }
+        if (tid == VS_THREADS - 1) s_pre[MAX_SLICES] = acc; // (= total)
+        if (own0) s_share[0] = (uint32_t)tid * VS_PER + n0;
+        if (own1) s_share[1] = (uint32_t)tid * VS_PER + n1;
+    }
+    __syncthreads();
     const VerifyConsts c(a, fw);
     uint32_t my_hits = 0, my_nmin = 0, my_maxlen = 0;
-    for (uint32_t cur = t_begin; cur < t_end;) { // (wave-uniform: one window of VS_WINDOW slices per round)
-        // entry `cur` lies in the slices of exactly one thread of the scan: the window starts at that thread's first slice
-        if (before <= cur && cur < before + run) {
-            s_first = (uint32_t)tid * VS_PER;
-            s_fine[0] = before;
-        }
-        __syncthreads();
-        const uint32_t sf = s_first;
-        if (tid < 64) { // the prefixes of slices sf + 1 .. sf + VS_WINDOW (a slice past the last one: nothing in it): one load, one wave scan
-            const uint32_t sl = sf + (uint32_t)tid;
-            uint32_t n = sl < fw.n_slices ? fw.slice_count[sl] : 0u;
-            n = n < fw.raw_slice ? n : fw.raw_slice;
-            const uint32_t incl = wave_inclusive_scan(n);
-            s_fine[tid + 1] = s_fine[0] + incl; // (s_fine[0] was written before the barrier; nobody writes it here)
-        }
-        __syncthreads();
-        const uint32_t w_end = t_end < s_fine[VS_WINDOW] ? t_end : s_fine[VS_WINDOW]; // (> cur: entry cur lies in the window's first VS_PER slices)
-        auto position_of = [&](uint32_t t) -> int64_t { // entry t of the ordered list, cur <= t < w_end
-            uint32_t lo = 0;
-#pragma unroll
-            for (int step = VS_WINDOW / 2; step >= 1; step >>= 1)
-                if (s_fine[lo + step] <= t) lo += step; // largest j with s_fine[j] <= t
-            return (int64_t)fw.raw_pos[(size_t)(sf + lo) * fw.raw_slice + (t - s_fine[lo])];
+    if (t_begin < t_end) { // (workgroup-uniform)
+        // the slices of this workgroup's share [t_begin, t_end): its candidates bisect only those (four or five of a full batch)
+        const uint32_t s_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_share[0]), s_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_share[1]);
+        uint32_t span_step = 1;
+        while (2 * span_step <= s_hi - s_lo) span_step *= 2; // (largest power of two <= the span, at least 1)
+        auto position_of = [&](uint32_t t) -> int64_t { // entry t of the ordered list, t_begin <= t < t_end
+            uint32_t lo = s_lo;
+            for (uint32_t step = span_step; step >= 1; step >>= 1)
+                if (lo + step <= s_hi && s_pre[lo + step] <= t) lo += step;
+            return (int64_t)fw.raw_pos[(size_t)lo * fw.raw_slice + (t - s_pre[lo])];
         };
         // (the position of this thread's next candidate is requested one round early: one round trip less in the chain of each)
-        int64_t gp_next = cur + tid < w_end ? position_of(cur + (uint32_t)tid) : 0;
-        for (uint32_t t = cur + (uint32_t)tid; t < w_end; t += VS_THREADS) {
+        int64_t gp_next = t_begin + tid < t_end ? position_of(t_begin + (uint32_t)tid) : 0;
+        for (uint32_t t = t_begin + (uint32_t)tid; t < t_end; t += VS_THREADS) {
             const int64_t gp = gp_next;
-            if (t + VS_THREADS < w_end) gp_next = position_of(t + VS_THREADS);
+            if (t + VS_THREADS < t_end) gp_next = position_of(t + VS_THREADS);
             VerifyOut o;
             if (!(fw.debug & 512u)) verify_one_lane<KC, PACKED>(a, fw, rc, c, gp, o, my_hits, my_nmin, my_maxlen); // (DRPRG_FT_DEBUG=512: measurement only, the scan and the positions alone)
             fw.cand_pos1[t] = o.pos1;
             fw.cand_info[t] = ((uint64_t)o.slot << 32) | ((uint64_t)o.strand << 31) | (uint64_t)o.read;
             fw.cand_rec[t] = o.crec;
         }
-        cur = w_end;
-        __syncthreads(); // (s_first and s_fine are written again)
     }
     // ---- per-workgroup totals ----
     const uint32_t wh = wave_inclusive_scan(my_hits), wn = wave_inclusive_scan(my_nmin), wm = wave_max(my_maxlen);
