@@ -205,6 +205,7 @@ struct FilterWork {
                              // persistent grid): as many words of wg_hits / wg_nmin / wg_maxlen hold its totals
     uint32_t *wg_hits, *wg_nmin, *wg_maxlen, *wg_base; // [ex_grid]
     unsigned long long* max_len; // longest read that holds a minimizer hit (this batch)
+    uint32_t wave_share[4];  // sketch_filter_kernel: tiles of the waves 4c .. 4c + 3 of a workgroup, in 1/256 of an even share (sum 1024); see its launch
     uint32_t debug;          // ablation switches for profiling (DRPRG_FT_DEBUG): 1 = skip the Bloom test, 8 = every read through the
                              // generic pipeline, 16 / 32 = verify_count_kernel without its window scan / table probe and
                              // everything after it (wrong results: timing only, tools/dbg16.sh)

@@ -37,7 +37,9 @@
 // whose filter fits the LDS of a CU; everything else takes the direct kernel.
 #include "filter_common.h"
 #include <algorithm>
+#include <array>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <string>
 #include <type_traits>
@@ -165,10 +167,21 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
     const uint32_t t_lo = (uint32_t)(win_lo / WPOS), t_hi = (uint32_t)((win_hi + WPOS - 1) / WPOS);
     const uint32_t n_waves = gridDim.x * FT_WAVES;
     const uint32_t tiles_per_wave = (t_hi - t_lo + n_waves - 1) / n_waves, tiles_per_slice = tiles_per_wave ? (tiles_per_wave + FT_SUB - 1) / FT_SUB : 1u;
-    uint32_t tile = t_lo + gw * tiles_per_wave;
-    const uint32_t tile_end = tile + tiles_per_wave < t_hi ? tile + tiles_per_wave : t_hi;
+    // The 16 waves of a workgroup do not run at one speed: a SIMD issues for its oldest wave first, so of the four waves it holds the first
+    // to arrive gets what it asks for and the last what is left -- with even shares waves 0-3 of a workgroup were through after 185 us, 4-7 after
+    // 227, 8-11 after 283 and 12-15 after 346 us of a 354 us launch (round 5, instrumented), the SIMDs ending the kernel on one wave each.  So the
+    // shares are uneven: fw.wave_share[c] / 256 of an even one for waves 4c .. 4c + 3, the ranges still in wave order (the slices stay ordered).
+    const uint32_t wv = (uint32_t)(tid >> 6);
+    auto bound = [&](uint32_t i) -> uint32_t { // first tile of wave i of this workgroup (i = FT_WAVES: of the next workgroup)
+        uint32_t cum = (i & 3u) * fw.wave_share[(i >> 2) & 3u];
+        for (uint32_t c = 0; c < (i >> 2); ++c) cum += 4u * fw.wave_share[c];
+        const uint64_t t = (uint64_t)t_lo + (uint64_t)blockIdx.x * FT_WAVES * tiles_per_wave + ((uint64_t)tiles_per_wave * FT_WAVES * cum) / 4096u;
+        return t < (uint64_t)t_hi ? (uint32_t)t : t_hi;
+    };
+    uint32_t tile = bound(wv);
+    const uint32_t tile_end = bound(wv + 1);
     constexpr uint32_t step = 1;
-    uint32_t slice = gw * FT_SUB, next_slice_at = tile + tiles_per_slice;
+    uint32_t slice = gw * FT_SUB, next_slice_at = FT_SUB > 1 ? tile + tiles_per_slice : 0xFFFFFFFFu; // (one slice per wave: never)
 
     auto load16 = [&](int64_t g) -> uint4 { // 16 bases at global position g (a multiple of 16)
         if (g + 16 <= n_bases) return *reinterpret_cast<const uint4*>(a.bases + g);
@@ -672,6 +685,30 @@ hipError_t launch_sketch_filter(const SketchArgs& a, uint32_t read_begin, uint32
     fw.midc_wbits = bt.midc_wbits;
     fw.stat = mid ? b.stat : nullptr;
     const uint32_t grid = filter_grid(level0, n_cus, filter_n_tiles(a.n_bases, filter_positions_per_lane(level0, a.packed != 0)));
+    {   // The shares of the four wave classes of a workgroup (sketch_filter_kernel: a SIMD issues for its oldest wave first).  Measured where the
+        // classes of the level-0 forms (one workgroup per CU, four waves per SIMD) end with even shares -- 8d index 208 / 243 / 291 / 351 us of a 366 us
+        // launch, packed 139 / 184 / 237 / 292 of 309 -- and set so that they end together there: 306 / 288 / 286 / 304 of 320 us, packed 219 / 226 /
+        // 240 / 257 of 270.  The other workloads of the level-0 forms gain less from the same shares (middle tier, dense 8d genes 501 -> 479 us,
+        // 8-fold index 1252 -> 1219; 4 kb reads 1966 -> 1801) and none loses; the forms with two workgroups per CU keep even shares.
+        // DRPRG_FT_SHARE=a,b,c,d (any scale): measurements.  Any shares give the same candidates: the ranges stay in wave order.
+        static const bool from_env = std::getenv("DRPRG_FT_SHARE") != nullptr;
+        static const std::array<uint32_t, 4> env_share = [] {
+            std::array<uint32_t, 4> s { 256, 256, 256, 256 };
+            if (const char* e = std::getenv("DRPRG_FT_SHARE")) {
+                double v[4] = { 1, 1, 1, 1 };
+                if (std::sscanf(e, "%lf,%lf,%lf,%lf", &v[0], &v[1], &v[2], &v[3]) == 4 && v[0] > 0 && v[1] > 0 && v[2] > 0 && v[3] > 0) {
+                    const double sum = v[0] + v[1] + v[2] + v[3];
+                    uint32_t acc = 0;
+                    for (int c = 0; c < 3; ++c) acc += s[c] = (uint32_t)(1024.0 * v[c] / sum + 0.5);
+                    s[3] = 1024u - acc;
+                }
+            }
+            return s;
+        }();
+        static const uint32_t even[4] = { 256, 256, 256, 256 }, ascii_l0[4] = { 397, 294, 200, 133 }, packed_l0[4] = { 422, 292, 184, 126 };
+        const uint32_t* share = from_env ? env_share.data() : !level0 ? even : a.packed ? packed_l0 : ascii_l0;
+        for (int c = 0; c < 4; ++c) fw.wave_share[c] = share[c];
+    }
     fw.n_slices = grid * FT_WAVES * FT_SUB;
     fw.raw_slice = (uint32_t)std::min<uint64_t>(b.raw_capacity / fw.n_slices, 0x7FFFFFFFull / fw.n_slices);
     fw.raw_pos = b.raw_pos;
