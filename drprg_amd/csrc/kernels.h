@@ -170,6 +170,11 @@ struct FilterBuffers {
     uint32_t* small;
     unsigned long long* max_len;
     unsigned long long* stat = nullptr; // middle tier, DRPRG_FT_STATS=1: four device counters (FilterWork::stat)
+    // sketch_filter_kernel's tile shares (FilterWork::wave_share) for this launch, or nullptr: its built-in ones; and five zeroed device words that
+    // receive ~(earliest start) and the latest end of each of the four wave classes on the 100 MHz wall clock -- what the host sets the next
+    // batch's shares by (mapper.cpp tune_filter_shares)
+    const uint32_t* wave_share = nullptr;
+    unsigned long long* class_clock = nullptr;
 };
 // device view of the workspace of one filtered launch sequence (filled by launch_sketch_filter)
 struct FilterWork {
@@ -205,6 +210,7 @@ struct FilterWork {
                              // persistent grid): as many words of wg_hits / wg_nmin / wg_maxlen hold its totals
     uint32_t *wg_hits, *wg_nmin, *wg_maxlen, *wg_base; // [ex_grid]
     unsigned long long* max_len; // longest read that holds a minimizer hit (this batch)
+    unsigned long long* class_clock; // FilterBuffers::class_clock (may be null)
     uint32_t wave_share[4];  // sketch_filter_kernel: tiles of the waves 4c .. 4c + 3 of a workgroup, in 1/256 of an even share (sum 1024); see its launch
     uint32_t debug;          // ablation switches for profiling (DRPRG_FT_DEBUG): 1 = skip the Bloom test, 8 = every read through the
                              // generic pipeline, 16 / 32 = verify_count_kernel without its window scan / table probe and

@@ -1,6 +1,7 @@
 // mapper.cpp -- device context and per-batch launch sequence.  See mapper.h.
 #include "mapper.h"
 #include <algorithm>
+#include <cmath>
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -390,6 +391,16 @@ void Mapper::launch_lane(Lane& lane, hipStream_t stream, const uint8_t* d_bases,
     dev::FilterBuffers fb { lane.raw_pos, lane.raw_grp, lane.cand_gp, lane.cand_info, lane.cand_pos1, lane.cand_rec, lane.raw_capacity, lane.small,
         &lane.d_scratch[L_MAXLEN] };
     fb.stat = d_ft_stat_;
+    {
+        static const bool adapt = [] { const char* e = std::getenv("DRPRG_FT_ADAPT"); return !e || std::atoi(e) != 0; }();
+        ft_adapt_ = adapt;
+        const int pk = packed_.count(d_bases) ? 1 : 0;
+        lane.ft_packed = pk != 0;
+        if (adapt) {
+            fb.class_clock = &lane.d_scratch[L_FT_CLOCK];
+            if (ft_share_[pk][0]) fb.wave_share = ft_share_[pk];
+        }
+    }
     dev::BloomTables bt { d_bloom_, bloom_wbits_, d_bloom0_, bloom0_wbits_, d_bloomr_, d_bloom0f_ };
     if (use_mid_) {
         bt.mid0 = d_mid0_;
@@ -803,7 +814,42 @@ void Mapper::finish_lane(Lane& lane, const uint8_t* d_bases, const uint64_t* d_o
     tot_minimizers_ += lane.h_scratch[L_MINIMIZERS];
     tot_hits_ += lane.h_scratch[L_HITS];
     tot_leftover_ += lane.h_scratch[L_COMPLEX];
+    tune_filter_shares(lane, lane.ft_packed, n_bases);
     leftovers(lane, d_bases, d_offsets, n_reads, n_bases, covg, prg_reads, stream);
+}
+
+// sketch_filter_kernel's four wave classes should end together (sketch_filter.hip: a SIMD issues for its oldest wave first).  How far apart they
+// ended in the batch just read back moves the next batch's shares: share_c *= (mean end / end_c)^0.6, every share kept within 0.35 .. 2.2 of an
+// even one, the sum at 1024.  Any shares give the same candidates; batches too small to time (under 64 M bases) change nothing.
+void Mapper::tune_filter_shares(const Lane& lane, bool packed, uint64_t n_bases)
+{
+    if (!ft_adapt_ || n_bases < (64ull << 20)) return;
+    const unsigned long long* ck = &lane.h_scratch[L_FT_CLOCK];
+    if (!ck[0] || !ck[1] || !ck[2] || !ck[3] || !ck[4]) return; // (a launch without the level-0 form, or with DRPRG_FT_SHARE)
+    const unsigned long long t0 = ~ck[0];
+    double end[4], mean = 0;
+    for (int c = 0; c < 4; ++c) {
+        if (ck[1 + c] <= t0) return;
+        end[c] = (double)(ck[1 + c] - t0);
+        mean += end[c] / 4;
+    }
+    uint32_t* s = ft_share_[packed ? 1 : 0];
+    if (!s[0]) { // the launcher's built-in shares were in use: the same numbers (sketch_filter.hip)
+        static const uint32_t ascii_l0[4] = { 397, 294, 200, 133 }, packed_l0[4] = { 422, 292, 184, 126 }, mid_l0[4] = { 356, 292, 220, 156 };
+        const uint32_t* from = use_mid_ ? mid_l0 : packed ? packed_l0 : ascii_l0;
+        for (int c = 0; c < 4; ++c) s[c] = from[c];
+    }
+    double v[4], sum = 0;
+    for (int c = 0; c < 4; ++c) {
+        v[c] = (double)s[c] * std::pow(mean / end[c], 0.6);
+        v[c] = std::min(std::max(v[c], 0.35 * 256), 2.2 * 256);
+        sum += v[c];
+    }
+    uint32_t acc = 0;
+    for (int c = 0; c < 3; ++c) acc += s[c] = (uint32_t)(1024.0 * v[c] / sum + 0.5);
+    s[3] = 1024u - acc;
+    static const bool verbose = [] { const char* e = std::getenv("DRPRG_FT_ADAPT"); return e && std::atoi(e) == 2; }();
+    if (verbose) std::fprintf(stderr, "[ft shares] classes ended at %.0f %.0f %.0f %.0f (10 ns) -> %u %u %u %u\n", end[0], end[1], end[2], end[3], s[0], s[1], s[2], s[3]);
 }
 
 void Mapper::map_device_async(const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n_reads, uint64_t n_bases, uint32_t* covg,

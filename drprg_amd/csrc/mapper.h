@@ -152,10 +152,11 @@ private:
         unsigned long long* h_scratch = nullptr; // pinned mirror
         unsigned long long* h_scratch_dev = nullptr; // its device address
         bool scratch_zero = false;               // d_scratch is known to be zero on the device
+        bool ft_packed = false;                  // the batch of the sequence in flight is a packed one (tune_filter_shares)
         dev::FilterWork fw {};
         uint32_t r0 = 0, r1 = 0;                 // read range of the current batch
     };
-    enum { L_HITS = 0, L_OVERFLOW = 1, L_MAXLEN = 2, L_UNSORTED = 3, L_COMPLEX = 4, L_CHUNK = 5, L_MINIMIZERS = 6, L_UNFIT = 7, L_N = 8 };
+    enum { L_HITS = 0, L_OVERFLOW = 1, L_MAXLEN = 2, L_UNSORTED = 3, L_COMPLEX = 4, L_CHUNK = 5, L_MINIMIZERS = 6, L_UNFIT = 7, L_FT_CLOCK = 8 /* five words: FilterBuffers::class_clock */, L_N = 13 };
     void ensure_lanes(int n, uint64_t raw_capacity);
     void grow_lane(Lane& lane, uint64_t raw_capacity);
     void free_lane(Lane& lane);
@@ -315,6 +316,10 @@ private:
     Stage stage_[2];
     int stage_next_ = 0;
     hipStream_t copy_stream_ = nullptr;
+    // sketch_filter_kernel's tile shares, followed from batch to batch ([0] ASCII, [1] packed input; {0}: the launcher's built-in ones so far)
+    uint32_t ft_share_[2][4] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };
+    bool ft_adapt_ = true;
+    void tune_filter_shares(const Lane& lane, bool packed, uint64_t n_bases);
     // keep_reads: device memory in large pieces, handed out front to back
     std::vector<std::pair<void*, size_t>> kept_arenas_;
     uint8_t* arena_at_ = nullptr;

@@ -172,6 +172,7 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
     // 227, 8-11 after 283 and 12-15 after 346 us of a 354 us launch (round 5, instrumented), the SIMDs ending the kernel on one wave each.  So the
     // shares are uneven: fw.wave_share[c] / 256 of an even one for waves 4c .. 4c + 3, the ranges still in wave order (the slices stay ordered).
     const uint32_t wv = (uint32_t)(tid >> 6);
+    if (fw.class_clock && tid == 0) atomicMax(&fw.class_clock[0], ~(unsigned long long)wall_clock64()); // (the earliest start, complemented)
     auto bound = [&](uint32_t i) -> uint32_t { // first tile of wave i of this workgroup (i = FT_WAVES: of the next workgroup)
         uint32_t cum = (i & 3u) * fw.wave_share[(i >> 2) & 3u];
         for (uint32_t c = 0; c < (i >> 2); ++c) cum += 4u * fw.wave_share[c];
@@ -544,6 +545,7 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
     close_slice();
     for (++slice; slice < (gw + 1) * FT_SUB; ++slice) // slices this wave never reached (the last waves of a short batch)
         if (lane == 0) (LEVEL0 && !FUSED ? fw.grp_count : fw.slice_count)[slice] = 0;
+    if (fw.class_clock && (tid & 255) == 0) atomicMax(&fw.class_clock[1 + (tid >> 8)], (unsigned long long)wall_clock64()); // (waves 4c: when class c was through)
     if constexpr (MID != 0)
         if (fw.stat) {
             atomicAdd(&fw.stat[1], (unsigned long long)st_a);
@@ -707,7 +709,8 @@ hipError_t launch_sketch_filter(const SketchArgs& a, uint32_t read_begin, uint32
         }();
         // (the middle tier's waves wait for the L2 more and for each other less: its classes end at 1 : 1.13 : 1.30 : 1.49 with even shares)
         static const uint32_t even[4] = { 256, 256, 256, 256 }, ascii_l0[4] = { 397, 294, 200, 133 }, packed_l0[4] = { 422, 292, 184, 126 }, mid_l0[4] = { 356, 292, 220, 156 };
-        const uint32_t* share = from_env ? env_share.data() : !level0 ? even : mid ? mid_l0 : a.packed ? packed_l0 : ascii_l0;
+        const uint32_t* share = from_env ? env_share.data() : !level0 ? even : b.wave_share ? b.wave_share : mid ? mid_l0 : a.packed ? packed_l0 : ascii_l0;
+        fw.class_clock = level0 && !from_env ? b.class_clock : nullptr;
         for (int c = 0; c < 4; ++c) fw.wave_share[c] = share[c];
     }
     fw.n_slices = grid * FT_WAVES * FT_SUB;
