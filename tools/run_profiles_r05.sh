@@ -19,9 +19,9 @@ for wl in mtb-dense mtb-x2 mtb-x4 mtb-x8 mtb-x16 mtb-x32; do
 done
 cd /tmp && export TMPDIR=/tmp
 for wl in mtb mtb-dense mtb-x2 mtb-x4 mtb-x8 mtb-x16 mtb-x32 nanopore big; do
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_$wl -o $wl -- python3 $R/bench.py --workload $wl --steps 20 --warmup 2 --cpu-sample 0 --e2e 0 --no-checks > /dev/null 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_$wl -o $wl -- python3 $R/bench.py --workload $wl --steps 60 --warmup 10 --cpu-sample 0 --e2e 0 --no-checks > /dev/null 2>&1
 done
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_mtb-packed -o mtb-packed -- python3 $R/bench.py --input packed --steps 20 --warmup 2 --cpu-sample 0 --e2e 0 --no-checks > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_mtb-packed -o mtb-packed -- python3 $R/bench.py --input packed --steps 60 --warmup 10 --cpu-sample 0 --e2e 0 --no-checks > /dev/null 2>&1
 for wl in mtb mtb-x8 nanopore big; do
   for c in FETCH_SIZE WRITE_SIZE; do
     timeout 300 rocprofv3 --pmc $c --output-format csv -d $R/$O/pmc_$wl -o $c -- python3 $R/bench.py --workload $wl --steps 3 --warmup 1 --cpu-sample 0 --e2e 0 --no-checks > /dev/null 2>&1
