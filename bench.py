@@ -594,7 +594,8 @@ def main():
     marks[0].record(stream)
     # (an event record is a barrier packet on the stream: ~5 us of idle GPU per mark, 1 % of a 0.53 ms step when every step is marked --
     # profiles/r05/verify_scan.txt; so a mark per ten steps, each entry of step_ms then being the mean of its ten.  DRPRG_BENCH_MARK_EVERY=1: every step)
-    mark_every = max(1, int(os.environ.get("DRPRG_BENCH_MARK_EVERY", "10" if args.steps >= 20 else "1")))
+    # Round 6: five groups at least (a median of two was the larger one -- ADVICE r05): 20 steps = five groups of four
+    mark_every = max(1, int(os.environ.get("DRPRG_BENCH_MARK_EVERY", str(max(1, args.steps // 5)) if args.steps >= 20 else "1")))
     marked = [0]
     for i in range(args.steps):
         acc = step()
@@ -606,6 +607,7 @@ def main():
     step_ms = sorted(marks[a].elapsed_time(marks[b]) / (b - a) for a, b in zip(marked, marked[1:]))
     covg, prg_reads = acc[: 2 * ctx.n_knodes], acc[2 * ctx.n_knodes:]  # the last step's (reduced) result
     k_ms, k_launches = ctx.kernel_timing(enable=False)
+    filter_schedule = ctx.filter_schedule()  # (of the last timed step: how sketch_filter_kernel's tiles were handed out, when its wave classes ended)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -662,11 +664,12 @@ def main():
         ctx.sync()
         torch.cuda.synchronize()
         pk_ms, pk_n = ctx.kernel_timing(enable=False)
+        pk_schedule = ctx.filter_schedule()
         p_steps = sorted(evs[a].elapsed_time(evs[b]) / (b - a) for a, b in zip(p_marked, p_marked[1:]))
         p_ms = evs[0].elapsed_time(evs[args.steps]) / args.steps
         packed_leg = {"ms_per_step": p_ms, "value": n_reads / (p_ms * 1e-3), "unit": "reads/s",
                       "step_ms": {"min": p_steps[0], "median": p_steps[len(p_steps) // 2], "max": p_steps[-1]},
-                      "dominant_kernel_avg_launch_ms": pk_ms / max(pk_n, 1),
+                      "dominant_kernel_avg_launch_ms": pk_ms / max(pk_n, 1), "filter_schedule": pk_schedule,
                       "coverage_equals_the_ascii_run": bool(torch.equal(bufs[(args.steps - 1) % 2], acc)),
                       "bytes_of_the_batch_as_stored": (n_bases + 15) // 16 * 4 + 8 * (n_reads + 1),
                       "how": "the batch packed on the device before this leg (drprg_hip_pack_device), then the same number of steps through "
@@ -737,7 +740,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "timed_region_s": elapsed,
             "step_ms": {"min": step_ms[0], "median": step_ms[len(step_ms) // 2], "max": step_ms[-1],
-                        "how": "HIP events on the hot path's stream behind the last launch of every %d%s step (device time per step%s)" % (mark_every, {1: "st", 2: "nd", 3: "rd"}.get(mark_every, "th"), "" if mark_every == 1 else ", mean of each group")},
+                        "groups": len(step_ms), "how": "HIP events on the hot path's stream behind the last launch of every %d%s step (device time per step%s)" % (mark_every, {1: "st", 2: "nd", 3: "rd"}.get(mark_every, "th"), "" if mark_every == 1 else ", mean of each group")},
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -778,6 +781,7 @@ def main():
                 "bytes_of_the_batch_as_stored": ((n_bases + 15) // 16 * 4 if packed else n_bases) + 8 * (n_reads + 1),
                 "avg_launch_ms": avg_ms, "launches_timed": k_launches, "launches_per_step": launches_per_step,
                 "secondary": secondary,
+                "filter_schedule": filter_schedule,
             },
         }
         if packed_leg is not None:

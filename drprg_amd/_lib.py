@@ -119,6 +119,7 @@ SIGNATURES = {
     "drprg_hip_report_json": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_char_p,
                                         C.c_size_t]),
     "drprg_hip_kernel_timing": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    "drprg_hip_filter_schedule": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
 }
 
 

@@ -15,33 +15,28 @@ namespace dev {
 // ---------------------------------------------------------------------------------------------
 // scans
 // ---------------------------------------------------------------------------------------------
-// one workgroup: cand_prefix = exclusive scan of min(slice_count, raw_slice)
+// one workgroup: cand_prefix = exclusive scan of min(slice_count, raw_slice) (the gathered form: DRPRG_VERIFY_FORM=gather, read_verify_kernel)
 __global__ __launch_bounds__(SCAN_THREADS) void cand_scan_kernel(FilterWork fw)
 {
     __shared__ uint32_t s_w[SCAN_THREADS / 64 + 1];
-    constexpr int PER = MAX_SLICES / SCAN_THREADS;
+    constexpr int PER = MAX_CHUNKS / SCAN_THREADS;
     const int tid = threadIdx.x;
-    uint32_t v[PER], cnt[PER], run = 0;
-    // (all the loads before the first use, without a branch -- an entry past the end reads entry 0 and drops it --: one after the other
-    // behind their own conditions they were PER memory round trips in a row, most of this kernel's 10 us)
-#pragma unroll
+    // two passes over this thread's PER consecutive slices: their sum, then -- behind the block scan -- their prefixes
+    uint32_t run = 0;
     for (int i = 0; i < PER; ++i) {
         const uint32_t s = (uint32_t)tid * PER + i;
-        cnt[i] = fw.slice_count[s < fw.n_slices ? s : 0u];
-    }
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const uint32_t s = (uint32_t)tid * PER + i;
-        const uint32_t n = s < fw.n_slices ? cnt[i] : 0u;
-        v[i] = run;
+        if (s >= fw.n_slices) break;
+        const uint32_t n = fw.slice_count[s];
         run += n < fw.raw_slice ? n : fw.raw_slice;
     }
     uint32_t total;
-    const uint32_t before = block_exclusive_scan<SCAN_THREADS / 64>(run, s_w, &total);
-#pragma unroll
+    uint32_t acc = block_exclusive_scan<SCAN_THREADS / 64>(run, s_w, &total);
     for (int i = 0; i < PER; ++i) {
         const uint32_t s = (uint32_t)tid * PER + i;
-        if (s < fw.n_slices) fw.cand_prefix[s] = before + v[i];
+        if (s >= fw.n_slices) break;
+        const uint32_t n = fw.slice_count[s];
+        fw.cand_prefix[s] = acc;
+        acc += n < fw.raw_slice ? n : fw.raw_slice;
     }
     if (tid == 0) fw.cand_prefix[fw.n_slices] = total;
 }
@@ -103,13 +98,15 @@ __global__ __launch_bounds__(EX_THREADS) void verify_count_kernel(SketchArgs a, 
 }
 
 // The same kernel WITHOUT cand_scan_kernel and cand_gather_kernel in front of it (round 5: 10 + 12 us of a 0.59 ms step, one workgroup's
-// latency and a copy of 14 MB).  Every workgroup scans the slice counts itself -- 8192 words at most, 16 per thread, one coalesced round trip
-// and a block scan: 16 MB of L2 reads over the whole grid --, leaves the exclusive prefix of every slice in LDS (32 KB), takes its share
-// [t_begin, t_end) of the ordered list from the total, and reads the positions of its candidates straight from the filter kernel's slices:
-// entry t lives in the slice s with prefix[s] <= t < prefix[s + 1], at raw_pos[s * raw_slice + t - prefix[s]]; a candidate bisects the
-// slices of its workgroup's share (four or five of a full batch).  Workgroup 0 leaves the total where read_cluster_kernel and the generic
-// pipeline look for it (*fw.cand_total).  The dense list of positions (fw.cand_gp) is not made: only the experimental read-by-read form
-// wants it, and gets the old sequence.
+// latency and a copy of 14 MB).  Every workgroup scans the counts itself -- since round 6 those of the SUPERBLOCKS, FT_SUPER slices each, which
+// the filter kernel keeps next to the slice counts: 8192 words at most, 16 per thread, one coalesced round trip and a block scan: 16 MB of L2
+// reads over the whole grid --, leaves the exclusive prefix of every superblock in LDS (32 KB), takes its share [t_begin, t_end) of the
+// ordered list from the total, and reads the positions of its candidates straight from the filter kernel's slices: entry t lives in the
+// superblock s with prefix[s] <= t < prefix[s + 1] (a candidate bisects the superblocks of its workgroup's share, a handful of a full batch),
+// there in the slice the eight slice counts of the superblock say (one more round trip to the L2, requested a candidate ahead like the
+// position itself), at raw_pos[slice * raw_slice + rest].  Workgroup 0 leaves the total where read_cluster_kernel and the generic pipeline
+// look for it (*fw.cand_total).  The dense list of positions (fw.cand_gp) is not made: only the experimental read-by-read form wants it,
+// and gets the old sequence.
 #ifndef DRPRG_VS_THREADS // (measurement builds)
 #define DRPRG_VS_THREADS 512
 #endif
@@ -117,24 +114,19 @@ __global__ __launch_bounds__(EX_THREADS) void verify_count_kernel(SketchArgs a, 
 // CU) measured 0.516 ms per step on the 8d index (packed 0.452), 512 (4 per CU) 0.503-0.512 (0.445), 1024 (2 per CU) 0.507-0.514 (0.447);
 // the larger indexes do not care (profiles/r05/verify_scan.txt)
 constexpr int VS_THREADS = DRPRG_VS_THREADS;
-constexpr int VS_PER = MAX_SLICES / VS_THREADS; // slices per thread of the scan
+constexpr int VS_PER = MAX_SLICES / VS_THREADS; // superblocks per thread of the scan
 template <int KC, bool PACKED>
 __global__ __launch_bounds__(VS_THREADS, 8) void verify_scan_kernel(SketchArgs a, FilterWork fw, ReadClusterArgs rc) // (8 waves per SIMD = 64 VGPRs: the ASCII form wants 74 and spills 28 bytes per lane, and is still faster for the eighth wave: 102 -> 97 us, nanopore 424 -> 383 us)
 {
     __shared__ uint32_t s_red[3][VS_THREADS / 64];
     __shared__ uint32_t s_w[VS_THREADS / 64 + 1];
     __shared__ uint32_t s_share[2];
-    __shared__ __attribute__((aligned(16))) uint32_t s_pre[MAX_SLICES + 4]; // exclusive prefix of ALL slices (32 KB; a slice past the last one: the total)
+    __shared__ __attribute__((aligned(16))) uint32_t s_pre[MAX_SLICES + 4]; // exclusive prefix of ALL superblocks (32 KB; one past the last: the total)
     const int tid = threadIdx.x;
-    // ---- the scan: my VS_PER consecutive slices (clamped counts, as cand_scan_kernel: an overflowing slice holds raw_slice entries) ----
-    auto my_count = [&](int i4) -> uint4 { // counts 4 i4 .. 4 i4 + 3 of this thread's slices
-        const uint4* __restrict__ c4 = reinterpret_cast<const uint4*>(fw.slice_count + (size_t)tid * VS_PER); // (b.small is 16-byte aligned; VS_PER is a multiple of 4)
-        uint4 v = (uint32_t)tid * VS_PER + 4u * (uint32_t)i4 < fw.n_slices ? c4[i4] : make_uint4(0, 0, 0, 0); // (n_slices is a multiple of 32)
-        v.x = v.x < fw.raw_slice ? v.x : fw.raw_slice;
-        v.y = v.y < fw.raw_slice ? v.y : fw.raw_slice;
-        v.z = v.z < fw.raw_slice ? v.z : fw.raw_slice;
-        v.w = v.w < fw.raw_slice ? v.w : fw.raw_slice;
-        return v;
+    // ---- the scan: my VS_PER consecutive superblocks (FT_SUPER slices each; the filter kernel summed their clamped counts) ----
+    static_assert(VS_PER % 4 == 0 && MAX_SLICES % (VS_THREADS * 4) == 0, "the counts are read 16 bytes at a time");
+    auto my_count = [&](int i4) -> uint4 { // counts 4 i4 .. 4 i4 + 3 of this thread's superblocks (those past the last slice are zero)
+        return reinterpret_cast<const uint4*>(fw.super_count + (size_t)tid * VS_PER)[i4]; // (16-byte aligned: filter_small_words)
     };
     uint32_t run = 0;
     uint4 v[VS_PER / 4];
@@ -188,7 +180,23 @@ __global__ __launch_bounds__(VS_THREADS, 8) void verify_scan_kernel(SketchArgs a
             uint32_t lo = s_lo;
             for (uint32_t step = span_step; step >= 1; step >>= 1)
                 if (lo + step <= s_hi && s_pre[lo + step] <= t) lo += step;
-            return (int64_t)fw.raw_pos[(size_t)lo * fw.raw_slice + (t - s_pre[lo])];
+            // ... in superblock lo; its slice: the counts of the FT_SUPER slices (two 16-byte loads from the L2), then the first one whose
+            // running sum exceeds the rest.  (Counts past the last slice of the batch are never reached: the superblock sums say where the list ends.)
+            static_assert(FT_SUPER == 8, "two uint4 of slice counts per superblock");
+            const uint4* __restrict__ c4 = reinterpret_cast<const uint4*>(fw.slice_count) + (size_t)lo * 2;
+            const uint4 ca = c4[0], cb = c4[1];
+            const uint32_t cap = fw.raw_slice;
+            const uint32_t cnt[8] = { ca.x < cap ? ca.x : cap, ca.y < cap ? ca.y : cap, ca.z < cap ? ca.z : cap, ca.w < cap ? ca.w : cap,
+                cb.x < cap ? cb.x : cap, cb.y < cap ? cb.y : cap, cb.z < cap ? cb.z : cap, cb.w < cap ? cb.w : cap };
+            uint32_t rest = t - s_pre[lo], j = 0, sum = 0, before = 0;
+#pragma unroll
+            for (int q = 0; q < 7; ++q) {
+                sum += cnt[q];
+                const bool past = rest >= sum;
+                j += past ? 1u : 0u;
+                before = past ? sum : before;
+            }
+            return (int64_t)fw.raw_pos[(size_t)(lo * FT_SUPER + j) * fw.raw_slice + (rest - before)];
         };
         // (the position of this thread's next candidate is requested one round early: one round trip less in the chain of each)
         int64_t gp_next = t_begin + tid < t_end ? position_of(t_begin + (uint32_t)tid) : 0;

@@ -1205,6 +1205,14 @@ int drprg_hip_kernel_timing(drprg_hip_ctx* ctx, int enable, int reset, double* m
     API_END(ctx)
 }
 
+int drprg_hip_filter_schedule(drprg_hip_ctx* ctx, uint64_t out[20])
+{
+    API_BEGIN(ctx)
+    if (!out) throw Error(DRPRG_EINVAL, "null pointer");
+    need_mapper(ctx).filter_schedule(out);
+    API_END(ctx)
+}
+
 } // extern "C"
 
 // ---- post-VCF stage ------------------------------------------------------------------------------------

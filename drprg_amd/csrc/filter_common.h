@@ -17,8 +17,14 @@ constexpr int FT_BLOOM_WORDS = 1 << 14; // levels 1+2 of the filter, at most (64
 constexpr int FT_L0_WORDS = 1 << 15;    // level 0 (128 KB; levels 1+2 then get 32 KB: all 160 KB of a CU)
 constexpr int EX_THREADS = 256;
 constexpr int SCAN_THREADS = 1024;
-constexpr int FT_SUB = 1;                    // slices per filter wave (two until round 5: more, shorter slices for cand_gather_kernel, which the default sequence no longer runs; every workgroup of verify_scan_kernel reads all the counts)
-constexpr int MAX_SLICES = SCAN_THREADS * 8;
+// Candidate slices (round 6): a slice holds the candidates of one CHUNK of consecutive wave tiles; sketch_filter_kernel's waves take their
+// first chunk by number and the later ones from a device counter (FilterSched, kernels.h), so a wave fills as many slices as it takes chunks
+// and the concatenation of the slices in chunk order is still the candidate list in position order.  FT_SUPER consecutive slices form a
+// superblock whose (clamped) candidate count the filter kernel keeps as well: verify_scan_kernel scans the superblocks -- MAX_SLICES of
+// them at most, as it scanned the slices themselves until round 5 -- and a candidate then finds its slice among the FT_SUPER of its superblock.
+constexpr int MAX_SLICES = SCAN_THREADS * 8; // superblocks
+constexpr int FT_SUPER = 8;                  // slices per superblock
+constexpr int MAX_CHUNKS = MAX_SLICES * FT_SUPER; // slices
 constexpr int MAX_EX_WG = SCAN_THREADS * 4;  // workgroups of verify_count_kernel / expand_kernel
 
 // the contiguous range of the ordered candidate list that workgroup `wg` of `n_wg` owns

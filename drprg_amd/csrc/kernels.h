@@ -171,11 +171,31 @@ struct FilterBuffers {
     unsigned long long* max_len;
     unsigned long long* stat = nullptr; // middle tier, DRPRG_FT_STATS=1: four device counters (FilterWork::stat)
     // sketch_filter_kernel's tile shares (FilterWork::wave_share) for this launch, or nullptr: its built-in ones; and five zeroed device words that
-    // receive ~(earliest start) and the latest end of each of the four wave classes on the 100 MHz wall clock -- what the host sets the next
-    // batch's shares by (mapper.cpp tune_filter_shares)
+    // receive ~(earliest start) and the latest end of each of the four wave classes on the 100 MHz wall clock (reported by bench.py; with the
+    // static schedule the host sets the next batch's shares by them: mapper.cpp tune_filter_shares)
     const uint32_t* wave_share = nullptr;
     unsigned long long* class_clock = nullptr;
 };
+// How sketch_filter_kernel hands its wave tiles out (round 6).  Every workgroup owns a contiguous range of the window's tiles (an even split).
+// Round 0 is static: wave i of the workgroup owns chunk i, the tiles of 16 * tpw0 split by FilterWork::wave_share (in wave order).  Rounds
+// 1 .. n_rounds - 1 are dynamic: ticket k >= first_ticket[r] (drawn from a counter in the workgroup's LDS when the wave's prefetch reaches the
+// end of its chunk) is the chunk of size[r] tiles that starts at tile first_tile[r] + (k - first_ticket[r]) * size[r] of the workgroup's range; the sizes
+// fall from round to round so that the waves -- which do NOT run at one speed: a SIMD issues for its oldest wave first -- end together
+// whatever their speeds are.  Chunk = slice: chunk k of workgroup b fills slice b * per_wg + k, and the chunks are numbered in position
+// order, so the slices in order are the ordered candidate list.  A workgroup's last chunk runs to the end of its range.  Every chunk of a
+// dynamic schedule holds at least two tiles that lie wholly inside the buffer (the kernel's prefetch runs two tiles ahead, into the next
+// chunk at most); per_wg == 16: static only, one chunk per wave as until round 5.
+constexpr int FT_MAX_ROUNDS = 8;
+struct FilterSched {
+    uint32_t tpw0;       // round 0: tiles per wave of an even split (0: the kernel divides its window itself -- a read range the host has no tile numbers for)
+    uint32_t per_wg;     // chunks = slices per workgroup
+    uint32_t first_ticket[FT_MAX_ROUNDS], first_tile[FT_MAX_ROUNDS], size[FT_MAX_ROUNDS]; // [0] unused; first_ticket[r] = 0xFFFFFFFF for r >= n_rounds
+    uint32_t n_rounds;
+    uint32_t lds_word;   // the workgroup's ticket counter: this word of the kernel's dynamic LDS (set by the launcher; next ticket = 16 + its value)
+};
+// the schedule of one workgroup for n_tiles wave tiles on n_wg workgroups (window_known: the host knows that the window is tiles [0, n_tiles));
+// DRPRG_FT_SCHED=static | f,d,m: share of round 0 in 1/256 of the tiles, divisor of the dynamic rounds (x 16), smallest chunk -- measurements
+FilterSched make_filter_sched(uint32_t n_tiles, uint32_t n_wg, bool window_known, const uint32_t share[4]);
 // device view of the workspace of one filtered launch sequence (filled by launch_sketch_filter)
 struct FilterWork {
     const uint32_t* bloom;
@@ -190,10 +210,13 @@ struct FilterWork {
     uint32_t read_begin, read_end; // this launch sequence maps reads [read_begin, read_end) of the batch: the filter kernel
                              // streams the wave tiles (FT_WPOS positions each) that cover their bases, candidates
                              // outside [offsets[read_begin], offsets[read_end]) are dropped by verify_count_kernel
-    uint32_t n_slices;       // slices of the candidate buffers (a fixed number per filter wave)
+    uint32_t n_slices;       // slices of the candidate buffers (= chunks of the filter kernel's schedule: its workgroups x sched.per_wg)
     uint32_t raw_slice;      // capacity of one slice
     uint64_t* raw_pos;       // [n_slices][raw_slice]: global base position of a candidate k-mer, ascending per slice
     uint32_t* slice_count;   // [n_slices] (may exceed raw_slice: overflow)
+    uint32_t* super_count;   // [MAX_SLICES], zero before the launch (counters_home_kernel clears it behind every sequence): the candidates of
+                             // slices 8 s .. 8 s + 7, each count clamped to raw_slice (what verify_scan_kernel scans)
+    FilterSched sched;       // sketch_filter_kernel's chunk schedule
     uint4* raw_grp;          // level-0 form only, [n_slices][raw_slice]: {position of a surviving group of four k-mers (lo, hi),
                              // its 16 bases, the 2 after them}, ascending per slice; refine_kernel turns them into raw_pos
     uint32_t* grp_count;     // [n_slices] (may exceed raw_slice: overflow)
@@ -261,8 +284,11 @@ struct ReadClusterArgs {
 };
 // DRPRG_RC_FORM=wave (read at every call): launch_read_cluster runs the wave form first; its flag words must be zero before the launch
 bool read_cluster_wave_form_requested();
-// from[0 .. n) -> to[0 .. n) (the device address of pinned host memory), then from[0 .. n) = 0; n <= 64
-hipError_t launch_counters_home(unsigned long long* from, unsigned long long* to, uint32_t n, hipStream_t stream);
+// from[0 .. n) -> to[0 .. n) (the device address of pinned host memory), then from[0 .. n) = 0; n <= 64.  zero != nullptr: zero[0 .. n_zero)
+// = 0 as well (n_zero a multiple of 4, zero 16-byte aligned: the superblock counts of the filtered sequence)
+hipError_t launch_counters_home(unsigned long long* from, unsigned long long* to, uint32_t n, hipStream_t stream, uint32_t* zero = nullptr, uint32_t n_zero = 0);
+uint32_t* filter_super_counts(uint32_t* small); // the superblock counts inside a FilterBuffers::small block ...
+uint32_t filter_super_words();                  // ... and how many words they are
 size_t filter_small_words();
 // the fields of fw that the consumers of a dense candidate list use (candidates.hip, read_cluster.hip)
 void init_candidate_work(FilterWork& fw, const FilterBuffers& b, int n_cus);

@@ -310,6 +310,8 @@ void Mapper::reset_coverage(bool new_sample)
     HIPCHK(hipMemsetAsync(d_counters_, 0, C_N * sizeof(unsigned long long), stream_));
     HIPCHK(hipStreamSynchronize(stream_));
     tot_reads_ = tot_bases_ = tot_hits_ = tot_leftover_ = tot_minimizers_ = 0;
+    for (auto& sh : ft_share_) // (a reset context starts from the launcher's built-in tile shares again: ADVICE r05)
+        for (uint32_t& v : sh) v = 0;
     if (new_sample) drop_kept();
 }
 
@@ -368,6 +370,7 @@ void Mapper::ensure_lanes(int n, uint64_t cap)
         HIPCHK(hipEventCreate(&lane.t0));
         HIPCHK(hipEventCreate(&lane.t1));
         dmalloc(lane.small, dev::filter_small_words());
+        zero_now(lane.small, 0, dev::filter_small_words() * sizeof(uint32_t)); // (the superblock counts start at zero; every sequence leaves them so)
         dmalloc(lane.d_scratch, (size_t)L_N);
         HIPCHK(hipHostMalloc((void**)&lane.h_scratch, L_N * sizeof(unsigned long long), hipHostMallocDefault));
         zero_now(lane.d_scratch, 0, L_N * sizeof(unsigned long long));
@@ -437,10 +440,11 @@ void Mapper::launch_lane(Lane& lane, hipStream_t stream, const uint8_t* d_bases,
     static const bool one_launch = [] { const char* e = std::getenv("DRPRG_HIP_COUNTERS_HOME"); return !e || std::atoi(e) != 0; }();
     if (one_launch) {
         if (!lane.h_scratch_dev) HIPCHK(hipHostGetDevicePointer((void**)&lane.h_scratch_dev, lane.h_scratch, 0));
-        HIPCHK(dev::launch_counters_home(lane.d_scratch, lane.h_scratch_dev, L_N, stream));
+        HIPCHK(dev::launch_counters_home(lane.d_scratch, lane.h_scratch_dev, L_N, stream, dev::filter_super_counts(lane.small), dev::filter_super_words()));
     } else {
         HIPCHK(hipMemcpyAsync(lane.h_scratch, lane.d_scratch, L_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipMemsetAsync(lane.d_scratch, 0, L_N * sizeof(unsigned long long), stream));
+        HIPCHK(hipMemsetAsync(dev::filter_super_counts(lane.small), 0, dev::filter_super_words() * sizeof(uint32_t), stream));
     }
     lane.scratch_zero = true;
 }
@@ -802,6 +806,7 @@ void Mapper::finish_lane(Lane& lane, const uint8_t* d_bases, const uint64_t* d_o
     for (int attempt = 0;; ++attempt) {
         const uint32_t ovf = (uint32_t)lane.h_scratch[L_OVERFLOW];
         if (ovf & 8u) throw Error(DRPRG_EIO, "sketch_filter_kernel: dynamic LDS does not start at address 0");
+        if (ovf & 16u) throw Error(DRPRG_EIO, "sketch_filter_kernel: a chunk of its schedule holds fewer than two whole tiles");
         if (ovf & 2u) throw Error(DRPRG_EOVERFLOW, "a read is longer than 2^" + std::to_string(dev::HIT_POS_BITS) + " bases");
         if (!(ovf & 4u)) break;
         // a candidate slice of this range was too small: its sequence counted nothing and touched no coverage
@@ -821,8 +826,28 @@ void Mapper::finish_lane(Lane& lane, const uint8_t* d_bases, const uint64_t* d_o
 // sketch_filter_kernel's four wave classes should end together (sketch_filter.hip: a SIMD issues for its oldest wave first).  How far apart they
 // ended in the batch just read back moves the next batch's shares: share_c *= (mean end / end_c)^0.6, every share kept within 0.35 .. 2.2 of an
 // even one, the sum at 1024.  Any shares give the same candidates; batches too small to time (under 64 M bases) change nothing.
+void Mapper::filter_schedule(uint64_t out[20])
+{
+    sync();
+    for (int i = 0; i < 20; ++i) out[i] = ft_last_[i];
+}
+
 void Mapper::tune_filter_shares(const Lane& lane, bool packed, uint64_t n_bases)
 {
+    {   // what the batch just completed ran with (whatever its size)
+        const dev::FilterSched& sc = lane.fw.sched;
+        const unsigned long long* ck = &lane.h_scratch[L_FT_CLOCK];
+        ft_last_[0] = sc.n_rounds;
+        ft_last_[1] = lane.fw.n_slices;
+        ft_last_[2] = sc.tpw0;
+        for (int c = 0; c < 4; ++c) {
+            ft_last_[3 + c] = lane.fw.wave_share[c];
+            ft_last_[7 + c] = ck[0] && ck[1 + c] > ~ck[0] ? ck[1 + c] - ~ck[0] : 0;
+        }
+        ft_last_[11] = sc.per_wg;
+        for (int r = 0; r < dev::FT_MAX_ROUNDS; ++r) ft_last_[12 + r] = r && r < (int)sc.n_rounds ? sc.size[r] : 0;
+    }
+    if (lane.fw.sched.n_rounds > 1) return; // a dynamic schedule balances itself: the shares of round 0 stay what they are
     if (!ft_adapt_ || n_bases < (64ull << 20)) return;
     const unsigned long long* ck = &lane.h_scratch[L_FT_CLOCK];
     if (!ck[0] || !ck[1] || !ck[2] || !ck[3] || !ck[4]) return; // (a launch without the level-0 form, or with DRPRG_FT_SHARE)
@@ -916,6 +941,7 @@ void Mapper::map_device_async_impl(const uint8_t* d_bases, const uint64_t* d_off
             HIPCHK(hipEventCreate(&lane.t0));
             HIPCHK(hipEventCreate(&lane.t1));
             dmalloc(lane.small, dev::filter_small_words());
+            zero_now(lane.small, 0, dev::filter_small_words() * sizeof(uint32_t));
             dmalloc(lane.d_scratch, (size_t)L_N);
             HIPCHK(hipHostMalloc((void**)&lane.h_scratch, L_N * sizeof(unsigned long long), hipHostMallocDefault));
             zero_now(lane.d_scratch, 0, L_N * sizeof(unsigned long long));

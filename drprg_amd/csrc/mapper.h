@@ -128,6 +128,10 @@ public:
     {
         return pending_.active && ((covg && pending_.covg == covg) || (prg_reads && pending_.prg_reads == prg_reads));
     }
+    // sketch_filter_kernel's schedule and how it went in the batch completed last (bench.py; drprg_hip_filter_schedule): out[0] rounds (1: static),
+    // [1] slices = tickets, [2] tiles per wave of round 0 (even share), [3..6] shares of the four wave classes in 1/256 of an even one,
+    // [7..10] when the classes were through in 10 ns from the kernel's first wave (0: not clocked), [11] slices per workgroup, [12..19] chunk size per round
+    void filter_schedule(uint64_t out[20]);
     void enable_kernel_timing(bool on) { timing_ = on; }
     double sketch_ms_total() const { return sketch_ms_; }
     uint64_t sketch_launches() const { return sketch_launches_; }
@@ -319,6 +323,7 @@ private:
     // sketch_filter_kernel's tile shares, followed from batch to batch ([0] ASCII, [1] packed input; {0}: the launcher's built-in ones so far)
     uint32_t ft_share_[2][4] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };
     bool ft_adapt_ = true;
+    uint64_t ft_last_[20] = {};
     void tune_filter_shares(const Lane& lane, bool packed, uint64_t n_bases);
     // keep_reads: device memory in large pieces, handed out front to back
     std::vector<std::pair<void*, size_t>> kept_arenas_;

@@ -678,18 +678,22 @@ __global__ __launch_bounds__(RC_THREADS, 4 * DRPRG_RC_WG_PER_CU) void read_clust
 #undef RC_MARK
 
 // The counters of a launch sequence to their pinned mirror on the host, and zero again on the device for the next batch: one small launch
-// where a copy and a memset were two (mapper.cpp launch_lane; to: the device address of the mirror)
-__global__ void counters_home_kernel(unsigned long long* from, unsigned long long* to, uint32_t n)
+// where a copy and a memset were two (mapper.cpp launch_lane; to: the device address of the mirror).  Round 6: the superblock counts of the
+// filtered sequence (FilterWork::super_count: the filter kernel's waves ADD to them) are cleared here as well, for the next batch.
+constexpr int CH_THREADS = 256;
+__global__ __launch_bounds__(CH_THREADS) void counters_home_kernel(unsigned long long* from, unsigned long long* to, uint32_t n, uint4* zero, uint32_t n_zero4)
 {
     const uint32_t i = threadIdx.x;
     if (i < n) {
         to[i] = from[i];
         from[i] = 0;
     }
+    for (uint32_t j = i; j < n_zero4; j += CH_THREADS) zero[j] = make_uint4(0, 0, 0, 0);
 }
-hipError_t launch_counters_home(unsigned long long* from, unsigned long long* to, uint32_t n, hipStream_t stream)
+hipError_t launch_counters_home(unsigned long long* from, unsigned long long* to, uint32_t n, hipStream_t stream, uint32_t* zero, uint32_t n_zero)
 {
-    hipLaunchKernelGGL(counters_home_kernel, dim3(1), dim3(64), 0, stream, from, to, n);
+    if (n > CH_THREADS || (n_zero & 3u) || (reinterpret_cast<uintptr_t>(zero) & 15u)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(counters_home_kernel, dim3(1), dim3(CH_THREADS), 0, stream, from, to, n, reinterpret_cast<uint4*>(zero), zero ? n_zero / 4 : 0u);
     return hipGetLastError();
 }
 

@@ -122,7 +122,8 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
     // everything a tile costs once (loop control, slice bookkeeping, the ballots and prefix sums of the ordered append) is paid half as often
     constexpr int G = filter_positions_per_lane(LEVEL0, PACKED), WPOS = 63 * G, NW = G / 16, NG = G / 4;
     constexpr uint32_t L12_BASE = LEVEL0 ? FT_L0_WORDS * 4u : 0u;
-    constexpr uint32_t STAGE_RECORDS = 128, STAGE_BASE_WORDS = FT_L0_WORDS;
+    // (a wave's stage is 128 records of 16 bytes; 127 are used: the last record of the last wave's is where the chunk counter lives -- the 160 KB are full)
+    constexpr uint32_t STAGE_RECORDS = 128, STAGE_CAP = STAGE_RECORDS - 1, STAGE_BASE_WORDS = FT_L0_WORDS;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int k = a.k;
@@ -159,30 +160,61 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
     if (!LEVEL0) fill(L12_BASE / 4, fw.bloom, n_words);    // (the level-0 form leaves levels 1+2 to refine_kernel)
     if (tid == 0 && (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)s_dyn != 0u) atomicOr(a.overflow, 8u);
 
-    // every wave owns a contiguous range of tiles and FT_SUB consecutive slices of the candidate buffers: it moves on to its
-    // next slice every tiles_per_slice tiles (more, shorter slices: more parallelism for refine_kernel / cand_gather_kernel)
-    const uint32_t gw = blockIdx.x * FT_WAVES + (uint32_t)(tid >> 6);
-    // the tiles that cover the bases of reads [read_begin, read_end), split evenly over the waves of the grid
+    // ---- the schedule (FilterSched, kernels.h).  Every workgroup owns a contiguous range of the window's tiles.  Round 0: wave i of the
+    // workgroup owns its chunk i, a share of 16 * tpw0 tiles; after that the wave draws tickets from the workgroup's own counter in device
+    // memory, one chunk ahead of its use.  Chunk k of workgroup b = slice b * per_wg + k: the slices in order are the candidates in order. ----
+    const uint32_t wv = (uint32_t)(tid >> 6);
+    // the tiles that cover the bases of reads [read_begin, read_end)
     const uint64_t win_lo = a.offsets[fw.read_begin], win_hi = a.offsets[fw.read_end];
     const uint32_t t_lo = (uint32_t)(win_lo / WPOS), t_hi = (uint32_t)((win_hi + WPOS - 1) / WPOS);
     const uint32_t n_waves = gridDim.x * FT_WAVES;
-    const uint32_t tiles_per_wave = (t_hi - t_lo + n_waves - 1) / n_waves, tiles_per_slice = tiles_per_wave ? (tiles_per_wave + FT_SUB - 1) / FT_SUB : 1u;
+    const uint32_t per_wg = fw.sched.per_wg;  // chunks = slices per workgroup
+    const bool dynamic = per_wg > FT_WAVES;   // (false: one chunk per wave, as until round 5)
+    const uint32_t tiles_per_wave = fw.sched.tpw0 ? fw.sched.tpw0 : (t_hi - t_lo + n_waves - 1) / n_waves;
+    // this workgroup's tiles: [wg_lo, wg_hi) -- a dynamic schedule splits the window to the tile (the schedule is made for the smaller of the
+    // two sizes that gives; a workgroup's last chunk takes the odd tile), the static one gives every wave tiles_per_wave
+    const uint32_t wg_lo = dynamic ? t_lo + (uint32_t)((uint64_t)blockIdx.x * (t_hi - t_lo) / gridDim.x) : (uint32_t)std::min<uint64_t>((uint64_t)t_lo + (uint64_t)blockIdx.x * FT_WAVES * tiles_per_wave, t_hi);
+    const uint32_t wg_hi = dynamic ? t_lo + (uint32_t)((uint64_t)(blockIdx.x + 1) * (t_hi - t_lo) / gridDim.x) : (uint32_t)std::min<uint64_t>((uint64_t)wg_lo + (uint64_t)FT_WAVES * tiles_per_wave, t_hi);
     // The 16 waves of a workgroup do not run at one speed: a SIMD issues for its oldest wave first, so of the four waves it holds the first
     // to arrive gets what it asks for and the last what is left -- with even shares waves 0-3 of a workgroup were through after 185 us, 4-7 after
     // 227, 8-11 after 283 and 12-15 after 346 us of a 354 us launch (round 5, instrumented), the SIMDs ending the kernel on one wave each.  So the
-    // shares are uneven: fw.wave_share[c] / 256 of an even one for waves 4c .. 4c + 3, the ranges still in wave order (the slices stay ordered).
-    const uint32_t wv = (uint32_t)(tid >> 6);
+    // shares of round 0 are uneven: fw.wave_share[c] / 256 of an even one for waves 4c .. 4c + 3, the ranges still in wave order (the slices
+    // stay ordered) -- and since round 6 what round 0 leaves is handed out in chunks that get smaller towards the end, to whichever wave asks.
     if (fw.class_clock && tid == 0) atomicMax(&fw.class_clock[0], ~(unsigned long long)wall_clock64()); // (the earliest start, complemented)
-    auto bound = [&](uint32_t i) -> uint32_t { // first tile of wave i of this workgroup (i = FT_WAVES: of the next workgroup)
+    auto bound = [&](uint32_t i) -> uint32_t { // first tile of wave i of this workgroup in round 0 (i = FT_WAVES: the end of round 0)
         uint32_t cum = (i & 3u) * fw.wave_share[(i >> 2) & 3u];
         for (uint32_t c = 0; c < (i >> 2); ++c) cum += 4u * fw.wave_share[c];
-        const uint64_t t = (uint64_t)t_lo + (uint64_t)blockIdx.x * FT_WAVES * tiles_per_wave + ((uint64_t)tiles_per_wave * FT_WAVES * cum) / 4096u;
-        return t < (uint64_t)t_hi ? (uint32_t)t : t_hi;
+        const uint64_t t = (uint64_t)wg_lo + ((uint64_t)tiles_per_wave * FT_WAVES * cum) / 4096u;
+        return t < (uint64_t)wg_hi ? (uint32_t)t : wg_hi;
     };
-    uint32_t tile = bound(wv);
-    const uint32_t tile_end = bound(wv + 1);
-    constexpr uint32_t step = 1;
-    uint32_t slice = gw * FT_SUB, next_slice_at = FT_SUB > 1 ? tile + tiles_per_slice : 0xFFFFFFFFu; // (one slice per wave: never)
+    auto chunk_of_ticket = [&](uint32_t kt, uint32_t& b, uint32_t& e) { // kt >= FT_WAVES: a chunk of the dynamic rounds (all scalar)
+        uint32_t ft = fw.sched.first_ticket[1], tl = fw.sched.first_tile[1], sz = fw.sched.size[1];
+#pragma unroll
+        for (int q = 2; q < FT_MAX_ROUNDS; ++q)
+            if (kt >= fw.sched.first_ticket[q]) { // (0xFFFFFFFF past the last round)
+                ft = fw.sched.first_ticket[q];
+                tl = fw.sched.first_tile[q];
+                sz = fw.sched.size[q];
+            }
+        b = wg_lo + tl + (kt - ft) * sz;
+        e = kt + 1u == per_wg ? wg_hi : b + sz; // (the workgroup's last chunk runs to the end of its range)
+    };
+    // (everything of the schedule is wave-uniform, and the compiler is told so: scalar registers and scalar branches)
+    uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)bound(wv));    // the current tile, in the current chunk ...
+    uint32_t c_all = (uint32_t)__builtin_amdgcn_readfirstlane((int)bound(wv + 1)); // ... which ends here
+    const uint32_t slice0 = blockIdx.x * per_wg; // the workgroup's first slice
+    uint32_t slice = (uint32_t)__builtin_amdgcn_readfirstlane((int)(slice0 + wv));
+    // the chunk after the current one: its ticket is drawn when the prefetch first reaches past the current one -- from a counter in the workgroup's
+    // LDS (fw.sched.lds_word): a round trip of ~100 ns, so nothing is reserved ahead and what a slow wave still holds when the tickets run out is
+    // one chunk.  (One counter in device memory for the whole grid served ~100 tickets per microsecond -- returning atomics on one address take
+    // their turn in the L2 -- and 35 k tickets made the kernel 570 us long; a counter per workgroup in device memory, drawn a chunk ahead of its
+    // use to hide the 2 us, worked -- 0.333 ms -- but left the slowest waves two chunks behind the others at the end: round 6.)
+    bool decoded = !dynamic, has_next = false;
+    uint32_t n_k = 0, n_begin = 0, n_all = 0;
+    uint32_t sw_tile = 0xFFFFFFFFu, sw_k = 0; // process() moves on to slice sw_k when it meets tile sw_tile
+    if (tid == 0) s_dyn[fw.sched.lds_word] = 0; // (before the one barrier below; a word no filter array and no wave's stage uses)
+    uint32_t tiles_done = 0;
+    (void)tiles_done;
 
     auto load16 = [&](int64_t g) -> uint4 { // 16 bases at global position g (a multiple of 16)
         if (g + 16 <= n_bases) return *reinterpret_cast<const uint4*>(a.bases + g);
@@ -211,13 +243,12 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
     // (packed: a tile is 126 words, its 64 lanes read 128: full while those lie inside the ceil(n_bases / 16) words of the batch)
     const uint32_t n_full = PACKED ? (n_pwords >= NW * 64 ? (uint32_t)((n_pwords - NW * 64) / (WPOS / 16)) + 1 : 0u)
                                    : (n_bases >= 64 * G ? (uint32_t)((n_bases - 64 * G) / WPOS) + 1 : 0u);
-    const uint32_t full_end = tile_end < n_full ? tile_end : n_full;
-    auto fetch = [&](uint32_t t, Pair& p) { // unconditional (a prefetch past the wave's range re-reads its last full tile)
-        const uint32_t tc = t < full_end ? t : full_end - 1;
+    uint32_t c_end = c_all < n_full ? c_all : n_full; // the current chunk's tiles that lie wholly inside the buffer end here
+    auto fetch = [&](uint32_t t, Pair& p) { // unconditional; t is a full tile (the callers clamp)
         if constexpr (PACKED) {
-            p = *reinterpret_cast<const Pair*>(words + (int64_t)tc * (WPOS / 16) + (int64_t)lane * NW);
+            p = *reinterpret_cast<const Pair*>(words + (int64_t)t * (WPOS / 16) + (int64_t)lane * NW);
         } else {
-            const uint8_t* g = a.bases + (int64_t)tc * WPOS + (int64_t)lane * G;
+            const uint8_t* g = a.bases + (int64_t)t * WPOS + (int64_t)lane * G;
             // (plain loads: non-temporal ones were measured on 10 M x 150 bp -- this kernel 382 -> 409 us, refine_kernel 45 -> 38 us
             // because the group records then survive in the L2, the step 0.720 -> 0.746 ms)
             p.a = *reinterpret_cast<const uint4*>(g);
@@ -325,17 +356,18 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
         if (lane == 0) {
             (LEVEL0 && !FUSED ? fw.grp_count : fw.slice_count)[slice] = wcur;
             if (wcur > fw.raw_slice) atomicOr(a.overflow, 4u);
+            if (!(LEVEL0 && !FUSED) && wcur) atomicAdd(&fw.super_count[slice / FT_SUPER], wcur < fw.raw_slice ? wcur : fw.raw_slice); // (the two-kernel form: refine_kernel adds)
         }
     };
 
     // one tile: my 32 positions start in words wa, wb; wc (the first word of lane+1) completes the last k-mers
     auto process = [&](uint32_t t, const Pair& p) {
-        if (t == next_slice_at) { // wave-uniform
+        if (t == sw_tile) { // wave-uniform: the first tile of the wave's next chunk -- the slice of the last one is complete
             close_slice();
-            ++slice;
-            next_slice_at += tiles_per_slice;
-            out += fw.raw_slice;
-            if (LEVEL0) grp_out += fw.raw_slice;
+            slice = sw_k;
+            sw_tile = 0xFFFFFFFFu;
+            out = fw.raw_pos + (size_t)slice * fw.raw_slice;
+            if (LEVEL0) grp_out = fw.raw_grp + (size_t)slice * fw.raw_slice;
             wcur = 0;
         }
         uint32_t wv[NW + 1]; // my words, then the first word of lane + 1 (it completes the last k-mers)
@@ -414,8 +446,8 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
                     const uint32_t total = wave_total;
                     // (running only the full rounds of 64 here and keeping the remainder staged was measured: 159.8 -> 156.7 M VALU
                     // wave-instructions per 10 M reads and no change in the kernel's time, 318 against 321 us)
-                    if (lcnt + total > STAGE_RECORDS) DRPRG_SECOND_STAGE(); // wave-uniform
-                    if (total <= STAGE_RECORDS) {
+                    if (lcnt + total > STAGE_CAP) DRPRG_SECOND_STAGE(); // wave-uniform
+                    if (total <= STAGE_CAP) {
                         uint32_t at = lcnt + lanes_below();
                         while (grp) {
                             const int g = __ffs(grp) - 1;
@@ -424,8 +456,8 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
                         }
                         lcnt += total;
                     } else { // a tile dense with index k-mers (amplicon reads): as many lanes at a time as the stage surely holds, in lane order
-                        constexpr int PART_LANES = (int)STAGE_RECORDS / NG;
-                        for (int part = 0; part < 64 / PART_LANES; ++part) {
+                        constexpr int PART_LANES = (int)STAGE_CAP / NG;
+                        for (int part = 0; part < (64 + PART_LANES - 1) / PART_LANES; ++part) {
                             uint32_t gq = (lane / PART_LANES) == part ? grp : 0u;
                             const uint32_t cq = (uint32_t)__popc(gq);
                             const uint64_t q0 = __ballot(cq & 1u), q1 = __ballot(cq & 2u), q2 = __ballot(cq & 4u), q3 = __ballot(cq & 8u);
@@ -502,30 +534,64 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
     // register ring, unrolled so that no tile is copied between registers: the tile being processed plus two in
     // flight (2 KB each per wave, 16 waves: 64 KB outstanding per CU; a fourth register set made the kernel slower,
     // with the group records going to global memory and again with the second stage inside: 0.368-0.377 against 0.364-0.369 ms)
+    // The tile two steps ahead of `tile` in this wave's stream: in the current chunk, or -- the ticket requested a chunk ago is waited for
+    // here, and the one after it requested -- in the next; a wave without a next chunk reads its last full tile again.
+    auto decode_next = [&]() {
+        uint32_t drawn = 0;
+        if (lane == 0) drawn = atomicAdd(&s_dyn[fw.sched.lds_word], 1u);
+        const uint32_t kt = (uint32_t)FT_WAVES + (uint32_t)__builtin_amdgcn_readfirstlane((int)drawn);
+        has_next = kt < per_wg;
+        if (has_next) {
+            n_k = slice0 + kt;
+            chunk_of_ticket(kt, n_begin, n_all);
+            if (lane == 0 && n_begin + 2 > (n_all < n_full ? n_all : n_full)) atomicOr(a.overflow, 16u); // (a schedule the host must not make: kernels.h FilterSched)
+        }
+        decoded = true;
+    };
+    auto ahead2 = [&]() -> uint32_t {
+        uint32_t ft = tile + 2;
+        if (ft >= c_end) { // wave-uniform
+            if (!decoded) decode_next();
+            ft = has_next ? n_begin + (ft - c_end) : c_end - 1;
+        }
+        return ft;
+    };
+    auto advance = [&]() -> bool { // `tile` is done: on to the next one of the stream (false: there is none)
+        ++tile;
+        if constexpr (MID != 0) ++tiles_done;
+        if (tile < c_end) return true;
+        if (!has_next) return false; // (a chunk of one full tile, static schedule: nothing was decoded and nothing follows)
+        sw_tile = tile = n_begin;
+        sw_k = n_k;
+        c_all = n_all;
+        c_end = n_all < n_full ? n_all : n_full;
+        has_next = false;
+        decoded = false;
+        return true;
+    };
     Pair r0 {}, r1 {}, r2 {};
-    const bool pipelined = tile < full_end; // wave-uniform
+    const bool pipelined = tile < c_end; // wave-uniform
     if (pipelined) {
         fetch(tile, r0);
-        fetch(tile + step, r1);
+        fetch(tile + 1 < c_end ? tile + 1 : tile, r1); // (a dynamic schedule's chunks hold two full tiles at least)
     }
     __syncthreads(); // Bloom filter in place; the only barrier
     // (middle tier: a tile's bitmap probes are waited for inside process() together with every load the wave has issued, the freshly
     // requested tile included; requesting that tile BEHIND process() instead was measured and changed nothing -- 522 / 534 / 1254 us
     // against 520 / 530 / 1234 on the dense, 2-fold and 8-fold indexes: the other three waves of the SIMD cover the wait)
-    while (tile < full_end) {
-        fetch(tile + 2 * step, r2);
-        process(tile, r0);
-        tile += step;
-        if (tile >= full_end) break;
-        fetch(tile + 2 * step, r0);
-        process(tile, r1);
-        tile += step;
-        if (tile >= full_end) break;
-        fetch(tile + 2 * step, r1);
-        process(tile, r2);
-        tile += step;
-    }
-    for (; tile < tile_end; tile += step) { // the end of the buffer, guarded loads
+    if (pipelined)
+        for (;;) {
+            fetch(ahead2(), r2);
+            process(tile, r0);
+            if (!advance()) break;
+            fetch(ahead2(), r0);
+            process(tile, r1);
+            if (!advance()) break;
+            fetch(ahead2(), r1);
+            process(tile, r2);
+            if (!advance()) break;
+        }
+    for (; tile < c_all; ++tile) { // the end of the buffer (the last chunk of the window only), guarded loads
         const int64_t g = (int64_t)tile * WPOS + (int64_t)lane * G;
         Pair p;
         if constexpr (PACKED) {
@@ -541,17 +607,16 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
             p.b = load16(g + 16);
         }
         process(tile, p);
+        if constexpr (MID != 0) ++tiles_done;
     }
     close_slice();
-    for (++slice; slice < (gw + 1) * FT_SUB; ++slice) // slices this wave never reached (the last waves of a short batch)
-        if (lane == 0) (LEVEL0 && !FUSED ? fw.grp_count : fw.slice_count)[slice] = 0;
     if (fw.class_clock && (tid & 255) == 0) atomicMax(&fw.class_clock[1 + (tid >> 8)], (unsigned long long)wall_clock64()); // (waves 4c: when class c was through)
     if constexpr (MID != 0)
         if (fw.stat) {
             atomicAdd(&fw.stat[1], (unsigned long long)st_a);
             atomicAdd(&fw.stat[2], (unsigned long long)st_b);
             atomicAdd(&fw.stat[3], (unsigned long long)st_c);
-            if (lane == 0) atomicAdd(&fw.stat[0], (unsigned long long)(tile_end > t_lo + gw * tiles_per_wave ? tile_end - (t_lo + gw * tiles_per_wave) : 0u) * 63ull * (G / 4));
+            if (lane == 0) atomicAdd(&fw.stat[0], (unsigned long long)tiles_done * 63ull * (G / 4));
         }
 }
 #undef DRPRG_SECOND_STAGE
@@ -611,6 +676,7 @@ __global__ __launch_bounds__(RF_THREADS) void refine_kernel(SketchArgs a, Filter
         if (lane == 0) {
             fw.slice_count[s] = written;
             if (n_raw > fw.raw_slice || written > fw.raw_slice) atomicOr(a.overflow, 4u);
+            if (written) atomicAdd(&fw.super_count[s / FT_SUPER], written < fw.raw_slice ? written : fw.raw_slice);
         }
     }
 }
@@ -632,11 +698,85 @@ uint32_t filter_grid(bool level0, int n_cus, uint32_t n_tiles)
     uint32_t grid = (uint32_t)n_cus * (level0 ? 1 : 2);
     const uint32_t need = (n_tiles + FT_WAVES - 1) / FT_WAVES;
     if (grid > need) grid = need;
-    if (grid > (uint32_t)(MAX_SLICES / (FT_WAVES * FT_SUB))) grid = MAX_SLICES / (FT_WAVES * FT_SUB);
+    if (grid > (uint32_t)(MAX_SLICES / FT_WAVES)) grid = MAX_SLICES / FT_WAVES;
+    if (const char* e = std::getenv("DRPRG_FT_GRID")) { // (tests: few workgroups, so that a small batch gives every wave a chunk schedule)
+        const int cap = std::atoi(e);
+        if (cap >= 1 && grid > (uint32_t)cap) grid = (uint32_t)cap;
+    }
     return grid ? grid : 1;
 }
 
-size_t filter_small_words() { return (size_t)MAX_SLICES * 3 + 1 + 4 * (size_t)MAX_EX_WG; }
+// FilterBuffers::small: [slice counts: MAX_CHUNKS][superblock counts: MAX_SLICES][prefix of the slices: MAX_CHUNKS + 4 (gathered form only; the word
+// behind the last slice's is the batch's candidate total)][group counts: MAX_CHUNKS (two-kernel form)][per-workgroup totals: 4 x MAX_EX_WG].  The
+// superblock counts are zero between two sequences (counters_home_kernel).
+constexpr size_t FT_SMALL_HEAD = (size_t)MAX_CHUNKS + MAX_SLICES;
+size_t filter_small_words() { return FT_SMALL_HEAD + (size_t)MAX_CHUNKS * 2 + 4 + 4 * (size_t)MAX_EX_WG; }
+uint32_t* filter_super_counts(uint32_t* small) { return small + MAX_CHUNKS; }
+uint32_t filter_super_words() { return (uint32_t)MAX_SLICES; }
+
+FilterSched make_filter_sched(uint32_t n_tiles, uint32_t n_wg, bool window_known, const uint32_t share[4])
+{
+    FilterSched s {};
+    for (int r = 0; r < FT_MAX_ROUNDS; ++r) s.first_ticket[r] = 0xFFFFFFFFu;
+    s.n_rounds = 1;
+    s.per_wg = FT_WAVES;
+    s.tpw0 = window_known ? (n_tiles + n_wg * FT_WAVES - 1) / (n_wg * FT_WAVES) : 0u;
+    // DRPRG_FT_SCHED (read at every launch: tests switch it): "static", or "f,d,m[,a]" = round 0's part of the tiles in 1/256, the divisor of
+    // the dynamic rounds x 16 (a round hands every wave 16 / d of an even share of what is left), the smallest chunk in tiles, and the
+    // fewest tiles per wave a batch must have for a dynamic schedule at all (64: below that the static split is as good, and cheaper)
+    struct Knobs {
+        bool is_static = false;
+        uint32_t f = 180, d = 32, m = 4, min_avg = 64;
+    } knobs;
+    if (const char* e = std::getenv("DRPRG_FT_SCHED")) {
+        if (std::string(e) == "static") knobs.is_static = true;
+        else {
+            unsigned a = 0, b = 0, c = 0, g = 64;
+            const int got = std::sscanf(e, "%u,%u,%u,%u", &a, &b, &c, &g);
+            if (got >= 3 && a >= 1 && a <= 250 && b >= 17 && b <= 1024 && c >= 4 && c <= 4096 && g >= 8) {
+                knobs.f = a;
+                knobs.d = b;
+                knobs.m = c;
+                knobs.min_avg = g;
+            }
+        }
+    }
+    uint32_t min_share = share[0];
+    for (int c = 1; c < 4; ++c) min_share = std::min(min_share, share[c]);
+    // the schedule of ONE workgroup, for the smaller of the two sizes an even split of the window gives (the kernel's workgroups find their
+    // own ranges; the last chunk of each takes the odd tile)
+    const uint64_t wg_tiles = n_tiles / n_wg, avg = wg_tiles / FT_WAVES;
+    const uint32_t tpw0 = (uint32_t)(avg * knobs.f / 256);
+    // every chunk of a dynamic schedule must hold two tiles that lie wholly inside the buffer (the last two tiles of a batch may not): the
+    // smallest share of round 0 -- the class split rounds down by up to a tile -- and the smallest chunk say whether this batch can have one
+    if (!window_known || knobs.is_static || avg < knobs.min_avg || (uint64_t)tpw0 * min_share / 256 < 4) return s;
+    const uint32_t max_per_wg = (uint32_t)MAX_CHUNKS / n_wg;
+    uint64_t done = (uint64_t)FT_WAVES * tpw0, rest = wg_tiles - done;
+    if (rest < 4) return s; // (the last chunk -- the whole dynamic part here -- must hold four tiles: the batch's last two may be partial)
+    uint32_t tk = FT_WAVES;
+    int r = 1;
+    for (; r < FT_MAX_ROUNDS - 1 && tk + 2 * FT_WAVES <= max_per_wg; ++r) {
+        const uint32_t sz = (uint32_t)(rest * 16 / ((uint64_t)FT_WAVES * knobs.d));
+        if (sz < 2 * knobs.m) break;
+        s.first_ticket[r] = tk;
+        s.first_tile[r] = (uint32_t)done;
+        s.size[r] = sz;
+        done += (uint64_t)FT_WAVES * sz;
+        rest -= (uint64_t)FT_WAVES * sz;
+        tk += FT_WAVES;
+    }
+    // the last round: chunks of the smallest size, or larger ones if the slices would not suffice; its last chunk takes the remainder
+    const uint32_t left = max_per_wg - tk;
+    const uint32_t sz = (uint32_t)std::max<uint64_t>(knobs.m, (rest + left - 1) / left);
+    const uint32_t cnt = (uint32_t)std::max<uint64_t>(1, rest / sz);
+    s.first_ticket[r] = tk;
+    s.first_tile[r] = (uint32_t)done;
+    s.size[r] = sz;
+    s.n_rounds = (uint32_t)r + 1;
+    s.per_wg = tk + cnt;
+    s.tpw0 = tpw0;
+    return s;
+}
 
 void init_candidate_work(FilterWork& fw, const FilterBuffers& b, int n_cus)
 {
@@ -644,7 +784,7 @@ void init_candidate_work(FilterWork& fw, const FilterBuffers& b, int n_cus)
     fw.cand_info = b.cand_info;
     fw.cand_pos1 = b.cand_pos1;
     fw.cand_rec = b.cand_rec;
-    fw.wg_hits = b.small + 3 * MAX_SLICES + 1;
+    fw.wg_hits = b.small + FT_SMALL_HEAD + 2 * MAX_CHUNKS + 4;
     fw.wg_nmin = fw.wg_hits + MAX_EX_WG;
     fw.wg_maxlen = fw.wg_nmin + MAX_EX_WG;
     fw.wg_base = fw.wg_maxlen + MAX_EX_WG;
@@ -693,27 +833,30 @@ hipError_t launch_sketch_filter(const SketchArgs& a, uint32_t read_begin, uint32
         // 240 / 257 of 270.  The other workloads of the level-0 forms gain less from the same shares (middle tier, dense 8d genes 501 -> 479 us,
         // 8-fold index 1252 -> 1219; 4 kb reads 1966 -> 1801) and none loses; the forms with two workgroups per CU keep even shares.
         // DRPRG_FT_SHARE=a,b,c,d (any scale): measurements.  Any shares give the same candidates: the ranges stay in wave order.
-        static const bool from_env = std::getenv("DRPRG_FT_SHARE") != nullptr;
-        static const std::array<uint32_t, 4> env_share = [] {
-            std::array<uint32_t, 4> s { 256, 256, 256, 256 };
-            if (const char* e = std::getenv("DRPRG_FT_SHARE")) {
-                double v[4] = { 1, 1, 1, 1 };
-                if (std::sscanf(e, "%lf,%lf,%lf,%lf", &v[0], &v[1], &v[2], &v[3]) == 4 && v[0] > 0 && v[1] > 0 && v[2] > 0 && v[3] > 0) {
-                    const double sum = v[0] + v[1] + v[2] + v[3];
-                    uint32_t acc = 0;
-                    for (int c = 0; c < 3; ++c) acc += s[c] = (uint32_t)(1024.0 * v[c] / sum + 0.5);
-                    s[3] = 1024u - acc;
-                }
+        // (read at every launch: the tests map one batch with several)
+        const char* const share_env = std::getenv("DRPRG_FT_SHARE");
+        const bool from_env = share_env != nullptr;
+        std::array<uint32_t, 4> env_share { 256, 256, 256, 256 };
+        if (share_env) {
+            double v[4] = { 1, 1, 1, 1 };
+            if (std::sscanf(share_env, "%lf,%lf,%lf,%lf", &v[0], &v[1], &v[2], &v[3]) == 4 && v[0] > 0 && v[1] > 0 && v[2] > 0 && v[3] > 0) {
+                const double sum = v[0] + v[1] + v[2] + v[3];
+                uint32_t acc = 0;
+                for (int c = 0; c < 3; ++c) acc += env_share[c] = (uint32_t)(1024.0 * v[c] / sum + 0.5);
+                env_share[3] = 1024u - acc;
             }
-            return s;
-        }();
+        }
         // (the middle tier's waves wait for the L2 more and for each other less: its classes end at 1 : 1.13 : 1.30 : 1.49 with even shares)
         static const uint32_t even[4] = { 256, 256, 256, 256 }, ascii_l0[4] = { 397, 294, 200, 133 }, packed_l0[4] = { 422, 292, 184, 126 }, mid_l0[4] = { 356, 292, 220, 156 };
         const uint32_t* share = from_env ? env_share.data() : !level0 ? even : b.wave_share ? b.wave_share : mid ? mid_l0 : a.packed ? packed_l0 : ascii_l0;
         fw.class_clock = level0 && !from_env ? b.class_clock : nullptr;
         for (int c = 0; c < 4; ++c) fw.wave_share[c] = share[c];
     }
-    fw.n_slices = grid * FT_WAVES * FT_SUB;
+    {   // the chunk schedule: dynamic when this sequence covers the whole batch (the host then knows the tile numbers) and the batch is large enough
+        const bool whole = read_begin == 0 && read_end == a.n_reads;
+        fw.sched = make_filter_sched(filter_n_tiles(a.n_bases, filter_positions_per_lane(level0, a.packed != 0)), grid, whole, fw.wave_share);
+    }
+    fw.n_slices = grid * fw.sched.per_wg;
     fw.raw_slice = (uint32_t)std::min<uint64_t>(b.raw_capacity / fw.n_slices, 0x7FFFFFFFull / fw.n_slices);
     fw.raw_pos = b.raw_pos;
     fw.cand_info = b.cand_info;
@@ -721,9 +864,10 @@ hipError_t launch_sketch_filter(const SketchArgs& a, uint32_t read_begin, uint32
     fw.cand_rec = b.cand_rec;
     init_candidate_work(fw, b, n_cus);
     fw.slice_count = b.small;
-    fw.cand_prefix = b.small + MAX_SLICES;
-    fw.cand_total = fw.cand_prefix + grid * FT_WAVES * FT_SUB;
-    fw.grp_count = b.small + 2 * MAX_SLICES + 1;
+    fw.super_count = filter_super_counts(b.small);
+    fw.cand_prefix = b.small + FT_SMALL_HEAD;
+    fw.cand_total = fw.cand_prefix + fw.n_slices;
+    fw.grp_count = b.small + FT_SMALL_HEAD + MAX_CHUNKS + 4;
     fw.raw_grp = b.raw_grp;
     {
         using Kernel = void (*)(SketchArgs, FilterWork);
@@ -741,7 +885,9 @@ hipError_t launch_sketch_filter(const SketchArgs& a, uint32_t read_begin, uint32
             : which == 1                 ? &sketch_filter_kernel<true, false, false, 0, true>
                                          : &sketch_filter_kernel<false, false, false, 0, true>;
         const Kernel kernel = a.packed ? packed : ascii;
-        const size_t dyn = level0 ? (size_t)FT_L0_WORDS * 4 + (fused ? (size_t)FT_WAVES * 2048 : 0) : ((size_t)4 << bt.bloom_wbits);
+        // (+ the chunk counter: 16 bytes of their own, or -- the level-0 form with the second stage inside fills the 160 KB -- the last record of the last wave's stage)
+        const size_t dyn = level0 ? (size_t)FT_L0_WORDS * 4 + (fused ? (size_t)FT_WAVES * 2048 : 16) : ((size_t)4 << bt.bloom_wbits) + 16;
+        fw.sched.lds_word = (uint32_t)(dyn / 4 - 4);
         static size_t configured[12][MAX_HIP_DEVICES] = {};
         HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), dyn, configured[which + (a.packed ? 6 : 0)]));
         launch_timed(timer, kernel, dim3(grid), dim3(FT_THREADS), dyn, stream, a, fw);

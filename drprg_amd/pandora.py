@@ -289,6 +289,15 @@ class Context:
         _check(lib.drprg_hip_prg_nodes(self._h, prg, _ptr(starts), _ptr(ends), n.value, C.byref(n), C.byref(ns)), self._h)
         return starts, ends, int(ns.value)
 
+    def filter_schedule(self):
+        """sketch_filter_kernel's chunk schedule in the batch completed last and when its wave classes were through (include/drprg_hip.h)"""
+        out = (C.c_uint64 * 20)()
+        _check(lib.drprg_hip_filter_schedule(self._h, out), self._h)
+        v = [int(x) for x in out]
+        return {"form": "dynamic" if v[0] > 1 else "static", "rounds": v[0], "slices": v[1], "slices_per_workgroup": v[11], "round0_tiles_per_wave": v[2],
+                "round0_class_shares_per_256": v[3:7], "chunk_tiles_per_round": [x for x in v[13:20] if x],
+                "class_end_us": [round(x / 100.0, 1) for x in v[7:11]]}
+
     def kernel_timing(self, enable=True, reset=False):
         ms, n = C.c_double(), C.c_uint64()
         _check(lib.drprg_hip_kernel_timing(self._h, 1 if enable else 0, 1 if reset else 0, C.byref(ms), C.byref(n)), self._h)

@@ -320,6 +320,11 @@ int drprg_hip_report_json(const char* index_dir, const char* annotated_vcf, cons
  * launches = launches of that kernel (a batch cut into several read ranges counts one per range).
  * enable != 0 starts/keeps timing; ms_total / launches may be NULL; reset != 0 clears the sums. */
 int drprg_hip_kernel_timing(drprg_hip_ctx* ctx, int enable, int reset, double* ms_total, uint64_t* launches);
+/* How sketch_filter_kernel handed its tiles out in the batch completed last, and when its four wave classes were through (bench.py prints
+ * it next to the roofline; csrc/kernels.h FilterSched).  out[0] rounds of the schedule (1: static, one chunk per wave), [1] chunks = slices,
+ * [2] tiles per wave of round 0, [3..6] the classes' shares of round 0 in 1/256 of an even one, [7..10] the classes' end times in 10 ns from
+ * the kernel's first wave (0: not clocked), [11] chunks per workgroup, [12..19] chunk size of every round in tiles.  Synchronises. */
+int drprg_hip_filter_schedule(drprg_hip_ctx* ctx, uint64_t out[20]);
 
 #ifdef __cplusplus
 }

@@ -1111,3 +1111,142 @@ def test_packed_reads_on_the_device_and_through_the_ingest(tmp_path, oracle):
     other = _ctx(tmp_path, panel, 11, 15, True, kernel=0)
     other.map_resident(ctx)
     assert np.array_equal(other.coverage()[0], ocov)
+
+
+# ---- sketch_filter_kernel's schedule (round 6): chunks handed out inside the kernel, tile shares that follow the batches ---------------
+def _ragged_reads(panel, seed=0, n=12000):
+    """the mix of test_ragged_and_degenerate_inputs: empty reads, reads shorter than k, N runs, lower case, lengths up to 8192"""
+    from drprg_amd import synth
+    rng = np.random.default_rng(seed)
+    g = synth.HaplotypeGenomes(panel, genome_size=20000, n_hap=2, seed=3).haps[0]
+    reads = []
+    for i in range(n):
+        L = int(rng.choice([0, 1, 14, 15, 24, 25, 26, 40, 150, 151, 300, 4064, 4096, 5000, 8160, 8192]))
+        s = int(rng.integers(0, len(g) - L))
+        r = g[s:s + L].copy()
+        if L and rng.random() < 0.3:
+            r[rng.integers(0, L, size=max(1, L // 50))] = ord("N")
+        if L and rng.random() < 0.2:
+            r = np.frombuffer(r.tobytes().lower(), dtype=np.uint8)
+        reads.append(r)
+    offs = np.zeros(len(reads) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(r) for r in reads])
+    return np.concatenate(reads), offs
+
+
+@pytest.mark.parametrize("sched", ["static", "180,32,4,8"])
+def test_filter_schedule_follows_the_batches(tmp_path, oracle, monkeypatch, sched):
+    """VERDICT r05 #2a.  The configs[1] batch (180 M bases: large enough for the host to time the wave classes) mapped eight times on one
+    context: with the static schedule the tile shares move from batch to batch (mapper.cpp tune_filter_shares), with the dynamic one the
+    waves draw their chunks in whatever order they get to them -- every one of the eight passes must add exactly the oracle's vector.
+    Then reset (coverage zero, built-in shares again) and once more."""
+    import torch
+    from drprg_amd import synth
+    monkeypatch.setenv("DRPRG_FT_SCHED", sched)
+    panel, genomes = _baseline_panel("mtb_8d")
+    ctx = _ctx(tmp_path, panel, 11, 15, True, genome_size=synth.MTB_GENOME_SIZE)
+    bases, offs = _baseline_reads("mtb_8d", False, 1_200_000)
+    idx = _oracle_index(oracle, ctx.prg_strings, 11, 15)
+    ocov, oprg, ocnt = _oracle_map(oracle, idx, bases, offs, 11, 15, True, threads=ORACLE_THREADS)
+    dev = torch.device("cuda", 0)
+    tb, to = torch.from_numpy(np.ascontiguousarray(bases)).to(dev), torch.from_numpy(offs.astype(np.int64)).to(dev)
+    torch.cuda.synchronize()
+    ctx.reset()
+    seen = []
+    for i in range(8):
+        ctx.map_device_async(tb.data_ptr(), to.data_ptr(), len(offs) - 1, int(offs[-1]))
+        if i >= 1:
+            seen.append(tuple(ctx.filter_schedule()["round0_class_shares_per_256"]))  # (synchronises: of the batch just completed)
+    cov, prg = ctx.coverage()
+    assert np.array_equal(cov.astype(np.uint64), 8 * ocov.astype(np.uint64)) and np.array_equal(prg.astype(np.uint64), 8 * oprg.astype(np.uint64))
+    info = ctx.filter_schedule()
+    assert ctx.counters()["kernel"] == 2 and ctx.counters()["hits"] == 8 * ocnt["hits"]
+    if sched == "static":
+        assert info["form"] == "static" and len(set(seen)) > 1, seen  # the shares did move
+    else:
+        assert info["form"] == "dynamic" and info["slices_per_workgroup"] > 16 and len(set(seen)) == 1, (info, seen)
+    ctx.reset()
+    ctx.map_device(tb.data_ptr(), to.data_ptr(), len(offs) - 1, int(offs[-1]))
+    cov, prg = ctx.coverage()
+    assert np.array_equal(cov, ocov) and np.array_equal(prg, oprg)
+    # ... and the same through the packed form, three passes
+    from drprg_amd.pandora import pack_reads
+    words, npos = pack_reads(bases)
+    ctx.reset()
+    for _ in range(3):
+        ctx.map_host_packed(words, offs, npos)
+    cov, prg = ctx.coverage()
+    assert np.array_equal(cov.astype(np.uint64), 3 * ocov.astype(np.uint64)) and np.array_equal(prg.astype(np.uint64), 3 * oprg.astype(np.uint64))
+
+
+def _schedule_forms(ctx, bases, offs):
+    """the schedule sketch_filter_kernel ran this batch with, from ASCII and from the packed words: ("static" | "dynamic") x 2"""
+    from drprg_amd.pandora import pack_reads
+    ctx.reset()
+    ctx.map_host(bases, offs)
+    a = ctx.filter_schedule()
+    words, npos = pack_reads(bases)
+    ctx.reset()
+    ctx.map_host_packed(words, offs, npos)
+    p = ctx.filter_schedule()
+    assert a["form"] == "static" or a["slices_per_workgroup"] > 16
+    return a["form"], p["form"]
+
+
+@pytest.mark.parametrize("share", ["2.2,0.35,0.35,2.2", "0.35,2.2,2.2,0.35"])
+@pytest.mark.parametrize("sched,grid", [("static", None), ("128,32,4,8", "4"), ("static", "3")])
+def test_extreme_tile_shares(tmp_path, oracle, monkeypatch, share, sched, grid):
+    """VERDICT r05 #2b.  The wave classes' shares at both clamps of the host's tuning (DRPRG_FT_SHARE), on the ragged / N / lower-case /
+    empty-read case and on 4 kb reads, ASCII and packed (_compare maps both): any shares give the oracle's vector -- with one chunk per
+    wave, and with the chunk schedule on top of them (few workgroups, so that these small batches have tiles enough for one)."""
+    from drprg_amd import synth
+    monkeypatch.setenv("DRPRG_FT_SHARE", share)
+    monkeypatch.setenv("DRPRG_FT_SCHED", sched)
+    if grid:
+        monkeypatch.setenv("DRPRG_FT_GRID", grid)
+    want = ("dynamic", "dynamic") if sched != "static" else ("static", "static")
+    panel = synth.small_panel(seed=2)
+    ctx = _ctx(tmp_path, panel, 11, 15, True, kernel=2)
+    bases, offs = _ragged_reads(panel)
+    _compare(ctx, oracle, bases, offs, 11, 15, True, 2)
+    assert _schedule_forms(ctx, bases, offs) == want
+    panel = synth.small_panel(seed=11, n_loci=6, length=1500)
+    ctx = _ctx(tmp_path, panel, 11, 15, False, kernel=2)
+    gen = synth.HaplotypeGenomes(panel, genome_size=60000, n_hap=4, seed=3)
+    bases, offs = synth.sample_long_reads(gen, 3000, seed=3)
+    cnt = _compare(ctx, oracle, bases, offs, 11, 15, False, 2)
+    assert cnt["clusters_kept"] > 0 and _schedule_forms(ctx, bases, offs) == want
+
+
+@pytest.mark.parametrize("grid,sched", [("1", "100,20,4,8"), ("3", "100,20,4,8"), ("7", "200,17,4,8"), ("5", "60,64,5,8"), ("2", "250,1024,4,8")])
+def test_chunk_schedule_edges(tmp_path, oracle, monkeypatch, grid, sched):
+    """VERDICT r05 #2c.  The chunk schedule with chunks small enough that a workgroup's last chunk is a partial one, the workgroups' ranges
+    differ by a tile, the batch ends in tiles that do not lie wholly inside the buffer, and most waves never get to draw a ticket (one
+    workgroup; seven): dense reads (slices that fill up), sparse reads, the middle tier, every case in both input formats."""
+    from drprg_amd import synth
+    monkeypatch.setenv("DRPRG_FT_GRID", grid)
+    monkeypatch.setenv("DRPRG_FT_SCHED", sched)
+    panel = synth.small_panel(seed=6, n_loci=3, length=900)
+    rng = np.random.default_rng(5)
+    haps = [synth.sample_haplotype(rng, t).encode() for t in panel.trees]
+    dense = _reads_from(rng, haps, 40000 + 37 * int(grid), 150)
+    sparse = _reads_from(rng, haps + [synth.random_seq(rng, 200000).encode()] * 9, 90000 + 11 * int(grid), 151)
+    forms = []
+    for bases, offs in (dense, sparse):
+        ctx = _ctx(tmp_path, panel, 11, 15, True, kernel=2)
+        cnt = _compare(ctx, oracle, bases, offs, 11, 15, True, 2)
+        assert cnt["clusters_kept"] > 3000
+        forms.append(_schedule_forms(ctx, bases, offs))
+    assert all(f[0] == "dynamic" for f in forms), forms
+    if sched != "60,64,5,8":  # (a quarter of the tiles in round 0: the packed form's 64 positions per lane leave too few tiles per wave for it)
+        assert all(f[1] == "dynamic" for f in forms), forms
+    # the middle tier (its own instantiation of the kernel) and w = 14 (another window) through the same schedule
+    monkeypatch.setenv("DRPRG_FORCE_MID_TIER", "1")
+    ctx = _ctx(tmp_path, panel, 14, 15, True, kernel=2)
+    _compare(ctx, oracle, sparse[0], sparse[1], 14, 15, True, 2)
+    assert _schedule_forms(ctx, sparse[0], sparse[1])[0] == "dynamic"
+    monkeypatch.delenv("DRPRG_FORCE_MID_TIER")
+    # k = 13 (the forms without level 0: two workgroups per CU, another LDS layout for the counter)
+    ctx = _ctx(tmp_path, panel, 16, 13, True, kernel=2)
+    _compare(ctx, oracle, sparse[0], sparse[1], 16, 13, True, 2)
+    assert _schedule_forms(ctx, sparse[0], sparse[1])[0] == "dynamic"
