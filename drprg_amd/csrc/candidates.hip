@@ -15,7 +15,7 @@ namespace dev {
 // ---------------------------------------------------------------------------------------------
 // scans
 // ---------------------------------------------------------------------------------------------
-// one workgroup: cand_prefix = exclusive scan of min(slice_count, raw_slice) (the gathered form: DRPRG_VERIFY_FORM=gather, read_verify_kernel)
+// one workgroup: cand_prefix = exclusive scan of slice_count (the gathered form: DRPRG_VERIFY_FORM=gather, read_verify_kernel)
 __global__ __launch_bounds__(SCAN_THREADS) void cand_scan_kernel(FilterWork fw)
 {
     __shared__ uint32_t s_w[SCAN_THREADS / 64 + 1];
@@ -27,7 +27,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void cand_scan_kernel(FilterWork fw)
         const uint32_t s = (uint32_t)tid * PER + i;
         if (s >= fw.n_slices) break;
         const uint32_t n = fw.slice_count[s];
-        run += n < fw.raw_slice ? n : fw.raw_slice;
+        run += n;
     }
     uint32_t total;
     uint32_t acc = block_exclusive_scan<SCAN_THREADS / 64>(run, s_w, &total);
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void cand_scan_kernel(FilterWork fw)
         if (s >= fw.n_slices) break;
         const uint32_t n = fw.slice_count[s];
         fw.cand_prefix[s] = acc;
-        acc += n < fw.raw_slice ? n : fw.raw_slice;
+        acc += n;
     }
     if (tid == 0) fw.cand_prefix[fw.n_slices] = total;
 }
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(64) void cand_gather_kernel(FilterWork fw)
 {
     const uint32_t s = blockIdx.x;
     const uint32_t n = fw.cand_prefix[s + 1] - fw.cand_prefix[s];
-    const uint64_t* __restrict__ src = fw.raw_pos + (size_t)s * fw.raw_slice;
+    const uint64_t* __restrict__ src = fw.raw_pos + fw.slice_base[s];
     uint64_t* __restrict__ dst = fw.cand_gp + fw.cand_prefix[s];
     for (uint32_t i = threadIdx.x; i < n; i += 64) dst[i] = src[i];
 }
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(EX_THREADS) void verify_count_kernel(SketchArgs a, 
 // ordered list from the total, and reads the positions of its candidates straight from the filter kernel's slices: entry t lives in the
 // superblock s with prefix[s] <= t < prefix[s + 1] (a candidate bisects the superblocks of its workgroup's share, a handful of a full batch),
 // there in the slice the eight slice counts of the superblock say (one more round trip to the L2, requested a candidate ahead like the
-// position itself), at raw_pos[slice * raw_slice + rest].  Workgroup 0 leaves the total where read_cluster_kernel and the generic pipeline
+// position itself), at raw_pos[start of the slice + rest].  Workgroup 0 leaves the total where read_cluster_kernel and the generic pipeline
 // look for it (*fw.cand_total).  The dense list of positions (fw.cand_gp) is not made: only the experimental read-by-read form wants it,
 // and gets the old sequence.
 #ifndef DRPRG_VS_THREADS // (measurement builds)
@@ -184,19 +184,18 @@ __global__ __launch_bounds__(VS_THREADS, 8) void verify_scan_kernel(SketchArgs a
             // running sum exceeds the rest.  (Counts past the last slice of the batch are never reached: the superblock sums say where the list ends.)
             static_assert(FT_SUPER == 8, "two uint4 of slice counts per superblock");
             const uint4* __restrict__ c4 = reinterpret_cast<const uint4*>(fw.slice_count) + (size_t)lo * 2;
-            const uint4 ca = c4[0], cb = c4[1];
-            const uint32_t cap = fw.raw_slice;
-            const uint32_t cnt[8] = { ca.x < cap ? ca.x : cap, ca.y < cap ? ca.y : cap, ca.z < cap ? ca.z : cap, ca.w < cap ? ca.w : cap,
-                cb.x < cap ? cb.x : cap, cb.y < cap ? cb.y : cap, cb.z < cap ? cb.z : cap, cb.w < cap ? cb.w : cap };
-            uint32_t rest = t - s_pre[lo], j = 0, sum = 0, before = 0;
+            const uint4* __restrict__ b4 = reinterpret_cast<const uint4*>(fw.slice_base) + (size_t)lo * 2;
+            const uint4 ca = c4[0], cb = c4[1], ba = b4[0], bb = b4[1]; // (counts and starts of the eight slices: one round trip)
+            const uint32_t cnt[7] = { ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z }, start[8] = { ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, bb.z, bb.w };
+            uint32_t rest = t - s_pre[lo], sum = 0, before = 0, at = start[0];
 #pragma unroll
             for (int q = 0; q < 7; ++q) {
                 sum += cnt[q];
                 const bool past = rest >= sum;
-                j += past ? 1u : 0u;
+                at = past ? start[q + 1] : at;
                 before = past ? sum : before;
             }
-            return (int64_t)fw.raw_pos[(size_t)(lo * FT_SUPER + j) * fw.raw_slice + (rest - before)];
+            return (int64_t)fw.raw_pos[(size_t)at + (rest - before)];
         };
         // (the position of this thread's next candidate is requested one round early: one round trip less in the chain of each)
         int64_t gp_next = t_begin + tid < t_end ? position_of(t_begin + (uint32_t)tid) : 0;

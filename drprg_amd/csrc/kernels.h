@@ -211,15 +211,21 @@ struct FilterWork {
                              // streams the wave tiles (FT_WPOS positions each) that cover their bases, candidates
                              // outside [offsets[read_begin], offsets[read_end]) are dropped by verify_count_kernel
     uint32_t n_slices;       // slices of the candidate buffers (= chunks of the filter kernel's schedule: its workgroups x sched.per_wg)
-    uint32_t raw_slice;      // capacity of one slice
-    uint64_t* raw_pos;       // [n_slices][raw_slice]: global base position of a candidate k-mer, ascending per slice
-    uint32_t* slice_count;   // [n_slices] (may exceed raw_slice: overflow)
+    // Where a slice lives (round 6: the chunks are not of one size, so neither are their slices): workgroup b's slices share slice_budget
+    // entries from b * slice_budget; chunk k of it, tiles [first, end) of the workgroup's range [lo, ..), starts (first - lo) * slice_cpt +
+    // k * slice_slack entries in and holds (end - first) * slice_cpt + slice_slack -- room in proportion to its tiles plus a floor for the
+    // small ones (a 4-tile chunk that meets five reads from the panel).  The filter kernel leaves start and room next to the count.
+    uint32_t slice_budget, slice_cpt, slice_slack;
+    uint64_t* raw_pos;       // global base position of a candidate k-mer, ascending per slice
+    uint32_t* slice_count;   // [n_slices], clamped to the slice's room (more: overflow bit 2, the host runs the batch again)
+    uint32_t* slice_base;    // [n_slices]: first entry of the slice in raw_pos (/ raw_grp)
+    uint32_t* slice_cap;     // [n_slices]: its room
     uint32_t* super_count;   // [MAX_SLICES], zero before the launch (counters_home_kernel clears it behind every sequence): the candidates of
-                             // slices 8 s .. 8 s + 7, each count clamped to raw_slice (what verify_scan_kernel scans)
+                             // slices 8 s .. 8 s + 7 (what verify_scan_kernel scans)
     FilterSched sched;       // sketch_filter_kernel's chunk schedule
-    uint4* raw_grp;          // level-0 form only, [n_slices][raw_slice]: {position of a surviving group of four k-mers (lo, hi),
+    uint4* raw_grp;          // level-0 form only, the slices' geometry: {position of a surviving group of four k-mers (lo, hi),
                              // its 16 bases, the 2 after them}, ascending per slice; refine_kernel turns them into raw_pos
-    uint32_t* grp_count;     // [n_slices] (may exceed raw_slice: overflow)
+    uint32_t* grp_count;     // [n_slices], clamped like slice_count
     uint32_t* cand_prefix;   // [n_slices + 1]: exclusive scan of the clamped counts
     const uint32_t* cand_total; // the number of candidates (filtered sequence: &cand_prefix[n_slices])
     uint64_t* cand_gp;       // [candidates]: global base position of the candidate k-mer, ascending (the slices gathered; nothing writes

@@ -383,11 +383,11 @@ void Mapper::ensure_lanes(int n, uint64_t cap)
 // counters to its pinned mirror, then the counters cleared again behind the copy (so that the next batch starts with its
 // first kernel instead of a memset).
 void Mapper::launch_lane(Lane& lane, hipStream_t stream, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads,
-    uint64_t n_bases, uint32_t* covg, uint32_t* prg_reads)
+    uint64_t n_bases, uint32_t* covg, uint32_t* prg_reads, const PackedInfo* pk)
 {
     if (!lane.scratch_zero) HIPCHK(hipMemsetAsync(lane.d_scratch, 0, L_N * sizeof(unsigned long long), stream));
     lane.scratch_zero = false;
-    dev::SketchArgs a = sketch_args(d_bases, d_offsets, n_reads, n_bases);
+    dev::SketchArgs a = sketch_args(d_bases, d_offsets, n_reads, n_bases, pk);
     a.n_hits = &lane.d_scratch[L_HITS];
     a.n_minimizers = &lane.d_scratch[L_MINIMIZERS];
     a.overflow = reinterpret_cast<uint32_t*>(&lane.d_scratch[L_OVERFLOW]);
@@ -397,11 +397,11 @@ void Mapper::launch_lane(Lane& lane, hipStream_t stream, const uint8_t* d_bases,
     {
         static const bool adapt = [] { const char* e = std::getenv("DRPRG_FT_ADAPT"); return !e || std::atoi(e) != 0; }();
         ft_adapt_ = adapt;
-        const int pk = packed_.count(d_bases) ? 1 : 0;
-        lane.ft_packed = pk != 0;
+        const int pi = pk ? 1 : 0;
+        lane.ft_packed = pi != 0;
         if (adapt) {
             fb.class_clock = &lane.d_scratch[L_FT_CLOCK];
-            if (ft_share_[pk][0]) fb.wave_share = ft_share_[pk];
+            if (ft_share_[pi][0]) fb.wave_share = ft_share_[pi];
         }
     }
     dev::BloomTables bt { d_bloom_, bloom_wbits_, d_bloom0_, bloom0_wbits_, d_bloomr_, d_bloom0f_ };
@@ -502,7 +502,7 @@ void Mapper::cluster_hits(const uint64_t* d_offsets, uint32_t n_hits, bool order
     HIPCHK(dev::launch_cluster_pipeline(c, n_hits, n_prgs_, stream));
 }
 
-dev::SketchArgs Mapper::sketch_args(const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads, uint64_t n_bases) const
+dev::SketchArgs Mapper::sketch_args(const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads, uint64_t n_bases, const PackedInfo* pk) const
 {
     dev::SketchArgs a {};
     a.bases = d_bases;
@@ -527,19 +527,17 @@ dev::SketchArgs Mapper::sketch_args(const uint8_t* d_bases, const uint64_t* d_of
     a.n_hits = &d_counters_[C_HITS];
     a.n_minimizers = &d_counters_[C_MINIMIZERS];
     a.overflow = reinterpret_cast<uint32_t*>(&d_counters_[C_OVERFLOW]);
-    const auto it = packed_.find(d_bases);
-    if (it != packed_.end()) {
+    if (pk) { // (a batch of 2-bit words: said by the caller, carried with the batch -- not looked up by its address)
         a.packed = 1;
-        a.npos = it->second.d_npos;
-        a.n_npos = it->second.n_npos;
+        a.npos = pk->d_npos;
+        a.n_npos = pk->n_npos;
     }
     return a;
 }
 
-const uint8_t* Mapper::ascii_view(int slot, const uint8_t* d_bases, uint64_t n_bases, hipStream_t stream)
+const uint8_t* Mapper::ascii_view(int slot, const uint8_t* d_bases, uint64_t n_bases, hipStream_t stream, const PackedInfo* pk)
 {
-    const auto it = packed_.find(d_bases);
-    if (it == packed_.end()) return d_bases;
+    if (!pk) return d_bases;
     const uint64_t need = (n_bases + 15) / 16 * 16 + 64;
     if (need > unpacked_cap_[slot]) {
         sync(); // (a batch in flight may still read the old buffer)
@@ -548,11 +546,7 @@ const uint8_t* Mapper::ascii_view(int slot, const uint8_t* d_bases, uint64_t n_b
         unpacked_cap_[slot] = need + need / 4;
         dmalloc(d_unpacked_[slot], unpacked_cap_[slot]);
     }
-    const PackedInfo info = it->second;
-    // (the expansion is ASCII whatever lived at its address before: a freed packed batch whose memory the allocator handed back here
-    // must not make sketch_args() call it packed -- ADVICE r04)
-    packed_.erase(d_unpacked_[slot]);
-    HIPCHK(dev::launch_unpack(reinterpret_cast<const uint32_t*>(d_bases), n_bases, info.d_npos, info.n_npos, d_unpacked_[slot], stream));
+    HIPCHK(dev::launch_unpack(reinterpret_cast<const uint32_t*>(d_bases), n_bases, pk->d_npos, pk->n_npos, d_unpacked_[slot], stream));
     return d_unpacked_[slot];
 }
 
@@ -573,10 +567,10 @@ void Mapper::note_kernel_time()
 
 // The reads read_cluster_kernel left over in this lane's candidate list: their hits -> the generic cluster pipeline.
 void Mapper::leftovers(Lane& lane, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads, uint64_t n_bases, uint32_t* covg,
-    uint32_t* prg_reads, hipStream_t stream)
+    uint32_t* prg_reads, hipStream_t stream, const PackedInfo* pk)
 {
     if (lane.h_scratch[L_COMPLEX] == 0) return;
-    dev::SketchArgs a = sketch_args(d_bases, d_offsets, n_reads, n_bases);
+    dev::SketchArgs a = sketch_args(d_bases, d_offsets, n_reads, n_bases, pk);
     a.n_hits = &lane.d_scratch[L_HITS];
     a.n_minimizers = &lane.d_scratch[L_MINIMIZERS]; // (the recount pass does not count minimizers again)
     a.overflow = reinterpret_cast<uint32_t*>(&lane.d_scratch[L_OVERFLOW]);
@@ -627,7 +621,7 @@ void Mapper::ensure_tile_workspace(TileSet& t, uint32_t n_tiles, uint32_t tile_c
 // there -- no hit list, no radix sort, no cluster kernels for the reads that fit it.
 // One attempt, asynchronous on `stream`: the launches, the lane's counters to their pinned mirror, the counters cleared behind the copy.
 void Mapper::direct_launch(int set, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads, uint64_t n_bases, uint32_t* covg,
-    uint32_t* prg_reads, hipStream_t stream, bool timed_by_set_events)
+    uint32_t* prg_reads, hipStream_t stream, bool timed_by_set_events, const PackedInfo* pk)
 {
     TileSet& t = tsets_[set];
     ts_ = &t;
@@ -666,8 +660,8 @@ void Mapper::direct_launch(int set, const uint8_t* d_bases, const uint64_t* d_of
     HIPCHK(hipMemsetAsync(t.d_tile_count + n_tiles, 0, sizeof(uint32_t), stream)); // the scan's closing zero
     // a packed batch: sketch_wave_kernel reads the words themselves (round 4; the positions of its npos as one bit per base, set here);
     // the general direct kernel reads an ASCII expansion made on the same stream (packed.hip)
-    const bool native_packed = packed_.count(d_bases) != 0 && dev::direct_uses_wave_form(params_.k, params_.w, wide_hash_);
-    dev::SketchArgs a = sketch_args(native_packed ? d_bases : ascii_view(set, d_bases, n_bases, stream), d_offsets, n_reads, n_bases);
+    const bool native_packed = pk != nullptr && dev::direct_uses_wave_form(params_.k, params_.w, wide_hash_);
+    dev::SketchArgs a = sketch_args(native_packed ? d_bases : ascii_view(set, d_bases, n_bases, stream, pk), d_offsets, n_reads, n_bases, native_packed ? pk : nullptr);
     if (native_packed && a.n_npos) {
         const uint64_t words16 = ((n_bases + 15) / 16 + 1) & ~1ull; // (an even number of u16 words: the marks are 32-bit atomics)
         if (words16 > t.nbits_cap) {
@@ -758,7 +752,7 @@ void Mapper::direct_launch(int set, const uint8_t* d_bases, const uint64_t* d_of
 // with fuse = -1 repeats exactly those additions as subtractions (same input, same slice capacity, so the same reads take that path).
 // true: totals taken, reads left to the generic pipeline queued on `stream`.
 bool Mapper::direct_finish(int set, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads, uint64_t n_bases, uint32_t* covg,
-    uint32_t* prg_reads, hipStream_t stream, int attempt)
+    uint32_t* prg_reads, hipStream_t stream, int attempt, const PackedInfo* pk)
 {
     TileSet& t = tsets_[set];
     ts_ = &t;
@@ -783,25 +777,25 @@ bool Mapper::direct_finish(int set, const uint8_t* d_bases, const uint64_t* d_of
     tot_leftover_ += lane.h_scratch[L_COMPLEX];
     if (t.mark && lane.h_scratch[L_COMPLEX]) // reads were left over: the generic pipeline wants the gathered list after all
         HIPCHK(dev::launch_tile_gather_marked(t.a_done, lane.fw, t.d_tile_prefix, t.n_tiles, lane.raw_capacity, t.mark, stream));
-    leftovers(lane, d_bases, d_offsets, n_reads, n_bases, covg, prg_reads, stream);
+    leftovers(lane, d_bases, d_offsets, n_reads, n_bases, covg, prg_reads, stream, pk);
     return true;
 }
 
 void Mapper::run_batch_direct_candidates(const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads, uint64_t n_bases,
-    uint32_t* covg, uint32_t* prg_reads, hipStream_t stream)
+    uint32_t* covg, uint32_t* prg_reads, hipStream_t stream, const PackedInfo* pk)
 {
     for (int attempt = 0;; ++attempt) {
-        direct_launch(0, d_bases, d_offsets, n_reads, n_bases, covg, prg_reads, stream, false);
+        direct_launch(0, d_bases, d_offsets, n_reads, n_bases, covg, prg_reads, stream, false, pk);
         wait_stream(stream);
         note_kernel_time();
-        if (direct_finish(0, d_bases, d_offsets, n_reads, n_bases, covg, prg_reads, stream, attempt)) break;
+        if (direct_finish(0, d_bases, d_offsets, n_reads, n_bases, covg, prg_reads, stream, attempt, pk)) break;
     }
 }
 
 // What the host does with a lane's read-back once its sequence has finished: a candidate slice that was too small -> the range
 // again with larger buffers; the totals; the reads read_cluster_kernel left over -> the generic pipeline on their hits.
 void Mapper::finish_lane(Lane& lane, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads, uint64_t n_bases, uint32_t* covg,
-    uint32_t* prg_reads, hipStream_t stream)
+    uint32_t* prg_reads, hipStream_t stream, const PackedInfo* pk)
 {
     for (int attempt = 0;; ++attempt) {
         const uint32_t ovf = (uint32_t)lane.h_scratch[L_OVERFLOW];
@@ -813,14 +807,14 @@ void Mapper::finish_lane(Lane& lane, const uint8_t* d_bases, const uint64_t* d_o
         // (hit_scan_kernel / read_cluster_kernel check the flag); grow the lane and run the range again, alone
         if (attempt > 8) throw Error(DRPRG_EOVERFLOW, "candidate buffer overflow after regrow");
         grow_lane(lane, lane.raw_capacity * 4);
-        launch_lane(lane, stream, d_bases, d_offsets, n_reads, n_bases, covg, prg_reads);
+        launch_lane(lane, stream, d_bases, d_offsets, n_reads, n_bases, covg, prg_reads, pk);
         wait_stream(stream);
     }
     tot_minimizers_ += lane.h_scratch[L_MINIMIZERS];
     tot_hits_ += lane.h_scratch[L_HITS];
     tot_leftover_ += lane.h_scratch[L_COMPLEX];
     tune_filter_shares(lane, lane.ft_packed, n_bases);
-    leftovers(lane, d_bases, d_offsets, n_reads, n_bases, covg, prg_reads, stream);
+    leftovers(lane, d_bases, d_offsets, n_reads, n_bases, covg, prg_reads, stream, pk);
 }
 
 // sketch_filter_kernel's four wave classes should end together (sketch_filter.hip: a SIMD issues for its oldest wave first).  How far apart they
@@ -880,18 +874,17 @@ void Mapper::tune_filter_shares(const Lane& lane, bool packed, uint64_t n_bases)
 void Mapper::map_device_async(const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n_reads, uint64_t n_bases, uint32_t* covg,
     uint32_t* prg_reads, hipStream_t stream)
 {
-    packed_.erase(d_bases);
-    map_device_async_impl(d_bases, d_offsets, n_reads, n_bases, covg, prg_reads, stream);
+    map_device_async_impl(d_bases, d_offsets, n_reads, n_bases, covg, prg_reads, stream, nullptr);
 }
 
 void Mapper::map_device_async_impl(const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n_reads, uint64_t n_bases, uint32_t* covg,
-    uint32_t* prg_reads, hipStream_t stream)
+    uint32_t* prg_reads, hipStream_t stream, const PackedInfo* pk)
 {
     if (n_reads == 0) return;
     const bool deferred_filter = use_filter_ && max_lanes_ == 1;
     const bool deferred_direct = !use_filter_ && use_direct_cands_ && !fuse_in_kernel_;
     if ((!deferred_filter && !deferred_direct) || n_bases == 0) { // (no deferred form of the other sequences: the batch is complete on return,
-        map_device_impl(d_bases, d_offsets, n_reads, n_bases, covg, prg_reads, stream); // including what its tail queued for the leftover reads)
+        map_device_impl(d_bases, d_offsets, n_reads, n_bases, covg, prg_reads, stream, pk); // including what its tail queued for the leftover reads)
         HIPCHK(hipSetDevice(device_));
         wait_stream(stream ? stream : stream_);
         return;
@@ -910,7 +903,7 @@ void Mapper::map_device_async_impl(const uint8_t* d_bases, const uint64_t* d_off
         // read-back looked at while the next batch runs (a batch whose slices overflowed, or that left reads to the generic pipeline,
         // is finished then -- from its own set, which the batch in flight does not touch)
         const int set = pipe_next_;
-        direct_launch(set, d_bases, d_offsets, (uint32_t)n_reads, n_bases, covg, prg_reads, stream, true);
+        direct_launch(set, d_bases, d_offsets, (uint32_t)n_reads, n_bases, covg, prg_reads, stream, true, pk);
         TileSet& t = tsets_[set];
         if (!t.done) HIPCHK(hipEventCreateWithFlags(&t.done, hipEventDisableTiming));
         HIPCHK(hipEventRecord(t.done, stream));
@@ -918,6 +911,8 @@ void Mapper::map_device_async_impl(const uint8_t* d_bases, const uint64_t* d_off
         cur.active = true;
         cur.direct = true;
         cur.lane = set;
+        cur.packed = pk != nullptr;
+        if (pk) cur.pk = *pk;
         cur.d_bases = d_bases;
         cur.d_offsets = d_offsets;
         cur.n_reads = (uint32_t)n_reads;
@@ -953,11 +948,13 @@ void Mapper::map_device_async_impl(const uint8_t* d_bases, const uint64_t* d_off
     grow_lane(lane, std::max<uint64_t>(1u << 20, n_bases / 64));
     lane.r0 = 0;
     lane.r1 = (uint32_t)n_reads;
-    launch_lane(lane, stream, d_bases, d_offsets, (uint32_t)n_reads, n_bases, covg, prg_reads);
+    launch_lane(lane, stream, d_bases, d_offsets, (uint32_t)n_reads, n_bases, covg, prg_reads, pk);
     HIPCHK(hipEventRecord(lane.done, stream));
     Pending cur;
     cur.active = true;
     cur.lane = pipe_next_;
+    cur.packed = pk != nullptr;
+    if (pk) cur.pk = *pk;
     cur.d_bases = d_bases;
     cur.d_offsets = d_offsets;
     cur.n_reads = (uint32_t)n_reads;
@@ -986,6 +983,7 @@ void Mapper::complete_pending()
 void Mapper::complete_batch(const Pending& p)
 {
     HIPCHK(hipSetDevice(device_));
+    const PackedInfo* const ppk = p.packed ? &p.pk : nullptr; // (the batch's own description: a re-run or its leftover reads see the format it came in)
     if (p.direct) {
         TileSet& t = tsets_[p.lane];
         static const bool spin_d = [] {
@@ -1008,9 +1006,9 @@ void Mapper::complete_batch(const Pending& p)
         }
         const uint64_t leftover_before = tot_leftover_;
         bool reran = false;
-        for (int attempt = 0; !direct_finish(p.lane, p.d_bases, p.d_offsets, p.n_reads, p.n_bases, p.covg, p.prg_reads, p.stream, attempt); ++attempt) {
+        for (int attempt = 0; !direct_finish(p.lane, p.d_bases, p.d_offsets, p.n_reads, p.n_bases, p.covg, p.prg_reads, p.stream, attempt, ppk); ++attempt) {
             // its slices were too small: nothing of it was counted; again, alone, behind whatever is queued on its stream
-            direct_launch(p.lane, p.d_bases, p.d_offsets, p.n_reads, p.n_bases, p.covg, p.prg_reads, p.stream, false);
+            direct_launch(p.lane, p.d_bases, p.d_offsets, p.n_reads, p.n_bases, p.covg, p.prg_reads, p.stream, false, ppk);
             wait_stream(p.stream);
             reran = true;
         }
@@ -1040,7 +1038,7 @@ void Mapper::complete_batch(const Pending& p)
     // completed batch from any stream
     const uint64_t leftover_before = tot_leftover_;
     const bool overflowed = ((uint32_t)lane.h_scratch[L_OVERFLOW] & 4u) != 0;
-    finish_lane(lane, p.d_bases, p.d_offsets, p.n_reads, p.n_bases, p.covg, p.prg_reads, p.stream);
+    finish_lane(lane, p.d_bases, p.d_offsets, p.n_reads, p.n_bases, p.covg, p.prg_reads, p.stream, ppk);
     if (overflowed || tot_leftover_ != leftover_before) wait_stream(p.stream);
 }
 
@@ -1052,7 +1050,7 @@ void Mapper::sync()
 }
 
 void Mapper::run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads, uint64_t n_bases,
-    uint32_t* covg, uint32_t* prg_reads, hipStream_t stream)
+    uint32_t* covg, uint32_t* prg_reads, hipStream_t stream, const PackedInfo* pk)
 {
     if (n_bases == 0) return; // only empty reads: no k-mers, no hits
     dev::KernelTimer timer;
@@ -1073,7 +1071,7 @@ void Mapper::run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32
             lane.r1 = (uint32_t)((uint64_t)n_reads * (uint64_t)(j + 1) / (uint64_t)n_lanes);
             hipStream_t ls = j == 0 ? stream : lane.stream;
             if (j > 0) HIPCHK(hipStreamWaitEvent(ls, ev_begin_, 0));
-            launch_lane(lane, ls, d_bases, d_offsets, n_reads, n_bases, covg, prg_reads);
+            launch_lane(lane, ls, d_bases, d_offsets, n_reads, n_bases, covg, prg_reads, pk);
             if (j > 0) HIPCHK(hipEventRecord(lane.done, ls));
         }
         for (int j = 1; j < n_lanes; ++j) HIPCHK(hipStreamWaitEvent(stream, lanes_[j].done, 0));
@@ -1086,11 +1084,11 @@ void Mapper::run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32
                 sketch_launches_ += 1;
             }
         }
-        for (int j = 0; j < n_lanes; ++j) finish_lane(lanes_[j], d_bases, d_offsets, n_reads, n_bases, covg, prg_reads, stream);
+        for (int j = 0; j < n_lanes; ++j) finish_lane(lanes_[j], d_bases, d_offsets, n_reads, n_bases, covg, prg_reads, stream, pk);
         return;
     }
     if (use_direct_cands_) {
-        run_batch_direct_candidates(d_bases, d_offsets, n_reads, n_bases, covg, prg_reads, stream);
+        run_batch_direct_candidates(d_bases, d_offsets, n_reads, n_bases, covg, prg_reads, stream, pk);
         return;
     }
     // ---- direct sequence, generic form: every k-mer hashed, hits in tile order, global radix sort ----
@@ -1102,11 +1100,11 @@ void Mapper::run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32
         ts_->first_cap = n_tiles + n_tiles / 4 + 16;
         dmalloc(ts_->d_tile_first, (size_t)ts_->first_cap);
     }
-    const uint8_t* const ascii = ascii_view(2, d_bases, n_bases, stream); // (a packed batch: expanded on the device for this kernel)
+    const uint8_t* const ascii = ascii_view(2, d_bases, n_bases, stream, pk); // (a packed batch: expanded on the device for this kernel)
     for (int attempt = 0;; ++attempt) {
         HIPCHK(hipMemsetAsync(&d_counters_[C_HITS], 0, 2 * sizeof(unsigned long long), stream)); // hits + minimizers of this attempt
         HIPCHK(hipMemsetAsync(&d_counters_[C_OVERFLOW], 0, sizeof(unsigned long long), stream));
-        const dev::SketchArgs a = sketch_args(ascii, d_offsets, n_reads, n_bases);
+        const dev::SketchArgs a = sketch_args(ascii, d_offsets, n_reads, n_bases, nullptr); // (the expansion is ASCII)
         HIPCHK(dev::launch_sketch_probe(a, wide_hash_, stream, timer));
         read_counters(stream);
         note_kernel_time();
@@ -1127,8 +1125,7 @@ void Mapper::run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32
 void Mapper::map_device(const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n_reads, uint64_t n_bases,
     uint32_t* covg, uint32_t* prg_reads, hipStream_t stream)
 {
-    packed_.erase(d_bases); // (an ASCII batch: whatever packed batch lived at this address before is gone)
-    map_device_impl(d_bases, d_offsets, n_reads, n_bases, covg, prg_reads, stream);
+    map_device_impl(d_bases, d_offsets, n_reads, n_bases, covg, prg_reads, stream, nullptr);
 }
 
 void Mapper::map_device_packed(const uint32_t* d_words, const uint64_t* d_offsets, uint64_t n_reads, uint64_t n_bases, const uint64_t* d_npos, uint64_t n_npos,
@@ -1140,18 +1137,13 @@ void Mapper::map_device_packed(const uint32_t* d_words, const uint64_t* d_offset
     if (!d_words || !d_offsets) throw Error(DRPRG_EINVAL, "null device pointer");
     if ((reinterpret_cast<uintptr_t>(d_words) & 15u) != 0) throw Error(DRPRG_EINVAL, "d_words must be 16-byte aligned");
     const uint8_t* key = reinterpret_cast<const uint8_t*>(d_words);
-    packed_[key] = PackedInfo { d_npos, n_npos };
-    try {
-        if (deferred) map_device_async_impl(key, d_offsets, n_reads, n_bases, covg, prg_reads, stream);
-        else map_device_impl(key, d_offsets, n_reads, n_bases, covg, prg_reads, stream);
-    } catch (...) {
-        packed_.erase(key);
-        throw;
-    }
+    const PackedInfo info { d_npos, n_npos }; // (travels with the batch through every function that touches it, and into Pending)
+    if (deferred) map_device_async_impl(key, d_offsets, n_reads, n_bases, covg, prg_reads, stream, &info);
+    else map_device_impl(key, d_offsets, n_reads, n_bases, covg, prg_reads, stream, &info);
 }
 
 void Mapper::map_device_impl(const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n_reads, uint64_t n_bases,
-    uint32_t* covg, uint32_t* prg_reads, hipStream_t stream)
+    uint32_t* covg, uint32_t* prg_reads, hipStream_t stream, const PackedInfo* pk)
 {
     if (n_reads == 0) return;
     if (!d_bases || !d_offsets) throw Error(DRPRG_EINVAL, "null device pointer");
@@ -1162,7 +1154,7 @@ void Mapper::map_device_impl(const uint8_t* d_bases, const uint64_t* d_offsets, 
     if (kept_cap_ && !in_keep_call_) kept_broken_ = true; // reads of the caller's own buffers: not among the kept ones
     complete_pending();
     run_batch(d_bases, d_offsets, (uint32_t)n_reads, n_bases, covg ? covg : d_covg_, prg_reads ? prg_reads : d_prg_reads_,
-        stream ? stream : stream_);
+        stream ? stream : stream_, pk);
     tot_reads_ += n_reads;
     tot_bases_ += n_bases;
 }
@@ -1185,7 +1177,6 @@ void Mapper::map_host(const HostBatch& b)
     if (b.offsets[0] != 0) throw Error(DRPRG_EINVAL, "offsets[0] must be 0");
     const uint64_t n_bases = b.n_bases(), bytes = b.payload_bytes();
     if (bytes + 64 > stage_bases_cap_) {
-        packed_.erase(d_bases_); // (the address goes back to the allocator)
         dfree(d_bases_);
         stage_bases_cap_ = bytes + bytes / 4 + 64;
         dmalloc(d_bases_, stage_bases_cap_);
@@ -1273,7 +1264,6 @@ void Mapper::drop_kept()
         HIPCHK(hipStreamSynchronize(stream_));
         for (auto& a : kept_arenas_) (void)hipFree(a.first);
     }
-    for (const KeptBatch& b : kept_) packed_.erase(b.d_bases); // (their memory goes back to the allocator)
     kept_arenas_.clear();
     kept_.clear();
     arena_at_ = nullptr;
@@ -1492,7 +1482,6 @@ void Mapper::map_host_async(const HostBatch& hb)
     if (!st.copied) HIPCHK(hipEventCreateWithFlags(&st.copied, hipEventDisableTiming));
     if (bytes + 64 > st.bases_cap) {
         sync(); // (freeing device memory waits for the device; be explicit about the batch in flight)
-        packed_.erase(st.d_bases); // (the address goes back to the allocator)
         dfree(st.d_bases);
         st.bases_cap = bytes + bytes / 4 + 64;
         dmalloc(st.d_bases, st.bases_cap);

@@ -6,7 +6,6 @@
 #pragma once
 #include "index.h"
 #include "kernels.h"
-#include <unordered_map>
 #include <vector>
 
 namespace drprg {
@@ -161,39 +160,38 @@ private:
         uint32_t r0 = 0, r1 = 0;                 // read range of the current batch
     };
     enum { L_HITS = 0, L_OVERFLOW = 1, L_MAXLEN = 2, L_UNSORTED = 3, L_COMPLEX = 4, L_CHUNK = 5, L_MINIMIZERS = 6, L_UNFIT = 7, L_FT_CLOCK = 8 /* five words: FilterBuffers::class_clock */, L_N = 13 };
+    // What makes a device batch a packed one (2-bit words instead of bytes): where its non-ACGT positions are.  Passed along with the batch
+    // pointer to everything that touches the batch (nullptr: ASCII) and kept in Pending for the deferred completion -- until round 5 the
+    // batch's ADDRESS was looked up in a map, which every free and every recycled address had to keep honest.
+    struct PackedInfo {
+        const uint64_t* d_npos = nullptr;
+        uint64_t n_npos = 0;
+    };
     void ensure_lanes(int n, uint64_t raw_capacity);
     void grow_lane(Lane& lane, uint64_t raw_capacity);
     void free_lane(Lane& lane);
     void launch_lane(Lane& lane, hipStream_t stream, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads,
-        uint64_t n_bases, uint32_t* covg, uint32_t* prg_reads);
+        uint64_t n_bases, uint32_t* covg, uint32_t* prg_reads, const PackedInfo* pk);
     void wait_stream(hipStream_t stream);
     void leftovers(Lane& lane, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads, uint64_t n_bases, uint32_t* covg,
-        uint32_t* prg_reads, hipStream_t stream);
+        uint32_t* prg_reads, hipStream_t stream, const PackedInfo* pk);
     void run_batch_direct_candidates(const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads, uint64_t n_bases,
-        uint32_t* covg, uint32_t* prg_reads, hipStream_t stream);
+        uint32_t* covg, uint32_t* prg_reads, hipStream_t stream, const PackedInfo* pk);
     void run_batch(const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads, uint64_t n_bases,
-        uint32_t* d_covg, uint32_t* d_prg_reads, hipStream_t stream);
+        uint32_t* d_covg, uint32_t* d_prg_reads, hipStream_t stream, const PackedInfo* pk);
     void cluster_hits(const uint64_t* d_offsets, uint32_t n_hits, bool ordered, unsigned long long* d_unsorted, uint32_t* d_covg,
         uint32_t* d_prg_reads, hipStream_t stream);
-    dev::SketchArgs sketch_args(const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads, uint64_t n_bases) const;
-    // Batches in the packed form are known by their device address (the launch sequences pass the batch pointer through a dozen
-    // functions and keep it for re-runs: the address is the one thing all of them have).  An ASCII batch at the same address takes
-    // the entry out again.
-    struct PackedInfo {
-        const uint64_t* d_npos;
-        uint64_t n_npos;
-    };
-    std::unordered_map<const void*, PackedInfo> packed_;
+    dev::SketchArgs sketch_args(const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads, uint64_t n_bases, const PackedInfo* pk) const;
     // d_bases itself, or -- for a packed batch -- its ASCII expansion in scratch buffer `slot` (0 / 1: the two tile sets of the direct
     // sequence's candidate form, 2: the generic sequence), made on `stream`
-    const uint8_t* ascii_view(int slot, const uint8_t* d_bases, uint64_t n_bases, hipStream_t stream);
+    const uint8_t* ascii_view(int slot, const uint8_t* d_bases, uint64_t n_bases, hipStream_t stream, const PackedInfo* pk);
     uint8_t* d_unpacked_[3] = { nullptr, nullptr, nullptr };
     unsigned long long* d_pack_count_ = nullptr; // pack_on_device's counter word
     uint64_t unpacked_cap_[3] = { 0, 0, 0 };
     void map_device_impl(const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n_reads, uint64_t n_bases, uint32_t* d_covg, uint32_t* d_prg_reads,
-        hipStream_t stream);
+        hipStream_t stream, const PackedInfo* pk);
     void map_device_async_impl(const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n_reads, uint64_t n_bases, uint32_t* d_covg, uint32_t* d_prg_reads,
-        hipStream_t stream);
+        hipStream_t stream, const PackedInfo* pk);
     void read_counters(hipStream_t stream);
     void note_kernel_time();
     // deferred completion: two lanes take the batches in turn; `pending_` is the batch whose read-back nobody has looked at yet
@@ -207,11 +205,13 @@ private:
         uint32_t *covg = nullptr, *prg_reads = nullptr;
         hipStream_t stream = nullptr;
         bool direct = false; // a batch of the direct sequence's candidate form (lane = its tile set)
+        bool packed = false; // the batch is 2-bit words ...
+        PackedInfo pk {};    // ... with these non-ACGT positions
     };
     void complete_pending();
     void complete_batch(const Pending& p);
     void finish_lane(Lane& lane, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads, uint64_t n_bases, uint32_t* covg,
-        uint32_t* prg_reads, hipStream_t stream);
+        uint32_t* prg_reads, hipStream_t stream, const PackedInfo* pk);
     Pending pending_;
     std::vector<Lane> pipe_lanes_;
     int pipe_next_ = 0;
@@ -298,9 +298,9 @@ private:
     void free_tile_set(TileSet& t);
     void ensure_tile_workspace(TileSet& t, uint32_t n_tiles, uint32_t tile_cap);
     void direct_launch(int set, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads, uint64_t n_bases, uint32_t* covg, uint32_t* prg_reads,
-        hipStream_t stream, bool timed_by_set_events);
+        hipStream_t stream, bool timed_by_set_events, const PackedInfo* pk);
     bool direct_finish(int set, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads, uint64_t n_bases, uint32_t* covg, uint32_t* prg_reads,
-        hipStream_t stream, int attempt);
+        hipStream_t stream, int attempt, const PackedInfo* pk);
     size_t temp_bytes_ = 0;
     // host staging
     uint8_t* h_bases_ = nullptr;

@@ -211,7 +211,16 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
     // use to hide the 2 us, worked -- 0.333 ms -- but left the slowest waves two chunks behind the others at the end: round 6.)
     bool decoded = !dynamic, has_next = false;
     uint32_t n_k = 0, n_begin = 0, n_all = 0;
-    uint32_t sw_tile = 0xFFFFFFFFu, sw_k = 0; // process() moves on to slice sw_k when it meets tile sw_tile
+    uint32_t sw_tile = 0xFFFFFFFFu, sw_k = 0, sw_base = 0, sw_cap = 0; // process() moves on to slice sw_k (there, that large) when it meets tile sw_tile
+    // where chunk kt of this workgroup, tiles [b, e), keeps its candidates, and how many fit (FilterWork::slice_budget)
+    auto slice_geometry = [&](uint32_t kt, uint32_t b, uint32_t e, uint32_t& base, uint32_t& cap) {
+        base = blockIdx.x * fw.slice_budget + (b - wg_lo) * fw.slice_cpt + kt * fw.slice_slack;
+        cap = (e - b) * fw.slice_cpt + fw.slice_slack;
+    };
+    uint32_t base_cur, cap_cur;
+    slice_geometry(wv, tile, c_all, base_cur, cap_cur);
+    base_cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)base_cur);
+    cap_cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)cap_cur);
     if (tid == 0) s_dyn[fw.sched.lds_word] = 0; // (before the one barrier below; a word no filter array and no wave's stage uses)
     uint32_t tiles_done = 0;
     (void)tiles_done;
@@ -255,8 +264,8 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
             p.b = *reinterpret_cast<const uint4*>(g + 16);
         }
     };
-    uint64_t* out = fw.raw_pos + (size_t)slice * fw.raw_slice;
-    uint4* grp_out = LEVEL0 ? fw.raw_grp + (size_t)slice * fw.raw_slice : nullptr;
+    uint64_t* out = fw.raw_pos + base_cur;
+    uint4* grp_out = LEVEL0 ? fw.raw_grp + base_cur : nullptr;
     (void)grp_out;
     uint32_t wcur = 0; // candidates in the current slice so far (wave-uniform)
     // FUSED: the groups that passed level 0 wait in the wave's 2 KB of LDS; when the next tile might not fit, they go through the
@@ -283,7 +292,7 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
             while (cand2) {                                                                                                           \
                 const int q2 = __ffs(cand2) - 1;                                                                                      \
                 cand2 &= cand2 - 1;                                                                                                   \
-                if (at2 < fw.raw_slice) out[at2] = pos2 + (uint64_t)q2;                                                               \
+                if (at2 < cap_cur) out[at2] = pos2 + (uint64_t)q2;                                                                    \
                 ++at2;                                                                                                                \
             }                                                                                                                         \
             wcur += (uint32_t)(__popcll(e0) + 2 * __popcll(e1) + 4 * __popcll(e2));                                                   \
@@ -354,9 +363,12 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
     auto close_slice = [&]() {
         if constexpr (FUSED) DRPRG_SECOND_STAGE(); // everything staged leaves now
         if (lane == 0) {
-            (LEVEL0 && !FUSED ? fw.grp_count : fw.slice_count)[slice] = wcur;
-            if (wcur > fw.raw_slice) atomicOr(a.overflow, 4u);
-            if (!(LEVEL0 && !FUSED) && wcur) atomicAdd(&fw.super_count[slice / FT_SUPER], wcur < fw.raw_slice ? wcur : fw.raw_slice); // (the two-kernel form: refine_kernel adds)
+            const uint32_t kept = wcur < cap_cur ? wcur : cap_cur;
+            (LEVEL0 && !FUSED ? fw.grp_count : fw.slice_count)[slice] = kept;
+            fw.slice_base[slice] = base_cur;
+            fw.slice_cap[slice] = cap_cur;
+            if (wcur > cap_cur) atomicOr(a.overflow, 4u);
+            if (!(LEVEL0 && !FUSED) && kept) atomicAdd(&fw.super_count[slice / FT_SUPER], kept); // (the two-kernel form: refine_kernel adds)
         }
     };
 
@@ -366,8 +378,10 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
             close_slice();
             slice = sw_k;
             sw_tile = 0xFFFFFFFFu;
-            out = fw.raw_pos + (size_t)slice * fw.raw_slice;
-            if (LEVEL0) grp_out = fw.raw_grp + (size_t)slice * fw.raw_slice;
+            base_cur = sw_base;
+            cap_cur = sw_cap;
+            out = fw.raw_pos + base_cur;
+            if (LEVEL0) grp_out = fw.raw_grp + base_cur;
             wcur = 0;
         }
         uint32_t wv[NW + 1]; // my words, then the first word of lane + 1 (it completes the last k-mers)
@@ -477,7 +491,7 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
                     while (grp) {
                         const int g = __ffs(grp) - 1;
                         grp &= grp - 1;
-                        if (at < fw.raw_slice) grp_out[at] = record(g);
+                        if (at < cap_cur) grp_out[at] = record(g);
                         ++at;
                     }
                     wcur += wave_total;
@@ -523,7 +537,7 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
                 while (cc) {
                     const int j = __ffs(cc) - 1;
                     cc &= cc - 1;
-                    if (at < fw.raw_slice) out[at] = base + (uint64_t)j;
+                    if (at < cap_cur) out[at] = base + (uint64_t)j;
                     ++at;
                 }
             }
@@ -542,7 +556,7 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
         const uint32_t kt = (uint32_t)FT_WAVES + (uint32_t)__builtin_amdgcn_readfirstlane((int)drawn);
         has_next = kt < per_wg;
         if (has_next) {
-            n_k = slice0 + kt;
+            n_k = kt;
             chunk_of_ticket(kt, n_begin, n_all);
             if (lane == 0 && n_begin + 2 > (n_all < n_full ? n_all : n_full)) atomicOr(a.overflow, 16u); // (a schedule the host must not make: kernels.h FilterSched)
         }
@@ -562,7 +576,8 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
         if (tile < c_end) return true;
         if (!has_next) return false; // (a chunk of one full tile, static schedule: nothing was decoded and nothing follows)
         sw_tile = tile = n_begin;
-        sw_k = n_k;
+        sw_k = slice0 + n_k;
+        slice_geometry(n_k, n_begin, n_all, sw_base, sw_cap);
         c_all = n_all;
         c_end = n_all < n_full ? n_all : n_full;
         has_next = false;
@@ -639,9 +654,9 @@ __global__ __launch_bounds__(RF_THREADS) void refine_kernel(SketchArgs a, Filter
     auto below = [&](uint64_t m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); };
     const uint32_t n_waves = gridDim.x * (RF_THREADS / 64);
     for (uint32_t s = blockIdx.x * (RF_THREADS / 64) + (uint32_t)(tid >> 6); s < fw.n_slices; s += n_waves) {
-        const uint32_t n_raw = fw.grp_count[s], n = n_raw < fw.raw_slice ? n_raw : fw.raw_slice;
-        const uint4* __restrict__ in = fw.raw_grp + (size_t)s * fw.raw_slice;
-        uint64_t* __restrict__ out = fw.raw_pos + (size_t)s * fw.raw_slice;
+        const uint32_t n = fw.grp_count[s], cap = fw.slice_cap[s];
+        const uint4* __restrict__ in = fw.raw_grp + fw.slice_base[s];
+        uint64_t* __restrict__ out = fw.raw_pos + fw.slice_base[s];
         uint32_t written = 0; // wave-uniform
         uint4 nxt = (uint32_t)lane < n ? in[lane] : make_uint4(0, 0, 0, 0);
         for (uint32_t c0 = 0; c0 < n; c0 += 64) {
@@ -667,16 +682,17 @@ __global__ __launch_bounds__(RF_THREADS) void refine_kernel(SketchArgs a, Filter
                 while (cand) {
                     const int q = __ffs(cand) - 1;
                     cand &= cand - 1;
-                    if (at < fw.raw_slice) out[at] = pos + (uint64_t)q;
+                    if (at < cap) out[at] = pos + (uint64_t)q;
                     ++at;
                 }
                 written += (uint32_t)(__popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2));
             }
         }
         if (lane == 0) {
-            fw.slice_count[s] = written;
-            if (n_raw > fw.raw_slice || written > fw.raw_slice) atomicOr(a.overflow, 4u);
-            if (written) atomicAdd(&fw.super_count[s / FT_SUPER], written < fw.raw_slice ? written : fw.raw_slice);
+            const uint32_t kept = written < cap ? written : cap;
+            fw.slice_count[s] = kept;
+            if (written > cap) atomicOr(a.overflow, 4u);
+            if (kept) atomicAdd(&fw.super_count[s / FT_SUPER], kept);
         }
     }
 }
@@ -706,10 +722,10 @@ uint32_t filter_grid(bool level0, int n_cus, uint32_t n_tiles)
     return grid ? grid : 1;
 }
 
-// FilterBuffers::small: [slice counts: MAX_CHUNKS][superblock counts: MAX_SLICES][prefix of the slices: MAX_CHUNKS + 4 (gathered form only; the word
-// behind the last slice's is the batch's candidate total)][group counts: MAX_CHUNKS (two-kernel form)][per-workgroup totals: 4 x MAX_EX_WG].  The
-// superblock counts are zero between two sequences (counters_home_kernel).
-constexpr size_t FT_SMALL_HEAD = (size_t)MAX_CHUNKS + MAX_SLICES;
+// FilterBuffers::small: [slice counts: MAX_CHUNKS][superblock counts: MAX_SLICES][slice starts: MAX_CHUNKS][slice rooms: MAX_CHUNKS][prefix of the
+// slices: MAX_CHUNKS + 4 (gathered form only; the word behind the last slice's is the batch's candidate total)][group counts: MAX_CHUNKS (two-kernel
+// form)][per-workgroup totals: 4 x MAX_EX_WG].  The superblock counts are zero between two sequences (counters_home_kernel).
+constexpr size_t FT_SMALL_HEAD = (size_t)MAX_CHUNKS * 3 + MAX_SLICES;
 size_t filter_small_words() { return FT_SMALL_HEAD + (size_t)MAX_CHUNKS * 2 + 4 + 4 * (size_t)MAX_EX_WG; }
 uint32_t* filter_super_counts(uint32_t* small) { return small + MAX_CHUNKS; }
 uint32_t filter_super_words() { return (uint32_t)MAX_SLICES; }
@@ -857,7 +873,15 @@ hipError_t launch_sketch_filter(const SketchArgs& a, uint32_t read_begin, uint32
         fw.sched = make_filter_sched(filter_n_tiles(a.n_bases, filter_positions_per_lane(level0, a.packed != 0)), grid, whole, fw.wave_share);
     }
     fw.n_slices = grid * fw.sched.per_wg;
-    fw.raw_slice = (uint32_t)std::min<uint64_t>(b.raw_capacity / fw.n_slices, 0x7FFFFFFFull / fw.n_slices);
+    {   // the slices' geometry (FilterWork::slice_budget): a floor of up to 256 entries per slice -- a quarter of the workgroup's budget at most --
+        // and the rest by the tile.  (A workgroup's range: an even split to the tile, or -- static schedule -- 16 waves x tiles per wave.)
+        const uint32_t n_tiles = filter_n_tiles(a.n_bases, filter_positions_per_lane(level0, a.packed != 0));
+        const uint64_t budget = std::min<uint64_t>(b.raw_capacity, 0x7FFFFFFFull) / grid;
+        const uint64_t wg_tiles = fw.sched.per_wg > (uint32_t)FT_WAVES ? (n_tiles + grid - 1) / grid : (uint64_t)FT_WAVES * ((n_tiles + grid * FT_WAVES - 1) / (grid * FT_WAVES));
+        fw.slice_budget = (uint32_t)budget;
+        fw.slice_slack = (uint32_t)std::min<uint64_t>(256, budget / (4ull * fw.sched.per_wg));
+        fw.slice_cpt = (uint32_t)((budget - (uint64_t)fw.slice_slack * fw.sched.per_wg) / std::max<uint64_t>(wg_tiles, 1));
+    }
     fw.raw_pos = b.raw_pos;
     fw.cand_info = b.cand_info;
     fw.cand_pos1 = b.cand_pos1;
@@ -865,6 +889,8 @@ hipError_t launch_sketch_filter(const SketchArgs& a, uint32_t read_begin, uint32
     init_candidate_work(fw, b, n_cus);
     fw.slice_count = b.small;
     fw.super_count = filter_super_counts(b.small);
+    fw.slice_base = b.small + MAX_CHUNKS + MAX_SLICES;
+    fw.slice_cap = fw.slice_base + MAX_CHUNKS;
     fw.cand_prefix = b.small + FT_SMALL_HEAD;
     fw.cand_total = fw.cand_prefix + fw.n_slices;
     fw.grp_count = b.small + FT_SMALL_HEAD + MAX_CHUNKS + 4;

@@ -1,4 +1,4 @@
-"""N>1 path on CPU: two gloo ranks shard the reads, reduce the coverage vector, genotype on rank 0.
+"""N>1 path on CPU: 2, 3 and 8 gloo ranks shard the reads, reduce the coverage vector, genotype on rank 0.
 
 The device mapping itself cannot run here (no GPU, no CPU fallback), so each rank fills its shard's
 coverage with the test oracle; what is under test is the product's sharding + reduce + set_coverage +
@@ -65,7 +65,14 @@ def test_shard_range_partitions():
             assert max(sizes) - min(sizes) <= 1
 
 
-def test_two_rank_reduce_equals_single_rank(tmp_path, oracle):
+import pytest
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_n_rank_reduce_equals_single_rank(tmp_path, oracle, world):
+    """5001 reads over 2, 3 and 8 ranks (uneven shards: 8 ranks get 625 or 626 reads, 3 ranks 1667 each) -- BASELINE.json configs[3]'s
+    layout, one process per rank over gloo: the reduced vector every rank-0 genotypes from is the single-process vector, and so is the
+    VCF.  (Unmeasured on > 1 GPU: no multi-GPU box in the pool; this is the control flow.)"""
     from drprg_amd import Context, synth
     script = tmp_path / "worker.py"
     script.write_text(WORKER.format(root=ROOT))
@@ -74,7 +81,7 @@ def test_two_rank_reduce_equals_single_rank(tmp_path, oracle):
         sock.bind(("127.0.0.1", 0))
         port = str(sock.getsockname()[1])
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="1")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
                         "--master-addr", "127.0.0.1", "--master-port", port, str(script), str(tmp_path)],
                        capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
