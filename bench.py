@@ -154,9 +154,9 @@ for _s in (2, 4, 8, 16, 32):
 # the source files of the dominant kernels: profiles/traffic.json and profiles/valu.json say which state of them their numbers were
 # measured on (tools/make_profile_json.py holds the same table)
 KERNEL_SOURCES = {
-    "sketch_filter_kernel": ["sketch_filter.hip", "filter_common.h", "device_common.h"],
-    "sketch_wave_kernel": ["sketch_wave.hip", "sketch_block.h", "device_common.h"],
-    "sketch_probe_kernel": ["sketch_probe.hip", "device_common.h"],
+    "sketch_filter_kernel": ["sketch_filter.hip", "filter_common.h", "device_common.h", "kernels.h", "common.h"],
+    "sketch_wave_kernel": ["sketch_wave.hip", "sketch_block.h", "device_common.h", "kernels.h", "common.h"],
+    "sketch_probe_kernel": ["sketch_probe.hip", "device_common.h", "kernels.h", "common.h"],
 }
 
 
@@ -179,7 +179,7 @@ def profile_entry_stale(entry, kernel):
     if was is None:
         return f"the profile entry does not name the kernel sources it was measured on ({', '.join(KERNEL_SOURCES[kernel])} are now {now})"
     if was != now:
-        return f"{', '.join(KERNEL_SOURCES[kernel])} changed since the profile was taken (sha256 {was} then, {now} now): run tools/run_profiles_r05.sh + tools/make_profile_json.py"
+        return f"{', '.join(KERNEL_SOURCES[kernel])} changed since the profile was taken (sha256 {was} then, {now} now): run tools/run_profiles_r06.sh + tools/make_profile_json.py"
     return None
 
 

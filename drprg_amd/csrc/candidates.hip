@@ -121,6 +121,7 @@ __global__ __launch_bounds__(VS_THREADS, 8) void verify_scan_kernel(SketchArgs a
     __shared__ uint32_t s_red[3][VS_THREADS / 64];
     __shared__ uint32_t s_w[VS_THREADS / 64 + 1];
     __shared__ uint32_t s_share[2];
+    __shared__ uint32_t s_ticket; // (interleaved order: the workgroup's round counter)
     __shared__ __attribute__((aligned(16))) uint32_t s_pre[MAX_SLICES + 4]; // exclusive prefix of ALL superblocks (32 KB; one past the last: the total)
     const int tid = threadIdx.x;
     // ---- the scan: my VS_PER consecutive superblocks (FT_SUPER slices each; the filter kernel summed their clamped counts) ----
@@ -165,38 +166,66 @@ __global__ __launch_bounds__(VS_THREADS, 8) void verify_scan_kernel(SketchArgs a
             n1 += (p.y <= x1 ? 1u : 0u) + (p.z <= x1 ? 1u : 0u) + (p.w <= x1 ? 1u : 0u) + (acc <= x1 ? 1u : 0u);
         }
         if (tid == VS_THREADS - 1) s_pre[MAX_SLICES] = acc; // (= total)
+        if (tid == 0) s_ticket = 0;
         if (own0) s_share[0] = (uint32_t)tid * VS_PER + n0;
         if (own1) s_share[1] = (uint32_t)tid * VS_PER + n1;
     }
     __syncthreads();
     const VerifyConsts c(a, fw);
     uint32_t my_hits = 0, my_nmin = 0, my_maxlen = 0;
-    if (t_begin < t_end) { // (workgroup-uniform)
-        // the slices of this workgroup's share [t_begin, t_end): its candidates bisect only those (four or five of a full batch)
+    // entry t of the ordered list, given superblocks lo0 <= .. <= hi0 that bound it and the largest power of two <= hi0 - lo0 (at least 1)
+    auto position_in = [&](uint32_t t, uint32_t lo0, uint32_t hi0, uint32_t step0) -> int64_t {
+        uint32_t lo = lo0;
+        for (uint32_t step = step0; step >= 1; step >>= 1)
+            if (lo + step <= hi0 && s_pre[lo + step] <= t) lo += step;
+        // ... in superblock lo; its slice: the counts and the starts of the FT_SUPER slices (four 16-byte loads from the L2, one round trip), then
+        // the first one whose running sum exceeds the rest.  (Counts past the last slice of the batch are never reached: the superblock sums say where the list ends.)
+        static_assert(FT_SUPER == 8, "two uint4 of slice counts per superblock");
+        const uint4* __restrict__ c4 = reinterpret_cast<const uint4*>(fw.slice_count) + (size_t)lo * 2;
+        const uint4* __restrict__ b4 = reinterpret_cast<const uint4*>(fw.slice_base) + (size_t)lo * 2;
+        const uint4 ca = c4[0], cb = c4[1], ba = b4[0], bb = b4[1];
+        const uint32_t cnt[7] = { ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z }, start[8] = { ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, bb.z, bb.w };
+        uint32_t rest = t - s_pre[lo], sum = 0, before = 0, at = start[0];
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+            sum += cnt[q];
+            const bool past = rest >= sum;
+            at = past ? start[q + 1] : at;
+            before = past ? sum : before;
+        }
+        return (int64_t)fw.raw_pos[(size_t)at + (rest - before)];
+    };
+    if (fw.verify_interleave) {
+        // Interleaved order (round 6): the list is cut into rounds of 64 consecutive candidates; round r belongs to workgroup r mod grid, whose
+        // waves take its rounds by ticket (an LDS counter; a wave's first is its own number).  A workgroup samples the whole list instead
+        // of owning one stretch of it -- stretches differ: reads off the panel end at the table probe, reads on it walk their windows --
+        // and a wave that drew cheap rounds draws more of them.
+        const uint32_t n_rounds = (total + 63u) >> 6;
+        const uint32_t lane = (uint32_t)tid & 63u;
+        uint32_t r = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(tid >> 6) * gridDim.x + blockIdx.x));
+        int64_t gp_next = (r < n_rounds && r * 64u + lane < total) ? position_in(r * 64u + lane, 0u, (uint32_t)MAX_SLICES - 1u, (uint32_t)MAX_SLICES / 2u) : 0;
+        while (r < n_rounds) { // (wave-uniform)
+            const uint32_t t = r * 64u + lane;
+            const int64_t gp = gp_next;
+            uint32_t drawn = 0;
+            if (lane == 0) drawn = atomicAdd(&s_ticket, 1u);
+            const uint32_t rn = ((uint32_t)(VS_THREADS / 64) + (uint32_t)__builtin_amdgcn_readfirstlane((int)drawn)) * gridDim.x + blockIdx.x;
+            if (rn < n_rounds && rn * 64u + lane < total) gp_next = position_in(rn * 64u + lane, 0u, (uint32_t)MAX_SLICES - 1u, (uint32_t)MAX_SLICES / 2u);
+            if (t < total) {
+                VerifyOut o;
+                if (!(fw.debug & 512u)) verify_one_lane<KC, PACKED>(a, fw, rc, c, gp, o, my_hits, my_nmin, my_maxlen);
+                fw.cand_pos1[t] = o.pos1;
+                fw.cand_info[t] = ((uint64_t)o.slot << 32) | ((uint64_t)o.strand << 31) | (uint64_t)o.read;
+                fw.cand_rec[t] = o.crec;
+            }
+            r = rn;
+        }
+    } else if (t_begin < t_end) { // (workgroup-uniform)
+        // the superblocks of this workgroup's share [t_begin, t_end): its candidates bisect only those (a handful of a full batch)
         const uint32_t s_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_share[0]), s_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_share[1]);
         uint32_t span_step = 1;
         while (2 * span_step <= s_hi - s_lo) span_step *= 2; // (largest power of two <= the span, at least 1)
-        auto position_of = [&](uint32_t t) -> int64_t { // entry t of the ordered list, t_begin <= t < t_end
-            uint32_t lo = s_lo;
-            for (uint32_t step = span_step; step >= 1; step >>= 1)
-                if (lo + step <= s_hi && s_pre[lo + step] <= t) lo += step;
-            // ... in superblock lo; its slice: the counts of the FT_SUPER slices (two 16-byte loads from the L2), then the first one whose
-            // running sum exceeds the rest.  (Counts past the last slice of the batch are never reached: the superblock sums say where the list ends.)
-            static_assert(FT_SUPER == 8, "two uint4 of slice counts per superblock");
-            const uint4* __restrict__ c4 = reinterpret_cast<const uint4*>(fw.slice_count) + (size_t)lo * 2;
-            const uint4* __restrict__ b4 = reinterpret_cast<const uint4*>(fw.slice_base) + (size_t)lo * 2;
-            const uint4 ca = c4[0], cb = c4[1], ba = b4[0], bb = b4[1]; // (counts and starts of the eight slices: one round trip)
-            const uint32_t cnt[7] = { ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z }, start[8] = { ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, bb.z, bb.w };
-            uint32_t rest = t - s_pre[lo], sum = 0, before = 0, at = start[0];
-#pragma unroll
-            for (int q = 0; q < 7; ++q) {
-                sum += cnt[q];
-                const bool past = rest >= sum;
-                at = past ? start[q + 1] : at;
-                before = past ? sum : before;
-            }
-            return (int64_t)fw.raw_pos[(size_t)at + (rest - before)];
-        };
+        auto position_of = [&](uint32_t t) -> int64_t { return position_in(t, s_lo, s_hi, span_step); }; // t_begin <= t < t_end
         // (the position of this thread's next candidate is requested one round early: one round trip less in the chain of each)
         int64_t gp_next = t_begin + tid < t_end ? position_of(t_begin + (uint32_t)tid) : 0;
         for (uint32_t t = t_begin + (uint32_t)tid; t < t_end; t += VS_THREADS) {
@@ -528,18 +557,36 @@ __global__ __launch_bounds__(TG_THREADS) void tile_gather_kernel(SketchArgs a, F
 // verify_count 116 -> 231 us (12 k atomics on one 64-byte line take their turn in the L2), step 0.59 -> 0.72 ms.  Round 4: the totals of
 // hit_scan_kernel are summed by workgroup 0 of read_cluster_kernel when that kernel follows (with_totals = false); scan + gather in one
 // launch -- a workgroup summing what lies before its 64 slices -- took 19.4 us against 9.1 + 11.8: cand_scan_kernel stays.)
+// DRPRG_VERIFY_FORM=gather keeps the three-kernel sequence of rounds 1-4 (A/B runs, a second way through the parity tests); the
+// experimental read-by-read form (make EXPERIMENTAL=1 + DRPRG_VERIFY_FORM=read: read_verify.hip, bit-exact and 8 % slower,
+// profiles/r05/read_verify.txt) needs the gathered list of positions as well.  Read at every launch (the tests switch it); the host
+// allocates FilterBuffers::cand_gp only for a launch that will gather (8 bytes per candidate slot the default sequence never touches: ADVICE r05).
+bool gathered_list_requested()
+{
+    const char* form = std::getenv("DRPRG_VERIFY_FORM");
+    if (!form) return false;
+    const std::string f(form);
+#ifdef DRPRG_EXPERIMENTAL
+    return f == "gather" || f == "read";
+#else
+    return f == "gather";
+#endif
+}
+
 hipError_t launch_candidate_stage(const SketchArgs& a, FilterWork& fw, const ReadClusterArgs& rc, int n_cus, hipStream_t stream, bool with_totals)
 {
     fw.verify_grid = fw.ex_grid;
-    // DRPRG_VERIFY_FORM=gather keeps the three-kernel sequence of rounds 1-4 (A/B runs, a second way through the parity tests); the
-    // experimental read-by-read form (make EXPERIMENTAL=1 + DRPRG_VERIFY_FORM=read: read_verify.hip, bit-exact and 8 % slower,
-    // profiles/r05/read_verify.txt) needs the gathered list of positions as well
     const char* form = std::getenv("DRPRG_VERIFY_FORM");
     bool gathered = form && std::string(form) == "gather";
+    {   // DRPRG_VERIFY_ORDER=contiguous | interleave (read at every launch): which candidates a workgroup of verify_scan_kernel takes
+        const char* order = std::getenv("DRPRG_VERIFY_ORDER");
+        fw.verify_interleave = order && std::string(order) == "interleave" ? 1u : 0u;
+    }
 #ifdef DRPRG_EXPERIMENTAL
     const bool by_read = read_verify_applies(a, fw);
     gathered = gathered || by_read;
 #endif
+    if (gathered && !fw.cand_gp) return hipErrorInvalidValue; // (the caller allocates it when gathered_list_requested())
     if (!gathered) { // one launch: verify_scan_kernel scans the slice counts itself and reads the slices
         // (DRPRG_VERIFY_WG_PER_CU: measurements.  The grid is what fills the CUs' 2048 thread slots: fewer or more workgroups per CU measured
         // within the noise or worse; profiles/r05/verify_scan.txt)

@@ -162,7 +162,7 @@ struct BloomTables {
 struct FilterBuffers {
     uint64_t* raw_pos;
     uint4* raw_grp; // raw_capacity entries: level-0 survivors (groups of four positions) on their way to refine_kernel
-    uint64_t* cand_gp; // raw_capacity entries: the dense, ordered list of candidate positions (cand_gather_kernel)
+    uint64_t* cand_gp; // raw_capacity entries: the dense, ordered list of candidate positions (cand_gather_kernel); nullptr unless gathered_list_requested()
     uint64_t* cand_info;
     uint32_t* cand_pos1;
     uint4* cand_rec; // raw_capacity entries
@@ -241,6 +241,7 @@ struct FilterWork {
     unsigned long long* max_len; // longest read that holds a minimizer hit (this batch)
     unsigned long long* class_clock; // FilterBuffers::class_clock (may be null)
     uint32_t wave_share[4];  // sketch_filter_kernel: tiles of the waves 4c .. 4c + 3 of a workgroup, in 1/256 of an even share (sum 1024); see its launch
+    uint32_t verify_interleave; // verify_scan_kernel: rounds of 64 candidates dealt out over the workgroups instead of one stretch of the list each
     uint32_t debug;          // ablation switches for profiling (DRPRG_FT_DEBUG): 1 = skip the Bloom test, 8 = every read through the
                              // generic pipeline, 16 / 32 = verify_count_kernel without its window scan / table probe and
                              // everything after it (wrong results: timing only, tools/dbg16.sh)
@@ -295,6 +296,7 @@ bool read_cluster_wave_form_requested();
 hipError_t launch_counters_home(unsigned long long* from, unsigned long long* to, uint32_t n, hipStream_t stream, uint32_t* zero = nullptr, uint32_t n_zero = 0);
 uint32_t* filter_super_counts(uint32_t* small); // the superblock counts inside a FilterBuffers::small block ...
 uint32_t filter_super_words();                  // ... and how many words they are
+bool gathered_list_requested(); // this launch of the filtered sequence will want FilterBuffers::cand_gp (DRPRG_VERIFY_FORM=gather / read)
 size_t filter_small_words();
 // the fields of fw that the consumers of a dense candidate list use (candidates.hip, read_cluster.hip)
 void init_candidate_work(FilterWork& fw, const FilterBuffers& b, int n_cus);

@@ -422,7 +422,13 @@ __global__ __launch_bounds__(RC_THREADS, 4 * DRPRG_RC_WG_PER_CU) void read_clust
             // a k-mer that several k-mer nodes share (a quarter of the minimizers of a PRG index): its further records, four at a
             // time with their eight loads requested together (one after the other they were up to three round trips that the
             // whole workgroup waited for at the barrier)
-            for (uint32_t r0 = 1; r0 < cnt; r0 += 4) {
+            if (fw.debug & 4096u) // (DRPRG_FT_DEBUG=4096: timing only, wrong results -- what fetching the further records costs: they repeat the first)
+                for (uint32_t r = 1; r < cnt; ++r) {
+                    s_grp[h0 + r] = (uint16_t)g;
+                    s_hpos[h0 + r] = (uint16_t)pos;
+                    s_cov[h0 + r] = crec[q].w;
+                }
+            for (uint32_t r0 = 1; r0 < cnt && !(fw.debug & 4096u); r0 += 4) {
                 uint32_t kn4[4], prg4[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {

@@ -17,9 +17,9 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNEL_SOURCES = {  # (bench.py holds the same table)
-    "sketch_filter_kernel": ["sketch_filter.hip", "filter_common.h", "device_common.h"],
-    "sketch_wave_kernel": ["sketch_wave.hip", "sketch_block.h", "device_common.h"],
-    "sketch_probe_kernel": ["sketch_probe.hip", "device_common.h"],
+    "sketch_filter_kernel": ["sketch_filter.hip", "filter_common.h", "device_common.h", "kernels.h", "common.h"],
+    "sketch_wave_kernel": ["sketch_wave.hip", "sketch_block.h", "device_common.h", "kernels.h", "common.h"],
+    "sketch_probe_kernel": ["sketch_probe.hip", "device_common.h", "kernels.h", "common.h"],
 }
 DOMINANT = {"big": "sketch_wave_kernel", "mtb-x16": "sketch_wave_kernel", "mtb-x32": "sketch_wave_kernel"}
 
