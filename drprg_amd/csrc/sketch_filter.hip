@@ -57,7 +57,13 @@ __device__ inline uint32_t pack16le(const uint4& in)
     constexpr uint32_t W = 0x40100401u;
     const uint32_t p0 = __builtin_amdgcn_udot4(in.x & 0x06060606u, W, 0u, false), p1 = __builtin_amdgcn_udot4(in.y & 0x06060606u, W, 0u, false);
     const uint32_t p2 = __builtin_amdgcn_udot4(in.z & 0x06060606u, W, 0u, false), p3 = __builtin_amdgcn_udot4(in.w & 0x06060606u, W, 0u, false);
-    return ((p0 | (p1 << 8) | (p2 << 16)) >> 1) | (p3 << 23); // (the doubled fields never collide: bit 0 of each is 0)
+    // (the doubled fields never collide -- bit 0 of each is 0 --, so the ors can be sums: two v_lshl_add_u32 where shift, shift and or3 were
+    // three; spelled out, because the compiler turns the expression back into the three)
+    // (Round 6 spelled the merge as two v_lshl_add_u32 in inline assembly -- one instruction fewer per word; the compiler turns the C expression
+    // back into shift, shift, or3 -- and got a kernel that lost five candidates in six: the assembler statement reads the v_dot4 results, the
+    // hazard recogniser does not look into it, and gfx950 wants three wait states between a dot instruction and another VALU instruction
+    // that reads its result.  Not worth the two s_nop it would need.)
+    return ((p0 | (p1 << 8) | (p2 << 16)) >> 1) | (p3 << 23);
 }
 
 
@@ -396,7 +402,7 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
             wv[0] = pack16le(p.a);
             wv[1] = pack16le(p.b);
         }
-        wv[NW] = __builtin_amdgcn_update_dpp(0u, wv[0], 0x130 /* wave_shl:1: lane i <- lane i+1 */, 0xF, 0xF, false);
+        wv[NW] = __builtin_amdgcn_update_dpp(0u, wv[0], 0x130 /* wave_shl:1: lane i <- lane i+1 */, 0xF, 0xF, true); // (bound_ctrl: lane 63 reads 0, no register to clear first)
         const uint32_t wa = wv[0], wb = wv[1], wc = wv[2];
         (void)wa; (void)wb; (void)wc;
         if constexpr (LEVEL0) {
