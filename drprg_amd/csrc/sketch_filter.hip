@@ -217,7 +217,6 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
     // use to hide the 2 us, worked -- 0.333 ms -- but left the slowest waves two chunks behind the others at the end: round 6.)
     bool decoded = !dynamic, has_next = false;
     uint32_t n_k = 0, n_begin = 0, n_all = 0;
-    uint32_t sw_tile = 0xFFFFFFFFu, sw_k = 0, sw_base = 0, sw_cap = 0; // process() moves on to slice sw_k (there, that large) when it meets tile sw_tile
     // where chunk kt of this workgroup, tiles [b, e), keeps its candidates, and how many fit (FilterWork::slice_budget)
     auto slice_geometry = [&](uint32_t kt, uint32_t b, uint32_t e, uint32_t& base, uint32_t& cap) {
         base = blockIdx.x * fw.slice_budget + (b - wg_lo) * fw.slice_cpt + kt * fw.slice_slack;
@@ -273,6 +272,8 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
     uint64_t* out = fw.raw_pos + base_cur;
     uint4* grp_out = LEVEL0 ? fw.raw_grp + base_cur : nullptr;
     (void)grp_out;
+    uint32_t lane_keep = (lane == 63 || (fw.debug & 1u)) ? 0u : 0xFFFFFFFFu;
+    asm volatile("" : "+v"(lane_keep)); // (a value the compiler knows nothing about: it turns a known per-lane condition back into a branch)
     uint32_t wcur = 0; // candidates in the current slice so far (wave-uniform)
     // FUSED: the groups that passed level 0 wait in the wave's 2 KB of LDS; when the next tile might not fit, they go through the
     // second stage, 64 at a time and one lane each, and the surviving positions are appended in order.  The second-stage bits live
@@ -380,16 +381,6 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
 
     // one tile: my 32 positions start in words wa, wb; wc (the first word of lane+1) completes the last k-mers
     auto process = [&](uint32_t t, const Pair& p) {
-        if (t == sw_tile) { // wave-uniform: the first tile of the wave's next chunk -- the slice of the last one is complete
-            close_slice();
-            slice = sw_k;
-            sw_tile = 0xFFFFFFFFu;
-            base_cur = sw_base;
-            cap_cur = sw_cap;
-            out = fw.raw_pos + base_cur;
-            if (LEVEL0) grp_out = fw.raw_grp + base_cur;
-            wcur = 0;
-        }
         uint32_t wv[NW + 1]; // my words, then the first word of lane + 1 (it completes the last k-mers)
         if constexpr (PACKED) {
             wv[0] = p.x;
@@ -423,7 +414,7 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
 #pragma unroll
             for (int g = NG - 1; g >= 0; --g)
                 grp = __builtin_amdgcn_alignbit(grp, MID == 1 ? ws[g] << (hs[g] & 31) : bloom_test(ws[g], hs[g], xs[g]), 31);
-            if (lane == 63 || (fw.debug & 1u)) grp = 0;
+            grp &= lane_keep; // (lane 63's word is only lane 62's right neighbour; as a mask: the branch cost eight scalar instructions per tile)
             if constexpr (MID != 0) {
                 // ---- the exact bitmap of the canonical index 12-mers, only for the groups that passed level 0: one exec-masked load
                 // each, all in flight before the first test (the L2 serves ~267 G such probes per second chip-wide whatever their
@@ -576,19 +567,26 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
         }
         return ft;
     };
-    auto advance = [&]() -> bool { // `tile` is done: on to the next one of the stream (false: there is none)
+    // `tile` is done: on to the next one of the stream.  At the end of a chunk its slice is closed -- whatever is staged leaves now, the count is
+    // written -- and the wave moves into the chunk it drew (if it drew none, tile stays at c_end: the caller's loop ends).  (Until late in
+    // round 6 process() made the move when it met the new chunk's first tile: a compare and a branch per tile, and the scalar instructions
+    // of this kernel are not free -- 2.4 cycles each where a vector instruction costs 3.7, fitted on the SQ counters of two builds.)
+    auto advance = [&]() {
         ++tile;
         if constexpr (MID != 0) ++tiles_done;
-        if (tile < c_end) return true;
-        if (!has_next) return false; // (a chunk of one full tile, static schedule: nothing was decoded and nothing follows)
-        sw_tile = tile = n_begin;
-        sw_k = slice0 + n_k;
-        slice_geometry(n_k, n_begin, n_all, sw_base, sw_cap);
-        c_all = n_all;
-        c_end = n_all < n_full ? n_all : n_full;
-        has_next = false;
-        decoded = false;
-        return true;
+        if (tile >= c_end && has_next) { // wave-uniform
+            close_slice();
+            slice = slice0 + n_k;
+            slice_geometry(n_k, n_begin, n_all, base_cur, cap_cur);
+            out = fw.raw_pos + base_cur;
+            if (LEVEL0) grp_out = fw.raw_grp + base_cur;
+            wcur = 0;
+            tile = n_begin;
+            c_all = n_all;
+            c_end = n_all < n_full ? n_all : n_full;
+            has_next = false;
+            decoded = false;
+        }
     };
     Pair r0 {}, r1 {}, r2 {};
     const bool pipelined = tile < c_end; // wave-uniform
@@ -604,13 +602,16 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
         for (;;) {
             fetch(ahead2(), r2);
             process(tile, r0);
-            if (!advance()) break;
+            advance();
+            if (tile >= c_end) break;
             fetch(ahead2(), r0);
             process(tile, r1);
-            if (!advance()) break;
+            advance();
+            if (tile >= c_end) break;
             fetch(ahead2(), r1);
             process(tile, r2);
-            if (!advance()) break;
+            advance();
+            if (tile >= c_end) break;
         }
     for (; tile < c_all; ++tile) { // the end of the buffer (the last chunk of the window only), guarded loads
         const int64_t g = (int64_t)tile * WPOS + (int64_t)lane * G;
