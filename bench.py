@@ -374,6 +374,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=-1, help="reads timed on the CPU oracle (0 = skip, -1 = ~10 s worth)")
     ap.add_argument("--e2e", type=int, default=1, help="1: add the end-to-end leg (FASTQ text in /dev/shm -> coverage through map_fastx, "
                                                        "plain and gzip) to the JSON line at N=1; 0: skip")
+    ap.add_argument("--spinup-ms", type=float, default=float(os.environ.get("DRPRG_BENCH_SPINUP_MS", "600")),
+                    help="untimed mapping of the same batch for this long BEFORE the warm-up steps, so that the timed region runs on a device at "
+                         "its clocks (0: none; the line's cold_start leg is the same command on the device as the preparation leaves it)")
     ap.add_argument("--no-checks", action="store_true",
                     help="skip the full-size property checks after the timed region (profiling runs: every launch is then a "
                          "timed full-size one, so rocprofv3 per-kernel averages compare directly with avg_launch_ms)")
@@ -583,6 +586,42 @@ def main():
         torch.cuda.synchronize()
 
     acc = accs[0]
+    # ---- the device's state (round 6).  A MI355X that has idled while the host built the batch (seconds) takes hundreds of milliseconds of
+    # work to reach the clocks it then holds: the same 20 steps take 0.49 ms each right after the preparation, 0.465 after 50 ms of mapping
+    # and 0.445 after half a second (profiles/r06/spinup.txt) -- and W = 5 warm-up steps are 2.5 ms.  So the line carries both: "cold_start",
+    # the W + K steps of this very command measured first, on the device as the preparation leaves it; and the headline, the same W + K steps
+    # after --spinup-ms (600) of untimed mapping of the same batch -- what a process that maps sample after sample runs at. ----
+    cold_start = None
+    if world == 1 and not args.no_checks and args.spinup_ms > 0:
+        for _ in range(args.warmup):
+            step()
+        drain()
+        torch.cuda.synchronize()
+        ctx.kernel_timing(enable=True, reset=True)
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record(stream)
+        for _ in range(args.steps):
+            step()
+        c1.record(stream)
+        drain()
+        torch.cuda.synchronize()
+        c_ms, c_n = ctx.kernel_timing(enable=False)
+        cold_ms = c0.elapsed_time(c1) / args.steps
+        cold_start = {"ms_per_step": cold_ms, "value": n_reads / (cold_ms * 1e-3), "unit": "reads/s", "dominant_kernel_avg_launch_ms": c_ms / max(c_n, 1),
+                      "how": f"{args.warmup} warm-up + {args.steps} timed steps (device time between two events) FIRST, before anything else ran on the "
+                             "device since the batch was built: a device that has idled for seconds"}
+    spinup_steps = 0
+    if args.spinup_ms > 0:
+        t_spin = time.perf_counter()
+        while (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms:
+            for _ in range(8):
+                step()
+            spinup_steps += 8
+            if not deferred:
+                continue
+            ctx.sync()  # (the host must not run far ahead of the device: the wall clock is the device's busy time)
+        drain()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     ctx.kernel_timing(enable=True, reset=True)
@@ -741,6 +780,9 @@ def main():
             "timed_region_s": elapsed,
             "step_ms": {"min": step_ms[0], "median": step_ms[len(step_ms) // 2], "max": step_ms[-1],
                         "groups": len(step_ms), "how": "HIP events on the hot path's stream behind the last launch of every %d%s step (device time per step%s)" % (mark_every, {1: "st", 2: "nd", 3: "rd"}.get(mark_every, "th"), "" if mark_every == 1 else ", mean of each group")},
+            "spinup": {"ms": args.spinup_ms, "steps": spinup_steps,
+                       "what": "untimed steps on the same batch before the warm-up steps: the device at the clocks it holds under load (cold_start: without)"},
+            "cold_start": cold_start,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

@@ -43,11 +43,11 @@ fi
 if has pmc; then
   for wl in mtb mtb-x8 nanopore big; do
     for c in FETCH_SIZE WRITE_SIZE; do
-      timeout 300 rocprofv3 --pmc $c --output-format csv -d $R/$O/pmc_$wl -o $c -- python3 $R/bench.py --workload $wl --steps 3 --warmup 1 --cpu-sample 0 --e2e 0 --no-checks > /dev/null 2>&1
+      timeout 300 rocprofv3 --pmc $c --output-format csv -d $R/$O/pmc_$wl -o $c -- python3 $R/bench.py --workload $wl --steps 3 --warmup 1 --spinup-ms 0 --cpu-sample 0 --e2e 0 --no-checks > /dev/null 2>&1
     done
   done
   for c in FETCH_SIZE WRITE_SIZE; do
-    timeout 300 rocprofv3 --pmc $c --output-format csv -d $R/$O/pmc_mtb-packed -o $c -- python3 $R/bench.py --input packed --steps 3 --warmup 1 --cpu-sample 0 --e2e 0 --no-checks > /dev/null 2>&1
+    timeout 300 rocprofv3 --pmc $c --output-format csv -d $R/$O/pmc_mtb-packed -o $c -- python3 $R/bench.py --input packed --steps 3 --warmup 1 --spinup-ms 0 --cpu-sample 0 --e2e 0 --no-checks > /dev/null 2>&1
   done
 fi
 if has sq; then
@@ -55,13 +55,13 @@ if has sq; then
     n=0
     for c in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU"; do
       n=$((n+1))
-      timeout 300 rocprofv3 --pmc $c --output-format csv -d $R/$O/sq_$wl -o p$n -- python3 $R/bench.py --workload $wl --steps 2 --warmup 1 --cpu-sample 0 --e2e 0 --no-checks > /dev/null 2>&1
+      timeout 300 rocprofv3 --pmc $c --output-format csv -d $R/$O/sq_$wl -o p$n -- python3 $R/bench.py --workload $wl --steps 2 --warmup 1 --spinup-ms 0 --cpu-sample 0 --e2e 0 --no-checks > /dev/null 2>&1
     done
   done
   n=0
   for c in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU"; do
     n=$((n+1))
-    timeout 300 rocprofv3 --pmc $c --output-format csv -d $R/$O/sq_mtb-packed -o p$n -- python3 $R/bench.py --input packed --steps 2 --warmup 1 --cpu-sample 0 --e2e 0 --no-checks > /dev/null 2>&1
+    timeout 300 rocprofv3 --pmc $c --output-format csv -d $R/$O/sq_mtb-packed -o p$n -- python3 $R/bench.py --input packed --steps 2 --warmup 1 --spinup-ms 0 --cpu-sample 0 --e2e 0 --no-checks > /dev/null 2>&1
   done
 fi
 cd $R
