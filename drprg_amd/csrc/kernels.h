@@ -161,7 +161,7 @@ struct BloomTables {
 // was too small.  The hits are written ordered by (read, position); a.n_hits receives their number.
 struct FilterBuffers {
     uint64_t* raw_pos;
-    uint4* raw_grp; // raw_capacity entries: level-0 survivors (groups of four positions) on their way to refine_kernel
+    uint4* raw_grp; // raw_capacity entries: level-0 survivors (groups of four positions) on their way to refine_kernel; nullptr unless group_records_requested()
     uint64_t* cand_gp; // raw_capacity entries: the dense, ordered list of candidate positions (cand_gather_kernel); nullptr unless gathered_list_requested()
     uint64_t* cand_info;
     uint32_t* cand_pos1;
@@ -296,6 +296,7 @@ bool read_cluster_wave_form_requested();
 hipError_t launch_counters_home(unsigned long long* from, unsigned long long* to, uint32_t n, hipStream_t stream, uint32_t* zero = nullptr, uint32_t n_zero = 0);
 uint32_t* filter_super_counts(uint32_t* small); // the superblock counts inside a FilterBuffers::small block ...
 uint32_t filter_super_words();                  // ... and how many words they are
+bool group_records_requested();  // ... will want FilterBuffers::raw_grp (DRPRG_FILTER_FORM=refine, experimental library)
 bool gathered_list_requested(); // this launch of the filtered sequence will want FilterBuffers::cand_gp (DRPRG_VERIFY_FORM=gather / read)
 size_t filter_small_words();
 // the fields of fw that the consumers of a dense candidate list use (candidates.hip, read_cluster.hip)

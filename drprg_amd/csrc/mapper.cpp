@@ -350,7 +350,6 @@ void Mapper::grow_lane(Lane& lane, uint64_t cap)
     if (cap >= (1ull << 31)) throw Error(DRPRG_EOVERFLOW, "more than 2^31 candidate k-mers in one read range; map smaller batches");
     dfree(lane.raw_pos); dfree(lane.raw_grp); dfree(lane.cand_gp); dfree(lane.cand_info); dfree(lane.cand_pos1); dfree(lane.cand_rec); dfree(lane.rc_flags);
     lane.raw_capacity = cap;
-    if (bloom0_wbits_) dmalloc(lane.raw_grp, cap);
     dmalloc(lane.raw_pos, cap); dmalloc(lane.cand_info, cap); dmalloc(lane.cand_pos1, cap); dmalloc(lane.cand_rec, cap); // (cand_gp: launch_lane, on demand)
     dmalloc(lane.rc_flags, (size_t)(cap / dev::RC_CHUNK_OWN + 3));
     if (!lane.rc_partials) dmalloc(lane.rc_partials, (size_t)dev::RC_WAVE_MAX_WG * ((size_t)n_prgs_ + 4));
@@ -388,6 +387,7 @@ void Mapper::launch_lane(Lane& lane, hipStream_t stream, const uint8_t* d_bases,
     if (!lane.scratch_zero) HIPCHK(hipMemsetAsync(lane.d_scratch, 0, L_N * sizeof(unsigned long long), stream));
     lane.scratch_zero = false;
     if (!lane.cand_gp && dev::gathered_list_requested()) dmalloc(lane.cand_gp, lane.raw_capacity); // (grow_lane frees it with the rest)
+    if (!lane.raw_grp && bloom0_wbits_ && dev::group_records_requested()) dmalloc(lane.raw_grp, lane.raw_capacity);
     dev::SketchArgs a = sketch_args(d_bases, d_offsets, n_reads, n_bases, pk);
     a.n_hits = &lane.d_scratch[L_HITS];
     a.n_minimizers = &lane.d_scratch[L_MINIMIZERS];

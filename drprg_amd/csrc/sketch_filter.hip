@@ -708,6 +708,19 @@ __global__ __launch_bounds__(RF_THREADS) void refine_kernel(SketchArgs a, Filter
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
+// DRPRG_FILTER_FORM=refine with the library of `make EXPERIMENTAL=1`: the level-0 survivors leave sketch_filter_kernel as 16-byte group
+// records (FilterBuffers::raw_grp) for refine_kernel.  Read at every launch; the host allocates raw_grp only then (16 bytes per
+// candidate slot that the default sequence never touches).
+bool group_records_requested()
+{
+#ifdef DRPRG_EXPERIMENTAL
+    const char* form = std::getenv("DRPRG_FILTER_FORM");
+    return form && std::string(form) == "refine";
+#else
+    return false;
+#endif
+}
+
 uint32_t filter_n_tiles(uint64_t n_bases, int positions_per_lane)
 {
     const uint64_t wpos = 63ull * (uint64_t)positions_per_lane;
@@ -828,18 +841,14 @@ hipError_t launch_sketch_filter(const SketchArgs& a, uint32_t read_begin, uint32
         return hipErrorInvalidValue;
     if (!mid && (1u << bt.bloom_wbits) > (uint32_t)FT_BLOOM_WORDS) return hipErrorInvalidValue;
     if (!mid && bt.bloom0 && (1u << bt.bloom0_wbits) != (uint32_t)FT_L0_WORDS) return hipErrorInvalidValue;
-    if (!mid && bt.bloom0 && (!b.raw_grp || !bt.bloomr || !bt.bloom0f)) return hipErrorInvalidValue;
+    if (!mid && bt.bloom0 && (!bt.bloomr || !bt.bloom0f)) return hipErrorInvalidValue;
     if (const char* dbg = std::getenv("DRPRG_FT_DEBUG")) fw.debug = (uint32_t)std::atoi(dbg); // 1 no filter test, 4 no level 0, 8 no read_cluster_kernel
     const bool level0 = mid || (bt.bloom0 != nullptr && a.k == 15 && ((size_t)4 << bt.bloom_wbits) + (size_t)FT_L0_WORDS * 4 <= 160 * 1024
         && !(fw.debug & 4u));
     // the second stage inside the streaming kernel (default; its bits share the level-0 array) or as refine_kernel behind it
     // (DRPRG_FILTER_FORM=refine): 0.64 against 0.69 ms per 10 M reads, DESIGN.md section 6
-#ifdef DRPRG_EXPERIMENTAL
-    const char* form = std::getenv("DRPRG_FILTER_FORM");
-    const bool fused = mid || (level0 && !(form && std::string(form) == "refine"));
-#else
-    const bool fused = mid || level0; // (the two-kernel form is part of `make EXPERIMENTAL=1` only)
-#endif
+    const bool fused = mid || (level0 && !group_records_requested()); // (the two-kernel form is part of `make EXPERIMENTAL=1` only)
+    if (level0 && !fused && !b.raw_grp) return hipErrorInvalidValue; // (the caller allocates the group records when group_records_requested())
     fw.bloom = bt.bloom;
     fw.bloom_wbits = bt.bloom_wbits;
     fw.bloomr = bt.bloomr;

@@ -285,10 +285,10 @@ def test_read_by_read_verification(tmp_path, oracle, w):
 
 
 def test_candidates_at_both_ends_of_the_batch(tmp_path, oracle):
-    """verify_scan_kernel reads the candidates from the filter kernel's slices through a window of 64 slice prefixes: a batch whose
-    candidates sit in its first and its last slices, with half a million reads that leave no candidate between them, makes the
-    workgroup whose share straddles the gap take several windows -- and the three-kernel sequence (DRPRG_VERIFY_FORM=gather) must
-    count the same"""
+    """verify_scan_kernel reads the candidates from the filter kernel's slices through the prefix of the superblock counts it keeps
+    in LDS: a batch whose candidates sit in its first and its last slices, with half a million reads that leave no candidate between
+    them, makes the workgroup whose share straddles the gap bisect across thousands of empty superblocks -- and the three-kernel
+    sequence (DRPRG_VERIFY_FORM=gather) must count the same"""
     from drprg_amd import synth
     rng = np.random.default_rng(77)
     panel = synth.small_panel(seed=31, n_loci=3, length=900)
