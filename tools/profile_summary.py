@@ -3,7 +3,7 @@
 again on profiles/r06 after copying: `python tools/profile_summary.py profiles/r06 z_`).  Every kernel line names the file it comes from
 and its call count, so that a summary cannot outlive the table it summarises.
 
-usage: python tools/profile_summary.py <dir> [file prefix]"""
+usage: python tools/profile_summary.py <dir> [file prefix ...]      (profiles/r06: z_ zb_)"""
 import collections
 import csv
 import glob
@@ -15,9 +15,15 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import kstats  # noqa: E402
 
 d = sys.argv[1]
-pre = sys.argv[2] if len(sys.argv) > 2 else ""
+pres = sys.argv[2:] or [""]
+
+
+def files(pattern):
+    return sorted(f for pre in pres for f in glob.glob(f"{d}/{pre}{pattern}"))
+
+
 print("== bench lines")
-for f in sorted(glob.glob(f"{d}/{pre}bench_*.json")):
+for f in files("bench_*.json"):
     try:
         j = json.loads(open(f).read().strip().splitlines()[-1])
         r = j["roofline"]
@@ -29,7 +35,7 @@ for f in sorted(glob.glob(f"{d}/{pre}bench_*.json")):
     except Exception as e:  # noqa: BLE001
         print(os.path.basename(f), "FAILED", e)
 print("\n== kernels (rocprofv3 --kernel-trace; full = launches >= a tenth of the kernel's median)")
-for f in sorted(glob.glob(f"{d}/{pre}*_kernel_trace.csv")) or sorted(glob.glob(f"{d}/{pre}*_kernel_stats.csv")):
+for f in files("*_kernel_trace.csv") or files("*_kernel_stats.csv"):
     print("--", os.path.basename(f))
     for r in kstats.load(f):
         if "rocclr" in r["name"]:
@@ -45,7 +51,7 @@ for f in sorted(glob.glob(f"{d}/{pre}*_kernel_trace.csv")) or sorted(glob.glob(f
         bad = {k: (a.get(k), b.get(k)) for k in set(a) | set(b) if a.get(k) != b.get(k) and "rocprim" not in k}
         print("   call counts equal those of", os.path.basename(st) + ":", not bad, bad or "")
 print("\n== counters (per launch)")
-for f in sorted(glob.glob(f"{d}/{pre}*counter_collection.csv")):
+for f in files("*counter_collection.csv"):
     acc = collections.defaultdict(lambda: [0.0, 0])
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
