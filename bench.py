@@ -807,9 +807,9 @@ def main():
                 "reduced_words": n_acc,
                 "all_ranks_hold_the_sum_of_the_ranks_vectors": reduce_consistent,
                 "bases_per_s": n_bases * world * args.steps / elapsed,
-                "hits_per_batch": counters.get("hits", 0) // (args.warmup + args.steps),
-                "clusters_kept_per_batch": counters.get("clusters_kept", 0) // (args.warmup + args.steps),
-                "leftover_reads_per_batch": counters.get("leftover_reads", 0) // (args.warmup + args.steps),
+                "hits_per_batch": counters.get("hits", 0) // max(step_no[0], 1),  # (every step() so far: cold leg, spin-up, warm-up, timed)
+                "clusters_kept_per_batch": counters.get("clusters_kept", 0) // max(step_no[0], 1),
+                "leftover_reads_per_batch": counters.get("leftover_reads", 0) // max(step_no[0], 1),
                 "filter_tiers": ctx.table_tier(),
                 "coverage_checksum": checksum, "full_size_shard_invariance": shard_invariant,
                 "full_size_direct_vs_filtered_kernel_identical": kernels_agree,

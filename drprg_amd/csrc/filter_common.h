@@ -23,6 +23,13 @@ constexpr int SCAN_THREADS = 1024;
 // superblock whose (clamped) candidate count the filter kernel keeps as well: verify_scan_kernel scans the superblocks -- MAX_SLICES of
 // them at most, as it scanned the slices themselves until round 5 -- and a candidate then finds its slice among the FT_SUPER of its superblock.
 constexpr int MAX_SLICES = SCAN_THREADS * 8; // superblocks
+#ifndef DRPRG_FT_DEPTH
+#define DRPRG_FT_DEPTH 3
+#endif
+// tiles a wave of sketch_filter_kernel has in flight behind the one it works on.  3 since round 6 (a fourth register set: the kernel's budget is
+// 128 VGPRs whatever it does -- 16 waves per CU -- and it uses 66-79): 4 kb reads 1.48-1.56 -> 1.44-1.45 ms per launch, 150-base reads and packed
+// input unchanged (profiles/r06/schedule.txt 7).  Round 2 had found a fourth set slower -- with the group records still going to global memory.
+constexpr int FT_DEPTH = DRPRG_FT_DEPTH;
 constexpr int FT_SUPER = 8;                  // slices per superblock
 constexpr int MAX_CHUNKS = MAX_SLICES * FT_SUPER; // slices
 constexpr int MAX_EX_WG = SCAN_THREADS * 4;  // workgroups of verify_count_kernel / expand_kernel

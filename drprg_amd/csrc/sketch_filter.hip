@@ -555,12 +555,12 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
         if (has_next) {
             n_k = kt;
             chunk_of_ticket(kt, n_begin, n_all);
-            if (lane == 0 && n_begin + 2 > (n_all < n_full ? n_all : n_full)) atomicOr(a.overflow, 16u); // (a schedule the host must not make: kernels.h FilterSched)
+            if (lane == 0 && n_begin + FT_DEPTH > (n_all < n_full ? n_all : n_full)) atomicOr(a.overflow, 16u); // (a schedule the host must not make: kernels.h FilterSched)
         }
         decoded = true;
     };
-    auto ahead2 = [&]() -> uint32_t {
-        uint32_t ft = tile + 2;
+    auto ahead2 = [&]() -> uint32_t { // (the tile FT_DEPTH steps ahead)
+        uint32_t ft = tile + FT_DEPTH;
         if (ft >= c_end) { // wave-uniform
             if (!decoded) decode_next();
             ft = has_next ? n_begin + (ft - c_end) : c_end - 1;
@@ -592,14 +592,36 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
     const bool pipelined = tile < c_end; // wave-uniform
     if (pipelined) {
         fetch(tile, r0);
-        fetch(tile + 1 < c_end ? tile + 1 : tile, r1); // (a dynamic schedule's chunks hold two full tiles at least)
+        fetch(tile + 1 < c_end ? tile + 1 : tile, r1); // (a dynamic schedule's chunks hold FT_DEPTH full tiles at least)
     }
+#if DRPRG_FT_DEPTH == 3
+    Pair r3 {};
+    if (pipelined) fetch(tile + 2 < c_end ? tile + 2 : tile, r2);
+#endif
     __syncthreads(); // Bloom filter in place; the only barrier
     // (middle tier: a tile's bitmap probes are waited for inside process() together with every load the wave has issued, the freshly
     // requested tile included; requesting that tile BEHIND process() instead was measured and changed nothing -- 522 / 534 / 1254 us
     // against 520 / 530 / 1234 on the dense, 2-fold and 8-fold indexes: the other three waves of the SIMD cover the wait)
     if (pipelined)
         for (;;) {
+#if DRPRG_FT_DEPTH == 3
+            fetch(ahead2(), r3);
+            process(tile, r0);
+            advance();
+            if (tile >= c_end) break;
+            fetch(ahead2(), r0);
+            process(tile, r1);
+            advance();
+            if (tile >= c_end) break;
+            fetch(ahead2(), r1);
+            process(tile, r2);
+            advance();
+            if (tile >= c_end) break;
+            fetch(ahead2(), r2);
+            process(tile, r3);
+            advance();
+            if (tile >= c_end) break;
+#else
             fetch(ahead2(), r2);
             process(tile, r0);
             advance();
@@ -612,6 +634,7 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
             process(tile, r2);
             advance();
             if (tile >= c_end) break;
+#endif
         }
     for (; tile < c_all; ++tile) { // the end of the buffer (the last chunk of the window only), guarded loads
         const int64_t g = (int64_t)tile * WPOS + (int64_t)lane * G;
@@ -785,10 +808,10 @@ FilterSched make_filter_sched(uint32_t n_tiles, uint32_t n_wg, bool window_known
     const uint32_t tpw0 = (uint32_t)(avg * knobs.f / 256);
     // every chunk of a dynamic schedule must hold two tiles that lie wholly inside the buffer (the last two tiles of a batch may not): the
     // smallest share of round 0 -- the class split rounds down by up to a tile -- and the smallest chunk say whether this batch can have one
-    if (!window_known || knobs.is_static || avg < knobs.min_avg || (uint64_t)tpw0 * min_share / 256 < 4) return s;
+    if (!window_known || knobs.is_static || avg < knobs.min_avg || (uint64_t)tpw0 * min_share / 256 < FT_DEPTH + 2) return s;
     const uint32_t max_per_wg = (uint32_t)MAX_CHUNKS / n_wg;
     uint64_t done = (uint64_t)FT_WAVES * tpw0, rest = wg_tiles - done;
-    if (rest < 4) return s; // (the last chunk -- the whole dynamic part here -- must hold four tiles: the batch's last two may be partial)
+    if (rest < FT_DEPTH + 2) return s; // (the last chunk -- the whole dynamic part here -- must hold FT_DEPTH whole tiles: the batch's last two may be partial)
     uint32_t tk = FT_WAVES;
     int r = 1;
     for (; r < FT_MAX_ROUNDS - 1 && tk + 2 * FT_WAVES <= max_per_wg; ++r) {
@@ -804,7 +827,7 @@ FilterSched make_filter_sched(uint32_t n_tiles, uint32_t n_wg, bool window_known
     // the last round: chunks of the smallest size, or larger ones if the slices would not suffice; its last chunk takes the remainder
     const uint32_t left = max_per_wg - tk;
     const uint32_t sz = (uint32_t)std::max<uint64_t>(knobs.m, (rest + left - 1) / left);
-    const uint32_t cnt = (uint32_t)std::max<uint64_t>(1, rest / sz);
+    const uint32_t cnt = (uint32_t)std::max<uint64_t>(1, (rest - (FT_DEPTH - 2)) / sz); // (the last chunk: sz + FT_DEPTH - 2 tiles at least)
     s.first_ticket[r] = tk;
     s.first_tile[r] = (uint32_t)done;
     s.size[r] = sz;

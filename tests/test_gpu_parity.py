@@ -1233,7 +1233,7 @@ def test_chunk_schedule_edges(tmp_path, oracle, monkeypatch, grid, sched):
     panel = synth.small_panel(seed=6, n_loci=3, length=900)
     rng = np.random.default_rng(5)
     haps = [synth.sample_haplotype(rng, t).encode() for t in panel.trees]
-    dense = _reads_from(rng, haps, 40000 + 37 * int(grid), 150)
+    dense = _reads_from(rng, haps, 60000 + 37 * int(grid), 150)
     sparse = _reads_from(rng, haps + [synth.random_seq(rng, 200000).encode()] * 9, 90000 + 11 * int(grid), 151)
     forms = []
     for bases, offs in (dense, sparse):
