@@ -844,6 +844,7 @@ void Mapper::tune_filter_shares(const Lane& lane, bool packed, uint64_t n_bases)
     }
     if (lane.fw.sched.n_rounds > 1) return; // a dynamic schedule balances itself: the shares of round 0 stay what they are
     if (!ft_adapt_ || n_bases < (64ull << 20)) return;
+    if (max_lanes_ > 1) return; // (read ranges on concurrent streams: the classes' clocks measure the overlap, not the shares -- ADVICE r05)
     const unsigned long long* ck = &lane.h_scratch[L_FT_CLOCK];
     if (!ck[0] || !ck[1] || !ck[2] || !ck[3] || !ck[4]) return; // (a launch without the level-0 form, or with DRPRG_FT_SHARE)
     const unsigned long long t0 = ~ck[0];
