@@ -70,7 +70,8 @@ struct SketchArgs {
     const uint32_t* pbloom; // direct kernel: Bloom tier in front of a table that does not fit L2 (nullptr: none)
     uint32_t pbloom_wbits;
     uint32_t* overflow; // bit 0: hit buffer too small, bit 1: read longer than 2^HIT_POS_BITS, bit 2: candidate slice
-                        // too small, bit 3: dynamic LDS does not start at address 0 (sketch_filter_kernel)
+                        // too small, bit 3: dynamic LDS does not start at address 0 (sketch_filter_kernel), bit 4: a chunk of its schedule holds too
+                        // few whole tiles, bit 5: the batch's offsets do not span [0, n_bases) (its chunk schedule was made for all of its tiles)
     // candidate form of the direct kernel (tile_cap != 0): instead of hits, every tile leaves the records
     // read_cluster_kernel wants (same layout as FilterWork::cand_info / cand_pos1 / cand_rec), in position order, in its own
     // slice of tile_cap entries; tile_count[t] = minimizers found, tile_hits[t] = their hits, tile_nmin[t] = all minimizers of the tile
@@ -189,6 +190,7 @@ constexpr int FT_MAX_ROUNDS = 8;
 struct FilterSched {
     uint32_t tpw0;       // round 0: tiles per wave of an even split (0: the kernel divides its window itself -- a read range the host has no tile numbers for)
     uint32_t per_wg;     // chunks = slices per workgroup
+    uint32_t n_tiles;    // the tiles the schedule was made for (a dynamic one: the kernel's window must be exactly tiles [0, n_tiles))
     uint32_t first_ticket[FT_MAX_ROUNDS], first_tile[FT_MAX_ROUNDS], size[FT_MAX_ROUNDS]; // [0] unused; first_ticket[r] = 0xFFFFFFFF for r >= n_rounds
     uint32_t n_rounds;
     uint32_t lds_word;   // the workgroup's ticket counter: this word of the kernel's dynamic LDS (set by the launcher; next ticket = 16 + its value)

@@ -801,7 +801,8 @@ void Mapper::finish_lane(Lane& lane, const uint8_t* d_bases, const uint64_t* d_o
     for (int attempt = 0;; ++attempt) {
         const uint32_t ovf = (uint32_t)lane.h_scratch[L_OVERFLOW];
         if (ovf & 8u) throw Error(DRPRG_EIO, "sketch_filter_kernel: dynamic LDS does not start at address 0");
-        if (ovf & 16u) throw Error(DRPRG_EIO, "sketch_filter_kernel: a chunk of its schedule holds fewer than two whole tiles");
+        if (ovf & 16u) throw Error(DRPRG_EIO, "sketch_filter_kernel: a chunk of its schedule holds too few whole tiles");
+        if (ovf & 32u) throw Error(DRPRG_EINVAL, "the batch's read offsets do not span its bases: offsets[0] must be 0 and offsets[n_reads] must be n_bases");
         if (ovf & 2u) throw Error(DRPRG_EOVERFLOW, "a read is longer than 2^" + std::to_string(dev::HIT_POS_BITS) + " bases");
         if (!(ovf & 4u)) break;
         // a candidate slice of this range was too small: its sequence counted nothing and touched no coverage

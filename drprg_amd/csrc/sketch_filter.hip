@@ -176,6 +176,12 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
     const uint32_t n_waves = gridDim.x * FT_WAVES;
     const uint32_t per_wg = fw.sched.per_wg;  // chunks = slices per workgroup
     const bool dynamic = per_wg > FT_WAVES;   // (false: one chunk per wave, as until round 5)
+    // (a chunk schedule is made by the host for the tiles of the whole batch: offsets that do not span [0, n_bases) would put its chunks somewhere
+    // else -- nothing is mapped then, the host reports it)
+    if (dynamic && (t_lo != 0 || t_hi != fw.sched.n_tiles)) {
+        if (tid == 0) atomicOr(a.overflow, 32u);
+        return;
+    }
     const uint32_t tiles_per_wave = fw.sched.tpw0 ? fw.sched.tpw0 : (t_hi - t_lo + n_waves - 1) / n_waves;
     // this workgroup's tiles: [wg_lo, wg_hi) -- a dynamic schedule splits the window to the tile (the schedule is made for the smaller of the
     // two sizes that gives; a workgroup's last chunk takes the odd tile), the static one gives every wave tiles_per_wave
@@ -779,6 +785,7 @@ FilterSched make_filter_sched(uint32_t n_tiles, uint32_t n_wg, bool window_known
     for (int r = 0; r < FT_MAX_ROUNDS; ++r) s.first_ticket[r] = 0xFFFFFFFFu;
     s.n_rounds = 1;
     s.per_wg = FT_WAVES;
+    s.n_tiles = n_tiles;
     s.tpw0 = window_known ? (n_tiles + n_wg * FT_WAVES - 1) / (n_wg * FT_WAVES) : 0u;
     // DRPRG_FT_SCHED (read at every launch: tests switch it): "static", or "f,d,m[,a]" = round 0's part of the tiles in 1/256, the divisor of
     // the dynamic rounds x 16 (a round hands every wave 16 / d of an even share of what is left), the smallest chunk in tiles, and the

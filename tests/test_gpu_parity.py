@@ -1254,3 +1254,36 @@ def test_chunk_schedule_edges(tmp_path, oracle, monkeypatch, grid, sched):
     ctx = _ctx(tmp_path, panel, 16, 13, True, kernel=2)
     _compare(ctx, oracle, sparse[0], sparse[1], 16, 13, True, 2)
     assert not ONE_LANE or _schedule_forms(ctx, sparse[0], sparse[1])[0] == "dynamic"
+
+
+def test_offsets_must_span_the_batch_under_a_chunk_schedule(tmp_path, oracle, monkeypatch):
+    """The chunk schedule is made by the host for the tiles of the WHOLE batch (it cannot read the offsets, they live on the device): a
+    device batch whose offsets do not span [0, n_bases) is refused -- loudly, nothing mapped -- and the context maps the next batch as if
+    nothing had happened.  (One chunk per wave, the schedule of small batches, takes its window from the offsets and does not care.)"""
+    import torch
+    from drprg_amd import DependencyError, synth
+    if not ONE_LANE:
+        pytest.skip("read ranges on concurrent streams keep one chunk per wave")
+    monkeypatch.setenv("DRPRG_FT_GRID", "2")
+    monkeypatch.setenv("DRPRG_FT_SCHED", "128,32,4,8")
+    panel = synth.small_panel(seed=4)
+    ctx = _ctx(tmp_path, panel, 11, 15, True, kernel=2)
+    gen = synth.HaplotypeGenomes(panel, genome_size=20000, n_hap=4, seed=3)
+    bases, offs = synth.sample_short_reads(gen, 20000, seed=8)
+    dev = torch.device("cuda", 0)
+    tb = torch.from_numpy(np.ascontiguousarray(bases)).to(dev)
+    bad = offs.astype(np.int64).copy()
+    bad[0] = bad[40]  # (the first 40 reads empty: still ascending, but the window starts 6000 bases in)
+    bad[:40] = bad[40]
+    tbad, tgood = torch.from_numpy(bad).to(dev), torch.from_numpy(offs.astype(np.int64)).to(dev)
+    torch.cuda.synchronize()
+    ctx.reset()
+    with pytest.raises(DependencyError, match="offsets"):
+        ctx.map_device(tb.data_ptr(), tbad.data_ptr(), len(offs) - 1, int(offs[-1]))
+    ctx.reset()
+    ctx.map_device(tb.data_ptr(), tgood.data_ptr(), len(offs) - 1, int(offs[-1]))
+    cov, prg = ctx.coverage()
+    assert ctx.filter_schedule()["form"] == ("dynamic" if ONE_LANE else "static")
+    idx = _oracle_index(oracle, ctx.prg_strings, 11, 15)
+    ocov, oprg, _ = _oracle_map(oracle, idx, bases, offs, 11, 15, True)
+    assert np.array_equal(cov, ocov) and np.array_equal(prg, oprg)
