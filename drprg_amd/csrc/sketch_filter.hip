@@ -5,20 +5,22 @@
 // hashing every k-mer of every read (sketch_probe.hip: ~86 VALU instructions per base, two 15-op hashes each):
 //
 //   this file
-//   sketch_filter_kernel   every wave streams one contiguous chunk of the concatenated base buffer, packs it to 2 bits
-//                          per base in registers and tests the k-mer *codes* against a Bloom filter of the index k-mer
-//                          codes that stays in LDS for the lifetime of the workgroup (level-0 form, k = 15: one 12-mer
-//                          per four positions against a 128 KB array).  Survivors are appended in position order to the
-//                          wave's own slices (cursor in a scalar register: no atomics, no barriers).  Two tiles of bases
-//                          are in flight per wave in a register ring, the right neighbour's packed word arrives through
-//                          a DPP wave shift.  Level-0 form, default: the groups that pass wait in the wave's 2 KB of LDS
+//   sketch_filter_kernel   every wave streams contiguous chunks of the concatenated base buffer -- a static first one, then smaller
+//                          ones it draws from a counter in its workgroup's LDS (round 6: kernels.h FilterSched; the waves of a
+//                          SIMD do not run at one speed) --, packs the bases to 2 bits in registers and tests the k-mer *codes*
+//                          against a Bloom filter of the index k-mer codes that stays in LDS for the lifetime of the workgroup
+//                          (level-0 form, k = 15: one 12-mer per four positions against a 128 KB array).  Survivors are appended
+//                          in position order to the chunk's own slice (cursor in a scalar register: no atomics, no barriers;
+//                          the slices in chunk order are the candidates in position order).  Three tiles of bases are in flight
+//                          per wave in a register ring, the right neighbour's packed word arrives through a DPP wave shift.
+//                          Level-0 form, default: the groups that pass wait in the wave's 2 KB of LDS
 //                          and go through the second-stage filter -- its bits share the level-0 array -- 64 at a time,
 //                          one lane per group; only surviving positions leave the kernel.
 //   refine_kernel          level-0 form with DRPRG_FILTER_FORM=refine: the groups leave sketch_filter_kernel as 16-byte
 //                          records; one lane per group, second-stage filter in LDS, ordered compaction per slice.
 //   candidates.hip
-//   verify_scan_kernel     (round 5) every workgroup scans the slice counts itself, takes its share of the ordered candidate
-//                          list and reads the positions from the slices; then one lane per candidate, start to finish, no
+//   verify_scan_kernel     (round 5) every workgroup scans the slice counts itself (round 6: the counts of superblocks of eight slices),
+//                          takes its share of the ordered candidate list and reads the positions from the slices; then one lane per candidate, start to finish, no
 //                          atomic: canonical hash from the raw bases -> exact table lookup, four slots per load (false
 //                          positives end here) -> read lookup -> window-minimizer test, walked outward from the candidate
 //                          (verify_lane.h).  Leaves one record per candidate and the totals per workgroup, which workgroup 0
