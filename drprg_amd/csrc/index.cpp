@@ -173,6 +173,39 @@ void PrgIndex::flatten()
                     f.bloom0f[(g >> 17) & wmask0] |= bits0;
                 }
         });
+        if (level0) { // the second stage for the L2 (index.h blkc)
+            uint32_t cw = 10;
+            while (cw < MID_C_MAX_WBITS && (size_t(4) << cw) < 4 * entries) ++cw;
+            f.blkc_wbits = cw;
+            f.blkc.assign(size_t(4) << cw, 0);
+            for_each_code([&](uint32_t code) {
+                const uint32_t h = code * BLOOM_CR;
+                for (int o = 0; o < 4; ++o) {
+                    const uint32_t key = (code >> (2 * o)) & 0xFFFFFFu;
+                    const uint32_t blk = (uint32_t)((uint64_t)key * BLOOM_C0) >> (32 - cw);
+                    uint32_t* b = &f.blkc[(size_t)blk * 4];
+                    b[0] |= 1u << (h >> 27);
+                    b[1] |= 1u << ((h >> 22) & 31);
+                    b[2] |= 1u << ((h >> 17) & 31);
+                    b[3] |= 1u << ((h >> 12) & 31);
+                }
+            });
+        }
+        if (level0 && std::getenv("DRPRG_FT_STATS")) { // how full the level-0 array is, alone and with the second stage's bits in it, and what
+            // a random 12-mer's three-bit test passes at in each (mean over the words of (bits / 32)^3: the third bit's position comes from the key itself)
+            auto stat = [](const std::vector<uint32_t>& a, const char* name) {
+                double bits = 0, p3 = 0;
+                for (uint32_t wd : a) {
+                    const double b = (double)__builtin_popcount(wd);
+                    bits += b;
+                    p3 += (b / 32) * (b / 32) * (b / 32);
+                }
+                std::fprintf(stderr, "[filter] %s: %.1f %% of %zu bits set, a random key passes the three-bit test at %.2f %%\n", name, 100 * bits / (32.0 * a.size()),
+                    32 * a.size(), 100 * p3 / a.size());
+            };
+            stat(f.bloom0, "level 0 alone");
+            stat(f.bloom0f, "level 0 + second-stage bits");
+        }
     } else if (k == 15 && entries > 0 && !std::getenv("DRPRG_NO_MID_TIER") && recs.size() <= mid_tier_max_records()) {
         // Middle tier (round 3): too many index k-mers for an LDS-resident filter of the whole codes.  Level 0 stays in LDS but
         // is keyed on the CANONICAL 12-mer (half the entries); what passes it is looked up in the exact bitmap of the canonical
@@ -300,7 +333,15 @@ void PrgIndex::filter_selfcheck(uint64_t out[8]) const
             const uint32_t hs = code * BLOOM_C2;
             miss_f |= !((wf >> (hr & 31)) & (wf >> ((hr >> 5) & 31)) & (wf >> ((hr >> 10) & 31)) & (wf >> (hs >> 27)) & (wf >> ((hs >> 22) & 31))
                 & (wf >> ((hs >> 17) & 31)) & 1u);
-            out[7] += miss_f;
+            // ... and the second stage of the L2 form: every block the code was entered in (the plain 12-mer at offset o picks it) holds its four bits
+            bool miss_blk = false;
+            if (f.blkc_wbits)
+                for (int o = 0; o < 4; ++o) {
+                    const uint32_t key = (code >> (2 * o)) & 0xFFFFFFu;
+                    const uint32_t* b = &f.blkc[(size_t)((uint32_t)((uint64_t)key * BLOOM_C0) >> (32 - f.blkc_wbits)) * 4];
+                    miss_blk |= !((b[0] >> (hr >> 27)) & (b[1] >> ((hr >> 22) & 31)) & (b[2] >> ((hr >> 17) & 31)) & (b[3] >> ((hr >> 12) & 31)) & 1u);
+                }
+            out[7] += miss_f || miss_blk;
         }
         const uint32_t x = code & kmask & 0xFFFFFFu;
         const uint32_t h = (uint32_t)((uint64_t)x * BLOOM_C1);

@@ -45,6 +45,11 @@ struct FlatIndex {
     // split-block Bloom filter of the whole codes (2^midc_wbits blocks of four words, block chosen by the 12-mer).  midc_wbits == 0: absent.
     uint32_t midc_wbits = 0, mid0_bits = 0;
     std::vector<uint32_t> mid0, mid_bitmap, midc;
+    // Small tier (level 0 present), round 6: the second stage as a split-block filter of the codes for global memory (2^blkc_wbits blocks of four
+    // words, <= 4 entries a block; block = hash of the PLAIN 12-mer at offset o of the code, o = 0..3; a code sets one bit in each word of each of
+    // its four blocks) -- what sketch_filter_kernel<.., MID = 2> tests a group against, so that `bloom0` can stay level 0 alone.  0: absent.
+    uint32_t blkc_wbits = 0;
+    std::vector<uint32_t> blkc;
     uint32_t total_knodes() const { return knode_base.empty() ? 0 : knode_base.back(); }
 };
 

@@ -155,6 +155,9 @@ struct BloomTables {
     const uint32_t* mid_bitmap = nullptr;
     const uint32_t* midc = nullptr;
     uint32_t midc_wbits = 0, mid0_bits = 0;
+    // small tier, second stage in the L2 (round 6; FlatIndex::blkc): split-block filter of the codes, block chosen by the group's plain 12-mer
+    const uint32_t* blkc = nullptr;
+    uint32_t blkc_wbits = 0;
 };
 // Scratch of the filtered launch sequence.  raw_pos: raw_capacity candidate positions (one slice per filter wave);
 // cand_info / cand_pos1: raw_capacity entries each; small: filter_small_words() u32; max_len: device scalar that

@@ -128,6 +128,11 @@ Mapper::Mapper(const FlatIndex& idx, const MapParams& p, int device) : device_(d
         HIPCHK(hipMemcpy(d_bloom0f_, idx.bloom0f.data(), idx.bloom0f.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         dmalloc(d_bloomr_, idx.bloomr.size());
         HIPCHK(hipMemcpy(d_bloomr_, idx.bloomr.data(), idx.bloomr.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        if (idx.blkc_wbits) { // the second stage for the L2 (round 6)
+            blkc_wbits_ = idx.blkc_wbits;
+            dmalloc(d_blkc_, idx.blkc.size());
+            HIPCHK(hipMemcpy(d_blkc_, idx.blkc.data(), idx.blkc.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        }
     }
     if (idx.midc_wbits) {
         const size_t max_records = mid_tier_max_records(); // (common.h: where the direct sequence takes over)
@@ -193,7 +198,7 @@ Mapper::~Mapper()
     dfree(d_head_); dfree(d_scan_); dfree(d_cstart_); dfree(d_order_); dfree(d_clusters_);
     if (d_temp_) (void)hipFree(d_temp_);
     for (TileSet& t : tsets_) free_tile_set(t);
-    dfree(d_bases_); dfree(d_offsets_); dfree(d_bloom_); dfree(d_bloom0_); dfree(d_bloom0f_); dfree(d_bloomr_); dfree(d_pbloom_); dfree(d_mid0_); dfree(d_mid_bitmap_); dfree(d_midc_); dfree(d_ft_stat_);
+    dfree(d_bases_); dfree(d_offsets_); dfree(d_bloom_); dfree(d_bloom0_); dfree(d_bloom0f_); dfree(d_bloomr_); dfree(d_pbloom_); dfree(d_mid0_); dfree(d_mid_bitmap_); dfree(d_midc_); dfree(d_blkc_); dfree(d_ft_stat_);
     for (Lane& lane : lanes_) free_lane(lane);
     for (Stage& st : stage_) {
         dfree(st.d_bases); dfree(st.d_offsets); dfree(st.d_npos);
@@ -406,6 +411,8 @@ void Mapper::launch_lane(Lane& lane, hipStream_t stream, const uint8_t* d_bases,
         }
     }
     dev::BloomTables bt { d_bloom_, bloom_wbits_, d_bloom0_, bloom0_wbits_, d_bloomr_, d_bloom0f_ };
+    bt.blkc = d_blkc_;
+    bt.blkc_wbits = blkc_wbits_;
     if (use_mid_) {
         bt.mid0 = d_mid0_;
         bt.mid_bitmap = d_mid_bitmap_;
@@ -1557,6 +1564,7 @@ void Mapper::upload(const std::vector<uint32_t>& covg, const std::vector<uint32_
 void Mapper::device_tables(uint64_t out[6]) const
 {
     out[4] = use_mid_ ? (uint64_t)MID_BITMAP_WORDS * 4 + ((uint64_t)16 << midc_wbits_) : 0; // global-memory (L2) tiers of the filter
+    if (!use_mid_ && use_filter_ && d_blkc_) out[4] = (uint64_t)16 << blkc_wbits_; // (small tier: the second stage's block filter, what packed batches are tested against)
     out[5] = 0;
     out[0] = d_pbloom_ ? (uint64_t)1 << pbloom_wbits_ : 0;
     out[1] = ((uint64_t)1 << table_bits_) * (wide_hash_ ? 16 : 12);

@@ -242,6 +242,8 @@ private:
     // middle tier of the filter (FlatIndex::mid0 / mid_bitmap / midc): level 0 in LDS, the other two in global memory (L2-resident)
     uint32_t *d_mid0_ = nullptr, *d_mid_bitmap_ = nullptr, *d_midc_ = nullptr;
     uint32_t midc_wbits_ = 0, mid0_bits_ = 0;
+    uint32_t* d_blkc_ = nullptr; // small tier: the second stage as a split-block filter in global memory (FlatIndex::blkc)
+    uint32_t blkc_wbits_ = 0;
     bool use_mid_ = false;                   // the filtered sequence runs in its middle-tier form
     unsigned long long* d_ft_stat_ = nullptr; // DRPRG_FT_STATS=1: groups tested / past level 0 / past the bitmap, candidate positions
     int n_cus_ = 256;

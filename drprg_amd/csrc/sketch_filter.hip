@@ -117,6 +117,19 @@ __device__ __forceinline__ uint32_t canon12_dev(uint32_t x)
 // LDS-resident filter.  Level 0 is keyed on the canonical 12-mer; a group that passes it is looked up in the exact bitmap of the
 // canonical index 12-mers in global memory (2 MB: L2-resident; one exec-masked four-byte load per surviving group, all of a tile's
 // loads in flight together), and the second stage tests the four codes of a group against a one-word Bloom filter in global memory.
+// MID == 2 (round 6; with LEVEL0 and FUSED): the SMALL tier with its second stage in the L2.  Level 0 as in the all-LDS form -- plain 12-mers, three
+// bits -- but the array holds level 0 ALONE (FlatIndex::bloom0: 17.5 % full for the 8d index, a random 12-mer passes at 1.2 %; with the
+// second stage's six bits per code in the same array -- bloom0f, the all-LDS form -- it is 28 % full and passes 4.3 %), and a group that passes
+// is tested against ONE 16-byte block of a split-block filter of the codes in global memory (FlatIndex::blkc, 256 KB for the 8d index: L2-
+// resident; the block is chosen by the group's 12-mer, every index code sets one bit in each of the block's four words -- the middle tier's
+// third stage, without its canonical keys and without its bitmap).  Fewer groups to stage, test and append -- 171.7 -> 140.2 M VALU and 10.0 ->
+// 8.0 M LDS wave-instructions per 10 M x 150 bp -- for 11 M lane probes of the L2 (174 k gather instructions; TCC requests 12.3 -> 22.9 M), and
+// the L2 answers ~267 G scattered probes a second whatever their width: 41 us of the texture path.  PACKED input has them to spare (the batch is
+// a quarter of the bytes): kernel 0.240 -> 0.193 ms, step 0.387 -> 0.330.  ASCII input has not -- TA_BUSY 51 % -> 92 % of the launch, kernel
+// 0.29-0.32 -> 0.33-0.35 ms on the same boxes -- so this is the default form for packed batches only (DRPRG_FILTER_STAGE2=l2|lds forces one).
+// (The wait for the blocks is not what ASCII loses: a form that asked for a round's blocks behind one tile and tested them two tiles later,
+// s_waitcnt vmcnt(4) instead of 0 -- checked in the ISA, nothing copied on the loop's back edge -- ran in the same 0.33-0.34 ms, and packed in
+// the same 0.19: profiles/r06/schedule.txt section 9.)
 // PACKED: the batch arrives as 2-bit packed words (SketchArgs::packed; the letters ARE the filter's alphabet): a lane's 32 positions
 // are the two words it loads -- 8 bytes instead of 32, no pack16le (eight v_and + eight v_dot4 + the merges per tile), a quarter of
 // the bytes from HBM.  Everything behind the two words is the same code, so both formats leave the same candidates.
@@ -130,6 +143,12 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
     // everything a tile costs once (loop control, slice bookkeeping, the ballots and prefix sums of the ordered append) is paid half as often
     constexpr int G = filter_positions_per_lane(LEVEL0, PACKED), WPOS = 63 * G, NW = G / 16, NG = G / 4;
     constexpr uint32_t L12_BASE = LEVEL0 ? FT_L0_WORDS * 4u : 0u;
+    constexpr bool CANON = MID == 1 || MID == 3; // the middle tier proper: canonical 12-mers, the exact bitmap behind level 0 (MID == 2: neither)
+    auto group_key = [](uint32_t x) -> uint32_t { // the 12-mer that picks a group's block of the code filter (the low 24 bits count)
+        if constexpr (CANON) return canon12_dev(x);
+        else return x;
+    };
+    (void)group_key;
     // (a wave's stage is 128 records of 16 bytes; 127 are used: the last record of the last wave's is where the chunk counter lives -- the 160 KB are full)
     constexpr uint32_t STAGE_RECORDS = 128, STAGE_CAP = STAGE_RECORDS - 1, STAGE_BASE_WORDS = FT_L0_WORDS;
 
@@ -333,11 +352,11 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
                     uint4 ra = make_uint4(0, 0, 0, 0), rb = ra, ba = ra, bb = ra;                                                     \
                     if (ia < lcnt) {                                                                                                  \
                         ra = stage[ia];                                                                                               \
-                        ba = reinterpret_cast<const uint4*>(fw.midc)[(uint32_t)__umul24(canon12_dev(__funnelshift_r(ra.z, ra.w, 6)), BLOOM_C0) >> sh_c]; /* (__umul24 returns int) */ \
+                        ba = reinterpret_cast<const uint4*>(fw.midc)[(uint32_t)__umul24(group_key(__funnelshift_r(ra.z, ra.w, 6)), BLOOM_C0) >> sh_c]; /* (__umul24 returns int) */ \
                     }                                                                                                                 \
                     if (ib < lcnt) {                                                                                                  \
                         rb = stage[ib];                                                                                               \
-                        bb = reinterpret_cast<const uint4*>(fw.midc)[(uint32_t)__umul24(canon12_dev(__funnelshift_r(rb.z, rb.w, 6)), BLOOM_C0) >> sh_c]; \
+                        bb = reinterpret_cast<const uint4*>(fw.midc)[(uint32_t)__umul24(group_key(__funnelshift_r(rb.z, rb.w, 6)), BLOOM_C0) >> sh_c]; \
                     }                                                                                                                 \
                     uint32_t ca = 0, cb = 0;                                                                                          \
                     DRPRG_BLOCK_TEST(ra, ba, ca); /* (an all-zero block rejects: lanes without a record) */                           \
@@ -415,7 +434,7 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
                 const int j = 4 * g + 3;
                 const uint32_t lo = wv[j >> 4], hi = wv[(j >> 4) + 1];
                 xs[g] = __builtin_amdgcn_alignbit(hi, lo, 2 * (j & 15));
-                if constexpr (MID != 0) xs[g] = canon12_dev(xs[g]);
+                if constexpr (CANON) xs[g] = canon12_dev(xs[g]);
                 hs[g] = __umul24(xs[g], BLOOM_C0);
                 ws[g] = lds_at((hs[g] >> 15) & amask0);
             }
@@ -423,7 +442,7 @@ __global__ __launch_bounds__(FT_THREADS) void sketch_filter_kernel(SketchArgs a,
             for (int g = NG - 1; g >= 0; --g)
                 grp = __builtin_amdgcn_alignbit(grp, MID == 1 ? ws[g] << (hs[g] & 31) : bloom_test(ws[g], hs[g], xs[g]), 31);
             grp &= lane_keep; // (lane 63's word is only lane 62's right neighbour; as a mask: the branch cost eight scalar instructions per tile)
-            if constexpr (MID != 0) {
+            if constexpr (CANON) {
                 // ---- the exact bitmap of the canonical index 12-mers, only for the groups that passed level 0: one exec-masked load
                 // each, all in flight before the first test (the L2 serves ~267 G such probes per second chip-wide whatever their
                 // width, so every group level 0 rejects is 3.7 ps saved) ----
@@ -880,15 +899,21 @@ hipError_t launch_sketch_filter(const SketchArgs& a, uint32_t read_begin, uint32
     // the second stage inside the streaming kernel (default; its bits share the level-0 array) or as refine_kernel behind it
     // (DRPRG_FILTER_FORM=refine): 0.64 against 0.69 ms per 10 M reads, DESIGN.md section 6
     const bool fused = mid || (level0 && !group_records_requested()); // (the two-kernel form is part of `make EXPERIMENTAL=1` only)
+    // Small tier: the second stage against a block filter in the L2 (sketch_filter_kernel<.., MID = 2>: the level-0 array then holds level 0 alone and
+    // lets a third as many groups through) for packed batches, round 2-5's all-LDS form for ASCII ones; DRPRG_FILTER_STAGE2=l2|lds asks for one of
+    // the two whatever the format (read at every launch: A/B runs, tests).  Both leave the same candidates behind verify: the tests map with both.
+    const char* const stage2 = std::getenv("DRPRG_FILTER_STAGE2");
+    const bool want_l2 = stage2 && *stage2 ? std::string(stage2) == "l2" : a.packed != 0; // (the kernel's header comment: packed batches have the L2 probes to spare)
+    const bool blk = !mid && level0 && fused && want_l2 && bt.blkc != nullptr && bt.blkc_wbits >= 1 && bt.blkc_wbits <= MID_C_MAX_WBITS;
     if (level0 && !fused && !b.raw_grp) return hipErrorInvalidValue; // (the caller allocates the group records when group_records_requested())
     fw.bloom = bt.bloom;
     fw.bloom_wbits = bt.bloom_wbits;
     fw.bloomr = bt.bloomr;
-    fw.bloom0 = mid ? bt.mid0 : (level0 ? (fused ? bt.bloom0f : bt.bloom0) : nullptr);
+    fw.bloom0 = mid ? bt.mid0 : (level0 ? (fused && !blk ? bt.bloom0f : bt.bloom0) : nullptr);
     fw.bloom0_wbits = mid ? 15 : (level0 ? bt.bloom0_wbits : 0);
     fw.mid_bitmap = bt.mid_bitmap;
-    fw.midc = bt.midc;
-    fw.midc_wbits = bt.midc_wbits;
+    fw.midc = blk ? bt.blkc : bt.midc;
+    fw.midc_wbits = blk ? bt.blkc_wbits : bt.midc_wbits;
     fw.stat = mid ? b.stat : nullptr;
     const uint32_t grid = filter_grid(level0, n_cus, filter_n_tiles(a.n_bases, filter_positions_per_lane(level0, a.packed != 0)));
     {   // The shares of the four wave classes of a workgroup (sketch_filter_kernel: a SIMD issues for its oldest wave first).  Measured where the
@@ -945,14 +970,16 @@ hipError_t launch_sketch_filter(const SketchArgs& a, uint32_t read_begin, uint32
     fw.raw_grp = b.raw_grp;
     {
         using Kernel = void (*)(SketchArgs, FilterWork);
-        const int which = mid ? (bt.mid0_bits == 3 ? 4 : 5) : level0 ? (fused ? 3 : 2) : (a.k < 12 ? 1 : 0);
-        const Kernel ascii = which == 5 ? &sketch_filter_kernel<false, true, true, 1>
+        const int which = mid ? (bt.mid0_bits == 3 ? 4 : 5) : blk ? 6 : level0 ? (fused ? 3 : 2) : (a.k < 12 ? 1 : 0);
+        const Kernel ascii = which == 6 ? &sketch_filter_kernel<false, true, true, 2>
+            : which == 5                ? &sketch_filter_kernel<false, true, true, 1>
             : which == 4                ? &sketch_filter_kernel<false, true, true, 3>
             : which == 3                ? &sketch_filter_kernel<false, true, true>
             : which == 2                ? &sketch_filter_kernel<false, true>
             : which == 1                ? &sketch_filter_kernel<true, false>
                                         : &sketch_filter_kernel<false, false>;
-        const Kernel packed = which == 5 ? &sketch_filter_kernel<false, true, true, 1, true>
+        const Kernel packed = which == 6 ? &sketch_filter_kernel<false, true, true, 2, true>
+            : which == 5                 ? &sketch_filter_kernel<false, true, true, 1, true>
             : which == 4                 ? &sketch_filter_kernel<false, true, true, 3, true>
             : which == 3                 ? &sketch_filter_kernel<false, true, true, 0, true>
             : which == 2                 ? &sketch_filter_kernel<false, true, false, 0, true>
@@ -962,8 +989,8 @@ hipError_t launch_sketch_filter(const SketchArgs& a, uint32_t read_begin, uint32
         // (+ the chunk counter: 16 bytes of their own, or -- the level-0 form with the second stage inside fills the 160 KB -- the last record of the last wave's stage)
         const size_t dyn = level0 ? (size_t)FT_L0_WORDS * 4 + (fused ? (size_t)FT_WAVES * 2048 : 16) : ((size_t)4 << bt.bloom_wbits) + 16;
         fw.sched.lds_word = (uint32_t)(dyn / 4 - 4);
-        static size_t configured[12][MAX_HIP_DEVICES] = {};
-        HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), dyn, configured[which + (a.packed ? 6 : 0)]));
+        static size_t configured[14][MAX_HIP_DEVICES] = {};
+        HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), dyn, configured[which + (a.packed ? 7 : 0)]));
         launch_timed(timer, kernel, dim3(grid), dim3(FT_THREADS), dyn, stream, a, fw);
     }
     HIP_TRY(hipGetLastError());

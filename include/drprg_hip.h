@@ -278,8 +278,8 @@ int drprg_hip_index_export(const drprg_hip_ctx* ctx, uint64_t* keys, uint32_t* r
 /* Device-side tables of an open context: out[0] = 32-bit words of the L2-resident Bloom tier in front of the probe table
  * (0: the table fits the L2, no tier), out[1] = bytes of the open-addressed probe table (keys + slot records), out[2] = bytes
  * of the LDS-resident filter arrays of the prefiltered sequence (0: index too large / k > 15), out[3] = sequence in use,
- * out[4] = bytes of the filter tiers of that sequence that live in global memory (L2-resident; middle tier of the filter,
- * 0 otherwise), out[5] = 0 (reserved). */
+ * out[4] = bytes of the filter tiers of that sequence that live in global memory (L2-resident: the middle tier's bitmap and
+ * code filter; the small tier's block filter, which is the second stage for packed batches; 0 otherwise), out[5] = 0 (reserved). */
 int drprg_hip_device_tables(drprg_hip_ctx* ctx, uint64_t out[6]);
 
 /* Local-graph introspection of PRG `prg` (node intervals are offsets into the PRG string, markers and their

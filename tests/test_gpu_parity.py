@@ -874,6 +874,41 @@ def test_second_stage_inside_the_streaming_kernel(tmp_path, oracle, monkeypatch)
         _compare(ctx, oracle, sparse[0], sparse[1], 11, 15, True, 2)
 
 
+@pytest.mark.parametrize("sched,grid", [("static", None), ("100,20,4,8", "3")])
+@pytest.mark.parametrize("stage2", ["lds", "l2"])
+def test_second_stage_in_lds_or_in_the_l2(tmp_path, oracle, monkeypatch, stage2, sched, grid):
+    """Round 6.  The small tier's second stage has two homes: the six bits per code that share the level-0 array in LDS (the default for
+    ASCII batches) and a split-block filter of the codes in the L2, probed once per surviving group, with level 0 alone in LDS (the default
+    for packed batches).  DRPRG_FILTER_STAGE2 forces one for both formats (_compare maps ASCII and packed): each gives the oracle's vector on
+    the ragged / N / lower-case / empty-read case, on dense reads whose tiles overflow the stage, on sparse reads and on 4 kb reads -- with
+    one chunk per wave and under the chunk schedule."""
+    from drprg_amd import synth
+    monkeypatch.setenv("DRPRG_FILTER_STAGE2", stage2)
+    monkeypatch.setenv("DRPRG_FT_SCHED", sched)
+    if grid:
+        monkeypatch.setenv("DRPRG_FT_GRID", grid)
+    panel = synth.small_panel(seed=2)
+    ctx = _ctx(tmp_path, panel, 11, 15, True, kernel=2)
+    sc = ctx.filter_selfcheck()
+    assert sc["codes"] > 0 and sc["shared_array_false_negatives"] == 0
+    bases, offs = _ragged_reads(panel)
+    _compare(ctx, oracle, bases, offs, 11, 15, True, 2)
+    panel = synth.small_panel(seed=6, n_loci=3, length=900)
+    rng = np.random.default_rng(15)
+    haps = [synth.sample_haplotype(rng, t).encode() for t in panel.trees]
+    dense = _reads_from(rng, haps, 40000, 150)
+    sparse = _reads_from(rng, haps + [synth.random_seq(rng, 200000).encode()] * 9, 70000, 149)
+    for bases, offs in (dense, sparse):
+        ctx = _ctx(tmp_path, panel, 11, 15, True, kernel=2)
+        cnt = _compare(ctx, oracle, bases, offs, 11, 15, True, 2)
+        assert cnt["clusters_kept"] > 3000
+    panel = synth.small_panel(seed=11, n_loci=6, length=1500)
+    ctx = _ctx(tmp_path, panel, 11, 15, False, kernel=2)
+    gen = synth.HaplotypeGenomes(panel, genome_size=60000, n_hap=4, seed=3)
+    bases, offs = synth.sample_long_reads(gen, 3000, seed=4)
+    assert _compare(ctx, oracle, bases, offs, 11, 15, False, 2)["clusters_kept"] > 0
+
+
 # ---- middle tier of the filter (round 3): level 0 on canonical 12-mers in LDS, exact 12-mer bitmap + code filter in the L2 ----------
 _SCALED = {}
 

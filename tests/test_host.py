@@ -331,7 +331,7 @@ def test_bloom_filters_have_no_false_negatives(tmp_path, w, k, panel_name):
     chk = Context(prg, w, k, device=-1, from_files=False).filter_selfcheck()
     assert chk["codes"] > 0
     assert chk["level0_false_negatives"] == 0 and chk["level12_false_negatives"] == 0 and chk["stage2_false_negatives"] == 0
-    assert chk["shared_array_false_negatives"] == 0  # level 0 + second-stage bits in one array (second stage inside the streaming kernel)
+    assert chk["shared_array_false_negatives"] == 0  # level 0 + second-stage bits in one array (second stage inside the streaming kernel); the block filter of its L2 form
     assert 0 < chk["level12_fill_permille"] < 450
     if k == 15:  # level 0 + second stage exist
         assert 0 < chk["level0_fill_permille"] < 300 and 0 < chk["stage2_fill_permille"] < 250
