@@ -1,7 +1,8 @@
 #!/bin/bash
 # everything profiles/r06/ holds of the final code, in one gpurun call (every command under its own timeout); parts by name so that a call
 # can be split: tools/run_profiles_r06.sh <tag> [bench] [ranks] [series] [trace] [pmc] [sq]   (default: all)
-#   bench : bench lines of mtb (defaults: 100 steps, cpu_baseline, e2e; and the driver's command --steps 20 --warmup 5), packed, nanopore, big
+#   bench : bench lines of mtb (defaults: 100 steps, cpu_baseline, e2e; and the driver's command --steps 20 --warmup 5), packed, nanopore (both formats), big,
+#           and the second stage's other home for each format (DRPRG_FILTER_STAGE2)
 #   ranks : bench.py --gpus 2 / 8 on one GPU over gloo, both --comm modes (control flow only: unmeasured on > 1 GPU)
 #   series: bench lines of the index-size series
 #   trace : rocprofv3 --kernel-trace --stats of every workload (per-dispatch rows kept: tools/kstats.py full-launch averages)
@@ -19,6 +20,9 @@ if has bench; then
   timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_mtb_driver_command.json 2> $O/bench_mtb_driver_command.err
   timeout 400 python bench.py --input packed --cpu-sample 0 --e2e 0 > $O/bench_mtb_packed.json 2> $O/bench_mtb_packed.err
   timeout 400 python bench.py --workload nanopore --steps 10 --warmup 3 --e2e 0 > $O/bench_nanopore.json 2> $O/bench_nanopore.err
+  timeout 400 python bench.py --workload nanopore --input packed --steps 10 --warmup 3 --cpu-sample 0 --e2e 0 > $O/bench_nanopore_packed.json 2> $O/bench_nanopore_packed.err
+  DRPRG_FILTER_STAGE2=lds timeout 400 python bench.py --input packed --steps 20 --warmup 5 --cpu-sample 0 --e2e 0 > $O/bench_mtb_packed_all_lds_second_stage.json 2> /dev/null
+  DRPRG_FILTER_STAGE2=l2 timeout 400 python bench.py --steps 20 --warmup 5 --cpu-sample 0 --e2e 0 > $O/bench_mtb_l2_second_stage.json 2> /dev/null
   timeout 400 python bench.py --workload big --steps 10 --warmup 3 --e2e 0 > $O/bench_big.json 2> $O/bench_big.err
   DRPRG_FT_SCHED=static timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 --cpu-sample 0 --e2e 0 > $O/bench_mtb_static_schedule.json 2> $O/bench_mtb_static_schedule.err
 fi
