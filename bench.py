@@ -542,7 +542,7 @@ def main():
         ev.record(cstream)
         return _Done(event=ev, work=work)
 
-    def step():
+    def step(reduce=True):
         b = step_no[0] % len(accs)
         step_no[0] += 1
         acc = accs[b]
@@ -558,7 +558,7 @@ def main():
                 ctx.map_device_async(bases.data_ptr(), offsets.data_ptr(), n_reads, n_bases, *out)
             else:
                 ctx.map_device(bases.data_ptr(), offsets.data_ptr(), n_reads, n_bases, *out)
-            if world > 1:
+            if world > 1 and reduce:
                 if deferred:
                     if unreduced[0] is not None:  # the batch before this one is complete now
                         pending[unreduced[0]] = all_reduce_async(accs[unreduced[0]])
@@ -612,10 +612,15 @@ def main():
                              "device since the batch was built: a device that has idled for seconds"}
     spinup_steps = 0
     if args.spinup_ms > 0:
+        # (mapping only, no reduce: the loop runs by the clock, so the ranks of a job do not run it equally often -- and collectives are matched
+        # by their order.  Until late in round 6 these steps reduced like the timed ones: eight ranks over gloo then waited for each other
+        # until the transport's timeout, profiles/r06/README.md.)
+        barrier()
+        spin_ms = args.spinup_ms + rank * float(os.environ.get("DRPRG_BENCH_SPINUP_SKEW_MS", "0"))  # (test hook: ranks that surely differ in their step counts)
         t_spin = time.perf_counter()
-        while (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms:
+        while (time.perf_counter() - t_spin) * 1e3 < spin_ms:
             for _ in range(8):
-                step()
+                step(reduce=False)
             spinup_steps += 8
             if not deferred:
                 continue

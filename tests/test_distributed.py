@@ -121,3 +121,21 @@ def test_reduce_coverage_refuses_tensors_it_cannot_update_in_place():
             assert reduce_coverage(a, a[:2], 7) == 7  # world size 1: still a no-op
         finally:
             dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("comm", ["torch", "native"])
+def test_bench_ranks_whose_spin_ups_differ(comm):
+    """bench.py --gpus 3 with every rank on the one GPU and gloo underneath (DRPRG_BENCH_BACKEND=gloo: control flow only).  The spin-up maps by the
+    clock, so no two ranks run it equally often (forced here: rank r maps 120 ms x r longer), and collectives are matched by their order:
+    a spin-up that reduced like the timed steps left the ranks waiting for each other until the transport's timeout (round 6, found by the
+    profile run's eight ranks).  The line must come out, with every rank holding the sum of the ranks' vectors."""
+    import json
+    env = dict(os.environ, DRPRG_BENCH_BACKEND="gloo", DRPRG_BENCH_SPINUP_SKEW_MS="120", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--reads-per-gpu", "300000", "--steps", "3", "--warmup", "2", "--spinup-ms", "60",
+           "--cpu-sample", "0", "--e2e", "0", "--comm", comm]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([x for x in p.stdout.splitlines() if x.startswith("{")][-1])
+    assert line["n_gpus"] == 3 and line["config"]["all_ranks_hold_the_sum_of_the_ranks_vectors"] is True
+    assert line["spinup"]["steps"] > 0 and line["value"] > 0
