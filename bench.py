@@ -174,6 +174,10 @@ def profile_entry_stale(entry, kernel):
         return None
     if kernel not in KERNEL_SOURCES:
         return f"no source table for {kernel}"
+    # (the profiles are of the default form of the kernel: a run that asks for another one -- A/B lines -- replays nothing)
+    forced = [f"{k}={os.environ[k]}" for k in ("DRPRG_FILTER_STAGE2", "DRPRG_FILTER_FORM", "DRPRG_DIRECT_FORM", "DRPRG_FT_DEBUG") if os.environ.get(k)]
+    if forced:
+        return "this run asks for a form of the kernel the profiles were not taken on (" + ", ".join(forced) + ")"
     was = entry.get("source_sha16")
     now = kernel_source_sha16(kernel)
     if was is None:

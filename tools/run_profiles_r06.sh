@@ -1,16 +1,17 @@
 #!/bin/bash
 # everything profiles/r06/ holds of the final code, in one gpurun call (every command under its own timeout); parts by name so that a call
-# can be split: tools/run_profiles_r06.sh <tag> [bench] [ranks] [series] [trace] [pmc] [sq]   (default: all)
+# can be split: tools/run_profiles_r06.sh <tag> [bench] [ranks] [series] [trace] [driver] [pmc] [sq]   (default: all)
 #   bench : bench lines of mtb (defaults: 100 steps, cpu_baseline, e2e; and the driver's command --steps 20 --warmup 5), packed, nanopore (both formats), big,
 #           and the second stage's other home for each format (DRPRG_FILTER_STAGE2)
 #   ranks : bench.py --gpus 2 / 8 on one GPU over gloo, both --comm modes (control flow only: unmeasured on > 1 GPU)
 #   series: bench lines of the index-size series
 #   trace : rocprofv3 --kernel-trace --stats of every workload (per-dispatch rows kept: tools/kstats.py full-launch averages)
+#   driver: the driver's command (--gpus 1 --steps 20 --warmup 5) under rocprofv3 --kernel-trace --stats
 #   pmc   : FETCH_SIZE / WRITE_SIZE passes of mtb (ASCII and packed), mtb-x8, nanopore, big
 #   sq    : SQ counters of mtb (ASCII and packed), mtb-x8, big
 # The summary is written LAST, from the csv files it sits beside (their call counts are in it).
 tag=${1:-z}; shift
-parts=${@:-bench ranks series trace pmc sq}
+parts=${@:-bench ranks series trace driver pmc sq}
 has() { [[ " $parts " == *" $1 "* ]]; }
 O=gpurun_out/r06/$tag; mkdir -p $O
 R=${GRAFT_REPO_ROOT:-$PWD}
@@ -43,6 +44,9 @@ if has trace; then
     timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_$wl -o $wl -- python3 $R/bench.py --workload $wl --steps 40 --warmup 10 --cpu-sample 0 --e2e 0 --no-checks > /dev/null 2>&1
   done
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_mtb-packed -o mtb-packed -- python3 $R/bench.py --input packed --steps 40 --warmup 10 --cpu-sample 0 --e2e 0 --no-checks > /dev/null 2>&1
+fi
+if has driver; then # the driver's own command under the profiler: the line's avg_launch_ms (HIP events) beside the profiler's table of the same process
+  timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_mtb_under_rocprofv3 -o mtb_under_rocprofv3 -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 > $R/$O/bench_mtb_under_rocprofv3.json 2> /dev/null
 fi
 if has pmc; then
   for wl in mtb mtb-x8 nanopore big; do
