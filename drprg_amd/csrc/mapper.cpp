@@ -850,6 +850,11 @@ void Mapper::tune_filter_shares(const Lane& lane, bool packed, uint64_t n_bases)
         ft_last_[11] = sc.per_wg;
         for (int r = 0; r < dev::FT_MAX_ROUNDS; ++r) ft_last_[12 + r] = r && r < (int)sc.n_rounds ? sc.size[r] : 0;
     }
+    if (lane.fw.cand_total && std::getenv("DRPRG_FT_STATS")) { // what the filter left for verify_scan_kernel (measurements; the batch is complete)
+        uint32_t total = 0;
+        if (hipMemcpy(&total, lane.fw.cand_total, sizeof(total), hipMemcpyDeviceToHost) == hipSuccess)
+            std::fprintf(stderr, "[sketch_filter] candidate positions of the batch: %u\n", total);
+    }
     if (lane.fw.sched.n_rounds > 1) return; // a dynamic schedule balances itself: the shares of round 0 stay what they are
     if (!ft_adapt_ || n_bases < (64ull << 20)) return;
     if (max_lanes_ > 1) return; // (read ranges on concurrent streams: the classes' clocks measure the overlap, not the shares -- ADVICE r05)
