@@ -447,6 +447,7 @@ def main():
         bases, offsets = gpu_sample_reads(torch, hap_pad, hap_lens, n_reads, args.read_len, 2 + rank, device)
     n_bases = int(bases.numel())
     del hap_pad
+    torch.cuda.synchronize()  # (torch made the batch on ITS stream; the context's calls below run on theirs)
     torch.cuda.empty_cache()
     packed = args.input == "packed"
     d_words = d_npos = None
