@@ -124,7 +124,10 @@ int drprg_hip_gunzip_file(const char* gz_path, int threads, uint64_t chunk_bytes
 int drprg_hip_map_host(drprg_hip_ctx* ctx, const uint8_t* bases, const uint64_t* offsets, uint64_t n_reads);
 /* Batch already resident in HBM.  d_bases: ASCII bases of all reads back to back, 16-byte aligned;
  * d_offsets: u64[n_reads+1], d_offsets[0] == 0, d_offsets[n_reads] == n_bases.  d_covg (u32[2*n_knodes]) and
- * d_prg_reads (u32[n_prgs]) may be NULL to use the context's accumulators; hip_stream may be NULL. */
+ * d_prg_reads (u32[n_prgs]) may be NULL to use the context's accumulators; hip_stream may be NULL.
+ * Stream rule of every call that takes device buffers (map_device*, map_device_packed*, pack_device, allreduce): the work is queued on
+ * hip_stream, or -- NULL -- on the context's own stream, which does NOT wait for the legacy default stream or anybody else's.  Whatever
+ * produced the buffers must be complete on that stream: a producer on another stream (a framework's, say) is synchronised by the caller first. */
 int drprg_hip_map_device(drprg_hip_ctx* ctx, const void* d_bases, const void* d_offsets, uint64_t n_reads,
     uint64_t n_bases, void* d_covg, void* d_prg_reads, void* hip_stream);
 /* The same without the host waiting for the batch: the launch sequence is queued and the call returns; the read-back the
