@@ -455,6 +455,7 @@ def main():
     if packed:  # the same batch, 2 bits per base (outside the timed region: what a packing ingest hands over)
         d_words = torch.zeros((n_bases + 15) // 16 + 4, dtype=torch.int32, device=device)
         d_npos = torch.zeros(1 << 16, dtype=torch.int64, device=device)
+        torch.cuda.synchronize()  # (the two fills above are on torch's stream, the packing on the context's)
         n_npos = ctx.pack_device(bases.data_ptr(), n_bases, d_words.data_ptr(), d_npos.data_ptr(), d_npos.numel())
     # the reduced vector: per-node coverage and per-PRG cluster counts in one buffer (one memset, one all-reduce).  With
     # N > 1 two buffers alternate: the all-reduce of step i runs on RCCL's stream while step i+1 maps into the other
@@ -691,6 +692,7 @@ def main():
     if world == 1 and not args.no_checks and not packed and os.environ.get("DRPRG_BENCH_PACKED_LEG", "1") != "0":
         pw = torch.zeros((n_bases + 15) // 16 + 4, dtype=torch.int32, device=device)
         pn = torch.zeros(1 << 16, dtype=torch.int64, device=device)
+        torch.cuda.synchronize()  # (as above)
         pn_n = ctx.pack_device(bases.data_ptr(), n_bases, pw.data_ptr(), pn.data_ptr(), pn.numel())
         bufs = [torch.zeros_like(acc) for _ in range(2)]
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
@@ -724,6 +726,47 @@ def main():
                       "how": "the batch packed on the device before this leg (drprg_hip_pack_device), then the same number of steps through "
                              "drprg_hip_map_device_packed, device time between HIP events on the hot path's stream; outside the timed region of the headline"}
         del pw, pn, bufs
+
+    # Different batches in rotation, outside the timed region: the headline maps ONE resident batch again and again, and a batch that comes round
+    # again finds a little of itself in the memory-side cache (256 MB).  What a stream of different batches runs at ("other_batches_in_rotation";
+    # profiles/r06/schedule.txt section 11: 1.3-2.8 % below the repeated batch for ASCII input, nothing for packed).
+    rotation_leg = None
+    if world == 1 and not args.no_checks and not packed and os.environ.get("DRPRG_BENCH_ROTATION_LEG", "1") != "0":
+        hp = torch.from_numpy(genomes.padded()).to(device)
+        rot = [(bases, offsets, n_bases)]
+        for sd in (101, 102):
+            if args.workload == "nanopore":
+                b2, o2 = gpu_sample_long_reads(torch, hp, hap_lens, n_reads, sd, device)
+            else:
+                b2, o2 = gpu_sample_reads(torch, hp, hap_lens, n_reads, args.read_len, sd, device)
+            rot.append((b2, o2, int(b2.numel())))
+        del hp
+        torch.cuda.synchronize()
+        bufs = [torch.zeros_like(acc) for _ in range(2)]
+        r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        warm = max(args.warmup, 3)
+        with torch.cuda.stream(stream):
+            for i in range(-warm, args.steps):
+                b = bufs[i % 2]
+                b.zero_()
+                rb, ro, rn = rot[i % len(rot)]
+                (ctx.map_device_async if deferred else ctx.map_device)(rb.data_ptr(), ro.data_ptr(), n_reads, rn, b.data_ptr(), b.data_ptr() + 8 * ctx.n_knodes,
+                                                                       stream.cuda_stream)
+                if i == -1:
+                    ctx.sync()
+                    torch.cuda.synchronize()
+                    ctx.kernel_timing(enable=True, reset=True)
+                    r0.record(stream)
+            r1.record(stream)
+        ctx.sync()
+        torch.cuda.synchronize()
+        rk_ms, rk_n = ctx.kernel_timing(enable=False)
+        r_ms = r0.elapsed_time(r1) / args.steps
+        rotation_leg = {"ms_per_step": r_ms, "value": n_reads / (r_ms * 1e-3), "unit": "reads/s", "batches": len(rot),
+                        "dominant_kernel_avg_launch_ms": rk_ms / max(rk_n, 1),
+                        "how": f"{len(rot)} different batches of the workload (other seeds) mapped in rotation, the same number of steps, device time between "
+                               "HIP events on the hot path's stream; outside the timed region of the headline, which repeats one resident batch"}
+        del rot, bufs
 
     if rank == 0:
         total_reads = n_reads * world * args.steps
@@ -846,6 +889,8 @@ def main():
             packed_leg["frac_of_bytes_read"] = (packed_read / (packed_leg["dominant_kernel_avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
                                                 if packed_leg["dominant_kernel_avg_launch_ms"] > 0 else None)
             out["packed_input"] = packed_leg
+        if rotation_leg is not None:
+            out["other_batches_in_rotation"] = rotation_leg
         # CPU baseline: the oracle (a scalar port of the same path, oracle/oracle.c) on a bounded sample of rank 0's shard,
         # once on one thread and once with the reads split over the host's cores (threads calling the same C function on
         # disjoint read ranges; integer coverage sums commute).  The multi-thread sample is as large as ~10 s allow -- with
