@@ -23,5 +23,11 @@ for i in 1 2 3 4 5 6 7 8 9 10; do
 import json,sys
 d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],4), round(d['roofline']['avg_launch_ms'],4), d['config']['coverage_checksum'], d['config']['hits_per_batch'])"
 done
+echo "# five bench runs with the packed batch (second stage in the L2): ms/step, kernel ms, coverage checksum of the last step, hits per batch"
+for i in 1 2 3 4 5; do
+  timeout 300 python bench.py --input packed --cpu-sample 0 --e2e 0 --steps 20 --warmup 5 --no-checks 2>/dev/null | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],4), round(d['roofline']['avg_launch_ms'],4), d['config']['coverage_checksum'], d['config']['hits_per_batch'])"
+done
 } >> $O/flaky_hunt.txt 2>&1
 tail -30 $O/flaky_hunt.txt
