@@ -900,7 +900,7 @@ hipError_t launch_sketch_filter(const SketchArgs& a, uint32_t read_begin, uint32
     // (DRPRG_FILTER_FORM=refine): 0.64 against 0.69 ms per 10 M reads, DESIGN.md section 6
     const bool fused = mid || (level0 && !group_records_requested()); // (the two-kernel form is part of `make EXPERIMENTAL=1` only)
     // Small tier: the second stage against a block filter in the L2 (sketch_filter_kernel<.., MID = 2>: the level-0 array then holds level 0 alone and
-    // lets a third as many groups through) for packed batches, round 2-5's all-LDS form for ASCII ones; DRPRG_FILTER_STAGE2=l2|lds asks for one of
+    // lets fewer groups through -- 11 M per 10 M x 150 bp) for packed batches, round 2-5's all-LDS form for ASCII ones; DRPRG_FILTER_STAGE2=l2|lds asks for one of
     // the two whatever the format (read at every launch: A/B runs, tests).  Both leave the same candidates behind verify: the tests map with both.
     const char* const stage2 = std::getenv("DRPRG_FILTER_STAGE2");
     const bool want_l2 = stage2 && *stage2 ? std::string(stage2) == "l2" : a.packed != 0; // (the kernel's header comment: packed batches have the L2 probes to spare)
